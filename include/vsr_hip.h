@@ -1,0 +1,211 @@
+/* libvsr_hip.so -- C-ABI of the MI355X (gfx950) STTN inpainting hot path.
+ *
+ * The reference (YaoFANGUK/video-subtitle-remover) has no FFI: its drop-in boundary is the
+ * duck-typed Python plugin selected by --inpaint-mode in backend/main.py:375-386.  The Python
+ * plugin classes of this repo (video-subtitle-remover_amd/backend/inpaint/ (sttn_auto_inpaint.py ...)) keep those
+ * signatures and bind the entry points below through ctypes.  Each
+ * entry point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes, no torch types; every function returns 0 on success
+ * or a negative VSR_ERR_* code (message via vsr_last_error(), thread-local); no exceptions
+ * cross the ABI; "dev" pointers are device memory of the model's GPU, everything else is
+ * host memory; `stream` is a hipStream_t passed as void* (NULL = default stream); a model
+ * handle is not thread-safe (one per stream).  There is NO CPU fallback: without a HIP
+ * device every compute entry point fails with VSR_ERR_NOGPU.
+ */
+#ifndef VSR_HIP_H
+#define VSR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSR_OK 0
+#define VSR_ERR_ARG (-1)
+#define VSR_ERR_STATE (-2)
+#define VSR_ERR_HIP (-3)
+#define VSR_ERR_NOGPU (-4)
+
+#define VSR_VARIANT_STTN_AUTO 0 /* backend/inpaint/sttn/auto_sttn.py InpaintGenerator, 640x120 */
+#define VSR_VARIANT_STTN_DET 1  /* backend/inpaint/sttn/network_sttn.py InpaintGenerator, 432x240 */
+
+typedef struct vsr_sttn vsr_sttn_t;
+typedef struct vsr_plan vsr_plan_t;
+
+int vsr_version(void);
+const char* vsr_last_error(void);
+int vsr_device_count(void); /* 0 when no HIP device is visible; never fails */
+
+/* ---------------------------------------------------------------------------------------
+ * Model lifecycle.  Replaces STTNInpaint.__init__ (backend/inpaint/sttn_auto_inpaint.py:29-41:
+ * InpaintGenerator().to(device); load_state_dict(torch.load(path)['netG']); eval()).
+ * set_param takes one state_dict entry (reference key, fp32, checkpoint shape); finalize
+ * verifies that exactly the 112 reference tensors are present with the reference shapes
+ * (strict load), repacks conv weights [Cout][Cin][kh][kw] -> [Cout][(ky*kw+kx)*Cin+ci],
+ * fuses Q/K/V 1x1 weights, and uploads to `device` (device < 0: pack only, host side).
+ * ------------------------------------------------------------------------------------- */
+int vsr_sttn_create(int variant, vsr_sttn_t** out);
+int vsr_sttn_set_param(vsr_sttn_t* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int vsr_sttn_finalize(vsr_sttn_t* h, int device);
+void vsr_sttn_destroy(vsr_sttn_t* h);
+int vsr_sttn_geometry(const vsr_sttn_t* h, int32_t* model_w, int32_t* model_h, int32_t* neighbor_stride,
+                      int32_t* ref_length);
+int vsr_sttn_set_window(vsr_sttn_t* h, int neighbor_stride, int ref_length); /* config.sttnNeighborStride / sttnReferenceLength */
+/* copy of the packed weight buffer (host) -- used by the CPU replay tests */
+int64_t vsr_sttn_packed_weights(const vsr_sttn_t* h, float* out, int64_t capacity);
+
+/* ---------------------------------------------------------------------------------------
+ * STTNInpaint.inpaint(frames) (backend/inpaint/sttn_auto_inpaint.py:122-164):
+ *   frames_dev : [L][model_h][model_w][3] uint8 BGR (already at model resolution)
+ *   comp_dev   : [L][model_h][model_w][3] float32 RGB; holds integral values (a uint8 image)
+ *                where counts[i] == 1, the pairwise 0.5/0.5 running average otherwise
+ *   counts     : host [L], number of windows that decoded frame i
+ * ------------------------------------------------------------------------------------- */
+int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* comp_dev, int32_t* counts,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One iteration of the chunk loop of STTNAutoInpaint.__call__
+ * (backend/inpaint/sttn_auto_inpaint.py:242-317; same math as STTNInpaint.__call__ :43-97):
+ * for every inpaint area (ymin,ymax,xmin,xmax as returned by get_inpaint_area_by_mask,
+ * tools/inpaint_tools.py:49-242; full width) crop the strip of the selected frames,
+ * cv2.resize to model size, inpaint, cv2.resize back, astype(uint8), RGB->BGR and write
+ * mask*comp + (1-mask)*frame IN PLACE into frames_dev.
+ *   frames_dev : [L][H][W][3] uint8 BGR, modified in place
+ *   mask_dev   : [H][W] uint8, non-zero = inpaint (the thresholded mask, cv2.threshold(.,127,1))
+ *   areas      : host [n_areas][4]
+ *   sel/nsel   : host indices (ascending) of the frames of this chunk that are inside the A/B
+ *                sections (is_frame_number_in_ab_sections); NULL/0 = all L frames
+ * ------------------------------------------------------------------------------------- */
+int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
+                        int n_areas, const int32_t* areas, const int32_t* sel, int nsel, void* stream);
+
+/* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded) */
+double vsr_sttn_flops(vsr_sttn_t* h, int L);
+
+/* per-op-tag GPU timing of the next calls (hipEvents on the launch stream) */
+int vsr_sttn_timing(vsr_sttn_t* h, int enable);
+int vsr_sttn_timing_get(vsr_sttn_t* h, const char* tag_prefix, double* total_ms, int32_t* launches, double* flops);
+int vsr_sttn_timing_reset(vsr_sttn_t* h);
+
+/* ---------------------------------------------------------------------------------------
+ * Kernel-level entry points (parity tests call the kernels through these).
+ * ------------------------------------------------------------------------------------- */
+#define VSR_GG_KC 32 /* K / N chunk granularity of the offset tables */
+enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
+enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1 };
+enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2 };
+
+/* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]
+ *   NK: B(k,n) = B[rowB[n]+colB[k/32]+k%32]   KN: B(k,n) = B[rowB[k]+colB[n/32]+n%32]
+ * covers torch conv2d / matmul on this path (auto_sttn.py:75-95,140-145,162-164,172-174,214-218) */
+typedef struct GGProblem {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* R;
+    const int32_t* rowA;
+    const int32_t* colA;
+    const int32_t* rowB;
+    const int32_t* colB;
+    const int32_t* rowC;
+    const int32_t* colC;
+    const int32_t* rowR;
+    int32_t M, N, K;
+    int32_t tilesM, tilesN;
+    int32_t splitK;
+    int32_t chunksPerSplit;
+    int32_t tileStart;
+    int32_t act;
+    float alpha;
+    int64_t splitStride;
+} GGProblem;
+
+/* P = softmax(scale * sum_splits S) row-wise (auto_sttn.py:141-143) */
+typedef struct SMProblem {
+    const float* S;
+    float* P;
+    int32_t M, N, ldS, ldP, nsplit;
+    int32_t rowStart;
+    float scale;
+    int32_t pad_;
+    int64_t splitStride;
+} SMProblem;
+
+/* probs: HOST array whose pointers are device pointers; tileStart / rowStart are filled in */
+int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, void* stream);
+int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
+
+/* cv2.resize(..., INTER_LINEAR) on uint8 (fixed-point path), tables from vsr_cv2_linear_tables;
+ * frame_idx (device, nullable) gathers source frames (sttn_auto_inpaint.py:269-271) */
+int vsr_launch_resize_u8(const uint8_t* src_dev, int64_t src_frame_stride, int src_row_stride, int sw, int sh,
+                         uint8_t* dst_dev, int dw, int dh, int nframes, const int32_t* frame_idx_dev,
+                         const int32_t* xofs_dev, const int16_t* ialpha_dev, const int32_t* yofs_dev,
+                         const int16_t* ibeta_dev, void* stream);
+/* Stack(BGR->RGB) + /255 + *2-1 (utils/sttn_utils.py:73,111; sttn_auto_inpaint.py:128) fused with
+ * the im2col of encoder conv1 (auto_sttn.py:76): out [n*(ih/2)*(iw/2)][32] */
+int vsr_launch_norm_im2col(const uint8_t* img_dev, int ih, int iw, int nframes, float* out_dev, int premask,
+                           const uint8_t* mask_dev, void* stream);
+/* F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC with halos (auto_sttn.py:124-126) */
+int vsr_launch_upsample2x(const float* src_dev, int H, int W, int C, int halo_src, float* dst_dev, int halo_dst,
+                          int nframes, void* stream);
+/* tanh, (x+1)/2, *255, astype(uint8), pairwise overlap average (sttn_auto_inpaint.py:150-162) */
+int vsr_launch_decode_out(const float* y_dev, int ldy, int pix, int nframes, const int32_t* frame_idx_dev,
+                          const int32_t* first_dev, float* comp_dev, void* stream);
+/* cv2.resize(comp,(W,split_h)) + astype(uint8) + BGR2RGB + mask blend (sttn_auto_inpaint.py:312-315) */
+int vsr_launch_upscale_blend(const float* comp_dev, int mw, int mh, const int32_t* is_float_dev,
+                             uint8_t* frames_dev, int64_t frame_stride, int row_stride,
+                             const int32_t* frame_idx_dev, const uint8_t* mask_dev, int mask_row_stride, int W,
+                             int sh, int nframes, const int32_t* xofs_dev, const int16_t* ialpha_dev,
+                             const float* falpha_dev, const int32_t* yofs_dev, const int16_t* ibeta_dev,
+                             const float* fbeta_dev, void* stream);
+/* host: OpenCV 4.11 resize() INTER_LINEAR tables: ofs[dsize], icoef[2*dsize] (x2048), fcoef[2*dsize] */
+int vsr_cv2_linear_tables(int ssize, int dsize, int clamp_x, int32_t* ofs, int16_t* icoef, float* fcoef);
+
+/* ---------------------------------------------------------------------------------------
+ * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
+ * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
+ * ------------------------------------------------------------------------------------- */
+typedef struct VsrOpInfo {
+    int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out */
+    int32_t nitems, tile_cfg, bmode;
+    int32_t buf_src, buf_dst, H, W, C, halo_src, halo_dst, n, ldy, pix, t_frame_idx, t_first, premask;
+    double flops;
+    char tag[32];
+} VsrOpInfo;
+typedef struct VsrGemmInfo {
+    int32_t bufA, bufB, bufC, bufR;
+    int64_t offA, offB, offC, offR, offBias;
+    int32_t tRowA, tColA, tRowB, tColB, tRowC, tColC, tRowR;
+    int32_t M, N, K, tilesM, tilesN, splitK, chunksPerSplit;
+    int64_t splitStride;
+    float alpha;
+    int32_t act;
+} VsrGemmInfo;
+typedef struct VsrSoftmaxInfo {
+    int32_t bufS, bufP;
+    int64_t offS, offP, splitStride;
+    int32_t M, N, ldS, ldP, nsplit;
+    float scale;
+} VsrSoftmaxInfo;
+
+int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
+void vsr_plan_destroy(vsr_plan_t* p);
+int vsr_plan_num_buffers(const vsr_plan_t* p);
+int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf);
+int vsr_plan_num_tables(const vsr_plan_t* p);
+int64_t vsr_plan_table_len(const vsr_plan_t* p, int t);
+int vsr_plan_table_copy(const vsr_plan_t* p, int t, int32_t* out);
+int vsr_plan_num_ops(const vsr_plan_t* p);
+int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* out);
+int vsr_plan_op_gemm(const vsr_plan_t* p, int i, int j, VsrGemmInfo* out);
+int vsr_plan_op_softmax(const vsr_plan_t* p, int i, int j, VsrSoftmaxInfo* out);
+int vsr_plan_counts(const vsr_plan_t* p, int32_t* counts);
+double vsr_plan_flops(const vsr_plan_t* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSR_HIP_H */

@@ -1,0 +1,181 @@
+"""CPU replay of an engine plan (test infrastructure).
+
+Reads the op list, symbolic buffers and offset tables the engine would run for
+STTNInpaint.inpaint(L) through the vsr_plan_* C entry points and executes them with numpy /
+torch-CPU.  This checks every table, descriptor and schedule decision of the host engine
+against the oracle without a GPU; the GPU tests then only have to establish that each kernel
+implements the same descriptor semantics.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+OP_NORM_IM2COL, OP_GEMM, OP_SOFTMAX, OP_UPSAMPLE2X, OP_DECODE_OUT = range(5)
+BUF_WEIGHTS, BUF_IN_U8 = 0, 1
+
+
+class PlanView:
+    def __init__(self, _lib, engine, L):
+        self._lib = _lib
+        lib = _lib.lib
+        self.p = C.c_void_p()
+        _lib.check(lib.vsr_plan_create(engine.handle, L, C.byref(self.p)))
+        self.L = L
+        self.buf_elems = [lib.vsr_plan_buffer_elems(self.p, b) for b in range(lib.vsr_plan_num_buffers(self.p))]
+        self.tables = []
+        for t in range(lib.vsr_plan_num_tables(self.p)):
+            n = lib.vsr_plan_table_len(self.p, t)
+            arr = np.empty(n, dtype=np.int32)
+            _lib.check(lib.vsr_plan_table_copy(self.p, t, arr.ctypes.data_as(C.c_void_p)))
+            self.tables.append(arr.astype(np.int64))
+        self.ops = []
+        for i in range(lib.vsr_plan_num_ops(self.p)):
+            info = _lib.VsrOpInfo()
+            _lib.check(lib.vsr_plan_op(self.p, i, C.byref(info)))
+            items = []
+            for j in range(info.nitems):
+                if info.kind == OP_GEMM:
+                    it = _lib.VsrGemmInfo()
+                    _lib.check(lib.vsr_plan_op_gemm(self.p, i, j, C.byref(it)))
+                else:
+                    it = _lib.VsrSoftmaxInfo()
+                    _lib.check(lib.vsr_plan_op_softmax(self.p, i, j, C.byref(it)))
+                items.append(it)
+            self.ops.append((info, items))
+        counts = np.zeros(L, dtype=np.int32)
+        _lib.check(lib.vsr_plan_counts(self.p, counts.ctypes.data_as(C.c_void_p)))
+        self.counts = counts
+        self.flops = lib.vsr_plan_flops(self.p)
+
+    def close(self):
+        if self.p:
+            self._lib.lib.vsr_plan_destroy(self.p)
+            self.p = None
+
+
+def _cols(table, n):
+    """32-element chunk offsets -> per-element offsets of the first n elements."""
+    full = (table[:, None] + np.arange(32, dtype=np.int64)[None, :]).reshape(-1)
+    return full[:n]
+
+
+def gemm_reference(it, bmode, bufs, tables):
+    """Execute one gather-GEMM descriptor exactly as include/vsr_hip.h defines it."""
+    M, N, K = it.M, it.N, it.K
+    A = bufs[it.bufA]
+    B = bufs[it.bufB]
+    rowA = tables[it.tRowA][:M]
+    colA = _cols(tables[it.tColA], K)
+    Am = torch.from_numpy(A[it.offA + rowA[:, None] + colA[None, :]])
+    if bmode == 0:      # NK
+        rowB = tables[it.tRowB][:N]
+        colB = _cols(tables[it.tColB], K)
+        Bm = torch.from_numpy(B[it.offB + rowB[:, None] + colB[None, :]]).t()      # K x N
+    else:               # KN
+        rowB = tables[it.tRowB][:K]
+        colB = _cols(tables[it.tColB], N)
+        Bm = torch.from_numpy(B[it.offB + rowB[:, None] + colB[None, :]])          # K x N
+    rowC = tables[it.tRowC][:M]
+    colC = _cols(tables[it.tColC], N)
+    Cbuf = bufs[it.bufC]
+    if it.splitK > 1:
+        for s in range(it.splitK):
+            k0 = s * it.chunksPerSplit * 32
+            k1 = min(K, k0 + it.chunksPerSplit * 32)
+            part = (Am[:, k0:k1] @ Bm[k0:k1, :]) * it.alpha
+            Cbuf[it.offC + s * it.splitStride + rowC[:, None] + colC[None, :]] = part.numpy()
+        return
+    acc = (Am @ Bm) * it.alpha
+    if it.offBias >= 0:
+        acc = acc + torch.from_numpy(bufs[BUF_WEIGHTS][it.offBias:it.offBias + N])[None, :]
+    if it.act == 1:
+        acc = torch.nn.functional.leaky_relu(acc, 0.2)
+    if it.bufR >= 0:
+        rowR = tables[it.tRowR][:M]
+        acc = acc + torch.from_numpy(bufs[it.bufR][it.offR + rowR[:, None] + colC[None, :]])
+    Cbuf[it.offC + rowC[:, None] + colC[None, :]] = acc.numpy()
+
+
+def softmax_reference(it, bufs):
+    S = bufs[it.bufS]
+    acc = np.zeros((it.M, it.N), dtype=np.float32)
+    for s in range(it.nsplit):
+        plane = S[it.offS + s * it.splitStride: it.offS + s * it.splitStride + it.M * it.ldS].reshape(it.M, it.ldS)
+        acc = acc + plane[:, :it.N] if s else plane[:, :it.N].copy()
+    p = torch.softmax(torch.from_numpy(acc * np.float32(it.scale)), dim=-1).numpy()
+    out = np.zeros((it.M, it.ldP), dtype=np.float32)
+    out[:, :it.N] = p
+    bufs[it.bufP][it.offP: it.offP + it.M * it.ldP] = out.reshape(-1)
+
+
+def upsample_reference(info, bufs):
+    H, W, Cc, hs, hd, n = info.H, info.W, info.C, info.halo_src, info.halo_dst, info.n
+    Hs, Ws = H + 2 * hs, W + 2 * hs
+    Hd, Wd = 2 * H + 2 * hd, 2 * W + 2 * hd
+    src = bufs[info.buf_src][: n * Hs * Ws * Cc].reshape(n, Hs, Ws, Cc)[:, hs:hs + H, hs:hs + W, :]
+    x = torch.from_numpy(np.ascontiguousarray(src)).permute(0, 3, 1, 2)
+    y = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    dst = bufs[info.buf_dst][: n * Hd * Wd * Cc].reshape(n, Hd, Wd, Cc)
+    dst[:, hd:hd + 2 * H, hd:hd + 2 * W, :] = y.permute(0, 2, 3, 1).numpy()
+
+
+def norm_im2col_reference(info, bufs):
+    ih, iw, n = info.H, info.W, info.n
+    img = bufs[info.buf_src][: n * ih * iw * 3].reshape(n, ih, iw, 3)
+    x = torch.from_numpy(np.ascontiguousarray(img[..., ::-1])).permute(0, 3, 1, 2).float().div(255) * 2 - 1
+    cols = torch.nn.functional.unfold(x, kernel_size=3, padding=1, stride=2)       # n, 27 (c,ky,kx), oh*ow
+    oh, ow = ih // 2, iw // 2
+    cols = cols.view(n, 3, 9, oh * ow).permute(0, 3, 2, 1).reshape(n * oh * ow, 27)   # k = tap*3 + c
+    out = np.zeros((n * oh * ow, 32), dtype=np.float32)
+    out[:, :27] = cols.numpy()
+    bufs[info.buf_dst][: out.size] = out.reshape(-1)
+
+
+def decode_out_reference(info, bufs, tables):
+    n, pix, ldy = info.n, info.pix, info.ldy
+    y = bufs[info.buf_src][: n * pix * ldy].reshape(n, pix, ldy)[:, :, :3]
+    v = torch.tanh(torch.from_numpy(np.ascontiguousarray(y)))
+    v = ((v + 1) / 2).numpy() * 255
+    img = v.astype(np.uint8).astype(np.float32)
+    comp = bufs[info.buf_dst]
+    idx = tables[info.t_frame_idx]
+    first = tables[info.t_first]
+    for i in range(n):
+        sl = slice(int(idx[i]) * pix * 3, (int(idx[i]) + 1) * pix * 3)
+        if first[i]:
+            comp[sl] = img[i].reshape(-1)
+        else:
+            comp[sl] = comp[sl] * np.float32(0.5) + img[i].reshape(-1) * np.float32(0.5)
+
+
+def replay(view, packed_weights, frames_u8):
+    """frames_u8: [L,mh,mw,3] uint8 BGR -> (comp float32 [L,mh,mw,3] RGB, counts)."""
+    bufs = []
+    for b, n in enumerate(view.buf_elems):
+        if b == BUF_WEIGHTS:
+            bufs.append(np.asarray(packed_weights, dtype=np.float32))
+        elif b == BUF_IN_U8:
+            a = np.zeros(n, dtype=np.uint8)
+            a[: frames_u8.size] = frames_u8.reshape(-1)
+            bufs.append(a)
+        else:
+            bufs.append(np.zeros(n, dtype=np.float32))
+    with torch.no_grad():
+        for info, items in view.ops:
+            if info.kind == OP_GEMM:
+                for it in items:
+                    gemm_reference(it, info.bmode, bufs, view.tables)
+            elif info.kind == OP_SOFTMAX:
+                for it in items:
+                    softmax_reference(it, bufs)
+            elif info.kind == OP_UPSAMPLE2X:
+                upsample_reference(info, bufs)
+            elif info.kind == OP_NORM_IM2COL:
+                norm_im2col_reference(info, bufs)
+            elif info.kind == OP_DECODE_OUT:
+                decode_out_reference(info, bufs, view.tables)
+            else:
+                raise AssertionError(f"unknown op kind {info.kind}")
+    comp = bufs[20][: frames_u8.size].reshape(frames_u8.shape).copy()     # BUF_COMP
+    return comp, view.counts, bufs

@@ -1,0 +1,79 @@
+"""Pin the oracle against fixtures generated from the reference's own modules (oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import sttn_auto
+from oracle.sttn_net import SttnNet
+from oracle.weights import make_state_dict, state_dict_spec
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 2e-4   # the fixtures were made on another CPU: oneDNN/MKL kernels differ in summation order
+
+
+def _close(a, b, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(1e-6, np.abs(b).max())
+    assert err < RTOL, f"{what}: rel err {err:.3e}"
+
+
+def test_state_dict_spec_matches_reference_counts():
+    spec = state_dict_spec("auto")
+    assert len(spec) == 112
+    assert sum(int(np.prod(s)) for _, s in spec) == 16556163
+
+
+def test_auto_net_matches_reference():
+    g = np.load(os.path.join(GOLD, "sttn_auto_net.npz"))
+    net = SttnNet(make_state_dict(0, "auto"), "auto")
+    frames = np.random.default_rng(int(g["frames_seed"])).integers(0, 256, size=(3, 120, 640, 3), dtype=np.uint8)
+    x = sttn_auto.STTNInpaintOracle.to_tensors(list(frames)) * 2 - 1
+    with torch.no_grad():
+        feat = net.encoder(x)
+        pred = net.infer(feat)
+        out = torch.tanh(net.decoder(pred[:2]))
+    _close(feat.reshape(-1).numpy()[g["feat_idx"]], g["feat_val"], "encoder samples")
+    _close(pred.reshape(-1).numpy()[g["pred_idx"]], g["pred_val"], "infer samples")
+    _close(out[:, :, ::2, ::4].numpy(), g["out_sub"], "decoder output")
+    for name, t in (("feat", feat), ("pred", pred), ("out", out)):
+        _close(float((t.double() ** 2).sum()), float(g[name + "_sq"]), name + " energy")
+
+
+def test_det_net_matches_reference_and_ignores_mask():
+    g = np.load(os.path.join(GOLD, "sttn_det_net.npz"))
+    net = SttnNet(make_state_dict(1, "det"), "det")
+    rng = np.random.default_rng(int(g["x_seed"]))
+    x = torch.from_numpy(rng.random((2, 3, 240, 432), dtype=np.float32) * 2 - 1)
+    with torch.no_grad():
+        pred = net.infer(net.encoder(x))      # the reference was given a mask; it must not matter
+        out = torch.tanh(net.decoder(pred[:1]))
+    _close(pred.reshape(-1).numpy()[g["pred_idx"]], g["pred_val"], "det infer samples")
+    _close(out[:, :, ::4, ::4].numpy(), g["out_sub"], "det decoder output")
+
+
+def test_batch_generator_matches_reference():
+    gold = json.load(open(os.path.join(GOLD, "batch_generator.json")))
+    for key, sizes in gold.items():
+        n, m = (int(v) for v in key.split(","))
+        assert [len(b) for b in sttn_auto.batch_generator(list(range(n)), m)] == sizes, key
+    # SURVEY.md 8(a) a19 spot values
+    assert gold["1200,50"] == [47] * 25 + [25]
+    assert gold["300,50"] == [46] * 6 + [24]
+
+
+def test_window_schedule_L50():
+    """Appendix A of SURVEY.md: (6,4),(11,3|4)...(10,4); 104 decodes; last 4 frames decoded once."""
+    o = sttn_auto.STTNInpaintOracle.__new__(sttn_auto.STTNInpaintOracle)
+    o.neighbor_stride, o.ref_length = 5, 10
+    sched = o.window_schedule(50)
+    assert len(sched) == 10
+    assert (len(sched[0][0]), len(sched[0][1])) == (6, 4)
+    assert (len(sched[-1][0]), len(sched[-1][1])) == (10, 4)
+    assert sum(len(n) for n, _ in sched) == 104 and sum(len(n) + len(r) for n, r in sched) == 140
+    visits = np.zeros(50, int)
+    for n, _ in sched:
+        visits[n] += 1
+    assert list(np.nonzero(visits == 1)[0]) == [46, 47, 48, 49]
+    assert list(np.nonzero(visits == 3)[0]) == list(range(5, 45, 5))

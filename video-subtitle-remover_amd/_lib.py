@@ -1,0 +1,128 @@
+"""ctypes binding of libvsr_hip.so (C-ABI declared in include/vsr_hip.h).
+
+There is deliberately no fallback: if the shared library has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C csrc``) importing this
+module raises, and every compute entry point returns VSR_ERR_NOGPU without a HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvsr_hip.so")
+
+VSR_OK, VSR_ERR_ARG, VSR_ERR_STATE, VSR_ERR_HIP, VSR_ERR_NOGPU = 0, -1, -2, -3, -4
+VARIANT = {"auto": 0, "det": 1}
+BMODE_NK, BMODE_KN = 0, 1
+ACT_NONE, ACT_LRELU02 = 0, 1
+TILE_128x128, TILE_256x32, TILE_256x64 = 0, 1, 2
+TILE_DIMS = {TILE_128x128: (128, 128), TILE_256x32: (256, 32), TILE_256x64: (256, 64)}
+
+
+class VsrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvsr_hip error {code}: {msg}")
+        self.code = code
+
+
+class GGProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+                ("rowA", C.c_void_p), ("colA", C.c_void_p), ("rowB", C.c_void_p), ("colB", C.c_void_p),
+                ("rowC", C.c_void_p), ("colC", C.c_void_p), ("rowR", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("tilesM", C.c_int32), ("tilesN", C.c_int32),
+                ("splitK", C.c_int32), ("chunksPerSplit", C.c_int32), ("tileStart", C.c_int32), ("act", C.c_int32),
+                ("alpha", C.c_float), ("splitStride", C.c_int64)]
+
+
+class SMProblem(C.Structure):
+    _fields_ = [("S", C.c_void_p), ("P", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldS", C.c_int32),
+                ("ldP", C.c_int32), ("nsplit", C.c_int32), ("rowStart", C.c_int32), ("scale", C.c_float),
+                ("pad_", C.c_int32), ("splitStride", C.c_int64)]
+
+
+class VsrOpInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("nitems", C.c_int32), ("tile_cfg", C.c_int32), ("bmode", C.c_int32),
+                ("buf_src", C.c_int32), ("buf_dst", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("halo_src", C.c_int32), ("halo_dst", C.c_int32), ("n", C.c_int32), ("ldy", C.c_int32),
+                ("pix", C.c_int32), ("t_frame_idx", C.c_int32), ("t_first", C.c_int32), ("premask", C.c_int32),
+                ("flops", C.c_double), ("tag", C.c_char * 32)]
+
+
+class VsrGemmInfo(C.Structure):
+    _fields_ = [("bufA", C.c_int32), ("bufB", C.c_int32), ("bufC", C.c_int32), ("bufR", C.c_int32),
+                ("offA", C.c_int64), ("offB", C.c_int64), ("offC", C.c_int64), ("offR", C.c_int64),
+                ("offBias", C.c_int64),
+                ("tRowA", C.c_int32), ("tColA", C.c_int32), ("tRowB", C.c_int32), ("tColB", C.c_int32),
+                ("tRowC", C.c_int32), ("tColC", C.c_int32), ("tRowR", C.c_int32),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("tilesM", C.c_int32), ("tilesN", C.c_int32),
+                ("splitK", C.c_int32), ("chunksPerSplit", C.c_int32), ("splitStride", C.c_int64),
+                ("alpha", C.c_float), ("act", C.c_int32)]
+
+
+class VsrSoftmaxInfo(C.Structure):
+    _fields_ = [("bufS", C.c_int32), ("bufP", C.c_int32), ("offS", C.c_int64), ("offP", C.c_int64),
+                ("splitStride", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("ldS", C.c_int32),
+                ("ldP", C.c_int32), ("nsplit", C.c_int32), ("scale", C.c_float)]
+
+
+# every symbol include/vsr_hip.h declares: name -> (restype, argtypes)
+_P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+SIGNATURES = {
+    "vsr_version": (_I, []),
+    "vsr_last_error": (C.c_char_p, []),
+    "vsr_device_count": (_I, []),
+    "vsr_sttn_create": (_I, [_I, C.POINTER(_P)]),
+    "vsr_sttn_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
+    "vsr_sttn_finalize": (_I, [_P, _I]),
+    "vsr_sttn_destroy": (None, [_P]),
+    "vsr_sttn_geometry": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vsr_sttn_set_window": (_I, [_P, _I, _I]),
+    "vsr_sttn_packed_weights": (_L, [_P, _P, _L]),
+    "vsr_sttn_inpaint": (_I, [_P, _P, _I, _P, _P, _P]),
+    "vsr_sttn_auto_chunk": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
+    "vsr_sttn_flops": (_D, [_P, _I]),
+    "vsr_sttn_timing": (_I, [_P, _I]),
+    "vsr_sttn_timing_get": (_I, [_P, C.c_char_p, C.POINTER(_D), C.POINTER(C.c_int32), C.POINTER(_D)]),
+    "vsr_sttn_timing_reset": (_I, [_P]),
+    "vsr_run_gather_gemm": (_I, [C.POINTER(GGProblem), _I, _I, _I, _P]),
+    "vsr_run_softmax": (_I, [C.POINTER(SMProblem), _I, _P]),
+    "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsr_launch_norm_im2col": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    "vsr_launch_upsample2x": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "vsr_launch_decode_out": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "vsr_launch_upscale_blend": (_I, [_P, _I, _I, _P, _P, _L, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsr_cv2_linear_tables": (_I, [_I, _I, _I, _P, _P, _P]),
+    "vsr_plan_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "vsr_plan_destroy": (None, [_P]),
+    "vsr_plan_num_buffers": (_I, [_P]),
+    "vsr_plan_buffer_elems": (_L, [_P, _I]),
+    "vsr_plan_num_tables": (_I, [_P]),
+    "vsr_plan_table_len": (_L, [_P, _I]),
+    "vsr_plan_table_copy": (_I, [_P, _I, _P]),
+    "vsr_plan_num_ops": (_I, [_P]),
+    "vsr_plan_op": (_I, [_P, _I, C.POINTER(VsrOpInfo)]),
+    "vsr_plan_op_gemm": (_I, [_P, _I, _I, C.POINTER(VsrGemmInfo)]),
+    "vsr_plan_op_softmax": (_I, [_P, _I, _I, C.POINTER(VsrSoftmaxInfo)]),
+    "vsr_plan_counts": (_I, [_P, _P]),
+    "vsr_plan_flops": (_D, [_P]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first (__graft_entry__.build() or "
+        f"`make -C {os.path.join(_HERE, 'csrc')}`); this package has no CPU fallback")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = library does not match the header
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return (lib.vsr_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise VsrError(rc, last_error())
+    return rc

@@ -1,0 +1,344 @@
+// HBM-bound kernels of the STTN hot path: u8 strip resize (cv2 INTER_LINEAR restated,
+// coefficient tables from the host), normalise + im2col for the first encoder conv, row
+// softmax over the materialised attention scores, x2 bilinear (align_corners) upsample,
+// tanh -> u8 + overlap averaging, and the final upscale + channel swap + mask blend.
+// All are 16 B/lane coalesced where the data allows; u8 RGB triplets are handled per pixel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "elementwise.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// K1: crop + cv2.resize(strip, (640,120)) on u8 (reference sttn_auto_inpaint.py:269-271).
+// Fixed-point INTER_LINEAR: horizontal taps scaled by 2^11 into int32, vertical pass
+//   dst = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+// (OpenCV 4.11 imgproc/resize.cpp HResizeLinear / VResizeLinear<uchar,int,short,...>).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int fixpt_lin(int s00, int s01, int s10, int s11, int a0, int a1, int b0, int b1)
+{
+    const int h0 = s00 * a0 + s01 * a1;
+    const int h1 = s10 * a0 + s11 * a1;
+    return (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+}
+
+__global__ void __launch_bounds__(256)
+k_resize_u8(const uint8_t* __restrict__ src, int64_t srcFrameStride, int srcRowStride, int sw, int sh,
+            uint8_t* __restrict__ dst, int dw, int dh, int nframes, const int32_t* __restrict__ frameIdx,
+            const int32_t* __restrict__ xofs, const int16_t* __restrict__ ialpha,
+            const int32_t* __restrict__ yofs, const int16_t* __restrict__ ibeta)
+{
+    const int64_t total = (int64_t)nframes * dh * dw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int dx = (int)(i % dw);
+        const int dy = (int)((i / dw) % dh);
+        const int fo = (int)(i / ((int64_t)dw * dh));
+        const int64_t f = frameIdx ? frameIdx[fo] : fo;
+        const int x0 = xofs[dx];
+        const int x1 = x0 + 1 < sw ? x0 + 1 : sw - 1;
+        const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+        const int sy = yofs[dy];
+        const int y0 = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+        const int y1 = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+        const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        const uint8_t* r0 = src + f * srcFrameStride + (int64_t)y0 * srcRowStride;
+        const uint8_t* r1 = src + f * srcFrameStride + (int64_t)y1 * srcRowStride;
+        uint8_t* o = dst + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = fixpt_lin(r0[x0 * 3 + c], r0[x1 * 3 + c], r1[x0 * 3 + c], r1[x1 * 3 + c], a0, a1, b0, b1);
+            o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K1b: Stack (BGR->RGB) + ToTorchFormatTensor (/255) + "*2-1" (sttn_utils.py:73,111;
+// sttn_auto_inpaint.py:128) fused with the im2col of encoder conv1 (3x3, stride 2, pad 1,
+// auto_sttn.py:76): row m = (frame, oy, ox), 32 columns: k = (ky*3+kx)*3 + c_rgb, 27..31 zero.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_norm_im2col_s2(const uint8_t* __restrict__ img /*[n][ih][iw][3] BGR*/, int ih, int iw, int nframes,
+                 float* __restrict__ out /*[n*oh*ow][32]*/, int premask,
+                 const uint8_t* __restrict__ mask /*[ih][iw] {0,1} or null*/)
+{
+    const int oh = ih / 2, ow = iw / 2;
+    const int64_t total = (int64_t)nframes * oh * ow * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 7);
+        const int64_t m = i >> 3;
+        const int ox = (int)(m % ow);
+        const int oy = (int)((m / ow) % oh);
+        const int f = (int)(m / ((int64_t)ow * oh));
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * q + j;
+            float val = 0.f;
+            if (k < 27) {
+                const int tap = k / 3, c = k - 3 * tap;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int y = 2 * oy - 1 + ky, x = 2 * ox - 1 + kx;
+                if (y >= 0 && y < ih && x >= 0 && x < iw) {
+                    const uint8_t u = img[(((int64_t)f * ih + y) * iw + x) * 3 + (2 - c)];
+                    val = ((float)u / 255.0f) * 2.0f - 1.0f;
+                    if (premask && mask[(int64_t)y * iw + x]) val = 0.f;
+                }
+            }
+            v[j] = val;
+        }
+        *reinterpret_cast<f32x4*>(out + m * 32 + 4 * q) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5b: row softmax of the scaled scores (auto_sttn.py:141-143), one wave per row, sums
+// split-K partial planes on the fly, zero-fills the padded tail of each P row.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_softmax_rows(const SMProblem* __restrict__ probs, int nprobs)
+{
+    const int lane = threadIdx.x & 63;
+    const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int pi = 0;
+    for (int i = 1; i < nprobs; ++i)
+        if (grow >= probs[i].rowStart) pi = i;
+    const SMProblem* __restrict__ P = probs + pi;
+    const int r = grow - P->rowStart;
+    if (r >= P->M) return;
+    const int N = P->N, ldP = P->ldP, nsplit = P->nsplit;
+    const int64_t ss = P->splitStride;
+    const float scale = P->scale;
+    const float* __restrict__ S = P->S + (int64_t)r * P->ldS;
+    float* __restrict__ O = P->P + (int64_t)r * ldP;
+
+    float mx = -INFINITY;
+    for (int n = lane; n < N; n += 64) {
+        float s = S[n];
+        for (int k = 1; k < nsplit; ++k) s += S[n + k * ss];
+        mx = fmaxf(mx, s * scale);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        float s = S[n];
+        for (int k = 1; k < nsplit; ++k) s += S[n + k * ss];
+        sum += expf(s * scale - mx);
+    }
+    sum = wave_sum(sum);
+    for (int n = lane; n < ldP; n += 64) {
+        float p = 0.f;
+        if (n < N) {
+            float s = S[n];
+            for (int k = 1; k < nsplit; ++k) s += S[n + k * ss];
+            p = expf(s * scale - mx) / sum;
+        }
+        O[n] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K9a: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+// (auto_sttn.py:124-126) on NHWC with physical halos; 4 channels per lane.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_upsample2x_nhwc(const float* __restrict__ src, int H, int W, int C, int haloS,
+                  float* __restrict__ dst, int haloD, int nframes)
+{
+    const int OH = 2 * H, OW = 2 * W, C4 = C / 4;
+    const int Hs = H + 2 * haloS, Ws = W + 2 * haloS, Hd = OH + 2 * haloD, Wd = OW + 2 * haloD;
+    const float rh = (float)(H - 1) / (float)(OH - 1);
+    const float rw = (float)(W - 1) / (float)(OW - 1);
+    const int64_t total = (int64_t)nframes * OH * OW * C4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int ox = (int)((i / C4) % OW);
+        const int oy = (int)((i / ((int64_t)C4 * OW)) % OH);
+        const int f = (int)(i / ((int64_t)C4 * OW * OH));
+        const float fy = rh * (float)oy, fx = rw * (float)ox;
+        int y0 = (int)fy; if (y0 > H - 1) y0 = H - 1;
+        int x0 = (int)fx; if (x0 > W - 1) x0 = W - 1;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        float ly = fy - (float)y0; ly = fminf(fmaxf(ly, 0.f), 1.f);
+        float lx = fx - (float)x0; lx = fminf(fmaxf(lx, 0.f), 1.f);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* b = src + (int64_t)f * Hs * Ws * C + 4 * c4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y0 + haloS) * Ws + x0 + haloS) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y0 + haloS) * Ws + x1 + haloS) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y1 + haloS) * Ws + x0 + haloS) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y1 + haloS) * Ws + x1 + haloS) * C);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+        *reinterpret_cast<f32x4*>(dst + (((int64_t)f * Hd + oy + haloD) * Wd + ox + haloD) * C + 4 * c4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K10 + K11: tanh, (x+1)/2, *255, astype(uint8) truncation, then the sequential pairwise
+// overlap average comp = comp*0.5 + img*0.5 in f32 (sttn_auto_inpaint.py:150-162).
+// comp is kept as f32 (u8 values are exact in f32); the host knows from the window
+// schedule whether this is the first visit of a frame.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_decode_out(const float* __restrict__ y /*[n*pix][ldy] first 3 cols = RGB pre-tanh*/, int ldy, int pix,
+             int nframes, const int32_t* __restrict__ frameIdx, const int32_t* __restrict__ first,
+             float* __restrict__ comp /*[L][pix][3]*/)
+{
+    const int64_t total = (int64_t)nframes * pix;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / pix);
+        const int p = (int)(i - (int64_t)f * pix);
+        const int idx = frameIdx[f];
+        const bool fst = first[f] != 0;
+        const float* s = y + i * ldy;
+        float* c = comp + ((int64_t)idx * pix + p) * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = tanhf(s[ch]);
+            v = (v + 1.0f) / 2.0f;
+            v = v * 255.0f;
+            const float img = (float)(uint8_t)(int)v; // astype(np.uint8) of a value in [0,255]
+            c[ch] = fst ? img : (c[ch] * 0.5f + img * 0.5f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K12: cv2.resize(comp, (W, split_h)) [u8 fixed-point path when the frame was decoded once,
+// f32 path when it was averaged], astype(uint8), RGB->BGR, integer mask select into the
+// frame (sttn_auto_inpaint.py:312-315).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_upscale_blend(const float* __restrict__ comp /*[n][mh][mw][3] RGB*/, int mw, int mh,
+                const int32_t* __restrict__ isFloat /*[n]*/,
+                uint8_t* __restrict__ frames, int64_t frameStride, int rowStride,
+                const int32_t* __restrict__ frameIdx, const uint8_t* __restrict__ mask, int maskRowStride, int W, int sh, int nframes,
+                const int32_t* __restrict__ xofs, const int16_t* __restrict__ ialpha, const float* __restrict__ falpha,
+                const int32_t* __restrict__ yofs, const int16_t* __restrict__ ibeta, const float* __restrict__ fbeta)
+{
+    const int64_t total = (int64_t)nframes * sh * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int dx = (int)(i % W);
+        const int dy = (int)((i / W) % sh);
+        const int f = (int)(i / ((int64_t)W * sh));
+        if (!mask[(int64_t)dy * maskRowStride + dx]) continue;
+        const int x0 = xofs[dx];
+        const int x1 = x0 + 1 < mw ? x0 + 1 : mw - 1;
+        const int sy = yofs[dy];
+        const int y0 = sy < 0 ? 0 : (sy < mh ? sy : mh - 1);
+        const int y1 = sy + 1 < 0 ? 0 : (sy + 1 < mh ? sy + 1 : mh - 1);
+        const float* c0 = comp + ((int64_t)f * mh + y0) * mw * 3;
+        const float* c1 = comp + ((int64_t)f * mh + y1) * mw * 3;
+        const int64_t fdst = frameIdx ? frameIdx[f] : f;
+        uint8_t* o = frames + fdst * frameStride + (int64_t)dy * rowStride + dx * 3;
+        if (isFloat[f]) {
+            const float a0 = falpha[2 * dx], a1 = falpha[2 * dx + 1];
+            const float b0 = fbeta[2 * dy], b1 = fbeta[2 * dy + 1];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float h0 = __fadd_rn(__fmul_rn(c0[x0 * 3 + ch], a0), __fmul_rn(c0[x1 * 3 + ch], a1));
+                const float h1 = __fadd_rn(__fmul_rn(c1[x0 * 3 + ch], a0), __fmul_rn(c1[x1 * 3 + ch], a1));
+                const float v = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+                o[2 - ch] = (uint8_t)(int)v;
+            }
+        } else {
+            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int v = fixpt_lin((int)c0[x0 * 3 + ch], (int)c0[x1 * 3 + ch],
+                                        (int)c1[x0 * 3 + ch], (int)c1[x1 * 3 + ch], a0, a1, b0, b1);
+                o[2 - ch] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers (C linkage; public ones are declared in include/vsr_hip.h)
+// ---------------------------------------------------------------------------------------
+static inline int grid_for(int64_t total)
+{
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int vsr_launch_resize_u8(const uint8_t* src, int64_t srcFrameStride, int srcRowStride, int sw, int sh,
+                                    uint8_t* dst, int dw, int dh, int nframes, const int32_t* frameIdx,
+                                    const int32_t* xofs, const int16_t* ialpha, const int32_t* yofs,
+                                    const int16_t* ibeta, void* stream)
+{
+    const int64_t total = (int64_t)nframes * dh * dw;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_resize_u8, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, srcFrameStride,
+                       srcRowStride, sw, sh, dst, dw, dh, nframes, frameIdx, xofs, ialpha, yofs, ibeta);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_norm_im2col(const uint8_t* img, int ih, int iw, int nframes, float* out, int premask,
+                                      const uint8_t* mask, void* stream)
+{
+    const int64_t total = (int64_t)nframes * (ih / 2) * (iw / 2) * 8;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_norm_im2col_s2, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, ih, iw,
+                       nframes, out, premask, mask);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_softmax_dev(const SMProblem* d_probs, int nprobs, int totalRows, void* stream)
+{
+    if (totalRows <= 0) return 0;
+    hipLaunchKernelGGL(k_softmax_rows, dim3((totalRows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_probs, nprobs);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_upsample2x(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
+                                     int nframes, void* stream)
+{
+    const int64_t total = (int64_t)nframes * 4 * H * W * (C / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_upsample2x_nhwc, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, C,
+                       haloS, dst, haloD, nframes);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_decode_out(const float* y, int ldy, int pix, int nframes, const int32_t* frameIdx,
+                                     const int32_t* first, float* comp, void* stream)
+{
+    const int64_t total = (int64_t)nframes * pix;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_decode_out, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, pix, nframes,
+                       frameIdx, first, comp);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_upscale_blend(const float* comp, int mw, int mh, const int32_t* isFloat, uint8_t* frames,
+                                        int64_t frameStride, int rowStride, const int32_t* frameIdx,
+                                        const uint8_t* mask, int maskRowStride, int W, int sh, int nframes,
+                                        const int32_t* xofs, const int16_t* ialpha, const float* falpha,
+                                        const int32_t* yofs, const int16_t* ibeta, const float* fbeta, void* stream)
+{
+    const int64_t total = (int64_t)nframes * sh * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_upscale_blend, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, comp, mw, mh,
+                       isFloat, frames, frameStride, rowStride, frameIdx, mask, maskRowStride, W, sh, nframes, xofs,
+                       ialpha, falpha, yofs, ibeta, fbeta);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}

@@ -1,0 +1,15 @@
+// Internal view of the grouped gather-GEMM: the descriptor (GGProblem) and its enums live in
+// the public C-ABI header; this adds the device-descriptor launcher used by the engine.
+//
+// Every dense contraction on the STTN hot path (reference backend/inpaint/sttn/auto_sttn.py:
+// 75-95 encoder/decoder convs, 172-174 QKV 1x1, 140-145 QK^T and PV, 162-164 output_linear,
+// 214-218 FFN convs) is one GGProblem: row / 32-element-chunk offset tables turn im2col,
+// zero padding (physical halos), patch (un)folding, window frame gathers and channel slicing
+// into pure addressing -- no tensor on this path is permuted or copied to be multiplied.
+#pragma once
+#include <stdint.h>
+#include "../../include/vsr_hip.h"
+
+// d_probs: DEVICE array (tileStart filled); totalBlocks = sum tilesM*tilesN*splitK
+extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
+                                          int bmode, void* stream);

@@ -1,0 +1,275 @@
+// Grouped gather-GEMM on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One launch runs a list of GGProblem descriptors (gather_gemm.h); a flat 1-D grid is
+// mapped problem -> (split-K slice, M tile, N tile) with an XCD-aware bijective remap so
+// that tiles sharing A rows / B columns sit on one XCD's L2.
+//
+// Structure (4 waves, one per SIMD; 3-4 workgroups per CU give the MFMA pipe its cover):
+//   global --(16 B/lane, 128 B per gathered row chunk)--> VGPR prefetch of chunk k+1
+//   LDS image A[BM][32+4], B[BN][32+4] (NK) or B[32][BN+4] (KN), single-buffered
+//   fragments by ds_read_b128 (A, B-NK: conflict-free at row stride 36) / ds_read_b32 (B-KN)
+//   each wave: (BM/WM)x(BN/WN) outputs as MIxNI 32x32 accumulators, 16 k-steps per chunk
+//
+// fp32-in/fp32-accumulate MFMA is exact f32 (an fmaf chain) and runs at the f32 vector
+// rate (64 cycles per 32x32x2), i.e. one chunk is 64 MFMAs = 4096 issue cycles per wave:
+// staging (8 x 16-B loads + 8 ds_write_b128 per lane) hides completely under it.
+#include <hip/hip_runtime.h>
+#include "gather_gemm.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GG_LD 36  // LDS row stride (floats) of a [rows][32] image
+
+// Pointers read out of a descriptor in memory are generic to the compiler (flat_load, which
+// also ticks lgkmcnt and so fences the LDS pipeline); they are all global, say so.
+typedef const float __attribute__((address_space(1)))* gcf32;
+typedef float __attribute__((address_space(1)))* gf32;
+typedef const int32_t __attribute__((address_space(1)))* gci32;
+typedef const f32x4 __attribute__((address_space(1)))* gcf32x4;
+// wave-uniform, read-only table entries (chunk offsets): constant address space -> s_load
+typedef const int32_t __attribute__((address_space(4)))* cci32;
+
+template <int BM, int BN, int WM, int WN, int BMODE>
+__global__ void __launch_bounds__(256)
+gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
+{
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
+    constexpr int A_IT = BM / 32;
+    constexpr int LDB_KN = BN + 4;
+    constexpr int TPR = BN / 4;    // KN: threads per k-row of the B tile
+    constexpr int RPP = 256 / TPR; // KN: k-rows per pass
+    constexpr int B_IT = (BMODE == VSR_BMODE_NK) ? (BN / 32) : (32 / RPP);
+    constexpr int BS_FLOATS = (BMODE == VSR_BMODE_NK) ? BN * GG_LD : 32 * LDB_KN;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(MI >= 1 && NI >= 1, "wave tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[BM * GG_LD + BS_FLOATS];
+    float* As = smem;
+    float* Bs = smem + BM * GG_LD;
+
+    // ---- which problem does this workgroup belong to (uniform) ----
+    const int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < nprobs; ++i)
+        if (bid >= probs[i].tileStart) pi = i;
+    const GGProblem* __restrict__ P = probs + pi;
+
+    const int M = P->M, N = P->N;
+    const int tilesM = P->tilesM, tilesN = P->tilesN, splitK = P->splitK;
+    const int tilesMN = tilesM * tilesN;
+    const int nblk = tilesMN * splitK;
+    int t = bid - P->tileStart;
+    {   // XCD-aware remap: workgroups with equal (t & 7) share an XCD; give each XCD a
+        // contiguous run of logical tiles (bijective for any nblk)
+        const int xcd = t & 7, q = nblk >> 3, r = nblk & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    }
+    const int split = t / tilesMN;
+    const int rem = t - split * tilesMN;
+    const int tm = rem / tilesN;
+    const int tn = rem - tm * tilesN;
+
+    const int nchunksTotal = P->K / VSR_GG_KC;
+    const int kcBeg = split * P->chunksPerSplit;
+    int kcEnd = kcBeg + P->chunksPerSplit;
+    if (kcEnd > nchunksTotal) kcEnd = nchunksTotal;
+
+    const gcf32 A = (gcf32)P->A;
+    const gcf32 B = (gcf32)P->B;
+    const gci32 rowA = (gci32)P->rowA;
+    const cci32 colA = (cci32)P->colA;
+    const gci32 rowB = (gci32)P->rowB;
+    const cci32 colB = (cci32)P->colB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- per-thread staging coordinates ----
+    const int s_r = tid >> 3, s_q = tid & 7; // row-in-pass, float4-in-chunk ([rows][32] images)
+    int aoff[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+        aoff[it] = rowA[tm * BM + s_r + 32 * it] + 4 * s_q;
+
+    int boff[B_IT];      // NK: row offsets (fixed) ; KN: row offsets of the chunk being loaded
+    int boffNext[B_IT];  // KN: row offsets one chunk ahead (table read is a dependent load)
+    const int k_r = tid / TPR, k_q = tid % TPR; // KN: k-row-in-pass, float4-in-row
+    int bcolKN = 0;
+    if constexpr (BMODE == VSR_BMODE_NK) {
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            boff[it] = rowB[tn * BN + s_r + 32 * it] + 4 * s_q;
+    } else {
+        bcolKN = colB[(tn * BN) / VSR_GG_KC + (k_q >> 3)] + 4 * (k_q & 7);
+    }
+
+    f32x4 ra[A_IT], rb[B_IT];
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto load_rowB_KN = [&](int kc, int (&dst)[B_IT]) {
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            dst[it] = rowB[kc * VSR_GG_KC + k_r + RPP * it];
+    };
+    auto load_tile = [&](int kc) {
+        const int ca = colA[kc];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            ra[it] = *(gcf32x4)(A + (aoff[it] + ca));
+        if constexpr (BMODE == VSR_BMODE_NK) {
+            const int cb = colB[kc];
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                rb[it] = *(gcf32x4)(B + (boff[it] + cb));
+        } else {
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                rb[it] = *(gcf32x4)(B + (boff[it] + bcolKN));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            *reinterpret_cast<f32x4*>(&As[(s_r + 32 * it) * GG_LD + 4 * s_q]) = ra[it];
+        if constexpr (BMODE == VSR_BMODE_NK) {
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                *reinterpret_cast<f32x4*>(&Bs[(s_r + 32 * it) * GG_LD + 4 * s_q]) = rb[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                *reinterpret_cast<f32x4*>(&Bs[(k_r + RPP * it) * LDB_KN + 4 * k_q]) = rb[it];
+        }
+    };
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // lane (l31, hi) owns k = 8g + 4hi + j, j = 0..3: MFMA step j contracts the
+            // pair {8g + j, 8g + 4 + j}; A and B use the same assignment.
+            f32x4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const f32x4*>(
+                    &As[(wm * WTM + mi * 32 + l31) * GG_LD + 8 * g + 4 * hi]);
+            if constexpr (BMODE == VSR_BMODE_NK) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    bf[ni] = *reinterpret_cast<const f32x4*>(
+                        &Bs[(wn * WTN + ni * 32 + l31) * GG_LD + 8 * g + 4 * hi]);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bf[ni][j] = Bs[(8 * g + 4 * hi + j) * LDB_KN + wn * WTN + ni * 32 + l31];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: prefetch chunk k+1 into VGPRs while chunk k is contracted from LDS ----
+    if (kcBeg < kcEnd) {
+        if constexpr (BMODE == VSR_BMODE_KN) {
+            load_rowB_KN(kcBeg, boff);
+            if (kcBeg + 1 < kcEnd) load_rowB_KN(kcBeg + 1, boffNext);
+        }
+        load_tile(kcBeg);
+        store_tile();
+        __syncthreads();
+        for (int kc = kcBeg; kc < kcEnd; ++kc) {
+            const bool hasNext = (kc + 1 < kcEnd);
+            if (hasNext) {
+                if constexpr (BMODE == VSR_BMODE_KN) {
+#pragma unroll
+                    for (int it = 0; it < B_IT; ++it) boff[it] = boffNext[it];
+                }
+                load_tile(kc + 1);
+                if constexpr (BMODE == VSR_BMODE_KN) {
+                    if (kc + 2 < kcEnd) load_rowB_KN(kc + 2, boffNext);
+                }
+            }
+            compute_tile();
+            __syncthreads();
+            if (hasNext) store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float alpha = P->alpha;
+    const int act = P->act;
+    const bool partial = (splitK > 1);
+    const gcf32 bias = partial ? (gcf32) nullptr : (gcf32)P->bias;
+    const gcf32 R = partial ? (gcf32) nullptr : (gcf32)P->R;
+    const gci32 rowC = (gci32)P->rowC;
+    const cci32 colC = (cci32)P->colC;
+    const gci32 rowR = (gci32)P->rowR;
+    const gf32 C = (gf32)(P->C + (partial ? (int64_t)split * P->splitStride : (int64_t)0));
+
+    int ccol[NI];
+    float bv[NI];
+    bool nok[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n0 = tn * BN + wn * WTN + ni * 32;
+        ccol[ni] = colC[n0 / VSR_GG_KC] + l31;
+        nok[ni] = (n0 + l31) < N;
+        bv[ni] = (bias != nullptr && nok[ni]) ? bias[n0 + l31] : 0.f;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int m = tm * BM + row;
+            const int rc = rowC[m];
+            const int rr = (R != nullptr) ? rowR[m] : 0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float v = acc[mi][ni][r] * alpha + bv[ni];
+                if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+                if (m < M && nok[ni]) {
+                    if (R != nullptr) v += R[rr + ccol[ni]];
+                    C[rc + ccol[ni]] = v;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
+                                          int bmode, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (totalBlocks <= 0) return 0;
+    dim3 grid(totalBlocks), block(256);
+    if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK)
+        hipLaunchKernelGGL((gather_gemm_f32<128, 128, 2, 2, VSR_BMODE_NK>), grid, block, 0, stream, d_probs, nprobs);
+    else if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_KN)
+        hipLaunchKernelGGL((gather_gemm_f32<128, 128, 2, 2, VSR_BMODE_KN>), grid, block, 0, stream, d_probs, nprobs);
+    else if (tileCfg == VSR_TILE_256x32 && bmode == VSR_BMODE_NK)
+        hipLaunchKernelGGL((gather_gemm_f32<256, 32, 4, 1, VSR_BMODE_NK>), grid, block, 0, stream, d_probs, nprobs);
+    else if (tileCfg == VSR_TILE_256x64 && bmode == VSR_BMODE_NK)
+        hipLaunchKernelGGL((gather_gemm_f32<256, 64, 4, 1, VSR_BMODE_NK>), grid, block, 0, stream, d_probs, nprobs);
+    else
+        return -1;
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}

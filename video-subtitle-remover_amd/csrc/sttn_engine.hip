@@ -1,0 +1,685 @@
+// Device engine + C-ABI (include/vsr_hip.h) of the STTN hot path.
+//
+// Host side of libvsr_hip.so: owns the HBM workspace (every activation is NHWC fp32 with a
+// physical zero halo, allocated once and zeroed once -- kernels only ever write interiors, so
+// the halos ARE the conv zero padding), materialises a vsr::Plan (sttn_plan.h) into device
+// descriptor arrays once per chunk length L, and replays it on the caller's stream: ~16
+// launches per transformer block, no host synchronisation, no allocation in steady state.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/vsr_hip.h"
+#include "elementwise.h"
+#include "gather_gemm.h"
+#include "sttn_plan.h"
+
+using namespace vsr;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(VSR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+#define RCCHK(expr)                                                                                        \
+    do {                                                                                                   \
+        int rc_ = (expr);                                                                                  \
+        if (rc_ != 0) return rc_;                                                                          \
+    } while (0)
+
+namespace {
+
+struct OpDev {
+    int kind = 0, tileCfg = 0, bmode = 0;
+    const void* dDesc = nullptr; // GGProblem* / SMProblem* (device)
+    int nitems = 0, total = 0;   // total = workgroups (GEMM) or padded rows (softmax)
+    // elementwise
+    const void* src = nullptr;
+    void* dst = nullptr;
+    int H = 0, W = 0, C = 0, haloS = 0, haloD = 0, n = 0, ldy = 0, pix = 0, premask = 0;
+    const int32_t* tFrameIdx = nullptr;
+    const int32_t* tFirst = nullptr;
+    double flops = 0;
+    std::string tag;
+};
+
+struct PlanDev {
+    std::unique_ptr<Plan> plan;
+    int32_t* dTables = nullptr;
+    void* dDescs = nullptr;
+    int32_t* dIsFloat = nullptr;
+    std::vector<OpDev> ops;
+    ~PlanDev()
+    {
+        if (dTables) (void)hipFree(dTables);
+        if (dDescs) (void)hipFree(dDescs);
+        if (dIsFloat) (void)hipFree(dIsFloat);
+    }
+};
+
+struct StripTables { // cv2.resize tables for one (W, split_h): down to model size and back up
+    void* dev = nullptr;
+    const int32_t *dxofs, *dyofs, *uxofs, *uyofs;
+    const int16_t *dialpha, *dibeta, *uialpha, *uibeta;
+    const float *ufalpha, *ufbeta;
+};
+
+struct TimingRec {
+    std::string tag;
+    double flops;
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct vsr_sttn {
+    Model model;
+    int device = -1;
+    bool finalized = false;
+    void* bufs[BUF_COUNT] = {};
+    int64_t cap[BUF_COUNT] = {};
+    std::map<int, std::unique_ptr<PlanDev>> plans;
+    std::map<std::pair<int, int>, StripTables> strips;
+    float* compAreas = nullptr;
+    int64_t compAreasCap = 0;
+    int32_t* dSel = nullptr;
+    int dSelCap = 0;
+    bool timing = false;
+    std::vector<TimingRec> pending;
+    std::map<std::string, std::pair<double, std::pair<int, double>>> timed; // tag -> (ms, (launches, flops))
+    explicit vsr_sttn(int variant) : model(variant) {}
+};
+
+struct vsr_plan {
+    std::unique_ptr<Plan> plan;
+};
+
+static int64_t bufBytes(int buf, int64_t elems) { return buf == BUF_IN_U8 ? elems : elems * 4; }
+
+static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
+{
+    auto it = h->plans.find(L);
+    if (it != h->plans.end()) { *out = it->second.get(); return 0; }
+    std::unique_ptr<PlanDev> pd(new PlanDev);
+    try {
+        pd->plan.reset(new Plan(h->model, L));
+    } catch (const std::exception& e) {
+        return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
+    }
+    const Plan& P = *pd->plan;
+    // ---- workspace: grow buffers if this L needs more; baked pointers of cached plans die with it
+    bool grow = false;
+    for (int b = 0; b < BUF_COUNT; ++b)
+        if (b != BUF_WEIGHTS && P.bufElems[b] > h->cap[b]) grow = true;
+    if (grow) {
+        h->plans.clear();
+        for (int b = 0; b < BUF_COUNT; ++b) {
+            if (b == BUF_WEIGHTS || P.bufElems[b] <= h->cap[b]) continue;
+            if (h->bufs[b]) { HIPCHK(hipFree(h->bufs[b])); h->bufs[b] = nullptr; h->cap[b] = 0; }
+            const int64_t bytes = bufBytes(b, P.bufElems[b]);
+            HIPCHK(hipMalloc(&h->bufs[b], (size_t)bytes));
+            HIPCHK(hipMemset(h->bufs[b], 0, (size_t)bytes)); // zero halos, once
+            h->cap[b] = P.bufElems[b];
+        }
+        HIPCHK(hipDeviceSynchronize());
+    }
+    // ---- tables: one allocation
+    std::vector<int64_t> toff(P.tables.size());
+    int64_t tot = 0;
+    for (size_t i = 0; i < P.tables.size(); ++i) { toff[i] = tot; tot += (int64_t)((P.tables[i].size() + 3) / 4 * 4); }
+    std::vector<int32_t> flat((size_t)tot, 0);
+    for (size_t i = 0; i < P.tables.size(); ++i)
+        memcpy(flat.data() + toff[i], P.tables[i].data(), P.tables[i].size() * sizeof(int32_t));
+    HIPCHK(hipMalloc((void**)&pd->dTables, (size_t)(tot > 0 ? tot : 4) * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(pd->dTables, flat.data(), (size_t)tot * sizeof(int32_t), hipMemcpyHostToDevice));
+    auto T = [&](int id) -> const int32_t* { return id < 0 ? nullptr : pd->dTables + toff[id]; };
+    auto F = [&](int buf, int64_t off) -> float* { return buf < 0 ? nullptr : (float*)h->bufs[buf] + off; };
+
+    // ---- descriptors: one allocation, 64-byte aligned records
+    size_t descBytes = 0;
+    for (const Op& op : P.ops) {
+        descBytes += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+        descBytes += (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
+    }
+    std::vector<char> hostDesc(descBytes + 64, 0);
+    HIPCHK(hipMalloc(&pd->dDescs, descBytes + 64));
+    size_t cursor = 0;
+    for (const Op& op : P.ops) {
+        OpDev od;
+        od.kind = op.kind; od.tileCfg = op.tileCfg; od.bmode = op.bmode; od.flops = op.flops; od.tag = op.tag;
+        if (op.kind == OP_GEMM) {
+            GGProblem* hp = (GGProblem*)(hostDesc.data() + cursor);
+            int tileStart = 0;
+            for (size_t j = 0; j < op.gemm.size(); ++j) {
+                const GemmItem& g = op.gemm[j];
+                GGProblem& q = hp[j];
+                q.A = F(g.bufA, g.offA); q.B = F(g.bufB, g.offB); q.C = F(g.bufC, g.offC);
+                q.bias = g.offBias >= 0 ? F(BUF_WEIGHTS, g.offBias) : nullptr;
+                q.R = g.bufR >= 0 ? F(g.bufR, g.offR) : nullptr;
+                q.rowA = T(g.tRowA); q.colA = T(g.tColA); q.rowB = T(g.tRowB); q.colB = T(g.tColB);
+                q.rowC = T(g.tRowC); q.colC = T(g.tColC); q.rowR = T(g.tRowR);
+                q.M = g.M; q.N = g.N; q.K = g.K; q.tilesM = g.tilesM; q.tilesN = g.tilesN;
+                q.splitK = g.splitK; q.chunksPerSplit = g.chunksPerSplit; q.tileStart = tileStart;
+                q.act = g.act; q.alpha = g.alpha; q.splitStride = g.splitStride;
+                tileStart += g.tilesM * g.tilesN * g.splitK;
+            }
+            od.dDesc = (char*)pd->dDescs + cursor;
+            od.nitems = (int)op.gemm.size();
+            od.total = tileStart;
+            cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+        } else if (op.kind == OP_SOFTMAX) {
+            SMProblem* hp = (SMProblem*)(hostDesc.data() + cursor);
+            int rowStart = 0;
+            for (size_t j = 0; j < op.softmax.size(); ++j) {
+                const SoftmaxItem& s = op.softmax[j];
+                SMProblem& q = hp[j];
+                q.S = F(s.bufS, s.offS); q.P = F(s.bufP, s.offP);
+                q.M = s.M; q.N = s.N; q.ldS = s.ldS; q.ldP = s.ldP; q.nsplit = s.nsplit; q.rowStart = rowStart;
+                q.scale = s.scale; q.pad_ = 0; q.splitStride = s.splitStride;
+                rowStart += (s.M + 3) / 4 * 4;
+            }
+            od.dDesc = (char*)pd->dDescs + cursor;
+            od.nitems = (int)op.softmax.size();
+            od.total = rowStart;
+            cursor += (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
+        } else {
+            od.src = op.bufSrc >= 0 ? h->bufs[op.bufSrc] : nullptr;
+            od.dst = op.bufDst >= 0 ? h->bufs[op.bufDst] : nullptr;
+            od.H = op.H; od.W = op.W; od.C = op.C; od.haloS = op.haloS; od.haloD = op.haloD; od.n = op.n;
+            od.ldy = op.ldy; od.pix = op.pix; od.premask = op.premask;
+            od.tFrameIdx = T(op.tFrameIdx); od.tFirst = T(op.tFirst);
+        }
+        pd->ops.push_back(std::move(od));
+    }
+    HIPCHK(hipMemcpy(pd->dDescs, hostDesc.data(), descBytes, hipMemcpyHostToDevice));
+    std::vector<int32_t> isf(L);
+    for (int i = 0; i < L; ++i) isf[i] = P.compCount[i] > 1 ? 1 : 0;
+    HIPCHK(hipMalloc((void**)&pd->dIsFloat, (size_t)L * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = pd.get();
+    h->plans[L] = std::move(pd);
+    return 0;
+}
+
+static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
+{
+    for (const OpDev& od : pd->ops) {
+        TimingRec tr;
+        if (h->timing) {
+            tr.tag = od.tag; tr.flops = od.flops;
+            HIPCHK(hipEventCreate(&tr.a));
+            HIPCHK(hipEventCreate(&tr.b));
+            HIPCHK(hipEventRecord(tr.a, stream));
+        }
+        int rc = 0;
+        switch (od.kind) {
+        case OP_GEMM:
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, stream);
+            break;
+        case OP_SOFTMAX:
+            rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
+            break;
+        case OP_NORM_IM2COL:
+            rc = vsr_launch_norm_im2col((const uint8_t*)od.src, od.H, od.W, od.n, (float*)od.dst, od.premask, nullptr, stream);
+            break;
+        case OP_UPSAMPLE2X:
+            rc = vsr_launch_upsample2x((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, stream);
+            break;
+        case OP_DECODE_OUT:
+            rc = vsr_launch_decode_out((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst, stream);
+            break;
+        default:
+            return fail(VSR_ERR_STATE, "unknown op kind");
+        }
+        if (rc != 0) return fail(VSR_ERR_HIP, "kernel launch failed: " + od.tag + ": " + hipGetErrorString(hipGetLastError()));
+        if (h->timing) {
+            HIPCHK(hipEventRecord(tr.b, stream));
+            h->pending.push_back(tr);
+        }
+    }
+    return 0;
+}
+
+static int collect_timing(vsr_sttn* h, hipStream_t stream)
+{
+    if (h->pending.empty()) return 0;
+    HIPCHK(hipStreamSynchronize(stream));
+    for (TimingRec& tr : h->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, tr.a, tr.b));
+        auto& acc = h->timed[tr.tag];
+        acc.first += ms;
+        acc.second.first += 1;
+        acc.second.second += tr.flops;
+        (void)hipEventDestroy(tr.a);
+        (void)hipEventDestroy(tr.b);
+    }
+    h->pending.clear();
+    return 0;
+}
+
+static int need_gpu(vsr_sttn* h)
+{
+    if (!h) return fail(VSR_ERR_ARG, "null handle");
+    if (!h->finalized || h->device < 0)
+        return fail(VSR_ERR_NOGPU, "model is not finalized on a HIP device (no GPU / finalize(device<0)); there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    return 0;
+}
+
+static int get_strip_tables(vsr_sttn* h, int W, int sh, StripTables** out)
+{
+    auto key = std::make_pair(W, sh);
+    auto it = h->strips.find(key);
+    if (it != h->strips.end()) { *out = &it->second; return 0; }
+    const int mw = h->model.g.modelW, mh = h->model.g.modelH;
+    std::vector<int32_t> dxo, dyo, uxo, uyo;
+    std::vector<int16_t> dxa, dya, uxa, uya;
+    std::vector<float> dxf, dyf, uxf, uyf;
+    cv2_linear_tables(W, mw, true, dxo, dxa, dxf);
+    cv2_linear_tables(sh, mh, false, dyo, dya, dyf);
+    cv2_linear_tables(mw, W, true, uxo, uxa, uxf);
+    cv2_linear_tables(mh, sh, false, uyo, uya, uyf);
+    // layout (bytes, each 16-aligned)
+    auto al = [](size_t v) { return (v + 15) / 16 * 16; };
+    size_t o = 0;
+    const size_t o_dxo = o; o += al(dxo.size() * 4);
+    const size_t o_dyo = o; o += al(dyo.size() * 4);
+    const size_t o_uxo = o; o += al(uxo.size() * 4);
+    const size_t o_uyo = o; o += al(uyo.size() * 4);
+    const size_t o_dxa = o; o += al(dxa.size() * 2);
+    const size_t o_dya = o; o += al(dya.size() * 2);
+    const size_t o_uxa = o; o += al(uxa.size() * 2);
+    const size_t o_uya = o; o += al(uya.size() * 2);
+    const size_t o_uxf = o; o += al(uxf.size() * 4);
+    const size_t o_uyf = o; o += al(uyf.size() * 4);
+    std::vector<char> hb(o, 0);
+    memcpy(hb.data() + o_dxo, dxo.data(), dxo.size() * 4);
+    memcpy(hb.data() + o_dyo, dyo.data(), dyo.size() * 4);
+    memcpy(hb.data() + o_uxo, uxo.data(), uxo.size() * 4);
+    memcpy(hb.data() + o_uyo, uyo.data(), uyo.size() * 4);
+    memcpy(hb.data() + o_dxa, dxa.data(), dxa.size() * 2);
+    memcpy(hb.data() + o_dya, dya.data(), dya.size() * 2);
+    memcpy(hb.data() + o_uxa, uxa.data(), uxa.size() * 2);
+    memcpy(hb.data() + o_uya, uya.data(), uya.size() * 2);
+    memcpy(hb.data() + o_uxf, uxf.data(), uxf.size() * 4);
+    memcpy(hb.data() + o_uyf, uyf.data(), uyf.size() * 4);
+    StripTables st;
+    HIPCHK(hipMalloc(&st.dev, o));
+    HIPCHK(hipMemcpy(st.dev, hb.data(), o, hipMemcpyHostToDevice));
+    char* d = (char*)st.dev;
+    st.dxofs = (const int32_t*)(d + o_dxo); st.dyofs = (const int32_t*)(d + o_dyo);
+    st.uxofs = (const int32_t*)(d + o_uxo); st.uyofs = (const int32_t*)(d + o_uyo);
+    st.dialpha = (const int16_t*)(d + o_dxa); st.dibeta = (const int16_t*)(d + o_dya);
+    st.uialpha = (const int16_t*)(d + o_uxa); st.uibeta = (const int16_t*)(d + o_uya);
+    st.ufalpha = (const float*)(d + o_uxf); st.ufbeta = (const float*)(d + o_uyf);
+    h->strips[key] = st;
+    *out = &h->strips[key];
+    return 0;
+}
+
+// =========================================================================================
+extern "C" {
+
+int vsr_version(void) { return 100; }
+const char* vsr_last_error(void) { return g_err.c_str(); }
+
+int vsr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int vsr_sttn_create(int variant, vsr_sttn_t** out)
+{
+    if (!out || (variant != VSR_VARIANT_STTN_AUTO && variant != VSR_VARIANT_STTN_DET)) return fail(VSR_ERR_ARG, "bad variant");
+    *out = new vsr_sttn(variant);
+    return 0;
+}
+
+int vsr_sttn_set_param(vsr_sttn_t* h, const char* key, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h || !key || !data || !shape || ndim <= 0 || ndim > 4) return fail(VSR_ERR_ARG, "bad argument");
+    if (h->finalized) return fail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.set_param(key, data, shape, ndim, err)) return fail(VSR_ERR_ARG, err);
+    return 0;
+}
+
+int vsr_sttn_finalize(vsr_sttn_t* h, int device)
+{
+    if (!h) return fail(VSR_ERR_ARG, "null handle");
+    if (h->finalized) return fail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.pack(err)) return fail(VSR_ERR_ARG, err);
+    if (device >= 0) {
+        if (device >= vsr_device_count()) return fail(VSR_ERR_NOGPU, "no such HIP device; there is no CPU fallback");
+        HIPCHK(hipSetDevice(device));
+        const size_t bytes = h->model.packed.size() * sizeof(float);
+        HIPCHK(hipMalloc(&h->bufs[BUF_WEIGHTS], bytes));
+        HIPCHK(hipMemcpy(h->bufs[BUF_WEIGHTS], h->model.packed.data(), bytes, hipMemcpyHostToDevice));
+        h->cap[BUF_WEIGHTS] = (int64_t)h->model.packed.size();
+    }
+    h->device = device;
+    h->finalized = true;
+    return 0;
+}
+
+void vsr_sttn_destroy(vsr_sttn_t* h)
+{
+    if (!h) return;
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        h->plans.clear();
+        for (int b = 0; b < BUF_COUNT; ++b)
+            if (h->bufs[b]) (void)hipFree(h->bufs[b]);
+        for (auto& kv : h->strips)
+            if (kv.second.dev) (void)hipFree(kv.second.dev);
+        if (h->compAreas) (void)hipFree(h->compAreas);
+        if (h->dSel) (void)hipFree(h->dSel);
+    }
+    delete h;
+}
+
+int vsr_sttn_geometry(const vsr_sttn_t* h, int32_t* mw, int32_t* mh, int32_t* ns, int32_t* rl)
+{
+    if (!h) return fail(VSR_ERR_ARG, "null handle");
+    if (mw) *mw = h->model.g.modelW;
+    if (mh) *mh = h->model.g.modelH;
+    if (ns) *ns = h->model.g.neighborStride;
+    if (rl) *rl = h->model.g.refLength;
+    return 0;
+}
+
+int vsr_sttn_set_window(vsr_sttn_t* h, int neighbor_stride, int ref_length)
+{
+    if (!h || neighbor_stride <= 0 || ref_length <= 0) return fail(VSR_ERR_ARG, "bad window");
+    if (h->device >= 0) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+    h->plans.clear();
+    h->model.g.neighborStride = neighbor_stride;
+    h->model.g.refLength = ref_length;
+    return 0;
+}
+
+int64_t vsr_sttn_packed_weights(const vsr_sttn_t* h, float* out, int64_t capacity)
+{
+    if (!h || !h->model.packed_ready()) return fail(VSR_ERR_STATE, "model not packed");
+    const int64_t n = (int64_t)h->model.packed.size();
+    if (out && capacity >= n) memcpy(out, h->model.packed.data(), (size_t)n * sizeof(float));
+    return n;
+}
+
+int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* comp_dev, int32_t* counts, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (!frames_dev || !comp_dev || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    PlanDev* pd = nullptr;
+    RCCHK(build_plan_dev(h, L, &pd));
+    const Geometry& g = h->model.g;
+    const size_t n = (size_t)L * g.modelH * g.modelW * 3;
+    HIPCHK(hipMemcpyAsync(h->bufs[BUF_IN_U8], frames_dev, n, hipMemcpyDeviceToDevice, stream));
+    RCCHK(run_plan(h, pd, stream));
+    HIPCHK(hipMemcpyAsync(comp_dev, h->bufs[BUF_COMP], n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (counts) memcpy(counts, pd->plan->compCount.data(), (size_t)L * sizeof(int32_t));
+    if (h->timing) RCCHK(collect_timing(h, stream));
+    return 0;
+}
+
+int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                        const int32_t* areas, const int32_t* sel, int nsel, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (!frames_dev || !mask_dev || L <= 0 || H <= 0 || W <= 0 || n_areas < 0 || (n_areas > 0 && !areas))
+        return fail(VSR_ERR_ARG, "bad argument");
+    if (n_areas == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Geometry& g = h->model.g;
+    const int mw = g.modelW, mh = g.modelH;
+    const int Ls = (sel && nsel > 0) ? nsel : L;
+    const int32_t* dSel = nullptr;
+    if (sel && nsel > 0) {
+        for (int i = 0; i < nsel; ++i)
+            if (sel[i] < 0 || sel[i] >= L) return fail(VSR_ERR_ARG, "frame selection out of range");
+        if (h->dSelCap < nsel) {
+            if (h->dSel) HIPCHK(hipFree(h->dSel));
+            HIPCHK(hipMalloc((void**)&h->dSel, (size_t)nsel * sizeof(int32_t)));
+            h->dSelCap = nsel;
+        }
+        HIPCHK(hipMemcpyAsync(h->dSel, sel, (size_t)nsel * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream)); // `sel` is caller memory
+        dSel = h->dSel;
+    }
+    PlanDev* pd = nullptr;
+    RCCHK(build_plan_dev(h, Ls, &pd));
+    const int64_t compElems = (int64_t)Ls * mh * mw * 3;
+    if (n_areas > 1 && h->compAreasCap < compElems * n_areas) {
+        if (h->compAreas) HIPCHK(hipFree(h->compAreas));
+        HIPCHK(hipMalloc((void**)&h->compAreas, (size_t)(compElems * n_areas) * sizeof(float)));
+        h->compAreasCap = compElems * n_areas;
+    }
+    const int64_t frameStride = (int64_t)H * W * 3;
+    // pass 1: every strip is cropped from the ORIGINAL frames and inpainted (reference
+    // sttn_auto_inpaint.py:257-283), pass 2 blends the strips back in order (:298-315)
+    for (int k = 0; k < n_areas; ++k) {
+        const int ymin = areas[4 * k], ymax = areas[4 * k + 1];
+        const int sh = ymax - ymin;
+        if (ymin < 0 || ymax > H || sh <= 0) return fail(VSR_ERR_ARG, "inpaint area outside the frame");
+        StripTables* st = nullptr;
+        RCCHK(get_strip_tables(h, W, sh, &st));
+        if (vsr_launch_resize_u8(frames_dev + (int64_t)ymin * W * 3, frameStride, W * 3, W, sh, (uint8_t*)h->bufs[BUF_IN_U8], mw,
+                                 mh, Ls, dSel, st->dxofs, st->dialpha, st->dyofs, st->dibeta, stream) != 0)
+            return fail(VSR_ERR_HIP, "resize launch failed");
+        RCCHK(run_plan(h, pd, stream));
+        if (n_areas > 1)
+            HIPCHK(hipMemcpyAsync(h->compAreas + compElems * k, h->bufs[BUF_COMP], (size_t)compElems * sizeof(float),
+                                  hipMemcpyDeviceToDevice, stream));
+    }
+    for (int k = 0; k < n_areas; ++k) {
+        const int ymin = areas[4 * k], ymax = areas[4 * k + 1];
+        const int sh = ymax - ymin;
+        StripTables* st = nullptr;
+        RCCHK(get_strip_tables(h, W, sh, &st));
+        const float* comp = n_areas > 1 ? h->compAreas + compElems * k : (const float*)h->bufs[BUF_COMP];
+        if (vsr_launch_upscale_blend(comp, mw, mh, pd->dIsFloat, frames_dev + (int64_t)ymin * W * 3, frameStride, W * 3, dSel,
+                                     mask_dev + (int64_t)ymin * W, W, W, sh, Ls, st->uxofs, st->uialpha, st->ufalpha, st->uyofs,
+                                     st->uibeta, st->ufbeta, stream) != 0)
+            return fail(VSR_ERR_HIP, "blend launch failed");
+    }
+    if (h->timing) RCCHK(collect_timing(h, stream));
+    return 0;
+}
+
+double vsr_sttn_flops(vsr_sttn_t* h, int L)
+{
+    if (!h || !h->model.packed_ready() || L <= 0) { fail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        Plan p(h->model, L);
+        return p.flops;
+    } catch (const std::exception& e) {
+        fail(VSR_ERR_ARG, e.what());
+        return -1.0;
+    }
+}
+
+int vsr_sttn_timing(vsr_sttn_t* h, int enable)
+{
+    if (!h) return fail(VSR_ERR_ARG, "null handle");
+    h->timing = enable != 0;
+    return 0;
+}
+
+int vsr_sttn_timing_reset(vsr_sttn_t* h)
+{
+    if (!h) return fail(VSR_ERR_ARG, "null handle");
+    h->timed.clear();
+    return 0;
+}
+
+int vsr_sttn_timing_get(vsr_sttn_t* h, const char* prefix, double* total_ms, int32_t* launches, double* flops)
+{
+    if (!h || !prefix) return fail(VSR_ERR_ARG, "bad argument");
+    double ms = 0, fl = 0;
+    int n = 0;
+    const size_t pl = strlen(prefix);
+    for (const auto& kv : h->timed)
+        if (kv.first.compare(0, pl, prefix) == 0) { ms += kv.second.first; n += kv.second.second.first; fl += kv.second.second.second; }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (flops) *flops = fl;
+    return 0;
+}
+
+// ---- kernel-level entry points -----------------------------------------------------------
+static void tile_dims(int cfg, int& BM, int& BN)
+{
+    BM = cfg == VSR_TILE_128x128 ? 128 : 256;
+    BN = cfg == VSR_TILE_128x128 ? 128 : (cfg == VSR_TILE_256x64 ? 64 : 32);
+}
+
+int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, void* stream_)
+{
+    if (!probs || nprobs <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (vsr_device_count() <= 0) return fail(VSR_ERR_NOGPU, "no HIP device; there is no CPU fallback");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<GGProblem> hp(probs, probs + nprobs);
+    int BM, BN;
+    tile_dims(tile_cfg, BM, BN);
+    int total = 0;
+    for (auto& p : hp) {
+        if (p.K % VSR_GG_KC) return fail(VSR_ERR_ARG, "K must be a multiple of 32");
+        if (p.tilesM != (p.M + BM - 1) / BM || p.tilesN != (p.N + BN - 1) / BN) return fail(VSR_ERR_ARG, "tile counts do not match the tile config");
+        if (p.splitK < 1 || (int64_t)p.splitK * p.chunksPerSplit < p.K / VSR_GG_KC) return fail(VSR_ERR_ARG, "bad split-K");
+        p.tileStart = total;
+        total += p.tilesM * p.tilesN * p.splitK;
+    }
+    GGProblem* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(GGProblem)));
+    HIPCHK(hipMemcpy(d, hp.data(), hp.size() * sizeof(GGProblem), hipMemcpyHostToDevice));
+    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, stream);
+    hipError_t e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");
+    if (e != hipSuccess) return fail(VSR_ERR_HIP, std::string("gather-gemm: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream_)
+{
+    if (!probs || nprobs <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (vsr_device_count() <= 0) return fail(VSR_ERR_NOGPU, "no HIP device; there is no CPU fallback");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<SMProblem> hp(probs, probs + nprobs);
+    int rows = 0;
+    for (auto& p : hp) { p.rowStart = rows; rows += (p.M + 3) / 4 * 4; }
+    SMProblem* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(SMProblem)));
+    HIPCHK(hipMemcpy(d, hp.data(), hp.size() * sizeof(SMProblem), hipMemcpyHostToDevice));
+    const int rc = vsr_launch_softmax_dev(d, nprobs, rows, stream);
+    hipError_t e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    if (rc != 0) return fail(VSR_ERR_HIP, "softmax launch failed");
+    if (e != hipSuccess) return fail(VSR_ERR_HIP, std::string("softmax: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int vsr_cv2_linear_tables(int ssize, int dsize, int clamp_x, int32_t* ofs, int16_t* icoef, float* fcoef)
+{
+    if (ssize <= 0 || dsize <= 0 || !ofs || !icoef || !fcoef) return fail(VSR_ERR_ARG, "bad argument");
+    std::vector<int32_t> o;
+    std::vector<int16_t> ic;
+    std::vector<float> fc;
+    cv2_linear_tables(ssize, dsize, clamp_x != 0, o, ic, fc);
+    memcpy(ofs, o.data(), o.size() * 4);
+    memcpy(icoef, ic.data(), ic.size() * 2);
+    memcpy(fcoef, fc.data(), fc.size() * 4);
+    return 0;
+}
+
+// ---- plan introspection (host only) ------------------------------------------------------
+int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out)
+{
+    if (!h || !out || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return fail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new Plan(h->model, L));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
+    }
+    return 0;
+}
+void vsr_plan_destroy(vsr_plan_t* p) { delete p; }
+int vsr_plan_num_buffers(const vsr_plan_t* p) { return p ? BUF_COUNT : 0; }
+int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf) { return (p && buf >= 0 && buf < BUF_COUNT) ? p->plan->bufElems[buf] : -1; }
+int vsr_plan_num_tables(const vsr_plan_t* p) { return p ? (int)p->plan->tables.size() : 0; }
+int64_t vsr_plan_table_len(const vsr_plan_t* p, int t) { return (p && t >= 0 && t < (int)p->plan->tables.size()) ? (int64_t)p->plan->tables[t].size() : -1; }
+int vsr_plan_table_copy(const vsr_plan_t* p, int t, int32_t* out)
+{
+    if (!p || !out || t < 0 || t >= (int)p->plan->tables.size()) return fail(VSR_ERR_ARG, "bad table");
+    memcpy(out, p->plan->tables[t].data(), p->plan->tables[t].size() * sizeof(int32_t));
+    return 0;
+}
+int vsr_plan_num_ops(const vsr_plan_t* p) { return p ? (int)p->plan->ops.size() : 0; }
+int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* o)
+{
+    if (!p || !o || i < 0 || i >= (int)p->plan->ops.size()) return fail(VSR_ERR_ARG, "bad op");
+    const Op& op = p->plan->ops[i];
+    memset(o, 0, sizeof(*o));
+    o->kind = op.kind;
+    o->nitems = (int)(op.kind == OP_GEMM ? op.gemm.size() : op.softmax.size());
+    o->tile_cfg = op.tileCfg; o->bmode = op.bmode;
+    o->buf_src = op.bufSrc; o->buf_dst = op.bufDst; o->H = op.H; o->W = op.W; o->C = op.C;
+    o->halo_src = op.haloS; o->halo_dst = op.haloD; o->n = op.n; o->ldy = op.ldy; o->pix = op.pix;
+    o->t_frame_idx = op.tFrameIdx; o->t_first = op.tFirst; o->premask = op.premask;
+    o->flops = op.flops;
+    strncpy(o->tag, op.tag.c_str(), sizeof(o->tag) - 1);
+    return 0;
+}
+int vsr_plan_op_gemm(const vsr_plan_t* p, int i, int j, VsrGemmInfo* o)
+{
+    if (!p || !o || i < 0 || i >= (int)p->plan->ops.size()) return fail(VSR_ERR_ARG, "bad op");
+    const Op& op = p->plan->ops[i];
+    if (op.kind != OP_GEMM || j < 0 || j >= (int)op.gemm.size()) return fail(VSR_ERR_ARG, "bad gemm item");
+    const GemmItem& g = op.gemm[j];
+    o->bufA = g.bufA; o->bufB = g.bufB; o->bufC = g.bufC; o->bufR = g.bufR;
+    o->offA = g.offA; o->offB = g.offB; o->offC = g.offC; o->offR = g.offR; o->offBias = g.offBias;
+    o->tRowA = g.tRowA; o->tColA = g.tColA; o->tRowB = g.tRowB; o->tColB = g.tColB; o->tRowC = g.tRowC;
+    o->tColC = g.tColC; o->tRowR = g.tRowR;
+    o->M = g.M; o->N = g.N; o->K = g.K; o->tilesM = g.tilesM; o->tilesN = g.tilesN; o->splitK = g.splitK;
+    o->chunksPerSplit = g.chunksPerSplit; o->splitStride = g.splitStride; o->alpha = g.alpha; o->act = g.act;
+    return 0;
+}
+int vsr_plan_op_softmax(const vsr_plan_t* p, int i, int j, VsrSoftmaxInfo* o)
+{
+    if (!p || !o || i < 0 || i >= (int)p->plan->ops.size()) return fail(VSR_ERR_ARG, "bad op");
+    const Op& op = p->plan->ops[i];
+    if (op.kind != OP_SOFTMAX || j < 0 || j >= (int)op.softmax.size()) return fail(VSR_ERR_ARG, "bad softmax item");
+    const SoftmaxItem& s = op.softmax[j];
+    o->bufS = s.bufS; o->bufP = s.bufP; o->offS = s.offS; o->offP = s.offP; o->splitStride = s.splitStride;
+    o->M = s.M; o->N = s.N; o->ldS = s.ldS; o->ldP = s.ldP; o->nsplit = s.nsplit; o->scale = s.scale;
+    return 0;
+}
+int vsr_plan_counts(const vsr_plan_t* p, int32_t* counts)
+{
+    if (!p || !counts) return fail(VSR_ERR_ARG, "bad argument");
+    memcpy(counts, p->plan->compCount.data(), p->plan->compCount.size() * sizeof(int32_t));
+    return 0;
+}
+double vsr_plan_flops(const vsr_plan_t* p) { return p ? p->plan->flops : -1.0; }
+
+} // extern "C"

@@ -1,0 +1,693 @@
+// Plan builder + weight packer for the STTN hot path (see sttn_plan.h).
+#include "sttn_plan.h"
+#include "gather_gemm.h"
+#include <assert.h>
+#include <math.h>
+#include <stdexcept>
+
+namespace vsr {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t rup(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+Geometry Geometry::make(int variant)
+{
+    Geometry g{};
+    g.variant = variant;
+    g.channels = 256;
+    g.blocks = 8;
+    g.nscales = 4;
+    g.neighborStride = 5;
+    g.refLength = 10;
+    if (variant == 0) { // auto_sttn.py:69 patchsize, sttn_auto_inpaint.py:39 model input
+        g.modelW = 640; g.modelH = 120;
+        const int pw[4] = {80, 32, 10, 5}, ph[4] = {15, 6, 5, 3};
+        for (int i = 0; i < 4; ++i) { g.patchW[i] = pw[i]; g.patchH[i] = ph[i]; }
+    } else {            // network_sttn.py:69 patchsize, sttn_det_inpaint.py model input 432x240
+        g.modelW = 432; g.modelH = 240;
+        const int pw[4] = {108, 36, 18, 9}, ph[4] = {60, 20, 10, 5};
+        for (int i = 0; i < 4; ++i) { g.patchW[i] = pw[i]; g.patchH[i] = ph[i]; }
+    }
+    g.featW = g.modelW / 4;
+    g.featH = g.modelH / 4;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------
+// Model
+// ------------------------------------------------------------------------------------
+Model::Model(int variant) : g(Geometry::make(variant)) { blk.resize(g.blocks); }
+
+std::vector<std::string> Model::expected_keys(int variant)
+{
+    (void)variant; // both generators share the parameter structure
+    std::vector<std::string> k;
+    for (int i = 0; i < 8; ++i) {
+        const std::string p = "transformer." + std::to_string(i) + ".";
+        for (const char* e : {"attention.query_embedding", "attention.value_embedding", "attention.key_embedding",
+                              "attention.output_linear.0", "feed_forward.conv.0", "feed_forward.conv.2"}) {
+            k.push_back(p + e + ".weight");
+            k.push_back(p + e + ".bias");
+        }
+    }
+    for (const char* e : {"encoder.0", "encoder.2", "encoder.4", "encoder.6", "decoder.0.conv", "decoder.2",
+                          "decoder.4.conv", "decoder.6"}) {
+        k.push_back(std::string(e) + ".weight");
+        k.push_back(std::string(e) + ".bias");
+    }
+    return k;
+}
+
+bool Model::set_param(const std::string& name, const float* data, const int64_t* shape, int ndim, std::string& err)
+{
+    bool known = false;
+    for (const auto& k : expected_keys(g.variant))
+        if (k == name) { known = true; break; }
+    if (!known) { err = "unexpected key in state_dict: " + name; return false; }
+    Raw r;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) { r.shape.push_back(shape[i]); n *= shape[i]; }
+    r.v.assign(data, data + n);
+    raw_[name] = std::move(r);
+    ready_ = false;
+    return true;
+}
+
+// [cout][cin][kh][kw] -> [cout][K], k = (ky*kw + kx)*cin + ci ; K padded up to a multiple of 32
+bool Model::pack_conv(const std::string& key, ConvW& cw, int /*cinPad*/, std::string& err)
+{
+    auto wi = raw_.find(key + ".weight"), bi = raw_.find(key + ".bias");
+    if (wi == raw_.end() || bi == raw_.end()) { err = "missing key in state_dict: " + key; return false; }
+    const Raw& w = wi->second;
+    if (w.shape.size() != 4) { err = "bad weight rank: " + key; return false; }
+    const int cout = (int)w.shape[0], cin = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
+    if ((int64_t)bi->second.v.size() != cout) { err = "bad bias shape: " + key; return false; }
+    const int Kreal = kh * kw * cin;
+    const int K = (int)rup(Kreal, VSR_GG_KC);
+    cw.cout = cout;
+    cw.K = K;
+    cw.w = (int64_t)packed.size();
+    packed.resize(packed.size() + (size_t)rup((int64_t)cout * K, 32), 0.f);
+    float* dst = packed.data() + cw.w;
+    for (int n = 0; n < cout; ++n)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx)
+                    dst[(int64_t)n * K + (ky * kw + kx) * cin + ci] =
+                        w.v[(((int64_t)n * cin + ci) * kh + ky) * kw + kx];
+    cw.b = (int64_t)packed.size();
+    packed.resize(packed.size() + (size_t)rup(cout, 32), 0.f);
+    for (int n = 0; n < cout; ++n) packed[cw.b + n] = bi->second.v[n];
+    return true;
+}
+
+bool Model::pack(std::string& err)
+{
+    packed.clear();
+    ready_ = false;
+    for (const auto& k : expected_keys(g.variant))
+        if (!raw_.count(k)) { err = "missing key in state_dict: " + k; return false; }
+    static const char* encKeys[4] = {"encoder.0", "encoder.2", "encoder.4", "encoder.6"};
+    static const char* decKeys[4] = {"decoder.0.conv", "decoder.2", "decoder.4.conv", "decoder.6"};
+    static const int encShape[4][2] = {{64, 3}, {64, 64}, {128, 64}, {256, 128}};
+    static const int decShape[4][2] = {{128, 256}, {64, 128}, {64, 64}, {3, 64}};
+    auto check = [&](const std::string& key, int cout, int cin, int ksz) {
+        const Raw& w = raw_[key + ".weight"];
+        if (w.shape.size() != 4 || w.shape[0] != cout || w.shape[1] != cin || w.shape[2] != ksz || w.shape[3] != ksz) {
+            err = "shape mismatch for " + key + ".weight";
+            return false;
+        }
+        return true;
+    };
+    for (int i = 0; i < 4; ++i) {
+        if (!check(encKeys[i], encShape[i][0], encShape[i][1], 3)) return false;
+        if (!pack_conv(encKeys[i], enc[i], 0, err)) return false;
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (!check(decKeys[i], decShape[i][0], decShape[i][1], 3)) return false;
+        if (!pack_conv(decKeys[i], dec[i], 0, err)) return false;
+    }
+    const int C = g.channels;
+    for (int b = 0; b < g.blocks; ++b) {
+        const std::string p = "transformer." + std::to_string(b) + ".";
+        // fused QKV 1x1: rows [0,C) query, [C,2C) key, [2C,3C) value (auto_sttn.py:172-174)
+        ConvW q, k, v;
+        for (const char* e : {"attention.query_embedding", "attention.key_embedding", "attention.value_embedding"})
+            if (!check(p + e, C, C, 1)) return false;
+        if (!pack_conv(p + "attention.query_embedding", q, 0, err)) return false;
+        if (!pack_conv(p + "attention.key_embedding", k, 0, err)) return false;
+        if (!pack_conv(p + "attention.value_embedding", v, 0, err)) return false;
+        ConvW& f = blk[b].qkv;
+        f.cout = 3 * C;
+        f.K = C;
+        f.w = (int64_t)packed.size();
+        packed.resize(packed.size() + (size_t)3 * C * C, 0.f);
+        f.b = (int64_t)packed.size();
+        packed.resize(packed.size() + (size_t)rup(3 * C, 32), 0.f);
+        const ConvW* src[3] = {&q, &k, &v};
+        for (int j = 0; j < 3; ++j) {
+            for (int64_t i = 0; i < (int64_t)C * C; ++i) packed[f.w + (int64_t)j * C * C + i] = packed[src[j]->w + i];
+            for (int i = 0; i < C; ++i) packed[f.b + j * C + i] = packed[src[j]->b + i];
+        }
+        if (!check(p + "attention.output_linear.0", C, C, 3)) return false;
+        if (!pack_conv(p + "attention.output_linear.0", blk[b].out, 0, err)) return false;
+        if (!check(p + "feed_forward.conv.0", C, C, 3)) return false;
+        if (!pack_conv(p + "feed_forward.conv.0", blk[b].ffn1, 0, err)) return false;
+        if (!check(p + "feed_forward.conv.2", C, C, 3)) return false;
+        if (!pack_conv(p + "feed_forward.conv.2", blk[b].ffn2, 0, err)) return false;
+    }
+    ready_ = true;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
+// Plan
+// ------------------------------------------------------------------------------------
+static void tileDims(int cfg, int& BM, int& BN)
+{
+    if (cfg == VSR_TILE_128x128) { BM = 128; BN = 128; }
+    else if (cfg == VSR_TILE_256x64) { BM = 256; BN = 64; }
+    else { BM = 256; BN = 32; }
+}
+static int pickTile(int N) { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : VSR_TILE_128x128); }
+
+static void checkFits(int64_t v)
+{
+    if (v > 2147483647LL || v < -2147483648LL) throw std::runtime_error("offset table entry exceeds int32");
+}
+
+int Plan::table(const std::string& key, std::vector<int32_t>&& v)
+{
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    tables.push_back(std::move(v));
+    const int id = (int)tables.size() - 1;
+    tableKey_[key] = id;
+    return id;
+}
+
+void Plan::need(int buf, int64_t elems)
+{
+    if (bufElems[buf] < elems) bufElems[buf] = elems;
+}
+
+static std::string idsKey(const std::vector<int>& ids)
+{
+    std::string s;
+    for (int i : ids) { s += std::to_string(i); s += ','; }
+    return s;
+}
+
+int Plan::tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add)
+{
+    const std::string key = "RA:" + std::to_string(a.buf) + ":" + std::to_string(a.halo) + ":" + std::to_string(a.H) +
+                            ":" + std::to_string(a.W) + ":" + std::to_string(a.C) + ":" + std::to_string(oh) + ":" +
+                            std::to_string(ow) + ":" + std::to_string(stride) + ":" + std::to_string(add) + ":" +
+                            std::to_string(padTo) + ":" + idsKey(ids);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    std::vector<int32_t> v;
+    const int64_t M = (int64_t)ids.size() * oh * ow;
+    v.reserve((size_t)rup(M, padTo));
+    for (size_t ti = 0; ti < ids.size(); ++ti)
+        for (int y = 0; y < oh; ++y)
+            for (int x = 0; x < ow; ++x) {
+                const int64_t o = a.pix(ids[ti], y * stride, x * stride) + add;
+                checkFits(o);
+                v.push_back((int32_t)o);
+            }
+    const int32_t first = v.empty() ? 0 : v[0];
+    while ((int64_t)v.size() % padTo) v.push_back(first);
+    return table(key, std::move(v));
+}
+
+int Plan::tColsConv(const Act& a, int ksz, int dil)
+{
+    const std::string key = "CC:" + std::to_string(a.halo) + ":" + std::to_string(a.W) + ":" + std::to_string(a.C) +
+                            ":" + std::to_string(ksz) + ":" + std::to_string(dil);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    if (a.halo < dil * (ksz / 2)) throw std::runtime_error("activation halo too small for conv");
+    if (a.C % VSR_GG_KC) throw std::runtime_error("conv input channels must be a multiple of 32");
+    std::vector<int32_t> v;
+    for (int ky = 0; ky < ksz; ++ky)
+        for (int kx = 0; kx < ksz; ++kx)
+            for (int c0 = 0; c0 < a.C; c0 += VSR_GG_KC)
+                v.push_back((int32_t)(((int64_t)(ky - ksz / 2) * dil * a.Wp() + (kx - ksz / 2) * dil) * a.C + c0));
+    return table(key, std::move(v));
+}
+
+int Plan::tRowsLinear(int count, int ld, int padTo)
+{
+    const std::string key = "RL:" + std::to_string(count) + ":" + std::to_string(ld) + ":" + std::to_string(padTo);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    std::vector<int32_t> v;
+    for (int i = 0; i < count; ++i) { checkFits((int64_t)i * ld); v.push_back((int32_t)((int64_t)i * ld)); }
+    while ((int)v.size() % padTo) v.push_back(0);
+    return table(key, std::move(v));
+}
+
+int Plan::tColsLinear(int nchunks, int padTo)
+{
+    const std::string key = "CL:" + std::to_string(nchunks) + ":" + std::to_string(padTo);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    std::vector<int32_t> v;
+    for (int i = 0; i < nchunks; ++i) v.push_back(i * VSR_GG_KC);
+    while ((int)v.size() < padTo) v.push_back(0);
+    return table(key, std::move(v));
+}
+
+// token (t, oy, ox) of scale s inside the plain QKV buffer [T*fh*fw][3C] (auto_sttn.py:182-190:
+// view(b,t,d_k,out_h,height,out_w,width).permute(0,1,3,5,2,4,6) => tokens ordered t, out_h, out_w)
+int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo)
+{
+    const std::string key = "RT:" + std::to_string(T) + ":" + std::to_string(s) + ":" + std::to_string(choff) + ":" +
+                            std::to_string(count) + ":" + std::to_string(padTo);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, C3 = 3 * g.channels;
+    std::vector<int32_t> v;
+    for (int t = 0; t < T; ++t)
+        for (int oy = 0; oy < oh; ++oy)
+            for (int ox = 0; ox < ow; ++ox) {
+                const int64_t o = (((int64_t)t * g.featH + oy * ph) * g.featW + ox * pw) * C3 + choff;
+                checkFits(o);
+                v.push_back((int32_t)o);
+            }
+    assert((int)v.size() == count);
+    (void)count;
+    const int32_t first = v[0];
+    while ((int)v.size() % padTo) v.push_back(first);
+    return table(key, std::move(v));
+}
+
+// the D = d_k*ph*pw elements of a token as 32-float chunks (y, x, half); the order inside a
+// token is free for QK^T (a sum) and is mirrored by tColsPatchAct for the PV scatter.
+int Plan::tColsPatch(int s, int padTo)
+{
+    const std::string key = "CP:" + std::to_string(s) + ":" + std::to_string(padTo);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    const int pw = g.patchW[s], ph = g.patchH[s], C3 = 3 * g.channels, dk = g.channels / g.nscales;
+    std::vector<int32_t> v;
+    for (int y = 0; y < ph; ++y)
+        for (int x = 0; x < pw; ++x)
+            for (int c0 = 0; c0 < dk; c0 += VSR_GG_KC) v.push_back((int32_t)(((int64_t)y * g.featW + x) * C3 + c0));
+    while ((int)v.size() < padTo) v.push_back(0);
+    return table(key, std::move(v));
+}
+
+int Plan::tRowsTokensAct(const Act& a, int T, int s, int padTo)
+{
+    const std::string key = "RTA:" + std::to_string(a.buf) + ":" + std::to_string(a.halo) + ":" + std::to_string(T) +
+                            ":" + std::to_string(s) + ":" + std::to_string(padTo);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, dk = g.channels / g.nscales;
+    std::vector<int32_t> v;
+    for (int t = 0; t < T; ++t)
+        for (int oy = 0; oy < oh; ++oy)
+            for (int ox = 0; ox < ow; ++ox) {
+                const int64_t o = a.pix(t, oy * ph, ox * pw) + (int64_t)dk * s;
+                checkFits(o);
+                v.push_back((int32_t)o);
+            }
+    const int32_t first = v[0];
+    while ((int)v.size() % padTo) v.push_back(first);
+    return table(key, std::move(v));
+}
+
+int Plan::tColsPatchAct(const Act& a, int s, int padTo)
+{
+    const std::string key = "CPA:" + std::to_string(a.halo) + ":" + std::to_string(a.W) + ":" + std::to_string(a.C) +
+                            ":" + std::to_string(s) + ":" + std::to_string(padTo);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    const int pw = g.patchW[s], ph = g.patchH[s], dk = g.channels / g.nscales;
+    std::vector<int32_t> v;
+    for (int y = 0; y < ph; ++y)
+        for (int x = 0; x < pw; ++x)
+            for (int c0 = 0; c0 < dk; c0 += VSR_GG_KC) v.push_back((int32_t)(((int64_t)y * a.Wp() + x) * a.C + c0));
+    while ((int)v.size() < padTo) v.push_back(0);
+    return table(key, std::move(v));
+}
+
+static std::vector<int> iota(int n)
+{
+    std::vector<int> v(n);
+    for (int i = 0; i < n; ++i) v[i] = i;
+    return v;
+}
+
+// conv (ksz 1 or 3, stride, dilation) + bias + optional LeakyReLU(0.2) + optional residual,
+// as one gather-GEMM: M = nOut*out.H*out.W pixels, N = cout, K = ksz*ksz*cin.
+void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut, int ksz,
+                   int stride, int dil, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds)
+{
+    if (w.K != ksz * ksz * in.C) throw std::runtime_error(std::string("conv K mismatch: ") + tag);
+    if ((int)inIds.size() != nOut) throw std::runtime_error("conv frame list mismatch");
+    Op op;
+    op.kind = OP_GEMM;
+    op.tag = tag;
+    op.bmode = VSR_BMODE_NK;
+    op.tileCfg = pickTile(w.cout);
+    int BM, BN;
+    tileDims(op.tileCfg, BM, BN);
+    GemmItem it{};
+    it.M = nOut * out.H * out.W;
+    it.N = w.cout;
+    it.K = w.K;
+    it.tilesM = cdiv(it.M, BM);
+    it.tilesN = cdiv(it.N, BN);
+    it.splitK = 1;
+    it.chunksPerSplit = it.K / VSR_GG_KC;
+    it.splitStride = 0;
+    it.alpha = 1.f;
+    it.act = act;
+    it.bufA = in.buf; it.offA = 0;
+    it.tRowA = tRowsAct(in, inIds, out.H, out.W, stride, BM, 0);
+    it.tColA = tColsConv(in, ksz, dil);
+    it.bufB = BUF_WEIGHTS; it.offB = w.w;
+    it.tRowB = tRowsLinear(it.N, it.K, BN);
+    it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
+    it.bufC = out.buf; it.offC = 0;
+    it.tRowC = tRowsAct(out, iota(nOut), out.H, out.W, 1, BM, 0);
+    it.tColC = tColsLinear(cdiv(it.N, VSR_GG_KC), it.tilesN * BN / VSR_GG_KC);
+    it.offBias = w.b;
+    if (res) {
+        it.bufR = res->buf; it.offR = 0;
+        it.tRowR = tRowsAct(*res, *resIds, out.H, out.W, 1, BM, 0);
+    } else {
+        it.bufR = -1; it.offR = 0; it.tRowR = -1;
+    }
+    op.flops = 2.0 * it.M * it.N * (double)(ksz * ksz * in.C);
+    op.gemm.push_back(it);
+    need(out.buf, (int64_t)nOut * out.frameElems());
+    flops += op.flops;
+    ops.push_back(std::move(op));
+}
+
+// multi-scale patch attention of one block (auto_sttn.py:167-206, Attention :140-145):
+// grouped QK^T (split-K on the coarse scales) -> grouped row softmax -> grouped PV that
+// scatters straight back into the NHWC attention buffer.
+void Plan::addAttention(int T, const BlockW&)
+{
+    const int C = g.channels, dk = C / g.nscales, C3 = 3 * C;
+    const Act att{BUF_ATT, T, g.featH, g.featW, C, 1};
+    Op qk, sm, pv;
+    qk.kind = OP_GEMM; qk.tag = "attn.qk"; qk.tileCfg = VSR_TILE_128x128; qk.bmode = VSR_BMODE_NK;
+    sm.kind = OP_SOFTMAX; sm.tag = "attn.softmax";
+    pv.kind = OP_GEMM; pv.tag = "attn.pv"; pv.tileCfg = VSR_TILE_128x128; pv.bmode = VSR_BMODE_KN;
+    const int BM = 128, BN = 128;
+    int64_t sOff = 0, pOff = 0;
+    (void)C3;
+    for (int s = 0; s < g.nscales; ++s) {
+        const int pw = g.patchW[s], ph = g.patchH[s];
+        const int Pn = (g.featW / pw) * (g.featH / ph);
+        const int Ntok = T * Pn;
+        const int D = dk * pw * ph;
+        const int ldS = (int)rup(Ntok, VSR_GG_KC);
+        const int tiles = cdiv(Ntok, BM);
+        const int nchunks = D / VSR_GG_KC;
+        int cps = nchunks < 32 ? nchunks : 32;
+        int splitK = cdiv(nchunks, cps);
+        cps = cdiv(nchunks, splitK);
+        splitK = cdiv(nchunks, cps);
+        const int64_t plane = (int64_t)Ntok * ldS;
+
+        GemmItem a{};
+        a.M = Ntok; a.N = Ntok; a.K = D;
+        a.tilesM = tiles; a.tilesN = tiles; a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
+        a.alpha = 1.f; a.act = VSR_ACT_NONE;
+        a.bufA = BUF_QKV; a.offA = 0;
+        a.tRowA = tRowsTokens(T, s, dk * s, Ntok, BM);
+        a.tColA = tColsPatch(s, nchunks);
+        a.bufB = BUF_QKV; a.offB = 0;
+        a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, BN);
+        a.tColB = a.tColA;
+        a.bufC = BUF_S; a.offC = sOff;
+        a.tRowC = tRowsLinear(Ntok, ldS, BM);
+        a.tColC = tColsLinear(tiles * BN / VSR_GG_KC, tiles * BN / VSR_GG_KC);
+        a.bufR = -1; a.tRowR = -1; a.offBias = -1;
+        qk.gemm.push_back(a);
+        qk.flops += 2.0 * Ntok * (double)Ntok * D;
+
+        SoftmaxItem m{};
+        m.bufS = BUF_S; m.offS = sOff; m.splitStride = plane; m.nsplit = splitK;
+        m.bufP = BUF_P; m.offP = pOff;
+        m.M = Ntok; m.N = Ntok; m.ldS = ldS; m.ldP = ldS;
+        m.scale = (float)(1.0 / sqrt((double)D)); // scores / math.sqrt(query.size(-1))
+        sm.softmax.push_back(m);
+
+        GemmItem b{};
+        b.M = Ntok; b.N = D; b.K = ldS;
+        b.tilesM = tiles; b.tilesN = cdiv(D, BN); b.splitK = 1; b.chunksPerSplit = ldS / VSR_GG_KC; b.splitStride = 0;
+        b.alpha = 1.f; b.act = VSR_ACT_NONE;
+        b.bufA = BUF_P; b.offA = pOff;
+        b.tRowA = tRowsLinear(Ntok, ldS, BM);
+        b.tColA = tColsLinear(ldS / VSR_GG_KC, ldS / VSR_GG_KC);
+        b.bufB = BUF_QKV; b.offB = 0;
+        b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
+        b.tColB = tColsPatch(s, b.tilesN * BN / VSR_GG_KC);
+        b.bufC = BUF_ATT; b.offC = 0;
+        b.tRowC = tRowsTokensAct(att, T, s, BM);
+        b.tColC = tColsPatchAct(att, s, b.tilesN * BN / VSR_GG_KC);
+        b.bufR = -1; b.tRowR = -1; b.offBias = -1;
+        pv.gemm.push_back(b);
+        pv.flops += 2.0 * Ntok * (double)Ntok * D;
+
+        sOff += rup(plane * splitK, 32);
+        pOff += rup(plane, 32);
+    }
+    need(BUF_S, sOff);
+    need(BUF_P, pOff);
+    need(BUF_ATT, att.elems());
+    flops += qk.flops + pv.flops;
+    ops.push_back(std::move(qk));
+    ops.push_back(std::move(sm));
+    ops.push_back(std::move(pv));
+}
+
+// one sliding window (sttn_auto_inpaint.py:142-162): infer over neighbours+refs, decode the
+// neighbours, tanh -> u8, pairwise overlap average into comp.
+void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>& refs, std::vector<int32_t>& visits)
+{
+    const int C = g.channels, fh = g.featH, fw = g.featW, mh = g.modelH, mw = g.modelW;
+    std::vector<int> ids = neighbors;
+    ids.insert(ids.end(), refs.begin(), refs.end());
+    const int T = (int)ids.size(), nn = (int)neighbors.size();
+    const Act feats{BUF_FEATS, L, fh, fw, C, 2};
+    const Act x0{BUF_X0, T, fh, fw, C, 2}, x1{BUF_X1, T, fh, fw, C, 2};
+    const Act att{BUF_ATT, T, fh, fw, C, 1}, f1{BUF_F1, T, fh, fw, C, 1};
+    const std::vector<int> idT = iota(T);
+
+    Act cur = feats;
+    std::vector<int> curIds = ids;
+    for (int b = 0; b < g.blocks; ++b) {
+        const BlockW& bw = m_.blk[b];
+        {   // fused Q/K/V 1x1 (auto_sttn.py:172-174) -> plain [T*fh*fw][3C]
+            Op op;
+            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = VSR_TILE_128x128; op.bmode = VSR_BMODE_NK;
+            const int BM = 128, BN = 128;
+            GemmItem it{};
+            it.M = T * fh * fw; it.N = 3 * C; it.K = C;
+            it.tilesM = cdiv(it.M, BM); it.tilesN = cdiv(it.N, BN);
+            it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
+            it.bufA = cur.buf; it.offA = 0;
+            it.tRowA = tRowsAct(cur, curIds, fh, fw, 1, BM, 0);
+            it.tColA = tColsConv(cur, 1, 1);
+            it.bufB = BUF_WEIGHTS; it.offB = bw.qkv.w;
+            it.tRowB = tRowsLinear(it.N, it.K, BN);
+            it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
+            it.bufC = BUF_QKV; it.offC = 0;
+            it.tRowC = tRowsLinear(it.M, 3 * C, BM);
+            it.tColC = tColsLinear(it.N / VSR_GG_KC, it.tilesN * BN / VSR_GG_KC);
+            it.offBias = bw.qkv.b;
+            it.bufR = -1; it.tRowR = -1;
+            op.flops = 2.0 * it.M * (double)it.N * it.K;
+            flops += op.flops;
+            op.gemm.push_back(it);
+            need(BUF_QKV, (int64_t)it.M * 3 * C);
+            ops.push_back(std::move(op));
+        }
+        addAttention(T, bw);
+        // x = x + LeakyReLU(conv3x3(att))            (auto_sttn.py:162-164,237)
+        addConv("attn.out", att, idT, x0, T, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIds);
+        // x = x + LeakyReLU(conv3x3(LeakyReLU(conv3x3 dil2(x))))   (auto_sttn.py:214-218,238)
+        addConv("ffn.1", x0, idT, f1, T, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr);
+        addConv("ffn.2", f1, idT, x1, T, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idT);
+        cur = x1;
+        curIds = idT;
+    }
+
+    // decoder on the neighbour frames only (sttn_auto_inpaint.py:150; auto_sttn.py:87-95,118-127)
+    const Act up1{BUF_UP1, nn, 2 * fh, 2 * fw, C, 1}, d1{BUF_D1, nn, 2 * fh, 2 * fw, 128, 1};
+    const Act d2{BUF_D2, nn, 2 * fh, 2 * fw, 64, 0}, up2{BUF_UP2, nn, mh, mw, 64, 1}, d3{BUF_D3, nn, mh, mw, 64, 1};
+    const std::vector<int> idN = iota(nn);
+    {
+        Op op;
+        op.kind = OP_UPSAMPLE2X; op.tag = "dec.up1";
+        op.bufSrc = x1.buf; op.H = fh; op.W = fw; op.C = C; op.haloS = x1.halo; op.bufDst = up1.buf; op.haloD = up1.halo;
+        op.n = nn;
+        need(up1.buf, up1.elems());
+        ops.push_back(std::move(op));
+    }
+    addConv("dec.1", up1, idN, d1, nn, 3, 1, 1, m_.dec[0], VSR_ACT_LRELU02, nullptr, nullptr);
+    addConv("dec.2", d1, idN, d2, nn, 3, 1, 1, m_.dec[1], VSR_ACT_LRELU02, nullptr, nullptr);
+    {
+        Op op;
+        op.kind = OP_UPSAMPLE2X; op.tag = "dec.up2";
+        op.bufSrc = d2.buf; op.H = 2 * fh; op.W = 2 * fw; op.C = 64; op.haloS = d2.halo; op.bufDst = up2.buf;
+        op.haloD = up2.halo; op.n = nn;
+        need(up2.buf, up2.elems());
+        ops.push_back(std::move(op));
+    }
+    addConv("dec.3", up2, idN, d3, nn, 3, 1, 1, m_.dec[2], VSR_ACT_LRELU02, nullptr, nullptr);
+    {   // 64 -> 3 conv into a plain [M][32] buffer (columns 0..2 valid)
+        const ConvW& w = m_.dec[3];
+        Op op;
+        op.kind = OP_GEMM; op.tag = "dec.4"; op.tileCfg = VSR_TILE_256x32; op.bmode = VSR_BMODE_NK;
+        const int BM = 256, BN = 32;
+        GemmItem it{};
+        it.M = nn * mh * mw; it.N = w.cout; it.K = w.K;
+        it.tilesM = cdiv(it.M, BM); it.tilesN = 1;
+        it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
+        it.bufA = d3.buf; it.offA = 0;
+        it.tRowA = tRowsAct(d3, idN, mh, mw, 1, BM, 0);
+        it.tColA = tColsConv(d3, 3, 1);
+        it.bufB = BUF_WEIGHTS; it.offB = w.w;
+        it.tRowB = tRowsLinear(it.N, it.K, BN);
+        it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
+        it.bufC = BUF_D4; it.offC = 0;
+        it.tRowC = tRowsLinear(it.M, 32, BM);
+        it.tColC = tColsLinear(1, 1);
+        it.offBias = w.b;
+        it.bufR = -1; it.tRowR = -1;
+        op.flops = 2.0 * it.M * (double)it.N * it.K;
+        flops += op.flops;
+        op.gemm.push_back(it);
+        need(BUF_D4, (int64_t)it.M * 32);
+        ops.push_back(std::move(op));
+    }
+    {
+        Op op;
+        op.kind = OP_DECODE_OUT; op.tag = "dec.out";
+        op.bufSrc = BUF_D4; op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
+        std::vector<int32_t> fi, fs;
+        for (int i = 0; i < nn; ++i) {
+            fi.push_back(neighbors[i]);
+            fs.push_back(visits[neighbors[i]] == 0 ? 1 : 0);
+            visits[neighbors[i]]++;
+        }
+        std::string k1 = "FI:", k2 = "FS:";
+        for (int v : fi) k1 += std::to_string(v) + ",";
+        for (int v : fs) k2 += std::to_string(v) + ",";
+        op.tFrameIdx = table(k1, std::move(fi));
+        op.tFirst = table(k2, std::move(fs));
+        ops.push_back(std::move(op));
+    }
+    need(BUF_X0, x0.elems());
+    need(BUF_X1, x1.elems());
+    need(BUF_F1, f1.elems());
+    ++nwindows;
+}
+
+Plan::Plan(const Model& model, int L_) : L(L_), g(model.g), m_(model)
+{
+    if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
+    if (L <= 0) throw std::runtime_error("empty frame list");
+    bufElems.assign(BUF_COUNT, 0);
+    bufElems[BUF_WEIGHTS] = (int64_t)model.packed.size();
+    const int mh = g.modelH, mw = g.modelW, fh = g.featH, fw = g.featW, C = g.channels;
+    need(BUF_IN_U8, (int64_t)L * mh * mw * 3);
+    need(BUF_COMP, (int64_t)L * mh * mw * 3);
+    const Act e1{BUF_E1, L, mh / 2, mw / 2, 64, 1}, e2{BUF_E2, L, mh / 2, mw / 2, 64, 1};
+    const Act e3{BUF_E3, L, fh, fw, 128, 1}, feats{BUF_FEATS, L, fh, fw, C, 2};
+    const std::vector<int> idL = iota(L);
+    {   // Stack/ToTorchFormatTensor/*2-1 fused with the im2col of encoder conv1
+        Op op;
+        op.kind = OP_NORM_IM2COL; op.tag = "enc.im2col";
+        op.bufSrc = BUF_IN_U8; op.bufDst = BUF_IM2COL; op.H = mh; op.W = mw; op.n = L; op.premask = 0;
+        need(BUF_IM2COL, (int64_t)L * (mh / 2) * (mw / 2) * 32);
+        ops.push_back(std::move(op));
+    }
+    {   // encoder conv1 3->64 s2 as a plain GEMM over the im2col rows (K = 27 padded to 32)
+        const ConvW& w = model.enc[0];
+        Op op;
+        op.kind = OP_GEMM; op.tag = "enc.1"; op.tileCfg = VSR_TILE_256x64; op.bmode = VSR_BMODE_NK;
+        const int BM = 256, BN = 64;
+        GemmItem it{};
+        it.M = L * e1.H * e1.W; it.N = w.cout; it.K = w.K;
+        it.tilesM = cdiv(it.M, BM); it.tilesN = cdiv(it.N, BN);
+        it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_LRELU02;
+        it.bufA = BUF_IM2COL; it.offA = 0;
+        it.tRowA = tRowsLinear(it.M, 32, BM);
+        it.tColA = tColsLinear(1, 1);
+        it.bufB = BUF_WEIGHTS; it.offB = w.w;
+        it.tRowB = tRowsLinear(it.N, it.K, BN);
+        it.tColB = tColsLinear(1, 1);
+        it.bufC = e1.buf; it.offC = 0;
+        it.tRowC = tRowsAct(e1, idL, e1.H, e1.W, 1, BM, 0);
+        it.tColC = tColsLinear(it.N / VSR_GG_KC, it.tilesN * BN / VSR_GG_KC);
+        it.offBias = w.b;
+        it.bufR = -1; it.tRowR = -1;
+        op.flops = 2.0 * it.M * (double)it.N * 27;
+        flops += op.flops;
+        op.gemm.push_back(it);
+        need(e1.buf, e1.elems());
+        ops.push_back(std::move(op));
+    }
+    addConv("enc.2", e1, idL, e2, L, 3, 1, 1, model.enc[1], VSR_ACT_LRELU02, nullptr, nullptr);
+    addConv("enc.3", e2, idL, e3, L, 3, 2, 1, model.enc[2], VSR_ACT_LRELU02, nullptr, nullptr);
+    addConv("enc.4", e3, idL, feats, L, 3, 1, 1, model.enc[3], VSR_ACT_LRELU02, nullptr, nullptr);
+
+    std::vector<int32_t> visits(L, 0);
+    const int ns = g.neighborStride;
+    for (int f = 0; f < L; f += ns) {
+        std::vector<int> neighbors, refs;
+        for (int i = (f - ns > 0 ? f - ns : 0); i < (f + ns + 1 < L ? f + ns + 1 : L); ++i) neighbors.push_back(i);
+        for (int i = 0; i < L; i += g.refLength) { // get_ref_index (sttn_auto_inpaint.py:107-120)
+            bool inN = false;
+            for (int n : neighbors) inN |= (n == i);
+            if (!inN) refs.push_back(i);
+        }
+        buildWindow(neighbors, refs, visits);
+    }
+    compCount = visits;
+}
+
+// ------------------------------------------------------------------------------------
+void cv2_linear_tables(int ssize, int dsize, bool clampX, std::vector<int32_t>& ofs, std::vector<int16_t>& icoef,
+                       std::vector<float>& fcoef)
+{
+    const double inv_scale = (double)dsize / (double)ssize;
+    const double scale = 1.0 / inv_scale;
+    ofs.resize(dsize);
+    icoef.resize(2 * (size_t)dsize);
+    fcoef.resize(2 * (size_t)dsize);
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (clampX) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        const float c0 = 1.f - f, c1 = f;
+        fcoef[2 * d] = c0;
+        fcoef[2 * d + 1] = c1;
+        auto sat = [](float v) {
+            long r = lrintf(v * 2048.f); // saturate_cast<short>(float) = cvRound (nearest-even) + clamp
+            if (r > 32767) r = 32767;
+            if (r < -32768) r = -32768;
+            return (int16_t)r;
+        };
+        icoef[2 * d] = sat(c0);
+        icoef[2 * d + 1] = sat(c1);
+    }
+}
+
+} // namespace vsr

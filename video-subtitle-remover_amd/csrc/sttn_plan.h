@@ -1,0 +1,140 @@
+// Host-side description of one STTNInpaint.inpaint() call (reference
+// backend/inpaint/sttn_auto_inpaint.py:122-164) as a flat list of device ops over
+// symbolic buffers and offset tables.  Pure C++ (no HIP): the engine (sttn_engine.hip)
+// materialises it on the GPU; tests read it back through the vsr_plan_* C entry points and
+// replay it on the CPU against the oracle, which checks every table / descriptor / schedule
+// decision without a GPU.
+#pragma once
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace vsr {
+
+// ---- network geometry (auto: auto_sttn.py:64-95 ; det: network_sttn.py:64-95) ----
+struct Geometry {
+    int variant;            // 0 = sttn-auto, 1 = sttn-det
+    int modelW, modelH;     // 640x120 (sttn_auto_inpaint.py:39) / 432x240 (sttn_det_inpaint.py)
+    int featW, featH;       // model / 4
+    int channels;           // 256
+    int blocks;             // 8
+    int nscales;            // 4
+    int patchW[4], patchH[4];
+    int neighborStride;     // config.sttnNeighborStride (5)
+    int refLength;          // config.sttnReferenceLength (10)
+    static Geometry make(int variant);
+};
+
+// ---- packed weights ----
+struct ConvW {
+    int64_t w = -1, b = -1; // element offsets into the packed weight buffer
+    int cout = 0, K = 0;    // packed as [cout][K], K = taps*cin (k = tap*cin + ci)
+};
+struct BlockW { ConvW qkv, out, ffn1, ffn2; };
+
+class Model {
+public:
+    explicit Model(int variant);
+    // name = reference state_dict key, data = fp32 contiguous, shape as in the checkpoint
+    bool set_param(const std::string& name, const float* data, const int64_t* shape, int ndim, std::string& err);
+    bool pack(std::string& err);             // all 112 tensors present -> packed buffer
+    bool packed_ready() const { return ready_; }
+    Geometry g;
+    ConvW enc[4], dec[4];
+    std::vector<BlockW> blk;
+    std::vector<float> packed;
+    static std::vector<std::string> expected_keys(int variant);
+private:
+    struct Raw { std::vector<float> v; std::vector<int64_t> shape; };
+    std::map<std::string, Raw> raw_;
+    bool ready_ = false;
+    bool pack_conv(const std::string& key, ConvW& cw, int cinPad, std::string& err);
+};
+
+// ---- plan IR ----
+enum BufId {
+    BUF_WEIGHTS = 0, BUF_IN_U8, BUF_IM2COL, BUF_E1, BUF_E2, BUF_E3, BUF_FEATS, BUF_X0, BUF_X1, BUF_QKV,
+    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_COUNT
+};
+
+enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4 };
+
+struct GemmItem {
+    int bufA, bufB, bufC, bufR;          // bufR = -1: no residual
+    int64_t offA, offB, offC, offR, offBias; // offBias (into BUF_WEIGHTS) = -1: none
+    int tRowA, tColA, tRowB, tColB, tRowC, tColC, tRowR; // table ids (tRowR = -1: none)
+    int M, N, K;
+    int tilesM, tilesN, splitK, chunksPerSplit;
+    int64_t splitStride;
+    float alpha;
+    int act;
+};
+struct SoftmaxItem {
+    int bufS, bufP;
+    int64_t offS, offP, splitStride;
+    int M, N, ldS, ldP, nsplit;
+    float scale;
+};
+struct Op {
+    int kind = 0;
+    int tileCfg = 0, bmode = 0;          // GEMM
+    std::vector<GemmItem> gemm;          // GEMM group
+    std::vector<SoftmaxItem> softmax;    // SOFTMAX group
+    // UPSAMPLE2X: src/dst buffers, H, W, C, halos, n ; DECODE_OUT: src, ldy, pix, n, tables
+    int bufSrc = -1, bufDst = -1, H = 0, W = 0, C = 0, haloS = 0, haloD = 0, n = 0;
+    int ldy = 0, pix = 0, tFrameIdx = -1, tFirst = -1;
+    int premask = 0;
+    double flops = 0;                    // algorithmic flops of this op (2*M*N*K, unpadded)
+    std::string tag;
+};
+
+struct Act {                              // NHWC activation with a physical zero halo
+    int buf, n, H, W, C, halo;
+    int Hp() const { return H + 2 * halo; }
+    int Wp() const { return W + 2 * halo; }
+    int64_t frameElems() const { return (int64_t)Hp() * Wp() * C; }
+    int64_t pix(int f, int y, int x) const { return (((int64_t)f * Hp() + y + halo) * Wp() + x + halo) * C; }
+    int64_t elems() const { return (int64_t)n * frameElems(); }
+};
+
+class Plan {
+public:
+    Plan(const Model& model, int L);
+    int L;
+    Geometry g;
+    std::vector<int64_t> bufElems;        // BUF_COUNT entries (BUF_IN_U8 in bytes, others floats)
+    std::vector<std::vector<int32_t>> tables;
+    std::vector<Op> ops;
+    std::vector<int32_t> compCount;       // decodes per frame (1 => comp stays u8)
+    double flops = 0;                     // algorithmic model flops of the whole call
+    int nwindows = 0;
+private:
+    const Model& m_;
+    std::map<std::string, int> tableKey_;
+    int table(const std::string& key, std::vector<int32_t>&& v);
+    int tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add);
+    int tColsConv(const Act& a, int ksz, int dil);
+    int tRowsLinear(int count, int ld, int padTo);
+    int tColsLinear(int nchunks, int padTo);
+    int tRowsTokens(int T, int s, int choff, int count, int padTo);
+    int tColsPatch(int s, int padTo);
+    int tRowsTokensAct(const Act& a, int T, int s, int padTo);
+    int tColsPatchAct(const Act& a, int s, int padTo);
+    void need(int buf, int64_t elems);
+    void addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut,
+                 int ksz, int stride, int dil, const ConvW& w, int act, const Act* res,
+                 const std::vector<int>* resIds);
+    void addAttention(int T, const BlockW& bw);
+    void buildWindow(const std::vector<int>& neighbors, const std::vector<int>& refs,
+                     std::vector<int32_t>& visits);
+};
+
+// cv2.resize INTER_LINEAR coefficient tables (OpenCV 4.11 imgproc/resize.cpp, resize()):
+// ofs[d], fixed-point (x2048, round-half-even) and float taps {1-f, f}.  clampX selects the
+// horizontal rule (index clamped, f reset to 0 at the borders); vertical keeps f and lets
+// the row index be clipped at use.
+void cv2_linear_tables(int ssize, int dsize, bool clampX, std::vector<int32_t>& ofs,
+                       std::vector<int16_t>& icoef, std::vector<float>& fcoef);
+
+} // namespace vsr

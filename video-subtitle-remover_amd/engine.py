@@ -1,0 +1,120 @@
+"""torch-tensor convenience layer over the C handle of libvsr_hip.so.
+
+PyTorch is plumbing here: device memory (tensors own the HBM buffers handed to the C-ABI as
+raw pointers), the current HIP stream and, for multi-GPU, torch.distributed.  All arithmetic
+of the hot path happens inside the library's hand-written kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if lib.vsr_device_count() <= 0 or not torch.cuda.is_available():
+        raise _lib.VsrError(_lib.VSR_ERR_NOGPU, "no HIP device visible: the MI355X path has no CPU fallback")
+
+
+class SttnEngine:
+    """One STTN generator resident on one GPU (weights + workspace), bound to the caller's stream."""
+
+    def __init__(self, state_dict, variant="auto", device=0, neighbor_stride=None, ref_length=None):
+        self.variant = variant
+        self._h = C.c_void_p()
+        check(lib.vsr_sttn_create(_lib.VARIANT[variant], C.byref(self._h)))
+        try:
+            for key, val in state_dict.items():
+                arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                shape = (C.c_int64 * arr.ndim)(*arr.shape)
+                check(lib.vsr_sttn_set_param(self._h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+            if device is not None and device >= 0:
+                require_gpu()
+            self.device_index = -1 if device is None else int(device)
+            check(lib.vsr_sttn_finalize(self._h, self.device_index))
+            if neighbor_stride is not None or ref_length is not None:
+                mw, mh, ns, rl = self.geometry()
+                check(lib.vsr_sttn_set_window(self._h, neighbor_stride or ns, ref_length or rl))
+        except Exception:
+            lib.vsr_sttn_destroy(self._h)
+            self._h = None
+            raise
+        self.device = torch.device("cuda", self.device_index) if self.device_index >= 0 else torch.device("cpu")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vsr_sttn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def geometry(self):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.vsr_sttn_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    def flops(self, L):
+        v = lib.vsr_sttn_flops(self._h, int(L))
+        if v < 0:
+            raise _lib.VsrError(_lib.VSR_ERR_ARG, _lib.last_error())
+        return v
+
+    def packed_weights(self):
+        n = lib.vsr_sttn_packed_weights(self._h, None, 0)
+        out = np.empty(n, dtype=np.float32)
+        lib.vsr_sttn_packed_weights(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    # ---- hot path -------------------------------------------------------------------------
+    def inpaint(self, frames_dev):
+        """STTNInpaint.inpaint: frames_dev uint8 [L,mh,mw,3] BGR on the GPU -> (comp f32 [L,mh,mw,3] RGB, counts)."""
+        assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
+        L = frames_dev.shape[0]
+        comp = torch.empty(frames_dev.shape, dtype=torch.float32, device=frames_dev.device)
+        counts = np.zeros(L, dtype=np.int32)
+        with torch.cuda.device(frames_dev.device):
+            check(lib.vsr_sttn_inpaint(self._h, C.c_void_p(frames_dev.data_ptr()), L, C.c_void_p(comp.data_ptr()),
+                                       counts.ctypes.data_as(C.c_void_p), _stream_ptr()))
+        return comp, counts
+
+    def auto_chunk(self, frames_dev, mask_dev, areas, sel=None):
+        """One chunk of STTNAutoInpaint.__call__, in place on frames_dev uint8 [L,H,W,3] BGR."""
+        assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
+        assert mask_dev.dtype == torch.uint8 and mask_dev.is_cuda and mask_dev.is_contiguous()
+        L, H, W, _ = frames_dev.shape
+        assert tuple(mask_dev.shape[:2]) == (H, W)
+        ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
+        sel_arr = None if sel is None else np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
+        with torch.cuda.device(frames_dev.device):
+            check(lib.vsr_sttn_auto_chunk(
+                self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()), ar.shape[0],
+                ar.ctypes.data_as(C.c_void_p), None if sel_arr is None else sel_arr.ctypes.data_as(C.c_void_p),
+                0 if sel_arr is None else int(sel_arr.size), _stream_ptr()))
+        return frames_dev
+
+    # ---- measurement ----------------------------------------------------------------------
+    def timing(self, enable=True):
+        check(lib.vsr_sttn_timing(self._h, 1 if enable else 0))
+
+    def timing_reset(self):
+        check(lib.vsr_sttn_timing_reset(self._h))
+
+    def timing_get(self, prefix=""):
+        ms, n, fl = C.c_double(), C.c_int32(), C.c_double()
+        check(lib.vsr_sttn_timing_get(self._h, prefix.encode(), C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
