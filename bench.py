@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: inpainted frames/sec @1080p, STTN (sttn-auto), 5-frame window stride.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one chunk: ``clip_gap`` (50) synthetic 1080p frames
+already resident in HBM go through vsr_sttn_auto_chunk (crop strip -> cv2-style resize to 640x120
+-> encoder -> 10 sliding windows x 8 transformer blocks -> decoder -> tanh/u8/overlap average ->
+resize back -> mask blend, in place).  Chunks are independent (sttn_auto_inpaint.py:242-328), so
+with N GPUs every rank runs its own chunks and no data-path collective exists ("weak" scaling:
+per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel (gather_gemm_f32<128,128,NK> running the 3x3 256->256 convs:
+                  59 % of the model FLOPs), algorithmic FLOPs / HIP-event time on the launch stream
+                  against the 157.3 TFLOP/s fp32 MFMA peak of MI355X_MICROARCH.md.
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference modules, "port") timed on
+                  this box's host cores on a bounded sample, scaled to frames/s of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+RES = {"720p": (720, 1280, (620, 700, 192, 1088)), "1080p": (1080, 1920, (950, 1070, 288, 1632)),
+       "4k": (2160, 3840, (1900, 2140, 576, 3264))}
+
+
+def make_chunk_on_device(L, H, W, box, seed, device):
+    """Seeded synthetic clip (vsr_amd.synth) -- 10 generated frames, extended to L by rolling."""
+    from vsr_amd import synth
+
+    base = synth.make_clip(min(L, 10), H, W, box, seed=seed)
+    d = torch.from_numpy(base).to(device)
+    reps = [torch.roll(d, shifts=(3 * k, 5 * k), dims=(1, 2)) for k in range((L + base.shape[0] - 1) // base.shape[0])]
+    return torch.cat(reps, 0)[:L].contiguous()
+
+
+def cpu_baseline(sd, flops_per_frame, sample_frames):
+    """Oracle timed on the host cores: STTNInpaint.inpaint on `sample_frames` model-res frames."""
+    from oracle.sttn_auto import STTNInpaintOracle
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    o = STTNInpaintOracle(sd, "auto")
+    frames = np.random.default_rng(0).integers(0, 256, size=(sample_frames, 120, 640, 3), dtype=np.uint8)
+    t0 = time.perf_counter()
+    ref = o.inpaint(list(frames))
+    dt = time.perf_counter() - t0
+    return o, frames, ref, dt, threads
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", default="1080p", choices=sorted(RES))
+    ap.add_argument("--chunk", type=int, default=50, help="frames per chunk (config.sttnMaxLoadNum)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import vsr_amd  # noqa: F401
+    from vsr_amd.backend.tools.inpaint_tools import create_mask, get_inpaint_area_by_mask, threshold_mask
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict      # stand-in checkpoint (the real .pth files are missing blobs)
+
+    H, W, box = RES[args.res]
+    L = args.chunk
+    sd = make_state_dict(0, "auto")
+    eng = SttnEngine(sd, "auto", device=local_rank)
+    mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
+    mask01 = threshold_mask(mask)
+    areas = get_inpaint_area_by_mask(W, H, int(W * 3 / 16), mask01)
+    dmask = torch.from_numpy(np.ascontiguousarray(mask01[:, :, 0])).to(device)
+    src = make_chunk_on_device(L, H, W, box, seed=1 + rank, device=device)
+    work = src.clone()
+
+    def step():
+        work.copy_(src)                          # device-to-device restore of the in-place chunk
+        eng.auto_chunk(work, dmask, areas)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # per-op HIP events on the launch stream during the timed region (one record pair per launch;
+    # ~1300 launches per chunk, read back once per chunk) -- feeds the roofline object
+    eng.timing(True)
+    eng.timing_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = args.steps * L * world
+    fps = total_frames / elapsed
+    flops_chunk = eng.flops(L)
+    flops_per_frame = flops_chunk / L
+
+    out = {
+        "metric": "inpainted frames/sec @1080p (STTN, 5-frame window)" if args.res == "1080p"
+        else f"inpainted frames/sec @{args.res} (STTN, 5-frame window)",
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.res} synthetic clip, --inpaint-mode sttn-auto, {L}-frame chunks resident in HBM, "
+                               f"neighbor stride 5 / refs every 10 (BASELINE.json metric; model cost is resolution-independent)",
+                   "frame_size": [W, H], "strip": [W, int(W * 3 / 16)], "chunk_frames": L, "parallelism": f"chunk-parallel x{world}",
+                   "weights": "synthetic variance-preserving (no checkpoint in the reference mount)"},
+        "model_tflops": round(flops_per_frame * fps / 1e12, 3),
+        "gflop_per_frame": round(flops_per_frame / 1e9, 2),
+    }
+
+    eng.timing(False)
+    if rank == 0:
+        # ---- roofline of the dominant kernel from the HIP events of the timed region
+        ms = n = fl = 0.0
+        for tag in ("attn.out", "ffn.1", "ffn.2"):
+            a, b, c = eng.timing_get(tag)
+            ms, n, fl = ms + a, n + b, fl + c
+        breakdown = {}
+        for tag in ("enc", "attn.qkv", "attn.qk", "attn.softmax", "attn.pv", "attn.out", "ffn", "dec"):
+            a, b, c = eng.timing_get(tag)
+            breakdown[tag] = {"ms": round(a, 3), "launches": b, "tflops": round(c / a / 1e9, 2) if a > 0 and c > 0 else None}
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "conv3x3_pmc.json")     # PMC passes are separate rocprofv3 runs
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ach = fl / ms / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "gather_gemm_f32<128,128,2,2,NK> (conv3x3 256->256 + bias + LeakyReLU + residual)",
+                           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "launches": int(n), "avg_launch_ms": round(ms / n, 4) if n else None,
+                           "flops_per_launch": round(fl / n) if n else None}
+        out["op_breakdown_timed_region"] = breakdown
+
+        if not args.no_cpu_baseline:
+            o, frames, ref, dt, threads = cpu_baseline(sd, flops_per_frame, args.cpu_sample_frames)
+            sample_flops = eng.flops(args.cpu_sample_frames)
+            cpu_fps = (sample_flops / dt) / flops_per_frame
+            comp, counts = eng.inpaint(torch.from_numpy(frames).to(device))
+            torch.cuda.synchronize()
+            refa = np.stack([r.astype(np.float32) for r in ref])
+            mse = float(np.mean((comp.cpu().numpy().astype(np.float64) - refa) ** 2))
+            psnr = float("inf") if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
+            out["cpu_baseline"] = {
+                "value": round(cpu_fps, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": f"oracle STTNInpaint.inpaint (torch-CPU fp32 restatement of the reference modules) on "
+                          f"{args.cpu_sample_frames} model-resolution frames ({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s), "
+                          f"scaled by FLOPs to the {flops_per_frame / 1e9:.1f} GFLOP/frame of a {L}-frame chunk"}
+            out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,7 +40,7 @@ def _sample(t, n=4096, seed=123):
 
 
 def main():
-    from oracle.weights import make_state_dict
+    from vsr_amd.synth import make_state_dict
 
     os.makedirs(OUT, exist_ok=True)
     auto_sttn, network_sttn, inpaint_tools = _import_reference()

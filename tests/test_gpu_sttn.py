@@ -1,0 +1,142 @@
+"""End-to-end parity of the HIP path (through the C-ABI) against the CPU oracle, plus the
+size-independent properties checked at BASELINE.json's full chunk size."""
+import numpy as np
+import pytest
+import torch
+
+from vsr_amd import synth
+from oracle.sttn_auto import (STTNInpaintOracle, calculate_psnr, create_mask, get_inpaint_area_by_mask)
+from oracle import cv2_restate as cv2r
+from vsr_amd.synth import make_state_dict
+
+pytestmark = pytest.mark.gpu
+
+PSNR_MIN_DB = 50.0      # BASELINE.json north_star: >= 50 dB PSNR vs the reference CPU path
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return make_state_dict(0, "auto")
+
+
+def _engine(sd, **kw):
+    from vsr_amd.engine import SttnEngine
+
+    return SttnEngine(sd, "auto", device=0, **kw)
+
+
+def _compare_comp(got, ref_list, counts):
+    ref = np.stack([r.astype(np.float32) for r in ref_list])
+    for i, r in enumerate(ref_list):
+        assert (r.dtype == np.uint8) == (counts[i] == 1)
+    d = np.abs(got - ref)
+    psnr = calculate_psnr(got, ref)
+    return psnr, d.max(), (d > 0).mean()
+
+
+def test_inpaint_small_windows_vs_oracle(built_lib, gpu_device, sd):
+    """STTNInpaint.inpaint on 6 frames, stride 2 / refs every 3 (3 windows, T=4,5,5)."""
+    eng = _engine(sd, neighbor_stride=2, ref_length=3)
+    frames = np.random.default_rng(11).integers(0, 256, size=(6, 120, 640, 3), dtype=np.uint8)
+    comp, counts = eng.inpaint(torch.from_numpy(frames).to(gpu_device))
+    torch.cuda.synchronize()
+    ref = STTNInpaintOracle(sd, "auto", 2, 3).inpaint(list(frames))
+    psnr, dmax, frac = _compare_comp(comp.cpu().numpy(), ref, counts)
+    print(f"psnr={psnr:.2f} dB max|d|={dmax} frac_diff={frac:.2e}")
+    assert counts.tolist() == [2, 2, 3, 2, 2, 1]
+    assert psnr >= PSNR_MIN_DB
+    assert dmax <= 2.0 and frac < 5e-3     # fp32 everywhere: only truncation-boundary flips
+    eng.close()
+
+
+def test_inpaint_default_windows_vs_oracle(built_lib, gpu_device, sd):
+    """Default schedule (stride 5, refs every 10) on a moving synthetic strip, 12 frames."""
+    eng = _engine(sd)
+    clip = synth.make_clip(12, 120, 640, (30, 90, 60, 580), seed=2)
+    comp, counts = eng.inpaint(torch.from_numpy(clip).to(gpu_device))
+    torch.cuda.synchronize()
+    ref = STTNInpaintOracle(sd, "auto").inpaint(list(clip))
+    psnr, dmax, frac = _compare_comp(comp.cpu().numpy(), ref, counts)
+    print(f"psnr={psnr:.2f} dB max|d|={dmax} frac_diff={frac:.2e}")
+    assert psnr >= PSNR_MIN_DB and dmax <= 2.0
+    eng.close()
+
+
+@pytest.mark.parametrize("H,W,box", [(720, 1280, (620, 700, 192, 1088)), (1080, 1920, (950, 1070, 288, 1632))])
+def test_auto_chunk_vs_oracle(built_lib, gpu_device, sd, H, W, box):
+    """One chunk of STTNAutoInpaint.__call__ (crop, cv2.resize, inpaint, resize back, blend)."""
+    eng = _engine(sd, neighbor_stride=2, ref_length=3)
+    L = 6
+    clip = synth.make_clip(L, H, W, box, seed=H)
+    ymin, ymax, xmin, xmax = box
+    mask = create_mask((H, W), [(xmin, xmax, ymin, ymax)])
+    mask01 = cv2r.threshold_binary(mask, 127, 1)
+    split_h = int(W * 3 / 16)
+    areas = get_inpaint_area_by_mask(W, H, split_h, mask01[:, :, None])
+    assert len(areas) == 1 and areas[0][1] - areas[0][0] == split_h
+    dfr = torch.from_numpy(clip).to(gpu_device)
+    eng.auto_chunk(dfr, torch.from_numpy(mask01).to(gpu_device), areas)
+    torch.cuda.synchronize()
+    got = dfr.cpu().numpy()
+    ref = np.stack(STTNInpaintOracle(sd, "auto", 2, 3).chunk(list(clip), mask01[:, :, None], areas))
+    m = mask01.astype(bool)
+    assert np.array_equal(got[:, ~m], clip[:, ~m]), "pixels outside the mask must be untouched"
+    psnr_masked = calculate_psnr(got[:, m], ref[:, m])
+    psnr_frame = calculate_psnr(got, ref)
+    print(f"{W}x{H}: PSNR masked strip pixels {psnr_masked:.2f} dB, whole frame {psnr_frame:.2f} dB")
+    assert psnr_masked >= PSNR_MIN_DB
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 2
+    eng.close()
+
+
+def test_auto_chunk_frame_selection_and_two_areas(built_lib, gpu_device, sd):
+    """A/B-section selection (only some frames of the chunk are inpainted) and two strips."""
+    eng = _engine(sd, neighbor_stride=2, ref_length=3)
+    H, W, L = 480, 852, 7
+    clip = synth.make_clip(L, H, W, (400, 450, 100, 760), seed=5)
+    mask = create_mask((H, W), [(100, 760, 400, 450), (200, 600, 30, 60)])
+    mask01 = cv2r.threshold_binary(mask, 127, 1)
+    split_h = int(W * 3 / 16)
+    areas = get_inpaint_area_by_mask(W, H, split_h, mask01[:, :, None])
+    assert len(areas) == 2
+    sel = [1, 2, 4, 5, 6]
+    dfr = torch.from_numpy(clip).to(gpu_device)
+    eng.auto_chunk(dfr, torch.from_numpy(mask01).to(gpu_device), areas, sel=sel)
+    torch.cuda.synchronize()
+    got = dfr.cpu().numpy()
+    ref = np.stack(STTNInpaintOracle(sd, "auto", 2, 3).chunk(list(clip), mask01[:, :, None], areas, sel=sel))
+    assert np.array_equal(got[[0, 3]], clip[[0, 3]]), "unselected frames pass through"
+    m = mask01.astype(bool)
+    assert calculate_psnr(got[sel][:, m], ref[sel][:, m]) >= PSNR_MIN_DB
+    eng.close()
+
+
+def test_full_chunk_properties_1080p(built_lib, gpu_device, sd):
+    """BASELINE size (50-frame 1080p chunk): properties that need no 70-second CPU oracle run:
+    determinism, untouched unmasked pixels, and workspace-halo integrity across plan changes."""
+    eng = _engine(sd)
+    H, W, L = 1080, 1920, 50
+    box = (950, 1070, 288, 1632)
+    clip = synth.make_clip(L, H, W, box, seed=3)
+    mask01 = cv2r.threshold_binary(create_mask((H, W), [(box[2], box[3], box[0], box[1])]), 127, 1)
+    areas = get_inpaint_area_by_mask(W, H, int(W * 3 / 16), mask01[:, :, None])
+    dmask = torch.from_numpy(mask01).to(gpu_device)
+
+    def run(frames):
+        d = torch.from_numpy(frames).to(gpu_device)
+        eng.auto_chunk(d, dmask, areas)
+        torch.cuda.synchronize()
+        return d.cpu().numpy()
+
+    a = run(clip)
+    small = run(clip[:7])            # a different L re-plans and reuses the same workspace
+    b = run(clip)
+    assert np.array_equal(a, b), "same input must give the same bytes after the workspace was reused"
+    m = mask01.astype(bool)
+    assert np.array_equal(a[:, ~m], clip[:, ~m])
+    assert (a[:, m] != clip[:, m]).mean() > 0.5, "masked pixels are actually replaced"
+    assert small.shape[0] == 7
+    # the first window of a 50-frame chunk and of its 7-frame prefix see different references,
+    # so only sanity is asserted on `small`; the strip is fully rewritten inside the mask
+    assert (small[:, m] != clip[:7][:, m]).mean() > 0.5
+    eng.close()

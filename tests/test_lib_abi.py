@@ -30,7 +30,7 @@ def test_no_cpu_fallback(built_lib):
     lib = built_lib.lib
     if lib.vsr_device_count() > 0:
         pytest.skip("GPU present")
-    from oracle.weights import make_state_dict
+    from vsr_amd.synth import make_state_dict
     from vsr_amd.engine import SttnEngine
 
     with pytest.raises(built_lib.VsrError):
@@ -46,7 +46,7 @@ def test_no_cpu_fallback(built_lib):
 
 
 def test_strict_state_dict(built_lib):
-    from oracle.weights import make_state_dict
+    from vsr_amd.synth import make_state_dict
     from vsr_amd.engine import SttnEngine
 
     sd = make_state_dict(0)
@@ -67,7 +67,7 @@ def test_strict_state_dict(built_lib):
 
 def test_weight_packing_layout(built_lib):
     """[Cout][Cin][3][3] -> [Cout][(ky*3+kx)*Cin + ci]; fused QKV rows = query | key | value."""
-    from oracle.weights import make_state_dict
+    from vsr_amd.synth import make_state_dict
     from vsr_amd.engine import SttnEngine
 
     sd = make_state_dict(5)

@@ -7,7 +7,7 @@ import torch
 
 from oracle import sttn_auto
 from oracle.sttn_net import SttnNet
-from oracle.weights import make_state_dict, state_dict_spec
+from vsr_amd.synth import make_state_dict, state_dict_spec
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RTOL = 2e-4   # the fixtures were made on another CPU: oneDNN/MKL kernels differ in summation order

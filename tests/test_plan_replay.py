@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle.sttn_auto import STTNInpaintOracle, calculate_psnr
-from oracle.weights import make_state_dict
+from vsr_amd.synth import make_state_dict
 
 from _replay import PlanView, replay
 

@@ -1,0 +1,158 @@
+"""sttn-auto plugins with the reference's signatures, running on the MI355X engine.
+
+Mirrors backend/inpaint/sttn_auto_inpaint.py:
+  STTNInpaint(device, model_path)                         :28-41
+      __call__(input_frames, input_mask) -> frames        :43-97   (generic plugin contract)
+      inpaint(frames) -> comp frames                      :122-164
+      get_ref_index(neighbor_ids, length)                 :107-120
+  STTNAutoInpaint(device, model_path, video_path, mask_path=None, clip_gap=None)   :182-197
+      __call__(input_mask=None, input_sub_remover=None, tbar=None)                 :199-336
+
+Arithmetic happens in libvsr_hip.so (there is no torch model and no CPU path here); this file
+is the host loop: move a chunk of frames to HBM, one C call per chunk, move it back, write.
+``model_path`` may also be an already loaded state_dict (the shipped checkpoints are absent
+from the reference mount); ``video_path`` may be an ArrayVideo.
+"""
+import gc
+import os
+
+import numpy as np
+import torch
+
+from ..config import config
+from ..tools.inpaint_tools import get_inpaint_area_by_mask, is_frame_number_in_ab_sections, threshold_mask
+from ..tools.video_io import ArrayWriter, open_video
+from ...engine import SttnEngine
+
+
+def _load_state_dict(model_path):
+    if isinstance(model_path, dict):
+        return model_path.get("netG", model_path)
+    return torch.load(model_path, map_location="cpu")["netG"]      # sttn_auto_inpaint.py:34
+
+
+def _device_index(device):
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"the MI355X path needs a HIP device, got '{device}' (no CPU fallback)")
+    return 0 if d.index is None else d.index
+
+
+class STTNInpaint:
+    def __init__(self, device, model_path):
+        self.device = device
+        self.neighbor_stride = config.sttnNeighborStride.value
+        self.ref_length = config.sttnReferenceLength.value
+        self.engine = SttnEngine(_load_state_dict(model_path), "auto", device=_device_index(device),
+                                 neighbor_stride=self.neighbor_stride, ref_length=self.ref_length)
+        self.model_input_width, self.model_input_height = 640, 120
+
+    def __call__(self, input_frames, input_mask):
+        mask = threshold_mask(input_mask)
+        H_ori, W_ori = mask.shape[:2]
+        split_h = int(W_ori * 3 / 16)
+        inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask)
+        if not inpaint_area or len(input_frames) == 0:
+            return [f.copy() for f in input_frames]
+        dev = self.engine.device
+        frames = torch.from_numpy(np.ascontiguousarray(np.stack(input_frames))).to(dev, non_blocking=True)
+        dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(dev, non_blocking=True)
+        self.engine.auto_chunk(frames, dmask, inpaint_area)
+        out = frames.cpu().numpy()
+        return [out[i] for i in range(out.shape[0])]
+
+    @staticmethod
+    def read_mask(path):
+        from PIL import Image
+
+        img = np.array(Image.open(path).convert("L"))
+        return threshold_mask(img)
+
+    def get_ref_index(self, neighbor_ids, length):
+        return [i for i in range(0, length, self.ref_length) if i not in neighbor_ids]
+
+    def inpaint(self, frames):
+        """frames: list of 120x640x3 uint8 BGR -> list of comp frames (uint8 where decoded once, else float32), RGB."""
+        dev = self.engine.device
+        d = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(dev)
+        comp, counts = self.engine.inpaint(d)
+        comp = comp.cpu().numpy()
+        return [comp[i].astype(np.uint8) if counts[i] == 1 else comp[i] for i in range(len(frames))]
+
+
+class STTNAutoInpaint:
+    def __init__(self, device, model_path, video_path, mask_path=None, clip_gap=None):
+        self.sttn_inpaint = STTNInpaint(device, model_path)
+        self.video_path = video_path
+        self.mask_path = mask_path
+        if isinstance(video_path, (str, os.PathLike)):
+            self.video_out_path = os.path.join(
+                os.path.dirname(os.path.abspath(video_path)),
+                f"{os.path.basename(video_path).rsplit('.', 1)[0]}_no_sub.mp4")
+        else:
+            self.video_out_path = None
+        self.clip_gap = config.getSttnMaxLoadNum() if clip_gap is None else clip_gap
+        self.writer = None
+
+    def __call__(self, input_mask=None, input_sub_remover=None, tbar=None):
+        reader = None
+        writer = None
+        try:
+            reader = open_video(self.video_path)
+            frame_info = reader.info()
+            if input_sub_remover is not None:
+                ab_sections = input_sub_remover.ab_sections
+                writer = input_sub_remover.video_writer
+            else:
+                ab_sections = None
+                writer = ArrayWriter()
+            self.writer = writer
+            W_ori, H_ori = frame_info["W_ori"], frame_info["H_ori"]
+            split_h = int(W_ori * 3 / 16)
+            mask = self.sttn_inpaint.read_mask(self.mask_path) if input_mask is None else threshold_mask(input_mask)
+            inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask)
+            # the reference clamps clip_gap by free VRAM / (W*H*12 B) (:228-238); 288 GB never binds
+            clip_gap = self.clip_gap
+            engine = self.sttn_inpaint.engine
+            dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(engine.device)
+            total = frame_info["len"]
+            rec_time = total // clip_gap if total % clip_gap == 0 else total // clip_gap + 1
+            for i in range(rec_time):
+                start_f, end_f = i * clip_gap, min((i + 1) * clip_gap, total)
+                frames_hr, sel = [], []
+                for j in range(start_f, end_f):
+                    ok, image = reader.read()
+                    if not ok:
+                        print(f"Warning: Failed to read frame {j}.")
+                        break
+                    frames_hr.append(image)
+                    if is_frame_number_in_ab_sections(j, ab_sections):
+                        sel.append(j - start_f)
+                if not frames_hr:
+                    print(f"Warning: No valid frames found in range {start_f + 1}-{end_f}. Skipping this segment.")
+                    continue
+                originals = frames_hr if (input_sub_remover is not None and getattr(input_sub_remover, "gui_mode", False)) else None
+                if inpaint_area and sel:
+                    d = torch.from_numpy(np.ascontiguousarray(np.stack(frames_hr))).to(engine.device, non_blocking=True)
+                    engine.auto_chunk(d, dmask, inpaint_area, sel=None if len(sel) == len(frames_hr) else sel)
+                    out = d.cpu().numpy()
+                else:
+                    out = frames_hr
+                for j in range(len(frames_hr)):
+                    writer.write(out[j])
+                    if input_sub_remover is not None:
+                        if tbar is not None:
+                            input_sub_remover.update_progress(tbar, increment=1)
+                        if originals is not None:
+                            input_sub_remover.update_preview_with_comp(originals[j], out[j])
+                del frames_hr, out
+                gc.collect()
+        except Exception as e:          # the reference swallows every error here (:329-331)
+            print(f"Error during video processing: {str(e)}")
+        finally:
+            if reader:
+                reader.release()
+            if writer:
+                writer.release()
