@@ -49,7 +49,22 @@ def cpu_baseline(sd, flops_per_frame, sample_frames):
     """Oracle timed on the host cores: STTNInpaint.inpaint on `sample_frames` model-res frames."""
     from oracle.sttn_auto import STTNInpaintOracle
 
-    threads = os.cpu_count() or 1
+    # pick the thread count that suits this host (oneDNN collapses when 256 threads fight over a
+    # 30x160 feature map): time one 3x3 256->256 conv per candidate, keep the fastest
+    ncpu = os.cpu_count() or 1
+    x = torch.randn(8, 256, 30, 160)
+    w = torch.randn(256, 256, 3, 3)
+    best, threads = None, 1
+    for cand in sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu}):
+        torch.set_num_threads(cand)
+        with torch.no_grad():
+            torch.nn.functional.conv2d(x, w, padding=1)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                torch.nn.functional.conv2d(x, w, padding=1)
+            dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, threads = dt, cand
     torch.set_num_threads(threads)
     o = STTNInpaintOracle(sd, "auto")
     frames = np.random.default_rng(0).integers(0, 256, size=(sample_frames, 120, 640, 3), dtype=np.uint8)

@@ -9,6 +9,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The float resize path restates cv2's mul + mul + add (no FMA at OpenCV's SSE baseline) and is
+// compared bit-for-bit with the oracle: no contraction anywhere in this file.
+#pragma clang fp contract(off)
+
 // ---------------------------------------------------------------------------------------
 // K1: crop + cv2.resize(strip, (640,120)) on u8 (reference sttn_auto_inpaint.py:269-271).
 // Fixed-point INTER_LINEAR: horizontal taps scaled by 2^11 into int32, vertical pass
@@ -251,9 +255,12 @@ k_upscale_blend(const float* __restrict__ comp /*[n][mh][mw][3] RGB*/, int mw, i
             const float b0 = fbeta[2 * dy], b1 = fbeta[2 * dy + 1];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const float h0 = __fadd_rn(__fmul_rn(c0[x0 * 3 + ch], a0), __fmul_rn(c0[x1 * 3 + ch], a1));
-                const float h1 = __fadd_rn(__fmul_rn(c1[x0 * 3 + ch], a0), __fmul_rn(c1[x1 * 3 + ch], a1));
-                const float v = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+                // plain expressions: the file-scope "fp contract(off)" keeps them unfused
+                const float p00 = c0[x0 * 3 + ch] * a0, p01 = c0[x1 * 3 + ch] * a1;
+                const float p10 = c1[x0 * 3 + ch] * a0, p11 = c1[x1 * 3 + ch] * a1;
+                const float h0 = p00 + p01, h1 = p10 + p11;
+                const float q0 = h0 * b0, q1 = h1 * b1;
+                const float v = q0 + q1;
                 o[2 - ch] = (uint8_t)(int)v;
             }
         } else {
