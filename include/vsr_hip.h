@@ -95,7 +95,7 @@ int vsr_sttn_timing_reset(vsr_sttn_t* h);
 #define VSR_GG_KC 32 /* K / N chunk granularity of the offset tables */
 enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
 enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1 };
-enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2 };
+enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3 };
 
 /* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]
  *   NK: B(k,n) = B[rowB[n]+colB[k/32]+k%32]   KN: B(k,n) = B[rowB[k]+colB[n/32]+n%32]
@@ -161,6 +161,10 @@ int vsr_launch_upscale_blend(const float* comp_dev, int mw, int mh, const int32_
                              int sh, int nframes, const int32_t* xofs_dev, const int16_t* ialpha_dev,
                              const float* falpha_dev, const int32_t* yofs_dev, const int16_t* ibeta_dev,
                              const float* fbeta_dev, void* stream);
+/* out[rowC[m]+colC[n/32]+n%32] = sum_s part[s*split_stride + m*N + n]: combines the split-K partial
+ * planes of a PV product and scatters them into the NHWC attention buffer */
+int vsr_launch_reduce_scatter(const float* part_dev, int nsplit, int64_t split_stride, int M, int N,
+                              const int32_t* rowC_dev, const int32_t* colC_dev, float* out_dev, void* stream);
 /* host: OpenCV 4.11 resize() INTER_LINEAR tables: ofs[dsize], icoef[2*dsize] (x2048), fcoef[2*dsize] */
 int vsr_cv2_linear_tables(int ssize, int dsize, int clamp_x, int32_t* ofs, int16_t* icoef, float* fcoef);
 
@@ -169,9 +173,12 @@ int vsr_cv2_linear_tables(int ssize, int dsize, int clamp_x, int32_t* ofs, int16
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
 typedef struct VsrOpInfo {
-    int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out */
+    int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter */
     int32_t nitems, tile_cfg, bmode;
     int32_t buf_src, buf_dst, H, W, C, halo_src, halo_dst, n, ldy, pix, t_frame_idx, t_first, premask;
+    /* reduce_scatter: part = buf_src + off_src, out = buf_dst + off_dst, M, N, nsplit, tables */
+    int32_t M, N, nsplit, t_rowC, t_colC, pad_;
+    int64_t off_src, off_dst, split_stride;
     double flops;
     char tag[32];
 } VsrOpInfo;

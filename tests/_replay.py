@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-OP_NORM_IM2COL, OP_GEMM, OP_SOFTMAX, OP_UPSAMPLE2X, OP_DECODE_OUT = range(5)
+OP_NORM_IM2COL, OP_GEMM, OP_SOFTMAX, OP_UPSAMPLE2X, OP_DECODE_OUT, OP_REDUCE_SCATTER = range(6)
 BUF_WEIGHTS, BUF_IN_U8 = 0, 1
 
 
@@ -149,6 +149,19 @@ def decode_out_reference(info, bufs, tables):
             comp[sl] = comp[sl] * np.float32(0.5) + img[i].reshape(-1) * np.float32(0.5)
 
 
+def reduce_scatter_reference(info, bufs, tables):
+    M, N = info.M, info.N
+    part = bufs[info.buf_src]
+    acc = None
+    for s in range(info.nsplit):
+        o = info.off_src + s * info.split_stride
+        plane = part[o: o + M * N].reshape(M, N)
+        acc = plane.copy() if acc is None else acc + plane
+    rowC = tables[info.t_rowC][:M]
+    colC = _cols(tables[info.t_colC], N)
+    bufs[info.buf_dst][info.off_dst + rowC[:, None] + colC[None, :]] = acc
+
+
 def replay(view, packed_weights, frames_u8):
     """frames_u8: [L,mh,mw,3] uint8 BGR -> (comp float32 [L,mh,mw,3] RGB, counts)."""
     bufs = []
@@ -175,6 +188,8 @@ def replay(view, packed_weights, frames_u8):
                 norm_im2col_reference(info, bufs)
             elif info.kind == OP_DECODE_OUT:
                 decode_out_reference(info, bufs, view.tables)
+            elif info.kind == OP_REDUCE_SCATTER:
+                reduce_scatter_reference(info, bufs, view.tables)
             else:
                 raise AssertionError(f"unknown op kind {info.kind}")
     comp = bufs[20][: frames_u8.size].reshape(frames_u8.shape).copy()     # BUF_COMP

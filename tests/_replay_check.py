@@ -1,0 +1,47 @@
+"""Stand-alone CPU replay-vs-oracle check (run in a subprocess so that tuning env vars, which
+the library reads once, can be varied per run).  Exit code 0 = parity."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def run(L=4, ns=2, rl=3, seed=11):
+    import vsr_amd  # noqa: F401
+    from vsr_amd import _lib
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+    from oracle.sttn_auto import STTNInpaintOracle, calculate_psnr
+    from _replay import PlanView, replay
+
+    sd = make_state_dict(0, "auto")
+    eng = SttnEngine(sd, "auto", device=None, neighbor_stride=ns, ref_length=rl)
+    frames = np.random.default_rng(seed).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8)
+    view = PlanView(_lib, eng, L)
+    kinds = [info.kind for info, _ in view.ops]
+    nsplit_pv = max([it.splitK for info, items in view.ops if info.kind == 1 and info.bmode == 1 for it in items] + [1])
+    comp, counts, _ = replay(view, eng.packed_weights(), frames)
+    view.close()
+    eng.close()
+    ref = STTNInpaintOracle(sd, "auto", neighbor_stride=ns, ref_length=rl).inpaint(list(frames))
+    for i, r in enumerate(ref):
+        assert (r.dtype == np.uint8) == (counts[i] == 1), "u8-vs-f32 path selection must follow the visit count"
+    refa = np.stack([r.astype(np.float32) for r in ref])
+    d = np.abs(comp - refa)
+    # same fp32 arithmetic up to summation order: only truncation-boundary flips (+-1 before averaging)
+    assert d.max() <= 1.0, d.max()
+    assert (d > 0).mean() < 2e-3, (d > 0).mean()
+    assert calculate_psnr(comp, refa) > 70.0
+    assert 20.0 < comp.std() < 120.0, "synthetic weights should give a full-range image"
+    return {"counts": counts.tolist(), "pv_split": int(nsplit_pv), "has_reduce": 5 in kinds,
+            "psnr": calculate_psnr(comp, refa), "max_abs": float(d.max())}
+
+
+if __name__ == "__main__":
+    import json
+
+    print(json.dumps(run()))

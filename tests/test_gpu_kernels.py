@@ -132,6 +132,34 @@ def test_gather_gemm_128x128_kn(built_lib, gpu_device, M, N, K):
     _assert_close(got, _reference(c), K, f"KN {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,splitK,bmode", [(300, 256, 2304, 1, 0), (129, 65, 64, 1, 0), (60, 60, 640, 5, 0),
+                                                 (200, 192, 96, 1, 1), (1440, 960, 320, 3, 1), (33, 64, 32, 1, 1)])
+def test_gather_gemm_128x64(built_lib, gpu_device, M, N, K, splitK, bmode):
+    rng = np.random.default_rng(M + N + K + bmode)
+    full = splitK == 1 and bmode == 0
+    c = _make_gemm_case(rng, M, N, K, 128, 64, bmode, splitK, full, 1 if full else 0, full)
+    got = _run_cases(built_lib, gpu_device, [c], built_lib.TILE_128x64, bmode)[0]
+    _assert_close(got, _reference(c), K, f"128x64 mode{bmode} {M}x{N}x{K} split{splitK}")
+
+
+def test_reduce_scatter(built_lib, gpu_device):
+    rng = np.random.default_rng(8)
+    M, N, ns = 333, 960, 3
+    part = rng.standard_normal((ns, M, N)).astype(np.float32)
+    ncc = N // 32
+    colC = (rng.permutation(ncc + 2)[:ncc] * 32).astype(np.int32)
+    rowC = (rng.permutation(M + 3)[:M] * ((ncc + 2) * 32)).astype(np.int32)
+    out = torch.full(((M + 3) * (ncc + 2) * 32,), -7.0, device=gpu_device)
+    dpart, drow, dcol = _dev(part, gpu_device), _dev(rowC, gpu_device), _dev(colC, gpu_device)   # keep alive
+    rc = built_lib.lib.vsr_launch_reduce_scatter(_ptr(dpart), ns, M * N, M, N, _ptr(drow), _ptr(dcol), _ptr(out), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = np.full(out.shape[0], -7.0, np.float32)
+    cols = (colC.astype(np.int64)[:, None] + np.arange(32)[None, :]).reshape(-1)
+    ref[rowC.astype(np.int64)[:, None] + cols[None, :]] = (part[0] + part[1]) + part[2]
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("cfg,bn,M,N,K", [("TILE_256x32", 32, 700, 3, 64), ("TILE_256x32", 32, 256, 32, 576),
                                            ("TILE_256x64", 64, 520, 64, 576), ("TILE_256x64", 64, 1000, 64, 32)])
 def test_gather_gemm_narrow_tiles(built_lib, gpu_device, cfg, bn, M, N, K):
@@ -239,7 +267,8 @@ def test_norm_im2col_exact(built_lib, gpu_device):
     rng = np.random.default_rng(2)
     img = rng.integers(0, 256, size=(2, 120, 640, 3), dtype=np.uint8)
     out = torch.zeros((2 * 60 * 320, 32), device=gpu_device)
-    assert built_lib.lib.vsr_launch_norm_im2col(_ptr(_dev(img, gpu_device)), 120, 640, 2, _ptr(out), 0, None, None) == 0
+    dimg = _dev(img, gpu_device)
+    assert built_lib.lib.vsr_launch_norm_im2col(_ptr(dimg), 120, 640, 2, _ptr(out), 0, None, None) == 0
     torch.cuda.synchronize()
     bufs = {0: img.reshape(-1), 1: np.zeros(2 * 60 * 320 * 32, np.float32)}
     _replay.norm_im2col_reference(SimpleNamespace(H=120, W=640, n=2, buf_src=0, buf_dst=1), bufs)
@@ -253,7 +282,8 @@ def test_upsample2x(built_lib, gpu_device, H, W, Cc, hs, hd):
     src = np.zeros((n, H + 2 * hs, W + 2 * hs, Cc), np.float32)
     src[:, hs:hs + H, hs:hs + W] = rng.standard_normal((n, H, W, Cc)).astype(np.float32)
     dst = torch.zeros((n, 2 * H + 2 * hd, 2 * W + 2 * hd, Cc), device=gpu_device)
-    assert built_lib.lib.vsr_launch_upsample2x(_ptr(_dev(src, gpu_device)), H, W, Cc, hs, _ptr(dst), hd, n, None) == 0
+    dsrc = _dev(src, gpu_device)
+    assert built_lib.lib.vsr_launch_upsample2x(_ptr(dsrc), H, W, Cc, hs, _ptr(dst), hd, n, None) == 0
     torch.cuda.synchronize()
     x = torch.from_numpy(src[:, hs:hs + H, hs:hs + W]).permute(0, 3, 1, 2)
     ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1).numpy()
@@ -270,8 +300,8 @@ def test_decode_out_and_average(built_lib, gpu_device):
     comp0 = rng.integers(0, 256, size=(L, pix, 3)).astype(np.float32)
     comp = _dev(comp0, gpu_device)
     fidx, first = np.array([4, 1, 2], np.int32), np.array([1, 0, 0], np.int32)
-    assert built_lib.lib.vsr_launch_decode_out(_ptr(_dev(y, gpu_device)), 32, pix, n, _ptr(_dev(fidx, gpu_device)),
-                                               _ptr(_dev(first, gpu_device)), _ptr(comp), None) == 0
+    dy, dfidx, dfirst = _dev(y, gpu_device), _dev(fidx, gpu_device), _dev(first, gpu_device)      # keep alive
+    assert built_lib.lib.vsr_launch_decode_out(_ptr(dy), 32, pix, n, _ptr(dfidx), _ptr(dfirst), _ptr(comp), None) == 0
     torch.cuda.synchronize()
     bufs = {0: y.reshape(-1), 1: comp0.reshape(-1).copy()}
     _replay.decode_out_reference(SimpleNamespace(n=n, pix=pix, ldy=32, buf_src=0, buf_dst=1, t_frame_idx=0, t_first=1),
@@ -299,8 +329,9 @@ def test_upscale_blend_bit_exact(built_lib, gpu_device, W, sh):
     (yo, ya, yf), _ = _tables(120, sh, False, gpu_device)
     dfr = _dev(frames, gpu_device)
     dmask = _dev(mask, gpu_device)
+    dcomp, disf = _dev(comp, gpu_device), _dev(isf, gpu_device)                                 # keep alive
     rc = built_lib.lib.vsr_launch_upscale_blend(
-        _ptr(_dev(comp, gpu_device)), 640, 120, _ptr(_dev(isf, gpu_device)), C.c_void_p(dfr.data_ptr() + ymin * W * 3), H * W * 3,
+        _ptr(dcomp), 640, 120, _ptr(disf), C.c_void_p(dfr.data_ptr() + ymin * W * 3), H * W * 3,
         W * 3, None, C.c_void_p(dmask.data_ptr() + ymin * W), W, W, sh, n, _ptr(xo), _ptr(xa), _ptr(xf), _ptr(yo), _ptr(ya), _ptr(yf), None)
     assert rc == 0
     torch.cuda.synchronize()

@@ -66,7 +66,8 @@ def test_strict_state_dict(built_lib):
 
 
 def test_weight_packing_layout(built_lib):
-    """[Cout][Cin][3][3] -> [Cout][(ky*3+kx)*Cin + ci]; fused QKV rows = query | key | value."""
+    """[Cout][Cin][3][3] -> [Cout][K] with k = ((ci//32)*9 + ky*3+kx)*32 + ci%32 (channel-chunk major,
+    taps inner: the default VSR_CONV_KORDER=1); the 3-channel first layer keeps k = tap*3 + c."""
     from vsr_amd.synth import make_state_dict
     from vsr_amd.engine import SttnEngine
 
@@ -75,8 +76,8 @@ def test_weight_packing_layout(built_lib):
     packed = eng.packed_weights()
     w = sd["encoder.2.weight"]                       # first packed tensors: encoder.0 (K 27->32), bias, encoder.2
     off = 64 * 32 + 64
-    got = packed[off: off + 64 * 576].reshape(64, 9, 64)
-    assert np.array_equal(got, w.transpose(0, 2, 3, 1).reshape(64, 9, 64))
+    got = packed[off: off + 64 * 576].reshape(64, 2, 9, 32)
+    assert np.array_equal(got, w.reshape(64, 2, 32, 9).transpose(0, 1, 3, 2))
     w0 = sd["encoder.0.weight"]
     got0 = packed[: 64 * 32].reshape(64, 32)
     assert np.array_equal(got0[:, :27], w0.transpose(0, 2, 3, 1).reshape(64, 27))

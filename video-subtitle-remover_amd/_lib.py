@@ -14,8 +14,8 @@ VSR_OK, VSR_ERR_ARG, VSR_ERR_STATE, VSR_ERR_HIP, VSR_ERR_NOGPU = 0, -1, -2, -3, 
 VARIANT = {"auto": 0, "det": 1}
 BMODE_NK, BMODE_KN = 0, 1
 ACT_NONE, ACT_LRELU02 = 0, 1
-TILE_128x128, TILE_256x32, TILE_256x64 = 0, 1, 2
-TILE_DIMS = {TILE_128x128: (128, 128), TILE_256x32: (256, 32), TILE_256x64: (256, 64)}
+TILE_128x128, TILE_256x32, TILE_256x64, TILE_128x64 = 0, 1, 2, 3
+TILE_DIMS = {TILE_128x128: (128, 128), TILE_256x32: (256, 32), TILE_256x64: (256, 64), TILE_128x64: (128, 64)}
 
 
 class VsrError(RuntimeError):
@@ -44,6 +44,8 @@ class VsrOpInfo(C.Structure):
                 ("buf_src", C.c_int32), ("buf_dst", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("halo_src", C.c_int32), ("halo_dst", C.c_int32), ("n", C.c_int32), ("ldy", C.c_int32),
                 ("pix", C.c_int32), ("t_frame_idx", C.c_int32), ("t_first", C.c_int32), ("premask", C.c_int32),
+                ("M", C.c_int32), ("N", C.c_int32), ("nsplit", C.c_int32), ("t_rowC", C.c_int32), ("t_colC", C.c_int32),
+                ("pad_", C.c_int32), ("off_src", C.c_int64), ("off_dst", C.c_int64), ("split_stride", C.c_int64),
                 ("flops", C.c_double), ("tag", C.c_char * 32)]
 
 
@@ -87,6 +89,7 @@ SIGNATURES = {
     "vsr_run_softmax": (_I, [C.POINTER(SMProblem), _I, _P]),
     "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsr_launch_norm_im2col": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    "vsr_launch_reduce_scatter": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P]),
     "vsr_launch_upsample2x": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "vsr_launch_decode_out": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "vsr_launch_upscale_blend": (_I, [_P, _I, _I, _P, _P, _L, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -277,6 +277,30 @@ k_upscale_blend(const float* __restrict__ comp /*[n][mh][mw][3] RGB*/, int mw, i
 }
 
 // ---------------------------------------------------------------------------------------
+// K6b: combine split-K partial planes of P.V and scatter the tokens back into NHWC
+// (auto_sttn.py:201-204 view/permute un-patching, done here as addressing).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_reduce_scatter(const float* __restrict__ part, int nsplit, int64_t splitStride, int M, int N,
+                 const int32_t* __restrict__ rowC, const int32_t* __restrict__ colC, float* __restrict__ out)
+{
+    const int N4 = N / 4;
+    const int64_t total = (int64_t)M * N4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n4 = (int)(i % N4);
+        const int m = (int)(i / N4);
+        const int n = 4 * n4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(part + (int64_t)m * N + n);
+        for (int s = 1; s < nsplit; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + s * splitStride + (int64_t)m * N + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        }
+        *reinterpret_cast<f32x4*>(out + rowC[m] + colC[n >> 5] + (n & 31)) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers (C linkage; public ones are declared in include/vsr_hip.h)
 // ---------------------------------------------------------------------------------------
 static inline int grid_for(int64_t total)
@@ -313,6 +337,16 @@ extern "C" int vsr_launch_softmax_dev(const SMProblem* d_probs, int nprobs, int 
 {
     if (totalRows <= 0) return 0;
     hipLaunchKernelGGL(k_softmax_rows, dim3((totalRows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_probs, nprobs);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_reduce_scatter(const float* part, int nsplit, int64_t splitStride, int M, int N,
+                                         const int32_t* rowC, const int32_t* colC, float* out, void* stream)
+{
+    const int64_t total = (int64_t)M * (N / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_reduce_scatter, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, part, nsplit,
+                       splitStride, M, N, rowC, colC, out);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 

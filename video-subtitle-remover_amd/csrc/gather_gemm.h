@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include "../../include/vsr_hip.h"
 
-// d_probs: DEVICE array (tileStart filled); totalBlocks = sum tilesM*tilesN*splitK
+// d_probs: DEVICE array (tileStart filled); totalBlocks = sum tilesM*tilesN*splitK.
+// variant 1: one workgroup per tile; 2 / 3: persistent kernels pulling tile ids from *queue (must be 0).
 extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
-                                          int bmode, void* stream);
+                                          int bmode, unsigned int* queue, int variant, void* stream);

@@ -30,7 +30,27 @@ typedef const f32x4 __attribute__((address_space(1)))* gcf32x4;
 // wave-uniform, read-only table entries (chunk offsets): constant address space -> s_load
 typedef const int32_t __attribute__((address_space(4)))* cci32;
 
-template <int BM, int BN, int WM, int WN, int BMODE>
+// Ablation hooks (scripts/gg_ablate.hip defines GG_ABLATE and adds an ABL template argument that
+// switches single mechanisms off to price them); compiled out of the product.
+#ifdef GG_ABLATE
+#define GG_ABL_PARAM , int ABL
+#define GG_ABL(x) ((ABL & (x)) != 0)
+__device__ unsigned long long gg_dbg[4096 * 8];   // 32: per-workgroup phase cycle sums (wave 0)
+#define GG_T(slot)                                                                              \
+    if constexpr (GG_ABL(32)) {                                                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter();                            \
+        if (tid == 0 && bid < 4096) gg_dbg[bid * 8 + (slot)] += now_ - tlast_;                   \
+        tlast_ = now_;                                                                           \
+    }
+#else
+#define GG_T(slot)
+#define GG_ABL_PARAM
+#define GG_ABL(x) false
+#endif
+// 1: no barriers  2: no global loads in the loop  4: no LDS stores in the loop  8: no LDS fragment reads
+// 16: chunk offsets by arithmetic instead of table s_loads
+
+template <int BM, int BN, int WM, int WN, int BMODE GG_ABL_PARAM>
 __global__ void __launch_bounds__(256)
 gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 {
@@ -123,12 +143,12 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
             dst[it] = rowB[kc * VSR_GG_KC + k_r + RPP * it];
     };
     auto load_tile = [&](int kc) {
-        const int ca = colA[kc];
+        const int ca = GG_ABL(16) ? kc * VSR_GG_KC : colA[kc];
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
             ra[it] = *(gcf32x4)(A + (aoff[it] + ca));
         if constexpr (BMODE == VSR_BMODE_NK) {
-            const int cb = colB[kc];
+            const int cb = GG_ABL(16) ? kc * VSR_GG_KC : colB[kc];
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
                 rb[it] = *(gcf32x4)(B + (boff[it] + cb));
@@ -158,6 +178,12 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
             // lane (l31, hi) owns k = 8g + 4hi + j, j = 0..3: MFMA step j contracts the
             // pair {8g + j, 8g + 4 + j}; A and B use the same assignment.
             f32x4 af[MI], bf[NI];
+            if constexpr (GG_ABL(8)) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = ra[mi % A_IT];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bf[ni] = rb[ni % B_IT];
+            } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 af[mi] = *reinterpret_cast<const f32x4*>(
@@ -173,6 +199,7 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         bf[ni][j] = Bs[(8 * g + 4 * hi + j) * LDB_KN + wn * WTN + ni * 32 + l31];
+            }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -194,9 +221,12 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
         load_tile(kcBeg);
         store_tile();
         __syncthreads();
+#ifdef GG_ABLATE
+        unsigned long long tlast_ = __builtin_readcyclecounter();
+#endif
         for (int kc = kcBeg; kc < kcEnd; ++kc) {
             const bool hasNext = (kc + 1 < kcEnd);
-            if (hasNext) {
+            if (hasNext && !GG_ABL(2)) {
                 if constexpr (BMODE == VSR_BMODE_KN) {
 #pragma unroll
                     for (int it = 0; it < B_IT; ++it) boff[it] = boffNext[it];
@@ -206,10 +236,15 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
                     if (kc + 2 < kcEnd) load_rowB_KN(kc + 2, boffNext);
                 }
             }
+            GG_T(0) // issue of the next chunk's loads
             compute_tile();
-            __syncthreads();
-            if (hasNext) store_tile();
-            __syncthreads();
+            GG_T(1) // ds_read + MFMA
+            if constexpr (!GG_ABL(1)) __syncthreads();
+            GG_T(2) // barrier 1 (everyone done reading LDS)
+            if (hasNext && !GG_ABL(4)) store_tile();
+            GG_T(3) // vmcnt wait + ds_write
+            if constexpr (!GG_ABL(1)) __syncthreads();
+            GG_T(4) // barrier 2
         }
     }
 
@@ -255,21 +290,56 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
     }
 }
 
-extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
-                                          int bmode, void* stream_)
+#include "gather_gemm_v2.h"
+#include "gather_gemm_v3.h"
+
+#ifndef GG_ABLATE
+// resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
+template <typename K>
+static int resident_blocks(K kernel)
 {
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0) occ = 1;
+    return cus * occ;
+}
+
+#define GG_LAUNCH(BM, BN, WM, WN, MODE)                                                                         \
+    do {                                                                                                        \
+        if (queue && variant == 3) {                                                                            \
+            static const int resident = resident_blocks(gather_gemm_f32_v3<BM, BN, WM, WN, MODE>);             \
+            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
+            hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream, d_probs, \
+                               nprobs, totalBlocks, queue);                                                    \
+        } else if (queue) {                                                                                     \
+            static const int resident = resident_blocks(gather_gemm_f32_v2<BM, BN, WM, WN, MODE>);             \
+            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
+            hipLaunchKernelGGL((gather_gemm_f32_v2<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream, d_probs, \
+                               nprobs, totalBlocks, queue);                                                    \
+        } else {                                                                                                \
+            hipLaunchKernelGGL((gather_gemm_f32<BM, BN, WM, WN, MODE>), dim3(totalBlocks), block, 0, stream,   \
+                               d_probs, nprobs);                                                               \
+        }                                                                                                       \
+    } while (0)
+
+// variant 1 (or queue == nullptr): one workgroup per tile.  variant 2 / 3: persistent kernels pulling tile
+// ids from *queue (must be 0): 2 = register-staged double buffer, 3 = LDS-DMA double buffer.
+extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
+                                          int bmode, unsigned int* queue, int variant, void* stream_)
+{
+    if (variant <= 1) queue = nullptr;
     hipStream_t stream = (hipStream_t)stream_;
     if (totalBlocks <= 0) return 0;
-    dim3 grid(totalBlocks), block(256);
-    if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK)
-        hipLaunchKernelGGL((gather_gemm_f32<128, 128, 2, 2, VSR_BMODE_NK>), grid, block, 0, stream, d_probs, nprobs);
-    else if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_KN)
-        hipLaunchKernelGGL((gather_gemm_f32<128, 128, 2, 2, VSR_BMODE_KN>), grid, block, 0, stream, d_probs, nprobs);
-    else if (tileCfg == VSR_TILE_256x32 && bmode == VSR_BMODE_NK)
-        hipLaunchKernelGGL((gather_gemm_f32<256, 32, 4, 1, VSR_BMODE_NK>), grid, block, 0, stream, d_probs, nprobs);
-    else if (tileCfg == VSR_TILE_256x64 && bmode == VSR_BMODE_NK)
-        hipLaunchKernelGGL((gather_gemm_f32<256, 64, 4, 1, VSR_BMODE_NK>), grid, block, 0, stream, d_probs, nprobs);
+    dim3 block(256);
+    if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_NK);
+    else if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_KN) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_KN);
+    else if (tileCfg == VSR_TILE_256x32 && bmode == VSR_BMODE_NK) GG_LAUNCH(256, 32, 4, 1, VSR_BMODE_NK);
+    else if (tileCfg == VSR_TILE_256x64 && bmode == VSR_BMODE_NK) GG_LAUNCH(256, 64, 4, 1, VSR_BMODE_NK);
+    else if (tileCfg == VSR_TILE_128x64 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 64, 2, 2, VSR_BMODE_NK);
+    else if (tileCfg == VSR_TILE_128x64 && bmode == VSR_BMODE_KN) GG_LAUNCH(128, 64, 2, 2, VSR_BMODE_KN);
     else
         return -1;
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
+#endif // GG_ABLATE

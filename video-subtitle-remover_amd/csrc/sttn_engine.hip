@@ -7,6 +7,7 @@
 // launches per transformer block, no host synchronisation, no allocation in steady state.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <memory>
@@ -50,6 +51,11 @@ struct OpDev {
     int H = 0, W = 0, C = 0, haloS = 0, haloD = 0, n = 0, ldy = 0, pix = 0, premask = 0;
     const int32_t* tFrameIdx = nullptr;
     const int32_t* tFirst = nullptr;
+    // reduce_scatter
+    int M = 0, N = 0, nsplit = 0;
+    int64_t splitStride = 0;
+    const int32_t* tRowC = nullptr;
+    const int32_t* tColC = nullptr;
     double flops = 0;
     std::string tag;
 };
@@ -59,9 +65,11 @@ struct PlanDev {
     int32_t* dTables = nullptr;
     void* dDescs = nullptr;
     int32_t* dIsFloat = nullptr;
+    unsigned int* dQueues = nullptr;   // one tile-queue counter per op (persistent gather-GEMM), zeroed per run
     std::vector<OpDev> ops;
     ~PlanDev()
     {
+        if (dQueues) (void)hipFree(dQueues);
         if (dTables) (void)hipFree(dTables);
         if (dDescs) (void)hipFree(dDescs);
         if (dIsFloat) (void)hipFree(dIsFloat);
@@ -76,7 +84,7 @@ struct StripTables { // cv2.resize tables for one (W, split_h): down to model si
 };
 
 struct TimingRec {
-    std::string tag;
+    std::string tag, kernel;
     double flops;
     hipEvent_t a, b;
 };
@@ -193,6 +201,11 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
             od.nitems = (int)op.softmax.size();
             od.total = rowStart;
             cursor += (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
+        } else if (op.kind == OP_REDUCE_SCATTER) {
+            od.src = F(op.bufSrc, op.offSrc);
+            od.dst = F(op.bufDst, op.offDst);
+            od.M = op.M; od.N = op.N; od.nsplit = op.nsplit; od.splitStride = op.splitStride;
+            od.tRowC = T(op.tRowC); od.tColC = T(op.tColC);
         } else {
             od.src = op.bufSrc >= 0 ? h->bufs[op.bufSrc] : nullptr;
             od.dst = op.bufDst >= 0 ? h->bufs[op.bufDst] : nullptr;
@@ -207,17 +220,42 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
     for (int i = 0; i < L; ++i) isf[i] = P.compCount[i] > 1 ? 1 : 0;
     HIPCHK(hipMalloc((void**)&pd->dIsFloat, (size_t)L * sizeof(int32_t)));
     HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * sizeof(unsigned int)));
     *out = pd.get();
     h->plans[L] = std::move(pd);
     return 0;
 }
 
+// gather-GEMM kernel variant (gather_gemm.hip): 1 = one workgroup per tile, 2 = persistent with
+// register-staged double buffer, 3 = persistent with LDS-DMA double buffer
+// Measured on the 1080p bench (profiles/): NK problems (convs, QKV, QK^T) are fastest on v3, the KN
+// problem (P.V, n-contiguous B) on v1.  VSR_GG_VARIANT / VSR_PV_VARIANT override for A/B runs.
+static int gg_variant(int bmode)
+{
+    static const int nk = [] { const char* e = getenv("VSR_GG_VARIANT"); int x = e ? atoi(e) : 3; return (x < 1 || x > 3) ? 3 : x; }();
+    static const int kn = [] {
+        const char* e = getenv("VSR_PV_VARIANT");
+        const char* g = getenv("VSR_GG_VARIANT");
+        int x = e ? atoi(e) : (g ? atoi(g) : 1);
+        return (x < 1 || x > 3) ? 1 : x;
+    }();
+    return bmode == VSR_BMODE_KN ? kn : nk;
+}
+static bool use_persistent() { return gg_variant(VSR_BMODE_NK) >= 2 || gg_variant(VSR_BMODE_KN) >= 2; }
+
 static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
 {
+    const bool persistent = use_persistent();
+    if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * sizeof(unsigned int), stream));
+    size_t opIndex = 0;
     for (const OpDev& od : pd->ops) {
+        unsigned int* queue = persistent ? pd->dQueues + opIndex : nullptr;
+        ++opIndex;
         TimingRec tr;
         if (h->timing) {
             tr.tag = od.tag; tr.flops = od.flops;
+            tr.kernel = od.kind == OP_GEMM ? ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode))
+                                           : ("kernel:op:" + std::to_string(od.kind));
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
             HIPCHK(hipEventRecord(tr.a, stream));
@@ -225,7 +263,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         int rc = 0;
         switch (od.kind) {
         case OP_GEMM:
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, stream);
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue, gg_variant(od.bmode), stream);
             break;
         case OP_SOFTMAX:
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
@@ -238,6 +276,10 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             break;
         case OP_DECODE_OUT:
             rc = vsr_launch_decode_out((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst, stream);
+            break;
+        case OP_REDUCE_SCATTER:
+            rc = vsr_launch_reduce_scatter((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,
+                                           (float*)od.dst, stream);
             break;
         default:
             return fail(VSR_ERR_STATE, "unknown op kind");
@@ -258,10 +300,12 @@ static int collect_timing(vsr_sttn* h, hipStream_t stream)
     for (TimingRec& tr : h->pending) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, tr.a, tr.b));
-        auto& acc = h->timed[tr.tag];
-        acc.first += ms;
-        acc.second.first += 1;
-        acc.second.second += tr.flops;
+        for (const std::string* key : {&tr.tag, &tr.kernel}) {
+            auto& acc = h->timed[*key];
+            acc.first += ms;
+            acc.second.first += 1;
+            acc.second.second += tr.flops;
+        }
         (void)hipEventDestroy(tr.a);
         (void)hipEventDestroy(tr.b);
     }
@@ -547,7 +591,8 @@ int vsr_sttn_timing_get(vsr_sttn_t* h, const char* prefix, double* total_ms, int
 static void tile_dims(int cfg, int& BM, int& BN)
 {
     BM = cfg == VSR_TILE_128x128 ? 128 : 256;
-    BN = cfg == VSR_TILE_128x128 ? 128 : (cfg == VSR_TILE_256x64 ? 64 : 32);
+    BM = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_128x64) ? 128 : 256;
+    BN = cfg == VSR_TILE_128x128 ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
 }
 
 int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, void* stream_)
@@ -567,9 +612,14 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
         total += p.tilesM * p.tilesN * p.splitK;
     }
     GGProblem* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(GGProblem)));
+    HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(GGProblem) + 64));
     HIPCHK(hipMemcpy(d, hp.data(), hp.size() * sizeof(GGProblem), hipMemcpyHostToDevice));
-    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, stream);
+    unsigned int* queue = nullptr;
+    if (use_persistent()) {
+        queue = (unsigned int*)((char*)d + (hp.size() * sizeof(GGProblem) + 15) / 16 * 16);
+        HIPCHK(hipMemset(queue, 0, sizeof(unsigned int)));
+    }
+    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, gg_variant(bmode), stream);
     hipError_t e = hipStreamSynchronize(stream);
     (void)hipFree(d);
     if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");
@@ -646,6 +696,8 @@ int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* o)
     o->buf_src = op.bufSrc; o->buf_dst = op.bufDst; o->H = op.H; o->W = op.W; o->C = op.C;
     o->halo_src = op.haloS; o->halo_dst = op.haloD; o->n = op.n; o->ldy = op.ldy; o->pix = op.pix;
     o->t_frame_idx = op.tFrameIdx; o->t_first = op.tFirst; o->premask = op.premask;
+    o->M = op.M; o->N = op.N; o->nsplit = op.nsplit; o->t_rowC = op.tRowC; o->t_colC = op.tColC;
+    o->off_src = op.offSrc; o->off_dst = op.offDst; o->split_stride = op.splitStride;
     o->flops = op.flops;
     strncpy(o->tag, op.tag.c_str(), sizeof(o->tag) - 1);
     return 0;

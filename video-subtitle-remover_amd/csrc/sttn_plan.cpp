@@ -4,8 +4,29 @@
 #include <assert.h>
 #include <math.h>
 #include <stdexcept>
+#include <stdlib.h>
 
 namespace vsr {
+
+static int envInt(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+const Tuning& Tuning::get()
+{
+    static const Tuning t = [] {
+        Tuning x;
+        x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
+        x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
+        x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
+        x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
+        x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
+        return x;
+    }();
+    return t;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t rup(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -89,12 +110,20 @@ bool Model::pack_conv(const std::string& key, ConvW& cw, int /*cinPad*/, std::st
     cw.w = (int64_t)packed.size();
     packed.resize(packed.size() + (size_t)rup((int64_t)cout * K, 32), 0.f);
     float* dst = packed.data() + cw.w;
+    // K order: (tap, ci) for the 3-channel first layer (it is consumed through an explicit im2col);
+    // otherwise (channel chunk of 32, tap, ci%32) when convChannelMajor: the 9 taps of one channel
+    // chunk are contracted back to back, so the gathered 128-byte lines are re-used from L1/L2
+    // while they are hot instead of once per tap pass.  Must mirror Plan::tColsConv.
+    const bool chanMajor = Tuning::get().convChannelMajor && (cin % VSR_GG_KC == 0);
+    const int taps = kh * kw;
     for (int n = 0; n < cout; ++n)
         for (int ci = 0; ci < cin; ++ci)
             for (int ky = 0; ky < kh; ++ky)
-                for (int kx = 0; kx < kw; ++kx)
-                    dst[(int64_t)n * K + (ky * kw + kx) * cin + ci] =
-                        w.v[(((int64_t)n * cin + ci) * kh + ky) * kw + kx];
+                for (int kx = 0; kx < kw; ++kx) {
+                    const int tap = ky * kw + kx;
+                    const int k = chanMajor ? ((ci / VSR_GG_KC) * taps + tap) * VSR_GG_KC + (ci % VSR_GG_KC) : tap * cin + ci;
+                    dst[(int64_t)n * K + k] = w.v[(((int64_t)n * cin + ci) * kh + ky) * kw + kx];
+                }
     cw.b = (int64_t)packed.size();
     packed.resize(packed.size() + (size_t)rup(cout, 32), 0.f);
     for (int n = 0; n < cout; ++n) packed[cw.b + n] = bi->second.v[n];
@@ -166,10 +195,11 @@ bool Model::pack(std::string& err)
 static void tileDims(int cfg, int& BM, int& BN)
 {
     if (cfg == VSR_TILE_128x128) { BM = 128; BN = 128; }
+    else if (cfg == VSR_TILE_128x64) { BM = 128; BN = 64; }
     else if (cfg == VSR_TILE_256x64) { BM = 256; BN = 64; }
     else { BM = 256; BN = 32; }
 }
-static int pickTile(int N) { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : VSR_TILE_128x128); }
+static int pickTile(int N) { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : Tuning::get().convTile); }
 
 static void checkFits(int64_t v)
 {
@@ -230,10 +260,18 @@ int Plan::tColsConv(const Act& a, int ksz, int dil)
     if (a.halo < dil * (ksz / 2)) throw std::runtime_error("activation halo too small for conv");
     if (a.C % VSR_GG_KC) throw std::runtime_error("conv input channels must be a multiple of 32");
     std::vector<int32_t> v;
-    for (int ky = 0; ky < ksz; ++ky)
-        for (int kx = 0; kx < ksz; ++kx)
-            for (int c0 = 0; c0 < a.C; c0 += VSR_GG_KC)
-                v.push_back((int32_t)(((int64_t)(ky - ksz / 2) * dil * a.Wp() + (kx - ksz / 2) * dil) * a.C + c0));
+    auto off = [&](int ky, int kx, int c0) {
+        return (int32_t)(((int64_t)(ky - ksz / 2) * dil * a.Wp() + (kx - ksz / 2) * dil) * a.C + c0);
+    };
+    if (Tuning::get().convChannelMajor) { // mirrors Model::pack_conv
+        for (int c0 = 0; c0 < a.C; c0 += VSR_GG_KC)
+            for (int ky = 0; ky < ksz; ++ky)
+                for (int kx = 0; kx < ksz; ++kx) v.push_back(off(ky, kx, c0));
+    } else {
+        for (int ky = 0; ky < ksz; ++ky)
+            for (int kx = 0; kx < ksz; ++kx)
+                for (int c0 = 0; c0 < a.C; c0 += VSR_GG_KC) v.push_back(off(ky, kx, c0));
+    }
     return table(key, std::move(v));
 }
 
@@ -391,25 +429,30 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
 
 // multi-scale patch attention of one block (auto_sttn.py:167-206, Attention :140-145):
 // grouped QK^T (split-K on the coarse scales) -> grouped row softmax -> grouped PV that
-// scatters straight back into the NHWC attention buffer.
+// scatters straight back into the NHWC attention buffer.  Problems are listed largest first
+// so that the long workgroups are dispatched first and the short ones fill the tail; a PV
+// whose token contraction is long is split into slices (fewer, longer workgroups than CUs
+// would otherwise leave half the chip idle) and combined by a reduce-scatter pass.
 void Plan::addAttention(int T, const BlockW&)
 {
-    const int C = g.channels, dk = C / g.nscales, C3 = 3 * C;
+    const Tuning& tu = Tuning::get();
+    const int C = g.channels, dk = C / g.nscales;
     const Act att{BUF_ATT, T, g.featH, g.featW, C, 1};
     Op qk, sm, pv;
-    qk.kind = OP_GEMM; qk.tag = "attn.qk"; qk.tileCfg = VSR_TILE_128x128; qk.bmode = VSR_BMODE_NK;
+    qk.kind = OP_GEMM; qk.tag = "attn.qk"; qk.tileCfg = tu.qkTile; qk.bmode = VSR_BMODE_NK;
     sm.kind = OP_SOFTMAX; sm.tag = "attn.softmax";
-    pv.kind = OP_GEMM; pv.tag = "attn.pv"; pv.tileCfg = VSR_TILE_128x128; pv.bmode = VSR_BMODE_KN;
-    const int BM = 128, BN = 128;
-    int64_t sOff = 0, pOff = 0;
-    (void)C3;
-    for (int s = 0; s < g.nscales; ++s) {
+    pv.kind = OP_GEMM; pv.tag = "attn.pv"; pv.tileCfg = tu.pvTile; pv.bmode = VSR_BMODE_KN;
+    int qBM, qBN, pBM, pBN;
+    tileDims(qk.tileCfg, qBM, qBN);
+    tileDims(pv.tileCfg, pBM, pBN);
+    std::vector<Op> reduces;
+    int64_t sOff = 0, pOff = 0, partOff = 0;
+    for (int s = g.nscales - 1; s >= 0; --s) { // finest scale (most tokens, most work) first
         const int pw = g.patchW[s], ph = g.patchH[s];
         const int Pn = (g.featW / pw) * (g.featH / ph);
         const int Ntok = T * Pn;
         const int D = dk * pw * ph;
         const int ldS = (int)rup(Ntok, VSR_GG_KC);
-        const int tiles = cdiv(Ntok, BM);
         const int nchunks = D / VSR_GG_KC;
         int cps = nchunks < 32 ? nchunks : 32;
         int splitK = cdiv(nchunks, cps);
@@ -419,17 +462,18 @@ void Plan::addAttention(int T, const BlockW&)
 
         GemmItem a{};
         a.M = Ntok; a.N = Ntok; a.K = D;
-        a.tilesM = tiles; a.tilesN = tiles; a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
+        a.tilesM = cdiv(Ntok, qBM); a.tilesN = cdiv(Ntok, qBN);
+        a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
         a.alpha = 1.f; a.act = VSR_ACT_NONE;
         a.bufA = BUF_QKV; a.offA = 0;
-        a.tRowA = tRowsTokens(T, s, dk * s, Ntok, BM);
+        a.tRowA = tRowsTokens(T, s, dk * s, Ntok, qBM);
         a.tColA = tColsPatch(s, nchunks);
         a.bufB = BUF_QKV; a.offB = 0;
-        a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, BN);
+        a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN);
         a.tColB = a.tColA;
         a.bufC = BUF_S; a.offC = sOff;
-        a.tRowC = tRowsLinear(Ntok, ldS, BM);
-        a.tColC = tColsLinear(tiles * BN / VSR_GG_KC, tiles * BN / VSR_GG_KC);
+        a.tRowC = tRowsLinear(Ntok, ldS, qBM);
+        a.tColC = tColsLinear(a.tilesN * qBN / VSR_GG_KC, a.tilesN * qBN / VSR_GG_KC);
         a.bufR = -1; a.tRowR = -1; a.offBias = -1;
         qk.gemm.push_back(a);
         qk.flops += 2.0 * Ntok * (double)Ntok * D;
@@ -441,19 +485,41 @@ void Plan::addAttention(int T, const BlockW&)
         m.scale = (float)(1.0 / sqrt((double)D)); // scores / math.sqrt(query.size(-1))
         sm.softmax.push_back(m);
 
+        const int kchunks = ldS / VSR_GG_KC;
+        int pvSplit = 1, pvCps = kchunks;
+        if (tu.pvSplitChunks > 0 && kchunks >= 2 * tu.pvSplitChunks) {
+            pvSplit = cdiv(kchunks, tu.pvSplitChunks);
+            pvCps = cdiv(kchunks, pvSplit);
+            pvSplit = cdiv(kchunks, pvCps);
+        }
         GemmItem b{};
         b.M = Ntok; b.N = D; b.K = ldS;
-        b.tilesM = tiles; b.tilesN = cdiv(D, BN); b.splitK = 1; b.chunksPerSplit = ldS / VSR_GG_KC; b.splitStride = 0;
+        b.tilesM = cdiv(Ntok, pBM); b.tilesN = cdiv(D, pBN);
+        b.splitK = pvSplit; b.chunksPerSplit = pvCps;
         b.alpha = 1.f; b.act = VSR_ACT_NONE;
         b.bufA = BUF_P; b.offA = pOff;
-        b.tRowA = tRowsLinear(Ntok, ldS, BM);
-        b.tColA = tColsLinear(ldS / VSR_GG_KC, ldS / VSR_GG_KC);
+        b.tRowA = tRowsLinear(Ntok, ldS, pBM);
+        b.tColA = tColsLinear(kchunks, kchunks);
         b.bufB = BUF_QKV; b.offB = 0;
         b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
-        b.tColB = tColsPatch(s, b.tilesN * BN / VSR_GG_KC);
-        b.bufC = BUF_ATT; b.offC = 0;
-        b.tRowC = tRowsTokensAct(att, T, s, BM);
-        b.tColC = tColsPatchAct(att, s, b.tilesN * BN / VSR_GG_KC);
+        b.tColB = tColsPatch(s, b.tilesN * pBN / VSR_GG_KC);
+        const int tRowAtt = tRowsTokensAct(att, T, s, pBM);
+        const int tColAtt = tColsPatchAct(att, s, b.tilesN * pBN / VSR_GG_KC);
+        if (pvSplit == 1) {
+            b.bufC = BUF_ATT; b.offC = 0; b.splitStride = 0;
+            b.tRowC = tRowAtt;
+            b.tColC = tColAtt;
+        } else {        // partial planes [pvSplit][Ntok][D], combined + scattered by the reduce op
+            b.bufC = BUF_PVPART; b.offC = partOff; b.splitStride = (int64_t)Ntok * D;
+            b.tRowC = tRowsLinear(Ntok, D, pBM);
+            b.tColC = tColsLinear(D / VSR_GG_KC, b.tilesN * pBN / VSR_GG_KC);
+            Op r;
+            r.kind = OP_REDUCE_SCATTER; r.tag = "attn.pv.reduce";
+            r.bufSrc = BUF_PVPART; r.offSrc = partOff; r.splitStride = b.splitStride; r.nsplit = pvSplit;
+            r.bufDst = BUF_ATT; r.offDst = 0; r.M = Ntok; r.N = D; r.tRowC = tRowAtt; r.tColC = tColAtt;
+            reduces.push_back(std::move(r));
+            partOff += rup(b.splitStride * pvSplit, 32);
+        }
         b.bufR = -1; b.tRowR = -1; b.offBias = -1;
         pv.gemm.push_back(b);
         pv.flops += 2.0 * Ntok * (double)Ntok * D;
@@ -463,11 +529,13 @@ void Plan::addAttention(int T, const BlockW&)
     }
     need(BUF_S, sOff);
     need(BUF_P, pOff);
+    need(BUF_PVPART, partOff);
     need(BUF_ATT, att.elems());
     flops += qk.flops + pv.flops;
     ops.push_back(std::move(qk));
     ops.push_back(std::move(sm));
     ops.push_back(std::move(pv));
+    for (Op& r : reduces) ops.push_back(std::move(r));
 }
 
 // one sliding window (sttn_auto_inpaint.py:142-162): infer over neighbours+refs, decode the
@@ -489,8 +557,9 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         const BlockW& bw = m_.blk[b];
         {   // fused Q/K/V 1x1 (auto_sttn.py:172-174) -> plain [T*fh*fw][3C]
             Op op;
-            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = VSR_TILE_128x128; op.bmode = VSR_BMODE_NK;
-            const int BM = 128, BN = 128;
+            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = Tuning::get().convTile; op.bmode = VSR_BMODE_NK;
+            int BM, BN;
+            tileDims(op.tileCfg, BM, BN);
             GemmItem it{};
             it.M = T * fh * fw; it.N = 3 * C; it.K = C;
             it.tilesM = cdiv(it.M, BM); it.tilesN = cdiv(it.N, BN);

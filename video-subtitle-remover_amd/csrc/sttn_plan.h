@@ -26,6 +26,17 @@ struct Geometry {
     static Geometry make(int variant);
 };
 
+// ---- tuning knobs (defaults = the measured best; env overrides are for A/B runs) ----
+struct Tuning {
+    int convTile;        // VSR_CONV_TILE: tile config of the N >= 128 convs / QKV GEMM (VSR_TILE_*)
+    int qkTile;          // VSR_QK_TILE
+    int pvTile;          // VSR_PV_TILE
+    int pvSplitChunks;   // VSR_PV_SPLIT_CHUNKS: split the P.V contraction into slices of ~this many 32-token
+                         //   chunks when it has at least twice as many (0 = never split)
+    int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
+    static const Tuning& get();
+};
+
 // ---- packed weights ----
 struct ConvW {
     int64_t w = -1, b = -1; // element offsets into the packed weight buffer
@@ -55,10 +66,10 @@ private:
 // ---- plan IR ----
 enum BufId {
     BUF_WEIGHTS = 0, BUF_IN_U8, BUF_IM2COL, BUF_E1, BUF_E2, BUF_E3, BUF_FEATS, BUF_X0, BUF_X1, BUF_QKV,
-    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_COUNT
+    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_COUNT
 };
 
-enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4 };
+enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5 };
 
 struct GemmItem {
     int bufA, bufB, bufC, bufR;          // bufR = -1: no residual
@@ -85,6 +96,9 @@ struct Op {
     int bufSrc = -1, bufDst = -1, H = 0, W = 0, C = 0, haloS = 0, haloD = 0, n = 0;
     int ldy = 0, pix = 0, tFrameIdx = -1, tFirst = -1;
     int premask = 0;
+    // REDUCE_SCATTER: out[bufDst+offDst][rowC[m]+colC[n/32]+n%32] = sum_s part[bufSrc+offSrc][s*splitStride + m*N + n]
+    int M = 0, N = 0, nsplit = 0, tRowC = -1, tColC = -1;
+    int64_t offSrc = 0, offDst = 0, splitStride = 0;
     double flops = 0;                    // algorithmic flops of this op (2*M*N*K, unpadded)
     std::string tag;
 };
