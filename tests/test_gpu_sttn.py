@@ -140,3 +140,38 @@ def test_full_chunk_properties_1080p(built_lib, gpu_device, sd):
     # so only sanity is asserted on `small`; the strip is fully rewritten inside the mask
     assert (small[:, m] != clip[:7][:, m]).mean() > 0.5
     eng.close()
+
+
+def test_plugin_host_loop_two_chunks(built_lib, gpu_device, sd):
+    """STTNAutoInpaint.__call__ over an in-memory clip (two chunks of 6) through SubtitleRemover.sttn_auto_mode,
+    against the oracle's chunk loop: exercises the plugin surface (writer, progress hook, mask construction)."""
+    from vsr_amd.backend.main import SubtitleRemover
+    from vsr_amd.backend.config import config
+    from vsr_amd.backend.tools.video_io import ArrayVideo
+
+    H, W, n = 480, 852, 12
+    box = (400, 450, 100, 760)
+    clip = synth.make_clip(n, H, W, box, seed=9)
+    old = config.sttnMaxLoadNum.value, config.sttnNeighborStride.value, config.sttnReferenceLength.value
+    config.sttnMaxLoadNum.value, config.sttnNeighborStride.value, config.sttnReferenceLength.value = 6, 1, 6
+    try:
+        assert config.getSttnMaxLoadNum() == 6
+        sr = SubtitleRemover(ArrayVideo(clip.copy()), device="cuda:0", model_path={"netG": sd})
+        sr.sub_areas = [box]
+        ticks = []
+        sr.update_progress = lambda tbar, increment: ticks.append(increment)
+        from vsr_amd.backend.inpaint.sttn_auto_inpaint import STTNAutoInpaint
+        mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
+        plug = STTNAutoInpaint("cuda:0", {"netG": sd}, ArrayVideo(clip.copy()))
+        plug(input_mask=mask, input_sub_remover=sr, tbar=object())
+        got = np.stack(sr.video_writer.frames)
+    finally:
+        config.sttnMaxLoadNum.value, config.sttnNeighborStride.value, config.sttnReferenceLength.value = old
+    assert got.shape == clip.shape and len(ticks) == n
+    mask01 = cv2r.threshold_binary(mask, 127, 1)
+    areas = get_inpaint_area_by_mask(W, H, int(W * 3 / 16), mask01[:, :, None])
+    o = STTNInpaintOracle(sd, "auto", 1, 6)
+    ref = np.concatenate([np.stack(o.chunk(list(clip[s:s + 6]), mask01[:, :, None], areas)) for s in (0, 6)])
+    m = mask01.astype(bool)
+    assert np.array_equal(got[:, ~m], clip[:, ~m])
+    assert calculate_psnr(got[:, m], ref[:, m]) >= PSNR_MIN_DB

@@ -96,10 +96,70 @@ class STTNAutoInpaint:
         self.clip_gap = config.getSttnMaxLoadNum() if clip_gap is None else clip_gap
         self.writer = None
 
+    def _distributed(self):
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+        return None
+
+    def _call_chunk_parallel(self, dist, input_mask, input_sub_remover, tbar):
+        """One process per GPU: the chunks are dealt round-robin, rank 0 owns the frame source and sink
+        (backend/tools/chunk_parallel.py).  Chunk boundaries are the reference's (clip_gap), so every frame
+        sees exactly the temporal context it sees in the single-GPU run."""
+        from ..tools import chunk_parallel as cp
+
+        rank = dist.get_rank()
+        engine = self.sttn_inpaint.engine
+        reader = open_video(self.video_path)
+        frame_info = reader.info()
+        W_ori, H_ori = frame_info["W_ori"], frame_info["H_ori"]
+        ab_sections = input_sub_remover.ab_sections if input_sub_remover is not None else None
+        writer = (input_sub_remover.video_writer if input_sub_remover is not None else ArrayWriter()) if rank == 0 else None
+        self.writer = writer
+        mask = self.sttn_inpaint.read_mask(self.mask_path) if input_mask is None else threshold_mask(input_mask)
+        inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, int(W_ori * 3 / 16), mask)
+        dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(engine.device)
+        ranges = cp.chunk_ranges(frame_info["len"], self.clip_gap)
+
+        def read_chunk(s, e):
+            frames = []
+            for j in range(s, e):
+                ok, image = reader.read()
+                if not ok:
+                    raise RuntimeError(f"Failed to read frame {j}.")
+                frames.append(image)
+            return np.stack(frames)
+
+        def process_chunk(i, frames):
+            s, e = ranges[i]
+            sel = [j - s for j in range(s, e) if is_frame_number_in_ab_sections(j, ab_sections)]
+            if inpaint_area and sel:
+                engine.auto_chunk(frames, dmask, inpaint_area, sel=None if len(sel) == e - s else sel)
+                torch.cuda.synchronize(engine.device)
+            return frames
+
+        def write_chunk(i, arr):
+            for j in range(arr.shape[0]):
+                writer.write(arr[j])
+                if input_sub_remover is not None and tbar is not None:
+                    input_sub_remover.update_progress(tbar, increment=1)
+
+        try:
+            cp.run_chunk_parallel(frame_info["len"], self.clip_gap, (H_ori, W_ori, 3), read_chunk, process_chunk,
+                                  write_chunk, dist=dist, device=engine.device)
+        finally:
+            reader.release()
+            if writer:
+                writer.release()
+
     def __call__(self, input_mask=None, input_sub_remover=None, tbar=None):
         reader = None
         writer = None
         try:
+            dist = self._distributed()
+            if dist is not None:
+                return self._call_chunk_parallel(dist, input_mask, input_sub_remover, tbar)
             reader = open_video(self.video_path)
             frame_info = reader.info()
             if input_sub_remover is not None:

@@ -1,0 +1,95 @@
+"""Command-line surface of the reference's backend/main.py for the accelerated path.
+
+    python -m vsr_amd.backend.main -i IN -o OUT [-c YMIN YMAX XMIN XMAX]... [--inpaint-mode sttn-auto]
+
+Same flags, enum names and call order as the reference (backend/main.py:473-488, tools/args_handler.py:6-30):
+SubtitleRemover(path).sub_areas / .ab_sections / .video_out_path / .run().  Only what the sttn-auto hot path needs
+is kept: mask construction (create_mask, +10 px), the plugin call and a frame sink.  Audio muxing, temp files,
+the GUI hooks' transport and the other modes stay with the reference (surface only, not accelerated).
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+from .config import config
+from .inpaint.sttn_auto_inpaint import STTNAutoInpaint
+from .tools.args_handler import parse_args
+from .tools.constant import InpaintMode
+from .tools.inpaint_tools import create_mask
+from .tools.video_io import ArrayWriter, open_video
+
+
+class SubtitleRemover:
+    def __init__(self, vd_path, gui_mode=False, device="cuda:0", model_path=None, video_writer=None):
+        self.sub_areas = []                      # [(ymin, ymax, xmin, xmax)] (args_handler.py:19 order)
+        self.gui_mode = gui_mode
+        self.video_path = vd_path
+        self.device = device
+        self.ab_sections = None
+        info = open_video(vd_path).info() if not isinstance(vd_path, (str, os.PathLike)) else None
+        if info is None:
+            src = open_video(vd_path)
+            info = src.info()
+            src.release()
+        self.frame_count = info["len"]
+        self.fps = info["fps"]
+        self.frame_height, self.frame_width = info["H_ori"], info["W_ori"]
+        self.mask_size = (self.frame_height, self.frame_width)
+        self.video_writer = video_writer if video_writer is not None else ArrayWriter()
+        if isinstance(vd_path, (str, os.PathLike)):
+            self.vd_name = Path(vd_path).stem
+            self.video_out_path = os.path.abspath(os.path.join(os.path.dirname(vd_path), f"{self.vd_name}_no_sub.mp4"))
+        else:
+            self.vd_name, self.video_out_path = "clip", None
+        self.model_path = model_path or os.environ.get(
+            "STTN_AUTO_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-auto", "infer_model.pth"))
+        self.progress_total = 0
+        self.isFinished = False
+
+    # hooks the plugin calls on its host object (main.py:109-151)
+    def update_progress(self, tbar, increment):
+        if tbar is not None:
+            tbar.update(increment)
+
+    def update_preview_with_comp(self, original, frame):
+        pass
+
+    def append_output(self, *args):
+        print(*args)
+
+    def sttn_auto_mode(self, tbar):
+        """backend/main.py:247-258."""
+        mask_area_coordinates = []
+        for ymin, ymax, xmin, xmax in self.sub_areas:
+            mask_area_coordinates.append((xmin, xmax, ymin, ymax))       # tuple order flips here (main.py:253-255)
+        mask = create_mask(self.mask_size, mask_area_coordinates)
+        sttn_video_inpaint = STTNAutoInpaint(self.device, self.model_path, self.video_path)
+        sttn_video_inpaint(input_mask=mask, input_sub_remover=self, tbar=tbar)
+
+    def run(self):
+        start_time = time.time()
+        if len(self.sub_areas) == 0:
+            self.sub_areas.append((0, self.frame_height, 0, self.frame_width))
+        mode = config.inpaintMode.value
+        if mode == InpaintMode.STTN_AUTO:
+            self.sttn_auto_mode(None)
+        else:
+            raise Exception(f"inpaint mode: {mode} not implemented")     # main.py:386
+        self.isFinished = True
+        self.progress_total = 100
+        self.append_output(f"Finished in {round(time.time() - start_time)} s")
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config.inpaintMode.value = args.inpaint_mode
+    sr = SubtitleRemover(args.input)
+    sr.sub_areas = [tuple(c) for c in args.subtitle_area_coords]
+    if args.output is not None:
+        sr.video_out_path = args.output
+    sr.run()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
