@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--res", default="1080p", choices=sorted(RES))
     ap.add_argument("--chunk", type=int, default=50, help="frames per chunk (config.sttnMaxLoadNum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=10)
+    ap.add_argument("--cpu-sample-frames", type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,9 +173,10 @@ def main():
         per_kernel = {}
         for cfg, (bm, bn, wm, wn) in dims.items():
             for bmode in (0, 1):
-                a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}")
-                if b:
-                    per_kernel[f"gather_gemm_f32<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)
+                for var, sym in ((1, "gather_gemm_f32"), (2, "gather_gemm_f32_v2"), (3, "gather_gemm_f32_v3")):
+                    a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}:v{var}")
+                    if b:
+                        per_kernel[f"{sym}<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)
         dom = max(per_kernel, key=lambda k: per_kernel[k][0])
         ms, n, fl = per_kernel[dom]
         breakdown = {}
@@ -183,10 +184,11 @@ def main():
             a, b, c = eng.timing_get(tag)
             breakdown[tag] = {"ms": round(a, 3), "launches": b, "tflops": round(c / a / 1e9, 2) if a > 0 and c > 0 else None}
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "conv3x3_pmc.json")     # PMC passes are separate rocprofv3 runs
+        prof = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")     # PMC passes are separate rocprofv3 runs (scripts/profile_round.sh)
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                pj = json.load(open(prof))
+                traffic = pj.get("hbm_bytes_per_launch") if pj.get("kernel", "").endswith(dom) else None
             except Exception:
                 traffic = None
         ach = fl / ms / 1e9 if ms > 0 else 0.0

@@ -81,6 +81,20 @@ int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* com
 int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                         int n_areas, const int32_t* areas, const int32_t* sel, int nsel, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * sttn-det (backend/inpaint/sttn_det_inpaint.py; model created with VSR_VARIANT_STTN_DET).
+ * vsr_sttn_det_inpaint = STTNDetInpaint.inpaint(frames, masks) (:124-174): frames [L][240][432][3] uint8 BGR,
+ * masks [L][240][432] uint8 as produced by cv2.resize of the 0/255 mask strip; the encoder sees
+ * frames*(1-(mask/255>0.5)), the output is pred*(mask>0)+frame*(1-(mask>0)) averaged like sttn-auto.
+ * vsr_sttn_det_batch = STTNDetInpaint.__call__(input_frames, input_mask) (:38-99): mask_dev is the raw
+ * [H][W] 0/255 mask; every area strip (height int(W*5/18) landscape, :48-51) is resized to 432x240 together
+ * with its mask strip, inpainted and the WHOLE strip is overwritten with the up-scaled composite (:93).
+ * ------------------------------------------------------------------------------------- */
+int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t* masks_dev, int L, float* comp_dev,
+                         int32_t* counts, void* stream);
+int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                       const int32_t* areas, void* stream);
+
 /* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded) */
 double vsr_sttn_flops(vsr_sttn_t* h, int L);
 
@@ -141,20 +155,26 @@ int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
 /* cv2.resize(..., INTER_LINEAR) on uint8 (fixed-point path), tables from vsr_cv2_linear_tables;
  * frame_idx (device, nullable) gathers source frames (sttn_auto_inpaint.py:269-271) */
 int vsr_launch_resize_u8(const uint8_t* src_dev, int64_t src_frame_stride, int src_row_stride, int sw, int sh,
-                         uint8_t* dst_dev, int dw, int dh, int nframes, const int32_t* frame_idx_dev,
+                         uint8_t* dst_dev, int dw, int dh, int nframes, int channels /*1 or 3*/,
+                         const int32_t* frame_idx_dev,
                          const int32_t* xofs_dev, const int16_t* ialpha_dev, const int32_t* yofs_dev,
                          const int16_t* ibeta_dev, void* stream);
 /* Stack(BGR->RGB) + /255 + *2-1 (utils/sttn_utils.py:73,111; sttn_auto_inpaint.py:128) fused with
- * the im2col of encoder conv1 (auto_sttn.py:76): out [n*(ih/2)*(iw/2)][32] */
+ * the im2col of encoder conv1 (auto_sttn.py:76): out [n*(ih/2)*(iw/2)][32].  premask (sttn-det,
+ * sttn_det_inpaint.py:134,143): pixels whose resized mask [n][ih][iw] is >= 128 enter as 0 */
 int vsr_launch_norm_im2col(const uint8_t* img_dev, int ih, int iw, int nframes, float* out_dev, int premask,
                            const uint8_t* mask_dev, void* stream);
 /* F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC with halos (auto_sttn.py:124-126) */
 int vsr_launch_upsample2x(const float* src_dev, int H, int W, int C, int halo_src, float* dst_dev, int halo_dst,
                           int nframes, void* stream);
-/* tanh, (x+1)/2, *255, astype(uint8), pairwise overlap average (sttn_auto_inpaint.py:150-162) */
+/* tanh, (x+1)/2, *255, astype(uint8), pairwise overlap average (sttn_auto_inpaint.py:150-162); with
+ * mask_dev != NULL the sttn-det model-resolution blend pred*(mask>0) + frame*(1-(mask>0))
+ * (sttn_det_inpaint.py:132,168) against the model-res BGR input frames in_bgr_dev */
 int vsr_launch_decode_out(const float* y_dev, int ldy, int pix, int nframes, const int32_t* frame_idx_dev,
-                          const int32_t* first_dev, float* comp_dev, void* stream);
-/* cv2.resize(comp,(W,split_h)) + astype(uint8) + BGR2RGB + mask blend (sttn_auto_inpaint.py:312-315) */
+                          const int32_t* first_dev, float* comp_dev, const uint8_t* in_bgr_dev,
+                          const uint8_t* mask_dev, void* stream);
+/* cv2.resize(comp,(W,split_h)) + astype(uint8) + BGR2RGB + mask blend (sttn_auto_inpaint.py:312-315);
+ * mask_dev == NULL overwrites the whole strip (sttn_det_inpaint.py:93) */
 int vsr_launch_upscale_blend(const float* comp_dev, int mw, int mh, const int32_t* is_float_dev,
                              uint8_t* frames_dev, int64_t frame_stride, int row_stride,
                              const int32_t* frame_idx_dev, const uint8_t* mask_dev, int mask_row_stride, int W,
@@ -177,7 +197,8 @@ typedef struct VsrOpInfo {
     int32_t nitems, tile_cfg, bmode;
     int32_t buf_src, buf_dst, H, W, C, halo_src, halo_dst, n, ldy, pix, t_frame_idx, t_first, premask;
     /* reduce_scatter: part = buf_src + off_src, out = buf_dst + off_dst, M, N, nsplit, tables */
-    int32_t M, N, nsplit, t_rowC, t_colC, pad_;
+    int32_t M, N, nsplit, t_rowC, t_colC;
+    int32_t buf_mask; /* sttn-det: resized-mask byte buffer used by norm_im2col (premask) and decode_out, else -1 */
     int64_t off_src, off_dst, split_stride;
     double flops;
     char tag[32];

@@ -32,22 +32,23 @@ static float run(const GGProblem* d, int blocks, int iters)
 template <int BM, int BN, int WM, int WN, int V>
 static float run_v2(const GGProblem* d, int blocks, int iters, int residentPerCU)
 {
-    void (*kern)(const GGProblem*, int, int, unsigned int*) = gather_gemm_f32_v2<BM, BN, WM, WN, VSR_BMODE_NK, 0>;
-    if (V == 3) kern = gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>;
+
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     unsigned int* q;
-    hipMalloc(&q, 64 * sizeof(unsigned int));
+    hipMalloc(&q, 64 * 8 * sizeof(unsigned int));
     int occ = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0);
+    if (V == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>, 256, 0);
+    else hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v2<BM, BN, WM, WN, VSR_BMODE_NK, 0>, 256, 0);
     if (residentPerCU > 0 && residentPerCU < occ) occ = residentPerCU;
     const int grid = blocks < 256 * occ ? blocks : 256 * occ;
     float best = 1e9f;
     for (int rep = 0; rep < 2; ++rep) {
-        hipMemset(q, 0, 64 * sizeof(unsigned int));
+        hipMemset(q, 0, 64 * 8 * sizeof(unsigned int));
         hipEventRecord(a, 0);
         for (int i = 0; i < iters; ++i)
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + i);
+            if (V == 3) hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8);
+            else hipLaunchKernelGGL((gather_gemm_f32_v2<BM, BN, WM, WN, VSR_BMODE_NK, 0>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;
@@ -112,8 +113,8 @@ static int sweep(int T)
     if (BM == 128 && BN == 64) {   // v3 timeline of a few workgroups: per-chunk durations, prologue, epilogue
         std::vector<unsigned long long> z(1024 * 256, 0), h(1024 * 256);
         hipMemcpyToSymbol(HIP_SYMBOL(gg_trace), z.data(), z.size() * 8);
-        unsigned int* q; hipMalloc(&q, 4); hipMemset(q, 0, 4);
-        hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 64>), dim3(768), dim3(256), 0, 0, d, 1, blocks, q);
+        unsigned int* q; hipMalloc(&q, 32); hipMemset(q, 0, 32);
+        hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 64>), dim3(768), dim3(256), 0, 0, d, 1, blocks, q, 8);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gg_trace), h.size() * 8);
         hipFree(q);

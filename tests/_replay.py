@@ -124,6 +124,9 @@ def norm_im2col_reference(info, bufs):
     ih, iw, n = info.H, info.W, info.n
     img = bufs[info.buf_src][: n * ih * iw * 3].reshape(n, ih, iw, 3)
     x = torch.from_numpy(np.ascontiguousarray(img[..., ::-1])).permute(0, 3, 1, 2).float().div(255) * 2 - 1
+    if getattr(info, "premask", 0):
+        m = bufs[info.buf_mask][: n * ih * iw].reshape(n, 1, ih, iw)
+        x = x * torch.from_numpy((m < 128).astype(np.float32))
     cols = torch.nn.functional.unfold(x, kernel_size=3, padding=1, stride=2)       # n, 27 (c,ky,kx), oh*ow
     oh, ow = ih // 2, iw // 2
     cols = cols.view(n, 3, 9, oh * ow).permute(0, 3, 2, 1).reshape(n * oh * ow, 27)   # k = tap*3 + c
@@ -139,9 +142,15 @@ def decode_out_reference(info, bufs, tables):
     v = ((v + 1) / 2).numpy() * 255
     img = v.astype(np.uint8).astype(np.float32)
     comp = bufs[info.buf_dst]
+    det_mask = bufs[info.buf_mask] if getattr(info, "buf_mask", -1) >= 0 else None
     idx = tables[info.t_frame_idx]
     first = tables[info.t_first]
     for i in range(n):
+        if det_mask is not None:
+            f = int(idx[i])
+            b = (det_mask[f * pix:(f + 1) * pix] > 0)[:, None]
+            rgb = bufs[BUF_IN_U8][f * pix * 3:(f + 1) * pix * 3].reshape(pix, 3)[:, ::-1].astype(np.float32)
+            img[i] = np.where(b, img[i], rgb)
         sl = slice(int(idx[i]) * pix * 3, (int(idx[i]) + 1) * pix * 3)
         if first[i]:
             comp[sl] = img[i].reshape(-1)
@@ -162,8 +171,11 @@ def reduce_scatter_reference(info, bufs, tables):
     bufs[info.buf_dst][info.off_dst + rowC[:, None] + colC[None, :]] = acc
 
 
-def replay(view, packed_weights, frames_u8):
-    """frames_u8: [L,mh,mw,3] uint8 BGR -> (comp float32 [L,mh,mw,3] RGB, counts)."""
+BUF_MASK_U8 = 22
+
+
+def replay(view, packed_weights, frames_u8, masks_u8=None):
+    """frames_u8: [L,mh,mw,3] uint8 BGR (+ masks_u8 [L,mh,mw] for sttn-det) -> (comp f32 [L,mh,mw,3] RGB, counts)."""
     bufs = []
     for b, n in enumerate(view.buf_elems):
         if b == BUF_WEIGHTS:
@@ -171,6 +183,11 @@ def replay(view, packed_weights, frames_u8):
         elif b == BUF_IN_U8:
             a = np.zeros(n, dtype=np.uint8)
             a[: frames_u8.size] = frames_u8.reshape(-1)
+            bufs.append(a)
+        elif b == BUF_MASK_U8:
+            a = np.zeros(n, dtype=np.uint8)
+            if masks_u8 is not None:
+                a[: masks_u8.size] = masks_u8.reshape(-1)
             bufs.append(a)
         else:
             bufs.append(np.zeros(n, dtype=np.float32))

@@ -10,6 +10,40 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
+def run_det(L=2, ns=1, rl=2, seed=5):
+    """sttn-det: pre-masked encoder input and model-resolution blend; windows T = 2, 2; counts [2, 2]."""
+    import vsr_amd  # noqa: F401
+    from vsr_amd import _lib
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+    from oracle.sttn_det import STTNDetOracle
+    from oracle.sttn_auto import calculate_psnr
+    from oracle import cv2_restate as cv2r
+    from _replay import PlanView, replay
+
+    sd = make_state_dict(1, "det")
+    eng = SttnEngine(sd, "det", device=None, neighbor_stride=ns, ref_length=rl)
+    rng = np.random.default_rng(seed)
+    frames = rng.integers(0, 256, size=(L, 240, 432, 3), dtype=np.uint8)
+    big = np.zeros((533, 1920, 1), np.uint8)
+    big[150:330, 300:1500] = 255
+    small = cv2r.resize_linear(big, (432, 240))[:, :, 0]
+    masks = np.stack([small] * L)
+    view = PlanView(_lib, eng, L)
+    comp, counts, _ = replay(view, eng.packed_weights(), frames, masks)
+    flops = view.flops
+    view.close()
+    eng.close()
+    ref = STTNDetOracle(sd, ns, rl).inpaint(list(frames), list(masks))
+    refa = np.stack([r.astype(np.float32) for r in ref])
+    d = np.abs(comp - refa)
+    assert d.max() <= 1.0, d.max()
+    assert (d > 0).mean() < 2e-3, (d > 0).mean()
+    outside = np.broadcast_to((small == 0)[None, :, :, None], comp.shape)
+    assert np.array_equal(comp[outside], frames[..., ::-1].astype(np.float32)[outside]), "outside the mask the RGB input comes back"
+    return {"counts": counts.tolist(), "psnr": calculate_psnr(comp, refa), "max_abs": float(d.max()), "flops": flops}
+
+
 def run(L=4, ns=2, rl=3, seed=11):
     import vsr_amd  # noqa: F401
     from vsr_amd import _lib
@@ -44,4 +78,4 @@ def run(L=4, ns=2, rl=3, seed=11):
 if __name__ == "__main__":
     import json
 
-    print(json.dumps(run()))
+    print(json.dumps(run_det() if "--det" in sys.argv else run()))

@@ -254,13 +254,33 @@ def test_resize_u8_down_bit_exact(built_lib, gpu_device, sw, sh):
     dst = torch.zeros((n, 120, 640, 3), dtype=torch.uint8, device=gpu_device)
     idx = _dev(np.array([2, 0, 1], np.int32), gpu_device)
     rc = built_lib.lib.vsr_launch_resize_u8(C.c_void_p(src.data_ptr() + ymin * sw * 3), H * sw * 3, sw * 3, sw, sh, _ptr(dst),
-                                            640, 120, n, _ptr(idx), _ptr(xo), _ptr(xa), _ptr(yo), _ptr(ya), None)
+                                            640, 120, n, 3, _ptr(idx), _ptr(xo), _ptr(xa), _ptr(yo), _ptr(ya), None)
     assert rc == 0
     torch.cuda.synchronize()
     got = dst.cpu().numpy()
     for o, f in enumerate([2, 0, 1]):
         ref = cv2r.resize_linear(frames[f, ymin:ymin + sh], (640, 120))
         assert np.array_equal(got[o], ref)
+
+
+def test_resize_u8_single_channel_mask(built_lib, gpu_device):
+    """sttn-det resizes the 0/255 mask strip with the frames (frame stride 0 replicates it per frame)."""
+    sw, sh, n = 1920, 533, 3
+    mask = np.zeros((sh + 10, sw), np.uint8)
+    mask[100:300, 288:1632] = 255
+    (xo, xa, _), _ = _tables(sw, 432, True, gpu_device)
+    (yo, ya, _), _ = _tables(sh, 240, False, gpu_device)
+    src = _dev(mask, gpu_device)
+    dst = torch.zeros((n, 240, 432), dtype=torch.uint8, device=gpu_device)
+    rc = built_lib.lib.vsr_launch_resize_u8(C.c_void_p(src.data_ptr() + 5 * sw), 0, sw, sw, sh, _ptr(dst), 432, 240, n, 1, None,
+                                            _ptr(xo), _ptr(xa), _ptr(yo), _ptr(ya), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = cv2r.resize_linear(mask[5:5 + sh, :, None], (432, 240))[:, :, 0]
+    got = dst.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], ref)
+    assert 0 < ((ref > 0) & (ref < 255)).sum(), "the resized mask has interpolated edge values"
 
 
 def test_norm_im2col_exact(built_lib, gpu_device):
@@ -301,7 +321,7 @@ def test_decode_out_and_average(built_lib, gpu_device):
     comp = _dev(comp0, gpu_device)
     fidx, first = np.array([4, 1, 2], np.int32), np.array([1, 0, 0], np.int32)
     dy, dfidx, dfirst = _dev(y, gpu_device), _dev(fidx, gpu_device), _dev(first, gpu_device)      # keep alive
-    assert built_lib.lib.vsr_launch_decode_out(_ptr(dy), 32, pix, n, _ptr(dfidx), _ptr(dfirst), _ptr(comp), None) == 0
+    assert built_lib.lib.vsr_launch_decode_out(_ptr(dy), 32, pix, n, _ptr(dfidx), _ptr(dfirst), _ptr(comp), None, None, None) == 0
     torch.cuda.synchronize()
     bufs = {0: y.reshape(-1), 1: comp0.reshape(-1).copy()}
     _replay.decode_out_reference(SimpleNamespace(n=n, pix=pix, ldy=32, buf_src=0, buf_dst=1, t_frame_idx=0, t_first=1),

@@ -175,3 +175,66 @@ def test_plugin_host_loop_two_chunks(built_lib, gpu_device, sd):
     m = mask01.astype(bool)
     assert np.array_equal(got[:, ~m], clip[:, ~m])
     assert calculate_psnr(got[:, m], ref[:, m]) >= PSNR_MIN_DB
+
+
+# ------------------------------------------------------------------------------------------------
+# sttn-det
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sd_det():
+    return make_state_dict(1, "det")
+
+
+def test_det_inpaint_vs_oracle(built_lib, gpu_device, sd_det):
+    """STTNDetInpaint.inpaint(frames, masks): pre-masked encoder input + model-resolution blend."""
+    from oracle.sttn_det import STTNDetOracle
+    from vsr_amd.engine import SttnEngine
+
+    eng = SttnEngine(sd_det, "det", device=0, neighbor_stride=2, ref_length=3)
+    L = 4
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, size=(L, 240, 432, 3), dtype=np.uint8)
+    big = np.zeros((533, 1920, 1), np.uint8)
+    big[150:330, 300:1500] = 255
+    small = cv2r.resize_linear(big, (432, 240))[:, :, 0]
+    masks = np.stack([small] * L)
+    comp, counts = eng.det_inpaint(torch.from_numpy(frames).to(gpu_device), torch.from_numpy(masks).to(gpu_device))
+    torch.cuda.synchronize()
+    ref = STTNDetOracle(sd_det, 2, 3).inpaint(list(frames), list(masks))
+    psnr, dmax, frac = _compare_comp(comp.cpu().numpy(), ref, counts)
+    print(f"det psnr={psnr:.2f} dB max|d|={dmax} frac_diff={frac:.2e}")
+    assert counts.tolist() == [2, 2, 2, 1]
+    assert psnr >= PSNR_MIN_DB and dmax <= 2.0
+    eng.close()
+
+
+@pytest.mark.parametrize("H,W,box", [(1080, 1920, (950, 1070, 288, 1632)), (720, 1280, (620, 700, 192, 1088))])
+def test_det_plugin_call_vs_oracle(built_lib, gpu_device, sd_det, H, W, box):
+    """STTNDetInpaint.__call__(frames, mask) -- the generic plugin contract of main.py:326 -- vs the oracle."""
+    from oracle.sttn_det import STTNDetOracle
+    from vsr_amd.backend.config import config
+    from vsr_amd.backend.inpaint.sttn_det_inpaint import STTNDetInpaint
+
+    old = config.sttnNeighborStride.value, config.sttnReferenceLength.value
+    config.sttnNeighborStride.value, config.sttnReferenceLength.value = 2, 3
+    try:
+        plug = STTNDetInpaint("cuda:0", {"netG": sd_det})
+        L = 4
+        clip = synth.make_clip(L, H, W, box, seed=W)
+        mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
+        frames_in = [f.copy() for f in clip]
+        got = np.stack(plug(frames_in, mask))
+        assert all(np.array_equal(a, b) for a, b in zip(frames_in, clip)), "inputs are not mutated"
+    finally:
+        config.sttnNeighborStride.value, config.sttnReferenceLength.value = old
+    ref = np.stack(STTNDetOracle(sd_det, 2, 3)(list(clip), mask))
+    split_h = int(W * 5 / 18)
+    areas = get_inpaint_area_by_mask(W, H, split_h, mask[:, :, None])
+    ymin, ymax = areas[0][0], areas[0][1]
+    assert ymax - ymin == split_h
+    assert np.array_equal(got[:, :ymin], clip[:, :ymin]) and np.array_equal(got[:, ymax:], clip[:, ymax:])
+    psnr_strip = calculate_psnr(got[:, ymin:ymax], ref[:, ymin:ymax])
+    print(f"det {W}x{H}: PSNR over the rewritten strip {psnr_strip:.2f} dB")
+    assert psnr_strip >= PSNR_MIN_DB
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 2
+    plug.engine.close()

@@ -34,6 +34,27 @@ def test_plan_replay_matches_oracle(built_lib):
     assert res["counts"] == [2, 2, 2, 1]
 
 
+def test_plan_replay_sttn_det(built_lib):
+    """sttn-det geometry (432x240, patch table of network_sttn.py:69), pre-masked input, model-res blend."""
+    import _replay_check
+
+    res = _replay_check.run_det()
+    assert res["counts"] == [2, 2]
+
+
+def test_plan_flops_det_matches_survey(built_lib):
+    """733.8 GFLOP per frame for a 50-frame sttn-det batch."""
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+
+    eng = SttnEngine(make_state_dict(1, "det"), "det", device=None)
+    try:
+        f50 = eng.flops(50)
+    finally:
+        eng.close()
+    assert abs(f50 / 50 / 1e9 - 733.8) < 1.5, f50 / 50 / 1e9
+
+
 def test_plan_replay_split_pv_and_square_tiles():
     """Non-default tuning in a fresh process: PV split-K + reduce-scatter, 128x128 conv tiles,
     tap-major K order (the library reads its tuning env once per process)."""

@@ -45,7 +45,7 @@ class VsrOpInfo(C.Structure):
                 ("halo_src", C.c_int32), ("halo_dst", C.c_int32), ("n", C.c_int32), ("ldy", C.c_int32),
                 ("pix", C.c_int32), ("t_frame_idx", C.c_int32), ("t_first", C.c_int32), ("premask", C.c_int32),
                 ("M", C.c_int32), ("N", C.c_int32), ("nsplit", C.c_int32), ("t_rowC", C.c_int32), ("t_colC", C.c_int32),
-                ("pad_", C.c_int32), ("off_src", C.c_int64), ("off_dst", C.c_int64), ("split_stride", C.c_int64),
+                ("buf_mask", C.c_int32), ("off_src", C.c_int64), ("off_dst", C.c_int64), ("split_stride", C.c_int64),
                 ("flops", C.c_double), ("tag", C.c_char * 32)]
 
 
@@ -81,17 +81,19 @@ SIGNATURES = {
     "vsr_sttn_packed_weights": (_L, [_P, _P, _L]),
     "vsr_sttn_inpaint": (_I, [_P, _P, _I, _P, _P, _P]),
     "vsr_sttn_auto_chunk": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
+    "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vsr_sttn_det_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_sttn_flops": (_D, [_P, _I]),
     "vsr_sttn_timing": (_I, [_P, _I]),
     "vsr_sttn_timing_get": (_I, [_P, C.c_char_p, C.POINTER(_D), C.POINTER(C.c_int32), C.POINTER(_D)]),
     "vsr_sttn_timing_reset": (_I, [_P]),
     "vsr_run_gather_gemm": (_I, [C.POINTER(GGProblem), _I, _I, _I, _P]),
     "vsr_run_softmax": (_I, [C.POINTER(SMProblem), _I, _P]),
-    "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsr_launch_norm_im2col": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_launch_reduce_scatter": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P]),
     "vsr_launch_upsample2x": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
-    "vsr_launch_decode_out": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "vsr_launch_decode_out": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsr_launch_upscale_blend": (_I, [_P, _I, _I, _P, _P, _L, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsr_cv2_linear_tables": (_I, [_I, _I, _I, _P, _P, _P]),
     "vsr_plan_create": (_I, [_P, _I, C.POINTER(_P)]),

@@ -26,6 +26,7 @@ __device__ __forceinline__ int fixpt_lin(int s00, int s01, int s10, int s11, int
     return (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
 }
 
+template <int CH>
 __global__ void __launch_bounds__(256)
 k_resize_u8(const uint8_t* __restrict__ src, int64_t srcFrameStride, int srcRowStride, int sw, int sh,
             uint8_t* __restrict__ dst, int dw, int dh, int nframes, const int32_t* __restrict__ frameIdx,
@@ -47,10 +48,10 @@ k_resize_u8(const uint8_t* __restrict__ src, int64_t srcFrameStride, int srcRowS
         const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
         const uint8_t* r0 = src + f * srcFrameStride + (int64_t)y0 * srcRowStride;
         const uint8_t* r1 = src + f * srcFrameStride + (int64_t)y1 * srcRowStride;
-        uint8_t* o = dst + i * 3;
+        uint8_t* o = dst + i * CH;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int v = fixpt_lin(r0[x0 * 3 + c], r0[x1 * 3 + c], r1[x0 * 3 + c], r1[x1 * 3 + c], a0, a1, b0, b1);
+        for (int c = 0; c < CH; ++c) {
+            const int v = fixpt_lin(r0[x0 * CH + c], r0[x1 * CH + c], r1[x0 * CH + c], r1[x1 * CH + c], a0, a1, b0, b1);
             o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         }
     }
@@ -64,7 +65,7 @@ k_resize_u8(const uint8_t* __restrict__ src, int64_t srcFrameStride, int srcRowS
 __global__ void __launch_bounds__(256)
 k_norm_im2col_s2(const uint8_t* __restrict__ img /*[n][ih][iw][3] BGR*/, int ih, int iw, int nframes,
                  float* __restrict__ out /*[n*oh*ow][32]*/, int premask,
-                 const uint8_t* __restrict__ mask /*[ih][iw] {0,1} or null*/)
+                 const uint8_t* __restrict__ mask /*[n][ih][iw] resized 0..255 mask or null*/)
 {
     const int oh = ih / 2, ow = iw / 2;
     const int64_t total = (int64_t)nframes * oh * ow * 8;
@@ -86,7 +87,8 @@ k_norm_im2col_s2(const uint8_t* __restrict__ img /*[n][ih][iw][3] BGR*/, int ih,
                 if (y >= 0 && y < ih && x >= 0 && x < iw) {
                     const uint8_t u = img[(((int64_t)f * ih + y) * iw + x) * 3 + (2 - c)];
                     val = ((float)u / 255.0f) * 2.0f - 1.0f;
-                    if (premask && mask[(int64_t)y * iw + x]) val = 0.f;
+                    // sttn-det: feats * (1 - (mask/255 > 0.5))  (sttn_det_inpaint.py:134,143)
+                    if (premask && mask[((int64_t)f * ih + y) * iw + x] >= 128) val = 0.f;
                 }
             }
             v[j] = val;
@@ -201,7 +203,9 @@ k_upsample2x_nhwc(const float* __restrict__ src, int H, int W, int C, int haloS,
 __global__ void __launch_bounds__(256)
 k_decode_out(const float* __restrict__ y /*[n*pix][ldy] first 3 cols = RGB pre-tanh*/, int ldy, int pix,
              int nframes, const int32_t* __restrict__ frameIdx, const int32_t* __restrict__ first,
-             float* __restrict__ comp /*[L][pix][3]*/)
+             float* __restrict__ comp /*[L][pix][3]*/,
+             const uint8_t* __restrict__ inBGR /*[L][pix][3] model-res input frames, sttn-det only*/,
+             const uint8_t* __restrict__ mask /*[L][pix] resized 0..255 mask, sttn-det only (null = sttn-auto)*/)
 {
     const int64_t total = (int64_t)nframes * pix;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -211,12 +215,16 @@ k_decode_out(const float* __restrict__ y /*[n*pix][ldy] first 3 cols = RGB pre-t
         const bool fst = first[f] != 0;
         const float* s = y + i * ldy;
         float* c = comp + ((int64_t)idx * pix + p) * 3;
+        // sttn-det: img = pred*binary_mask + frame*(1-binary_mask), binary_mask = resized mask > 0.5 on 0..255
+        // data, i.e. any non-zero value (sttn_det_inpaint.py:132,168); frame is the RGB model-res input
+        const bool keepIn = (mask != nullptr) && (mask[(int64_t)idx * pix + p] == 0);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float v = tanhf(s[ch]);
             v = (v + 1.0f) / 2.0f;
             v = v * 255.0f;
-            const float img = (float)(uint8_t)(int)v; // astype(np.uint8) of a value in [0,255]
+            float img = (float)(uint8_t)(int)v; // astype(np.uint8) of a value in [0,255]
+            if (keepIn) img = (float)inBGR[((int64_t)idx * pix + p) * 3 + (2 - ch)];
             c[ch] = fst ? img : (c[ch] * 0.5f + img * 0.5f);
         }
     }
@@ -240,7 +248,7 @@ k_upscale_blend(const float* __restrict__ comp /*[n][mh][mw][3] RGB*/, int mw, i
         const int dx = (int)(i % W);
         const int dy = (int)((i / W) % sh);
         const int f = (int)(i / ((int64_t)W * sh));
-        if (!mask[(int64_t)dy * maskRowStride + dx]) continue;
+        if (mask != nullptr && !mask[(int64_t)dy * maskRowStride + dx]) continue;   // null: whole strip (sttn-det :93)
         const int x0 = xofs[dx];
         const int x1 = x0 + 1 < mw ? x0 + 1 : mw - 1;
         const int sy = yofs[dy];
@@ -312,14 +320,20 @@ static inline int grid_for(int64_t total)
 }
 
 extern "C" int vsr_launch_resize_u8(const uint8_t* src, int64_t srcFrameStride, int srcRowStride, int sw, int sh,
-                                    uint8_t* dst, int dw, int dh, int nframes, const int32_t* frameIdx,
+                                    uint8_t* dst, int dw, int dh, int nframes, int channels, const int32_t* frameIdx,
                                     const int32_t* xofs, const int16_t* ialpha, const int32_t* yofs,
                                     const int16_t* ibeta, void* stream)
 {
     const int64_t total = (int64_t)nframes * dh * dw;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_resize_u8, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, srcFrameStride,
-                       srcRowStride, sw, sh, dst, dw, dh, nframes, frameIdx, xofs, ialpha, yofs, ibeta);
+    if (channels == 3)
+        hipLaunchKernelGGL(k_resize_u8<3>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, srcFrameStride,
+                           srcRowStride, sw, sh, dst, dw, dh, nframes, frameIdx, xofs, ialpha, yofs, ibeta);
+    else if (channels == 1)
+        hipLaunchKernelGGL(k_resize_u8<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, srcFrameStride,
+                           srcRowStride, sw, sh, dst, dw, dh, nframes, frameIdx, xofs, ialpha, yofs, ibeta);
+    else
+        return VSR_ERR_ARG;
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
@@ -361,12 +375,13 @@ extern "C" int vsr_launch_upsample2x(const float* src, int H, int W, int C, int 
 }
 
 extern "C" int vsr_launch_decode_out(const float* y, int ldy, int pix, int nframes, const int32_t* frameIdx,
-                                     const int32_t* first, float* comp, void* stream)
+                                     const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
+                                     void* stream)
 {
     const int64_t total = (int64_t)nframes * pix;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_decode_out, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, pix, nframes,
-                       frameIdx, first, comp);
+                       frameIdx, first, comp, inBGR, mask);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 

@@ -15,8 +15,9 @@
 //   * chunk offsets (colA / colB tables) are held in a VGPR (one table entry per lane, refreshed
 //     every 64 chunks, prefetched one refresh ahead) and picked with v_readlane: no scalar load
 //     and no lgkmcnt(0) stall in front of every chunk.
-//   * persistent workgroups pulling tiles from an atomic queue (see v2 for the measurement that
-//     motivates it: the dispatcher packs a partial last round onto few CUs).
+//   * persistent workgroups pulling tiles from per-XCD atomic queues with stealing (see v2 for the
+//     measurement that motivates persistence: the dispatcher packs a partial last round onto few
+//     CUs; one global queue scattered neighbouring tiles over all XCDs and tripled the fabric reads).
 #pragma once
 #include <type_traits>
 
@@ -50,7 +51,7 @@ __device__ unsigned long long gg_trace[1024 * 256];
 
 template <int BM, int BN, int WM, int WN, int BMODE GG_ABL_PARAM>
 __global__ void __launch_bounds__(256)
-gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue)
+gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue, int nQueues)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
@@ -80,7 +81,25 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
     for (int g = 0; g < 4; ++g) rdOff[g] = (((2 * g + hi) ^ ((l31 >> 1) & 7)) << 2);
 
-    if (tid == 0) *nextTile = (int)atomicAdd(queue, 1u);
+    // Tile queue: the flat tile-id space is cut into 8 contiguous ranges, one per XCD, each with its
+    // own counter (queue[0..7], zeroed by the host).  A workgroup drains the range of the XCD it runs
+    // on (blockIdx % 8 -- observed placement, used for L2 locality only: tiles that share A rows or
+    // weight columns are neighbours in id space and so meet in one L2) and then steals from the
+    // following ranges, so every id is handed out exactly once whatever the placement is.
+    int qFirst = 0;                                    // ranges before (home + qFirst) are known to be empty
+    auto fetchTile = [&]() -> int {
+        const int home = blockIdx.x % nQueues;             // nQueues = 8 (one per XCD) or 1 (single global queue)
+        for (; qFirst < nQueues; ++qFirst) {
+            const int x = (home + qFirst) % nQueues;
+            const int lo = (int)(((long long)totalTiles * x) / nQueues), hi = (int)(((long long)totalTiles * (x + 1)) / nQueues);
+            if (lo < hi) {
+                const int i = lo + (int)atomicAdd(queue + x, 1u);
+                if (i < hi) return i;
+            }
+        }
+        return totalTiles;
+    };
+    if (tid == 0) *nextTile = fetchTile();
     __syncthreads();
 #ifdef GG_ABLATE
     int tr_ = 0;
@@ -90,7 +109,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const int bid = __builtin_amdgcn_readfirstlane(*nextTile);
         __syncthreads();
         if (bid >= totalTiles) break;
-        if (tid == 0) *nextTile = (int)atomicAdd(queue, 1u);
+        if (tid == 0) *nextTile = fetchTile();
         GG_STAMP()   // tile start
 
         int pi = 0;

@@ -45,12 +45,15 @@ struct OpDev {
     int kind = 0, tileCfg = 0, bmode = 0;
     const void* dDesc = nullptr; // GGProblem* / SMProblem* (device)
     int nitems = 0, total = 0;   // total = workgroups (GEMM) or padded rows (softmax)
+    int nQueues = 1;             // persistent gather-GEMM: 8 = per-XCD tile ranges, 1 = global queue
     // elementwise
     const void* src = nullptr;
     void* dst = nullptr;
     int H = 0, W = 0, C = 0, haloS = 0, haloD = 0, n = 0, ldy = 0, pix = 0, premask = 0;
     const int32_t* tFrameIdx = nullptr;
     const int32_t* tFirst = nullptr;
+    const uint8_t* maskU8 = nullptr;   // sttn-det: resized mask bytes
+    const uint8_t* inU8 = nullptr;     // sttn-det: model-res input frames (decode blend)
     // reduce_scatter
     int M = 0, N = 0, nsplit = 0;
     int64_t splitStride = 0;
@@ -65,7 +68,7 @@ struct PlanDev {
     int32_t* dTables = nullptr;
     void* dDescs = nullptr;
     int32_t* dIsFloat = nullptr;
-    unsigned int* dQueues = nullptr;   // one tile-queue counter per op (persistent gather-GEMM), zeroed per run
+    unsigned int* dQueues = nullptr;   // 8 tile-queue counters (one per XCD) per op (persistent gather-GEMM), zeroed per run
     std::vector<OpDev> ops;
     ~PlanDev()
     {
@@ -113,7 +116,7 @@ struct vsr_plan {
     std::unique_ptr<Plan> plan;
 };
 
-static int64_t bufBytes(int buf, int64_t elems) { return buf == BUF_IN_U8 ? elems : elems * 4; }
+static int64_t bufBytes(int buf, int64_t elems) { return (buf == BUF_IN_U8 || buf == BUF_MASK_U8) ? elems : elems * 4; }
 
 static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
 {
@@ -185,6 +188,9 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
             od.dDesc = (char*)pd->dDescs + cursor;
             od.nitems = (int)op.gemm.size();
             od.total = tileStart;
+            od.nQueues = 8;
+            for (const GemmItem& g : op.gemm)
+                if (g.tilesN > 4) od.nQueues = 1;
             cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
         } else if (op.kind == OP_SOFTMAX) {
             SMProblem* hp = (SMProblem*)(hostDesc.data() + cursor);
@@ -212,6 +218,8 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
             od.H = op.H; od.W = op.W; od.C = op.C; od.haloS = op.haloS; od.haloD = op.haloD; od.n = op.n;
             od.ldy = op.ldy; od.pix = op.pix; od.premask = op.premask;
             od.tFrameIdx = T(op.tFrameIdx); od.tFirst = T(op.tFirst);
+            od.maskU8 = op.bufMask >= 0 ? (const uint8_t*)h->bufs[op.bufMask] : nullptr;
+            od.inU8 = (const uint8_t*)h->bufs[BUF_IN_U8];
         }
         pd->ops.push_back(std::move(od));
     }
@@ -220,7 +228,7 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
     for (int i = 0; i < L; ++i) isf[i] = P.compCount[i] > 1 ? 1 : 0;
     HIPCHK(hipMalloc((void**)&pd->dIsFloat, (size_t)L * sizeof(int32_t)));
     HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 8 * sizeof(unsigned int)));
     *out = pd.get();
     h->plans[L] = std::move(pd);
     return 0;
@@ -246,15 +254,16 @@ static bool use_persistent() { return gg_variant(VSR_BMODE_NK) >= 2 || gg_varian
 static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
 {
     const bool persistent = use_persistent();
-    if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * sizeof(unsigned int), stream));
+    if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
     size_t opIndex = 0;
     for (const OpDev& od : pd->ops) {
-        unsigned int* queue = persistent ? pd->dQueues + opIndex : nullptr;
+        unsigned int* queue = persistent ? pd->dQueues + 8 * opIndex : nullptr;
         ++opIndex;
         TimingRec tr;
         if (h->timing) {
             tr.tag = od.tag; tr.flops = od.flops;
-            tr.kernel = od.kind == OP_GEMM ? ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode))
+            tr.kernel = od.kind == OP_GEMM ? ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode) + ":v" +
+                                              std::to_string(gg_variant(od.bmode)))
                                            : ("kernel:op:" + std::to_string(od.kind));
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
@@ -263,19 +272,20 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         int rc = 0;
         switch (od.kind) {
         case OP_GEMM:
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue, gg_variant(od.bmode), stream);
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue, gg_variant(od.bmode), od.nQueues, stream);
             break;
         case OP_SOFTMAX:
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
             break;
         case OP_NORM_IM2COL:
-            rc = vsr_launch_norm_im2col((const uint8_t*)od.src, od.H, od.W, od.n, (float*)od.dst, od.premask, nullptr, stream);
+            rc = vsr_launch_norm_im2col((const uint8_t*)od.src, od.H, od.W, od.n, (float*)od.dst, od.premask, od.maskU8, stream);
             break;
         case OP_UPSAMPLE2X:
             rc = vsr_launch_upsample2x((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, stream);
             break;
         case OP_DECODE_OUT:
-            rc = vsr_launch_decode_out((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst, stream);
+            rc = vsr_launch_decode_out((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
+                                       od.maskU8 ? od.inU8 : nullptr, od.maskU8, stream);
             break;
         case OP_REDUCE_SCATTER:
             rc = vsr_launch_reduce_scatter((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,
@@ -466,16 +476,16 @@ int64_t vsr_sttn_packed_weights(const vsr_sttn_t* h, float* out, int64_t capacit
     return n;
 }
 
-int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* comp_dev, int32_t* counts, void* stream_)
+static int inpaint_common(vsr_sttn* h, const uint8_t* frames_dev, const uint8_t* masks_dev, int L, float* comp_dev,
+                          int32_t* counts, hipStream_t stream)
 {
-    RCCHK(need_gpu(h));
-    if (!frames_dev || !comp_dev || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
-    hipStream_t stream = (hipStream_t)stream_;
     PlanDev* pd = nullptr;
     RCCHK(build_plan_dev(h, L, &pd));
     const Geometry& g = h->model.g;
     const size_t n = (size_t)L * g.modelH * g.modelW * 3;
     HIPCHK(hipMemcpyAsync(h->bufs[BUF_IN_U8], frames_dev, n, hipMemcpyDeviceToDevice, stream));
+    if (masks_dev)
+        HIPCHK(hipMemcpyAsync(h->bufs[BUF_MASK_U8], masks_dev, n / 3, hipMemcpyDeviceToDevice, stream));
     RCCHK(run_plan(h, pd, stream));
     HIPCHK(hipMemcpyAsync(comp_dev, h->bufs[BUF_COMP], n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (counts) memcpy(counts, pd->plan->compCount.data(), (size_t)L * sizeof(int32_t));
@@ -483,14 +493,32 @@ int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* com
     return 0;
 }
 
-int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
-                        const int32_t* areas, const int32_t* sel, int nsel, void* stream_)
+int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* comp_dev, int32_t* counts, void* stream_)
 {
     RCCHK(need_gpu(h));
+    if (!frames_dev || !comp_dev || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (h->model.g.variant != VSR_VARIANT_STTN_AUTO) return fail(VSR_ERR_STATE, "sttn-det model: use vsr_sttn_det_inpaint (it needs the masks)");
+    return inpaint_common(h, frames_dev, nullptr, L, comp_dev, counts, (hipStream_t)stream_);
+}
+
+int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t* masks_dev, int L, float* comp_dev,
+                         int32_t* counts, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (!frames_dev || !masks_dev || !comp_dev || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
+    return inpaint_common(h, frames_dev, masks_dev, L, comp_dev, counts, (hipStream_t)stream_);
+}
+
+// shared body of the strip-level entries: crop + resize down, inpaint, resize up + write back.
+//   det == false: sttn-auto (mask01 thresholded, blend only where the mask is set)
+//   det == true : sttn-det  (raw 0..255 mask resized with the frames, whole strip overwritten)
+static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                         const int32_t* areas, const int32_t* sel, int nsel, hipStream_t stream)
+{
     if (!frames_dev || !mask_dev || L <= 0 || H <= 0 || W <= 0 || n_areas < 0 || (n_areas > 0 && !areas))
         return fail(VSR_ERR_ARG, "bad argument");
     if (n_areas == 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
     const Geometry& g = h->model.g;
     const int mw = g.modelW, mh = g.modelH;
     const int Ls = (sel && nsel > 0) ? nsel : L;
@@ -517,7 +545,7 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
     }
     const int64_t frameStride = (int64_t)H * W * 3;
     // pass 1: every strip is cropped from the ORIGINAL frames and inpainted (reference
-    // sttn_auto_inpaint.py:257-283), pass 2 blends the strips back in order (:298-315)
+    // sttn_auto_inpaint.py:257-283 / sttn_det_inpaint.py:66-82), pass 2 writes the strips back in order
     for (int k = 0; k < n_areas; ++k) {
         const int ymin = areas[4 * k], ymax = areas[4 * k + 1];
         const int sh = ymax - ymin;
@@ -525,8 +553,12 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
         StripTables* st = nullptr;
         RCCHK(get_strip_tables(h, W, sh, &st));
         if (vsr_launch_resize_u8(frames_dev + (int64_t)ymin * W * 3, frameStride, W * 3, W, sh, (uint8_t*)h->bufs[BUF_IN_U8], mw,
-                                 mh, Ls, dSel, st->dxofs, st->dialpha, st->dyofs, st->dibeta, stream) != 0)
+                                 mh, Ls, 3, dSel, st->dxofs, st->dialpha, st->dyofs, st->dibeta, stream) != 0)
             return fail(VSR_ERR_HIP, "resize launch failed");
+        if (det) // cv2.resize(mask_crop, (432, 240)) -- the same strip mask for every frame (frame stride 0)
+            if (vsr_launch_resize_u8(mask_dev + (int64_t)ymin * W, 0, W, W, sh, (uint8_t*)h->bufs[BUF_MASK_U8], mw, mh, Ls, 1,
+                                     nullptr, st->dxofs, st->dialpha, st->dyofs, st->dibeta, stream) != 0)
+                return fail(VSR_ERR_HIP, "mask resize launch failed");
         RCCHK(run_plan(h, pd, stream));
         if (n_areas > 1)
             HIPCHK(hipMemcpyAsync(h->compAreas + compElems * k, h->bufs[BUF_COMP], (size_t)compElems * sizeof(float),
@@ -539,12 +571,28 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
         RCCHK(get_strip_tables(h, W, sh, &st));
         const float* comp = n_areas > 1 ? h->compAreas + compElems * k : (const float*)h->bufs[BUF_COMP];
         if (vsr_launch_upscale_blend(comp, mw, mh, pd->dIsFloat, frames_dev + (int64_t)ymin * W * 3, frameStride, W * 3, dSel,
-                                     mask_dev + (int64_t)ymin * W, W, W, sh, Ls, st->uxofs, st->uialpha, st->ufalpha, st->uyofs,
-                                     st->uibeta, st->ufbeta, stream) != 0)
+                                     det ? nullptr : mask_dev + (int64_t)ymin * W, W, W, sh, Ls, st->uxofs, st->uialpha,
+                                     st->ufalpha, st->uyofs, st->uibeta, st->ufbeta, stream) != 0)
             return fail(VSR_ERR_HIP, "blend launch failed");
     }
     if (h->timing) RCCHK(collect_timing(h, stream));
     return 0;
+}
+
+int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                        const int32_t* areas, const int32_t* sel, int nsel, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (h->model.g.variant != VSR_VARIANT_STTN_AUTO) return fail(VSR_ERR_STATE, "not an sttn-auto model");
+    return strips_common(h, false, frames_dev, L, H, W, mask_dev, n_areas, areas, sel, nsel, (hipStream_t)stream_);
+}
+
+int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                       const int32_t* areas, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
+    return strips_common(h, true, frames_dev, L, H, W, mask_dev, n_areas, areas, nullptr, 0, (hipStream_t)stream_);
 }
 
 double vsr_sttn_flops(vsr_sttn_t* h, int L)
@@ -612,14 +660,17 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
         total += p.tilesM * p.tilesN * p.splitK;
     }
     GGProblem* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(GGProblem) + 64));
+    HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(GGProblem) + 64));   // + 8 queue counters
     HIPCHK(hipMemcpy(d, hp.data(), hp.size() * sizeof(GGProblem), hipMemcpyHostToDevice));
     unsigned int* queue = nullptr;
     if (use_persistent()) {
         queue = (unsigned int*)((char*)d + (hp.size() * sizeof(GGProblem) + 15) / 16 * 16);
-        HIPCHK(hipMemset(queue, 0, sizeof(unsigned int)));
+        HIPCHK(hipMemset(queue, 0, 8 * sizeof(unsigned int)));
     }
-    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, gg_variant(bmode), stream);
+    int nQueues = 8;
+    for (const auto& p : hp)
+        if (p.tilesN > 4) nQueues = 1;
+    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, gg_variant(bmode), nQueues, stream);
     hipError_t e = hipStreamSynchronize(stream);
     (void)hipFree(d);
     if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");
@@ -697,6 +748,7 @@ int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* o)
     o->halo_src = op.haloS; o->halo_dst = op.haloD; o->n = op.n; o->ldy = op.ldy; o->pix = op.pix;
     o->t_frame_idx = op.tFrameIdx; o->t_first = op.tFirst; o->premask = op.premask;
     o->M = op.M; o->N = op.N; o->nsplit = op.nsplit; o->t_rowC = op.tRowC; o->t_colC = op.tColC;
+    o->buf_mask = op.bufMask;
     o->off_src = op.offSrc; o->off_dst = op.offDst; o->split_stride = op.splitStride;
     o->flops = op.flops;
     strncpy(o->tag, op.tag.c_str(), sizeof(o->tag) - 1);

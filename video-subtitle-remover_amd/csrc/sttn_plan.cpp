@@ -644,6 +644,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         Op op;
         op.kind = OP_DECODE_OUT; op.tag = "dec.out";
         op.bufSrc = BUF_D4; op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
+        op.bufMask = g.variant == 1 ? BUF_MASK_U8 : -1;   // sttn-det: model-resolution blend with the input frames
         std::vector<int32_t> fi, fs;
         for (int i = 0; i < nn; ++i) {
             fi.push_back(neighbors[i]);
@@ -678,7 +679,11 @@ Plan::Plan(const Model& model, int L_) : L(L_), g(model.g), m_(model)
     {   // Stack/ToTorchFormatTensor/*2-1 fused with the im2col of encoder conv1
         Op op;
         op.kind = OP_NORM_IM2COL; op.tag = "enc.im2col";
-        op.bufSrc = BUF_IN_U8; op.bufDst = BUF_IM2COL; op.H = mh; op.W = mw; op.n = L; op.premask = 0;
+        op.bufSrc = BUF_IN_U8; op.bufDst = BUF_IM2COL; op.H = mh; op.W = mw; op.n = L;
+        // sttn-det feeds feats*(1-mask) to the encoder (sttn_det_inpaint.py:143); sttn-auto never sees the mask
+        op.premask = g.variant == 1 ? 1 : 0;
+        op.bufMask = g.variant == 1 ? BUF_MASK_U8 : -1;
+        if (g.variant == 1) need(BUF_MASK_U8, (int64_t)L * mh * mw);
         need(BUF_IM2COL, (int64_t)L * (mh / 2) * (mw / 2) * 32);
         ops.push_back(std::move(op));
     }

@@ -66,7 +66,7 @@ private:
 // ---- plan IR ----
 enum BufId {
     BUF_WEIGHTS = 0, BUF_IN_U8, BUF_IM2COL, BUF_E1, BUF_E2, BUF_E3, BUF_FEATS, BUF_X0, BUF_X1, BUF_QKV,
-    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_COUNT
+    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_MASK_U8, BUF_COUNT
 };
 
 enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5 };
@@ -96,6 +96,7 @@ struct Op {
     int bufSrc = -1, bufDst = -1, H = 0, W = 0, C = 0, haloS = 0, haloD = 0, n = 0;
     int ldy = 0, pix = 0, tFrameIdx = -1, tFirst = -1;
     int premask = 0;
+    int bufMask = -1;                    // sttn-det: model-res resized mask [L][mh][mw] u8 (BUF_MASK_U8)
     // REDUCE_SCATTER: out[bufDst+offDst][rowC[m]+colC[n/32]+n%32] = sum_s part[bufSrc+offSrc][s*splitStride + m*N + n]
     int M = 0, N = 0, nsplit = 0, tRowC = -1, tColC = -1;
     int64_t offSrc = 0, offDst = 0, splitStride = 0;
@@ -117,7 +118,7 @@ public:
     Plan(const Model& model, int L);
     int L;
     Geometry g;
-    std::vector<int64_t> bufElems;        // BUF_COUNT entries (BUF_IN_U8 in bytes, others floats)
+    std::vector<int64_t> bufElems;        // BUF_COUNT entries (BUF_IN_U8 / BUF_MASK_U8 in bytes, others floats)
     std::vector<std::vector<int32_t>> tables;
     std::vector<Op> ops;
     std::vector<int32_t> compCount;       // decodes per frame (1 => comp stays u8)

@@ -107,6 +107,30 @@ class SttnEngine:
                 0 if sel_arr is None else int(sel_arr.size), _stream_ptr()))
         return frames_dev
 
+    def det_inpaint(self, frames_dev, masks_dev):
+        """STTNDetInpaint.inpaint: frames uint8 [L,240,432,3] BGR + resized masks uint8 [L,240,432] -> (comp, counts)."""
+        assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
+        assert masks_dev.dtype == torch.uint8 and masks_dev.is_cuda and masks_dev.is_contiguous()
+        assert tuple(masks_dev.shape) == tuple(frames_dev.shape[:3])
+        L = frames_dev.shape[0]
+        comp = torch.empty(frames_dev.shape, dtype=torch.float32, device=frames_dev.device)
+        counts = np.zeros(L, dtype=np.int32)
+        with torch.cuda.device(frames_dev.device):
+            check(lib.vsr_sttn_det_inpaint(self._h, C.c_void_p(frames_dev.data_ptr()), C.c_void_p(masks_dev.data_ptr()), L,
+                                           C.c_void_p(comp.data_ptr()), counts.ctypes.data_as(C.c_void_p), _stream_ptr()))
+        return comp, counts
+
+    def det_batch(self, frames_dev, mask_dev, areas):
+        """STTNDetInpaint.__call__ on one batch, in place on frames_dev uint8 [L,H,W,3] BGR; mask_dev raw 0/255 [H,W]."""
+        assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
+        assert mask_dev.dtype == torch.uint8 and mask_dev.is_cuda and mask_dev.is_contiguous()
+        L, H, W, _ = frames_dev.shape
+        ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
+        with torch.cuda.device(frames_dev.device):
+            check(lib.vsr_sttn_det_batch(self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()),
+                                         ar.shape[0], ar.ctypes.data_as(C.c_void_p), _stream_ptr()))
+        return frames_dev
+
     # ---- measurement ----------------------------------------------------------------------
     def timing(self, enable=True):
         check(lib.vsr_sttn_timing(self._h, 1 if enable else 0))
