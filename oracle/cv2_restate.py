@@ -65,7 +65,7 @@ def resize_linear(img, dsize):
         h0 = r0[:, x0] * a0 + r0[:, x1] * a1
         h1 = r1[:, x0] * a0 + r1[:, x1] * a1
         v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
-        return np.clip(v, 0, 255).astype(np.uint8)
+        return np.ascontiguousarray(np.clip(v, 0, 255).astype(np.uint8))
     if img.dtype == np.float32:
         s = img
         a0 = falpha[:, 0][None, :, None]
@@ -75,7 +75,7 @@ def resize_linear(img, dsize):
         r0, r1 = s[y0], s[y1]
         h0 = (r0[:, x0] * a0).astype(np.float32) + (r0[:, x1] * a1).astype(np.float32)
         h1 = (r1[:, x0] * a0).astype(np.float32) + (r1[:, x1] * a1).astype(np.float32)
-        return ((h0 * b0).astype(np.float32) + (h1 * b1).astype(np.float32)).astype(np.float32)
+        return np.ascontiguousarray(((h0 * b0).astype(np.float32) + (h1 * b1).astype(np.float32)).astype(np.float32))
     raise TypeError(f"resize_linear: unsupported dtype {img.dtype}")
 
 

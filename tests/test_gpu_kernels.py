@@ -267,7 +267,7 @@ def test_resize_u8_single_channel_mask(built_lib, gpu_device):
     """sttn-det resizes the 0/255 mask strip with the frames (frame stride 0 replicates it per frame)."""
     sw, sh, n = 1920, 533, 3
     mask = np.zeros((sh + 10, sw), np.uint8)
-    mask[100:300, 288:1632] = 255
+    mask[100:300, 291:1632] = 255
     (xo, xa, _), _ = _tables(sw, 432, True, gpu_device)
     (yo, ya, _), _ = _tables(sh, 240, False, gpu_device)
     src = _dev(mask, gpu_device)
