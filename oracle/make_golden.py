@@ -21,16 +21,89 @@ REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
+class _Permissive(types.ModuleType):
+    """Stub module: any attribute is another stub, any call returns a stub (for unrelated top-level imports)."""
+
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        m = _Permissive(self.__name__ + "." + n)
+        setattr(self, n, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return _Permissive("call")
+
+
+class _Item:
+    def __init__(self, v):
+        self.value = v
+
+
 def _import_reference():
-    for n in ("cv2", "torchvision", "torchvision.models"):
-        sys.modules.setdefault(n, types.ModuleType(n))
-    cfg = types.ModuleType("backend.config")          # qfluentwidgets-free stand-in for inpaint_tools
-    cfg.config = types.SimpleNamespace()
+    for n in ("cv2", "torchvision", "torchvision.models", "onnxruntime", "qfluentwidgets", "paddleocr", "fsplit",
+              "fsplit.filesplit"):
+        sys.modules.setdefault(n, _Permissive(n))
+    cfg = _Permissive("backend.config")               # qfluentwidgets-free stand-in (defaults of backend/config.py:59-68)
+    cfg.config = types.SimpleNamespace(subtitleAreaPixelToleranceXPixel=_Item(20), subtitleAreaPixelToleranceYPixel=_Item(20))
+    cfg.tr = {}
+    cfg.BASE_DIR = "/tmp"
     sys.path.insert(0, REF)
     from backend.inpaint.sttn import auto_sttn, network_sttn
     sys.modules["backend.config"] = cfg
-    from backend.tools import inpaint_tools
+    sys.modules["backend.scenedetect"] = _Permissive("backend.scenedetect")
+    sys.modules["backend.scenedetect.detectors"] = _Permissive("backend.scenedetect.detectors")
+    from backend.tools import inpaint_tools, ocr, subtitle_detect
+    inpaint_tools.subtitle_detect = subtitle_detect
+    inpaint_tools.ocr = ocr
     return auto_sttn, network_sttn, inpaint_tools
+
+
+def _bookkeeping_fixture(inpaint_tools):
+    """Temporal bookkeeping of the detector modes, executed from the reference."""
+    sd = inpaint_tools.subtitle_detect.SubtitleDetect
+    rng = np.random.default_rng(2024)
+    out = {"filter_and_merge": [], "expand": [], "coords": [], "unify": [], "ranges": [], "ranges_same_mask": []}
+    for _ in range(60):
+        n = int(rng.integers(1, 9))
+        starts = np.sort(rng.choice(np.arange(1, 400), size=n, replace=False))
+        iv = []
+        last = 0
+        for s0 in starts:
+            s0 = max(int(s0), last + 1)
+            e0 = s0 + int(rng.choice([0, 0, 1, 3, 8, 15, 40]))
+            iv.append((s0, e0))
+            last = e0
+        tl = int(rng.choice([5, 10, 10, 12]))
+        out["filter_and_merge"].append({"in": iv, "target": tl, "out": sd.filter_and_merge_intervals(list(iv), tl)})
+        b, f = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+        out["expand"].append({"in": iv, "b": b, "f": f, "out": inpaint_tools.expand_frame_ranges(list(iv), b, f)})
+    for _ in range(30):
+        k = int(rng.integers(1, 4))
+        polys = []
+        for _ in range(k):
+            x1, y1 = int(rng.integers(0, 500)), int(rng.integers(0, 300))
+            w, h = int(rng.integers(5, 400)), int(rng.integers(5, 80))
+            j = lambda: int(rng.integers(-3, 4))
+            polys.append([[x1 + j(), y1 + j()], [x1 + w + j(), y1 + j()], [x1 + w + j(), y1 + h + j()], [x1 + j(), y1 + h + j()]])
+        out["coords"].append({"in": polys, "out": inpaint_tools.ocr.get_coordinates([list(p) for p in polys])})
+    det = sd.__new__(sd)
+    for _ in range(30):
+        frames = sorted(set(int(v) for v in rng.integers(1, 60, size=int(rng.integers(1, 25)))))
+        base = [(100, 700, 400, 450), (120, 600, 300, 340)]
+        regs = {}
+        for fno in frames:
+            boxes = []
+            for bx in base[: int(rng.integers(1, 3))]:
+                d = [int(v) for v in rng.integers(-30, 31, size=4)]
+                boxes.append((bx[0] + d[0], bx[1] + d[1], bx[2] + d[2], bx[3] + d[3]))
+            regs[fno] = boxes
+        uni = det.unify_regions({k: list(v) for k, v in regs.items()})
+        out["unify"].append({"in": {str(k): v for k, v in regs.items()}, "out": {str(k): v for k, v in uni.items()}})
+        out["ranges"].append({"in": frames, "out": sd.find_continuous_ranges({k: 1 for k in frames})})
+        out["ranges_same_mask"].append({"in": {str(k): v for k, v in uni.items()},
+                                        "out": sd.find_continuous_ranges_with_same_mask(uni)})
+    return out
 
 
 def _sample(t, n=4096, seed=123):
@@ -91,6 +164,8 @@ def main():
     res = {f"{n},{m}": [len(b) for b in inpaint_tools.batch_generator(list(range(n)), m)] for n, m in cases}
     with open(os.path.join(OUT, "batch_generator.json"), "w") as f:
         json.dump(res, f, indent=0, sort_keys=True)
+    with open(os.path.join(OUT, "bookkeeping.json"), "w") as f:
+        json.dump(_bookkeeping_fixture(inpaint_tools), f)
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -16,7 +16,8 @@ from .config import config
 from .inpaint.sttn_auto_inpaint import STTNAutoInpaint
 from .tools.args_handler import parse_args
 from .tools.constant import InpaintMode
-from .tools.inpaint_tools import create_mask
+from .tools.inpaint_tools import batch_generator, create_mask, expand_frame_ranges
+from .tools.subtitle_detect import SubtitleDetect
 from .tools.video_io import ArrayWriter, open_video
 
 
@@ -67,6 +68,53 @@ class SubtitleRemover:
         sttn_video_inpaint = STTNAutoInpaint(self.device, self.model_path, self.video_path)
         sttn_video_inpaint(input_mask=mask, input_sub_remover=self, tbar=tbar)
 
+    def video_inpaint(self, tbar, model, text_detector=None):
+        """backend/main.py:260-333 -- detector pass, interval construction, then `model(batch, mask)` per batch.
+        Frame numbers are 1-based here exactly as in the reference."""
+        detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
+        sub_list = detector.find_subtitle_frame_no(sub_remover=self)
+        if len(sub_list) == 0:
+            raise Exception(f"No subtitle detected in {self.video_path}")
+        ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
+        ranges = expand_frame_ranges(ranges, config.subtitleTimelineBackwardFrameCount.value,
+                                     config.subtitleTimelineForwardFrameCount.value)
+        ranges = detector.filter_and_merge_intervals(ranges, config.sttnReferenceLength.value)
+        start_end = {s: min(e, self.frame_count) for s, e in ranges}
+        reader = open_video(self.video_path)
+        idx = 0
+        while True:
+            ok, frame = reader.read()
+            if not ok:
+                break
+            idx += 1
+            if idx not in start_end:
+                self.video_writer.write(frame)
+                self.update_progress(tbar, increment=1)
+                continue
+            first, last = idx, start_end[idx]
+            frames = [frame]
+            for _ in range(last - first):
+                ok, frame = reader.read()
+                if not ok:
+                    break
+                idx += 1
+                frames.append(frame)
+            coords = []
+            for no in range(first, last):                      # NB: the reference's range excludes `last` (:310)
+                for area in sub_list.get(no, []):
+                    xmin, xmax, ymin, ymax = area
+                    if (ymax - ymin) - (xmax - xmin) > config.subtitleYXAxisDifferencePixel.value:
+                        continue                               # taller than wide: treated as a false detection
+                    if area not in coords:
+                        coords.append(area)
+            mask = create_mask(self.mask_size, coords)
+            for batch in batch_generator(frames, config.getSttnMaxLoadNum()):
+                if len(batch) >= 1:
+                    for out in model(batch, mask):
+                        self.video_writer.write(out)
+                self.update_progress(tbar, increment=len(batch))
+        reader.release()
+
     def run(self):
         start_time = time.time()
         if len(self.sub_areas) == 0:
@@ -74,6 +122,11 @@ class SubtitleRemover:
         mode = config.inpaintMode.value
         if mode == InpaintMode.STTN_AUTO:
             self.sttn_auto_mode(None)
+        elif mode == InpaintMode.STTN_DET:
+            from .inpaint.sttn_det_inpaint import STTNDetInpaint
+
+            det_path = os.environ.get("STTN_DET_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-det", "sttn.pth"))
+            self.video_inpaint(None, STTNDetInpaint(self.device, det_path), text_detector=getattr(self, "text_detector", None))
         else:
             raise Exception(f"inpaint mode: {mode} not implemented")     # main.py:386
         self.isFinished = True

@@ -132,6 +132,26 @@ def get_inpaint_area_by_mask(W, H, h, mask, multiple=1):
     return inpaint_area
 
 
+def expand_frame_ranges(frame_ranges, backward_frame_count, forward_frame_count):
+    """tools/inpaint_tools.py:244-301 -- widen every (start, end) backwards/forwards without overlapping neighbours."""
+    if not frame_ranges:
+        return []
+    ordered = sorted(frame_ranges)
+    out = []
+    for i, (start, end) in enumerate(ordered):
+        new_start = max(1, start - backward_frame_count)
+        new_end = end + forward_frame_count
+        if i < len(ordered) - 1:
+            next_start = ordered[i + 1][0]
+            if new_end >= next_start:
+                # contiguous neighbours keep their boundary, others stop one frame short of the neighbour
+                new_end = end if next_start - end == 1 else min(new_end, next_start - 1)
+        if out and new_start <= out[-1][1]:
+            new_start = out[-1][1] + 1
+        out.append((new_start, new_end) if new_start <= new_end else (start, end))
+    return out
+
+
 def is_frame_number_in_ab_sections(frame_no, ab_sections):
     if ab_sections is None or len(ab_sections) <= 0:
         return True

@@ -73,4 +73,7 @@ class Cv2Video:
 
 
 def open_video(video):
+    """A fresh reader positioned at frame 0 (the reference re-opens the file for every pass over the video)."""
+    if isinstance(video, ArrayVideo):
+        return ArrayVideo(video.frames, video.fps)
     return video if hasattr(video, "read") and hasattr(video, "info") else Cv2Video(video)
