@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--res", default="1080p", choices=sorted(RES))
     ap.add_argument("--chunk", type=int, default=50, help="frames per chunk (config.sttnMaxLoadNum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     args = ap.parse_args()
 
@@ -173,7 +174,8 @@ def main():
         per_kernel = {}
         for cfg, (bm, bn, wm, wn) in dims.items():
             for bmode in (0, 1):
-                for var, sym in ((1, "gather_gemm_f32"), (2, "gather_gemm_f32_v2"), (3, "gather_gemm_f32_v3")):
+                for var, sym in ((1, "gather_gemm_f32"), (2, "gather_gemm_f32_v2"), (3, "gather_gemm_f32_v3"),
+                                 (4, "gather_gemm_f32_v4")):
                     a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}:v{var}")
                     if b:
                         per_kernel[f"{sym}<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)
@@ -216,6 +218,29 @@ def main():
                           f"{args.cpu_sample_frames} model-resolution frames ({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s), "
                           f"scaled by FLOPs to the {flops_per_frame / 1e9:.1f} GFLOP/frame of a {L}-frame chunk"}
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"
+        if not args.no_split_half:
+            # informational: the same workload with split-half operands on the f16 matrix cores (fp32 data,
+            # fp32 accumulation, 22-bit operands, device-side range guard with fp32 fallback).  NOT `value`.
+            eng.set_precision("split")
+            for _ in range(max(1, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            sp = {"value": round(args.steps * L / dt, 3), "unit": "frames/s (this rank)", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                  "fp32_fallback_chunks": eng.fallbacks(),
+                  "arithmetic": "fp32 data + fp32 accumulate; operands as fp16 hi/lo pairs, a*b = a_lo*b_hi + a_hi*b_lo + a_hi*b_hi "
+                                "(3x v_mfma_f32_32x32x16_f16)"}
+            if not args.no_cpu_baseline:
+                comp2, _ = eng.inpaint(torch.from_numpy(frames).to(device))
+                torch.cuda.synchronize()
+                mse2 = float(np.mean((comp2.cpu().numpy().astype(np.float64) - refa) ** 2))
+                sp["psnr_db_vs_oracle"] = "inf" if mse2 == 0 else round(20 * np.log10(255.0 / np.sqrt(mse2)), 2)
+            eng.set_precision("f32")
+            out["split_half_mode"] = sp
         print(json.dumps(out), flush=True)
 
     eng.close()

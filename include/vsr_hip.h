@@ -95,6 +95,15 @@ int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t
 int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
                        const int32_t* areas, void* stream);
 
+/* Arithmetic of the contractions.  0 (default): exact fp32 -- v_mfma_f32_32x32x2_f32, bitwise an fmaf chain.
+ * 1: split-half -- fp32 data and fp32 accumulation, each fp32 operand fed to the f16 matrix cores as
+ * hi = fp16(x), lo = fp16(x - hi) and a*b taken as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (22 significand bits per
+ * operand; 5.3x the fp32-MFMA rate).  Operands beyond the fp16 range make a result non-finite; that is detected
+ * on the device and the chunk is then recomputed with the exact kernels (vsr_sttn_fallbacks counts them).
+ * Environment default: VSR_PRECISION=split. */
+int vsr_sttn_set_precision(vsr_sttn_t* h, int mode);
+int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h);
+
 /* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded) */
 double vsr_sttn_flops(vsr_sttn_t* h, int L);
 
@@ -150,6 +159,9 @@ typedef struct SMProblem {
 
 /* probs: HOST array whose pointers are device pointers; tileStart / rowStart are filled in */
 int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, void* stream);
+/* same with an explicit kernel variant: 1 one workgroup per tile, 2 persistent (register staged), 3 persistent
+ * LDS-DMA (fp32 MFMA), 4 persistent split-half operands on the f16 matrix cores (see vsr_sttn_set_precision) */
+int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream);
 int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
 
 /* cv2.resize(..., INTER_LINEAR) on uint8 (fixed-point path), tables from vsr_cv2_linear_tables;

@@ -77,7 +77,7 @@ def _reference(case):
     return bufs[3]
 
 
-def _run_cases(_lib, device, cases, tile_cfg, bmode):
+def _run_cases(_lib, device, cases, tile_cfg, bmode, variant=None):
     keep = []
     probs = (_lib.GGProblem * len(cases))()
     outs = []
@@ -96,7 +96,10 @@ def _run_cases(_lib, device, cases, tile_cfg, bmode):
         p.splitK, p.chunksPerSplit, p.act, p.alpha, p.splitStride = c.splitK, c.chunksPerSplit, c.act, c.alpha, c.splitStride
         outs.append(d["Cbuf"])
     torch.cuda.synchronize()
-    _lib.check(_lib.lib.vsr_run_gather_gemm(probs, len(cases), tile_cfg, bmode, None))
+    if variant is None:
+        _lib.check(_lib.lib.vsr_run_gather_gemm(probs, len(cases), tile_cfg, bmode, None))
+    else:
+        _lib.check(_lib.lib.vsr_run_gather_gemm_variant(probs, len(cases), tile_cfg, bmode, variant, None))
     torch.cuda.synchronize()
     return [o.cpu().numpy() for o in outs]
 
@@ -167,6 +170,26 @@ def test_gather_gemm_narrow_tiles(built_lib, gpu_device, cfg, bn, M, N, K):
     c = _make_gemm_case(rng, M, N, K, 256, bn, 0, 1, True, 1, N > 3)
     got = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), 0)[0]
     _assert_close(got, _reference(c), K, f"{cfg} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("cfg,bm,bn,bmode,M,N,K,splitK", [
+    ("TILE_128x128", 128, 128, 0, 513, 257, 2304, 1), ("TILE_128x64", 128, 64, 0, 300, 256, 576, 1),
+    ("TILE_128x128", 128, 128, 0, 375, 375, 384, 3), ("TILE_256x64", 256, 64, 0, 520, 64, 576, 1),
+    ("TILE_256x32", 256, 32, 0, 700, 3, 64, 1),
+    ("TILE_128x128", 128, 128, 1, 200, 192, 96, 1), ("TILE_128x64", 128, 64, 1, 1440, 960, 320, 3),
+    ("TILE_128x128", 128, 128, 1, 129, 960, 4800 // 32 * 32, 1),
+])
+def test_gather_gemm_every_variant(built_lib, gpu_device, variant, cfg, bm, bn, bmode, M, N, K, splitK):
+    """All four kernel variants implement the same descriptor semantics (v4 = split-half f16 MFMA: operands
+    here are O(1), far inside the fp16 range; its error is ~2^-22 relative per product)."""
+    if variant == 2 and bmode == 1 and False:
+        pytest.skip("n/a")
+    rng = np.random.default_rng(variant * 1000 + M + N + K)
+    full = splitK == 1 and bmode == 0
+    c = _make_gemm_case(rng, M, N, K, bm, bn, bmode, splitK, full, 1 if full else 0, full and N > 3)
+    got = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), bmode, variant)[0]
+    _assert_close(got, _reference(c), K, f"v{variant} {cfg} mode{bmode} {M}x{N}x{K}")
 
 
 def test_gather_gemm_grouped_launch(built_lib, gpu_device):

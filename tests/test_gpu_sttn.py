@@ -238,3 +238,49 @@ def test_det_plugin_call_vs_oracle(built_lib, gpu_device, sd_det, H, W, box):
     assert psnr_strip >= PSNR_MIN_DB
     assert np.abs(got.astype(int) - ref.astype(int)).max() <= 2
     plug.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# split-half (f16 matrix core) mode
+# ------------------------------------------------------------------------------------------------
+def test_split_half_mode_matches_oracle_and_fp32(built_lib, gpu_device, sd):
+    from vsr_amd.engine import SttnEngine
+
+    frames = np.random.default_rng(11).integers(0, 256, size=(6, 120, 640, 3), dtype=np.uint8)
+    d = torch.from_numpy(frames).to(gpu_device)
+    e32 = SttnEngine(sd, "auto", device=0, neighbor_stride=2, ref_length=3, precision="f32")
+    c32, counts = e32.inpaint(d)
+    e32.close()
+    esp = SttnEngine(sd, "auto", device=0, neighbor_stride=2, ref_length=3, precision="split")
+    csp, counts2 = esp.inpaint(d)
+    torch.cuda.synchronize()
+    assert esp.fallbacks() == 0, "synthetic activations are far inside the fp16 range"
+    esp.close()
+    ref = STTNInpaintOracle(sd, "auto", 2, 3).inpaint(list(frames))
+    psnr, dmax, frac = _compare_comp(csp.cpu().numpy(), ref, counts2)
+    d32 = (csp - c32).abs()
+    print(f"split-half: psnr vs oracle {psnr:.2f} dB, max|d| {dmax}; vs fp32 kernels max|d| {d32.max().item()} "
+          f"frac {(d32 > 0).float().mean().item():.2e}")
+    assert psnr >= PSNR_MIN_DB and dmax <= 2.0
+    assert d32.max().item() <= 1.0 and (d32 > 0).float().mean().item() < 5e-3
+
+
+def test_split_half_range_guard_falls_back_to_fp32(built_lib, gpu_device, sd):
+    """Operands beyond the fp16 range: the device-side guard fires and the chunk is recomputed with the exact
+    fp32 kernels, so the result is bit-identical to the fp32 engine."""
+    from vsr_amd.engine import SttnEngine
+
+    big = {k: v.copy() for k, v in sd.items()}
+    big["encoder.6.weight"] = big["encoder.6.weight"] * np.float32(3.0e4)      # features ~1e5 > 65504
+    frames = np.random.default_rng(12).integers(0, 256, size=(4, 120, 640, 3), dtype=np.uint8)
+    d = torch.from_numpy(frames).to(gpu_device)
+    e32 = SttnEngine(big, "auto", device=0, neighbor_stride=2, ref_length=3, precision="f32")
+    c32, _ = e32.inpaint(d)
+    e32.close()
+    esp = SttnEngine(big, "auto", device=0, neighbor_stride=2, ref_length=3, precision="split")
+    csp, _ = esp.inpaint(d)
+    torch.cuda.synchronize()
+    assert esp.fallbacks() == 1
+    assert torch.equal(csp, c32)
+    assert torch.isfinite(csp).all()
+    esp.close()

@@ -83,11 +83,14 @@ SIGNATURES = {
     "vsr_sttn_auto_chunk": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
     "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vsr_sttn_det_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "vsr_sttn_set_precision": (_I, [_P, _I]),
+    "vsr_sttn_fallbacks": (_L, [_P]),
     "vsr_sttn_flops": (_D, [_P, _I]),
     "vsr_sttn_timing": (_I, [_P, _I]),
     "vsr_sttn_timing_get": (_I, [_P, C.c_char_p, C.POINTER(_D), C.POINTER(C.c_int32), C.POINTER(_D)]),
     "vsr_sttn_timing_reset": (_I, [_P]),
     "vsr_run_gather_gemm": (_I, [C.POINTER(GGProblem), _I, _I, _I, _P]),
+    "vsr_run_gather_gemm_variant": (_I, [C.POINTER(GGProblem), _I, _I, _I, _I, _P]),
     "vsr_run_softmax": (_I, [C.POINTER(SMProblem), _I, _P]),
     "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsr_launch_norm_im2col": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),

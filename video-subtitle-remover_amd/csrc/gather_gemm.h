@@ -13,5 +13,7 @@
 // d_probs: DEVICE array (tileStart filled); totalBlocks = sum tilesM*tilesN*splitK.
 // variant 1: one workgroup per tile; 2 / 3: persistent kernels pulling tile ids from queue[0..7] (must be 0);
 // nQueues = 8: per-XCD tile ranges with stealing, 1: one global queue (v3 only).
+// variant 4 = split-half f16-MFMA kernels; rangeFlag (device, nullable) is OR-ed with 1 on a non-finite result.
 extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
-                                          int bmode, unsigned int* queue, int variant, int nQueues, void* stream);
+                                          int bmode, unsigned int* queue, int variant, int nQueues,
+                                          unsigned int* rangeFlag, void* stream);

@@ -293,6 +293,7 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 
 #include "gather_gemm_v2.h"
 #include "gather_gemm_v3.h"
+#include "gather_gemm_v4.h"
 
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
@@ -308,7 +309,12 @@ static int resident_blocks(K kernel)
 
 #define GG_LAUNCH(BM, BN, WM, WN, MODE)                                                                         \
     do {                                                                                                        \
-        if (queue && variant == 3) {                                                                            \
+        if (queue && variant == 4) {                                                                            \
+            static const int resident = resident_blocks(gather_gemm_f32_v4<BM, BN, WM, WN, MODE>);             \
+            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
+            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream,          \
+                               d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag);          \
+        } else if (queue && variant >= 3) {                                                                            \
             static const int resident = resident_blocks(gather_gemm_f32_v3<BM, BN, WM, WN, MODE>);             \
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
             hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream, d_probs, \
@@ -324,13 +330,16 @@ static int resident_blocks(K kernel)
         }                                                                                                       \
     } while (0)
 
-// variant 1 (or queue == nullptr): one workgroup per tile.  variant 2 / 3: persistent kernels pulling tile
-// ids from queue[0..7] (must be 0): 2 = register-staged double buffer, 3 = LDS-DMA double buffer.
+// variant 1 (or queue == nullptr): one workgroup per tile.  variant 2 / 3 / 4: persistent kernels pulling tile
+// ids from queue[0..7] (must be 0): 2 = register-staged double buffer, 3 = LDS-DMA double buffer,
+// 4 = split-half operands on the f16 matrix cores.
 // nQueues (v3): 8 = one tile range per XCD with stealing (few N tiles per A row block: neighbours share A
 // through one L2), 1 = a single global queue (many N tiles per row block: spreading them over the XCDs
 // avoids hammering one L2 with the same lines -- measured 101 vs 86 TF on the QKV GEMM).
+// rangeFlag (variant 4): device word that is OR-ed with 1 when an accumulator comes out non-finite.
 extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
-                                          int bmode, unsigned int* queue, int variant, int nQueues, void* stream_)
+                                          int bmode, unsigned int* queue, int variant, int nQueues,
+                                          unsigned int* rangeFlag, void* stream_)
 {
     if (variant <= 1) queue = nullptr;
     hipStream_t stream = (hipStream_t)stream_;

@@ -106,10 +106,17 @@ struct vsr_sttn {
     int64_t compAreasCap = 0;
     int32_t* dSel = nullptr;
     int dSelCap = 0;
+    int precision = 0;                 // 0 = exact fp32 MFMA, 1 = split-half f16 MFMA with range guard + fp32 fallback
+    unsigned int* dRangeFlag = nullptr;
+    int64_t fallbacks = 0;             // chunks recomputed in fp32 because the range guard fired
     bool timing = false;
     std::vector<TimingRec> pending;
     std::map<std::string, std::pair<double, std::pair<int, double>>> timed; // tag -> (ms, (launches, flops))
-    explicit vsr_sttn(int variant) : model(variant) {}
+    explicit vsr_sttn(int variant) : model(variant)
+    {
+        const char* e = getenv("VSR_PRECISION");
+        precision = (e && (e[0] == '1' || e[0] == 's')) ? 1 : 0;   // "1" / "split"
+    }
 };
 
 struct vsr_plan {
@@ -118,13 +125,14 @@ struct vsr_plan {
 
 static int64_t bufBytes(int buf, int64_t elems) { return (buf == BUF_IN_U8 || buf == BUF_MASK_U8) ? elems : elems * 4; }
 
-static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
+static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 {
-    auto it = h->plans.find(L);
+    const int key = L * 2 + (precision ? 1 : 0);
+    auto it = h->plans.find(key);
     if (it != h->plans.end()) { *out = it->second.get(); return 0; }
     std::unique_ptr<PlanDev> pd(new PlanDev);
     try {
-        pd->plan.reset(new Plan(h->model, L));
+        pd->plan.reset(new Plan(h->model, L, precision));
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
     }
@@ -230,7 +238,7 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
     HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 8 * sizeof(unsigned int)));
     *out = pd.get();
-    h->plans[L] = std::move(pd);
+    h->plans[key] = std::move(pd);
     return 0;
 }
 
@@ -238,13 +246,14 @@ static int build_plan_dev(vsr_sttn* h, int L, PlanDev** out)
 // register-staged double buffer, 3 = persistent with LDS-DMA double buffer
 // Measured on the 1080p bench (profiles/): NK problems (convs, QKV, QK^T) are fastest on v3, the KN
 // problem (P.V, n-contiguous B) on v1.  VSR_GG_VARIANT / VSR_PV_VARIANT override for A/B runs.
-static int gg_variant(int bmode)
+static int gg_variant(int bmode, int precision = 0)
 {
-    static const int nk = [] { const char* e = getenv("VSR_GG_VARIANT"); int x = e ? atoi(e) : 3; return (x < 1 || x > 3) ? 3 : x; }();
+    if (precision) return 4;
+    static const int nk = [] { const char* e = getenv("VSR_GG_VARIANT"); int x = e ? atoi(e) : 3; return (x < 1 || x > 4) ? 3 : x; }();
     static const int kn = [] {
         const char* e = getenv("VSR_PV_VARIANT");
         const char* g = getenv("VSR_GG_VARIANT");
-        int x = e ? atoi(e) : (g ? atoi(g) : 1);
+        int x = e ? atoi(e) : ((g && atoi(g) <= 3) ? atoi(g) : 1);
         return (x < 1 || x > 3) ? 1 : x;
     }();
     return bmode == VSR_BMODE_KN ? kn : nk;
@@ -253,7 +262,8 @@ static bool use_persistent() { return gg_variant(VSR_BMODE_NK) >= 2 || gg_varian
 
 static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
 {
-    const bool persistent = use_persistent();
+    const int prec = pd->plan->precision;
+    const bool persistent = prec ? true : use_persistent();
     if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
     size_t opIndex = 0;
     for (const OpDev& od : pd->ops) {
@@ -263,7 +273,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         if (h->timing) {
             tr.tag = od.tag; tr.flops = od.flops;
             tr.kernel = od.kind == OP_GEMM ? ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode) + ":v" +
-                                              std::to_string(gg_variant(od.bmode)))
+                                              std::to_string(gg_variant(od.bmode, prec)))
                                            : ("kernel:op:" + std::to_string(od.kind));
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
@@ -272,7 +282,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         int rc = 0;
         switch (od.kind) {
         case OP_GEMM:
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue, gg_variant(od.bmode), od.nQueues, stream);
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue, gg_variant(od.bmode, prec), od.nQueues,
+                                            prec ? h->dRangeFlag : nullptr, stream);
             break;
         case OP_SOFTMAX:
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
@@ -443,6 +454,7 @@ void vsr_sttn_destroy(vsr_sttn_t* h)
         for (auto& kv : h->strips)
             if (kv.second.dev) (void)hipFree(kv.second.dev);
         if (h->compAreas) (void)hipFree(h->compAreas);
+        if (h->dRangeFlag) (void)hipFree(h->dRangeFlag);
         if (h->dSel) (void)hipFree(h->dSel);
     }
     delete h;
@@ -476,17 +488,44 @@ int64_t vsr_sttn_packed_weights(const vsr_sttn_t* h, float* out, int64_t capacit
     return n;
 }
 
+// split-half mode: clear the range flag before the GEMMs run, read it back afterwards (one 4-byte copy and
+// a stream sync per chunk); `fired` tells the caller to recompute with the exact fp32 plan
+static int guard_begin(vsr_sttn* h, hipStream_t stream)
+{
+    if (!h->precision) return 0;
+    if (!h->dRangeFlag) HIPCHK(hipMalloc((void**)&h->dRangeFlag, sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(h->dRangeFlag, 0, sizeof(unsigned int), stream));
+    return 0;
+}
+static int guard_end(vsr_sttn* h, hipStream_t stream, bool* fired)
+{
+    *fired = false;
+    if (!h->precision) return 0;
+    unsigned int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->dRangeFlag, sizeof(v), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (v) { *fired = true; h->fallbacks++; }
+    return 0;
+}
+
 static int inpaint_common(vsr_sttn* h, const uint8_t* frames_dev, const uint8_t* masks_dev, int L, float* comp_dev,
                           int32_t* counts, hipStream_t stream)
 {
     PlanDev* pd = nullptr;
-    RCCHK(build_plan_dev(h, L, &pd));
+    RCCHK(build_plan_dev(h, L, h->precision, &pd));
     const Geometry& g = h->model.g;
     const size_t n = (size_t)L * g.modelH * g.modelW * 3;
     HIPCHK(hipMemcpyAsync(h->bufs[BUF_IN_U8], frames_dev, n, hipMemcpyDeviceToDevice, stream));
     if (masks_dev)
         HIPCHK(hipMemcpyAsync(h->bufs[BUF_MASK_U8], masks_dev, n / 3, hipMemcpyDeviceToDevice, stream));
+    RCCHK(guard_begin(h, stream));
     RCCHK(run_plan(h, pd, stream));
+    bool fired = false;
+    RCCHK(guard_end(h, stream, &fired));
+    if (fired) {                                   // out of fp16 range somewhere: exact fp32 kernels
+        RCCHK(build_plan_dev(h, L, 0, &pd));
+        RCCHK(run_plan(h, pd, stream));
+    }
     HIPCHK(hipMemcpyAsync(comp_dev, h->bufs[BUF_COMP], n * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (counts) memcpy(counts, pd->plan->compCount.data(), (size_t)L * sizeof(int32_t));
     if (h->timing) RCCHK(collect_timing(h, stream));
@@ -536,7 +575,7 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
         dSel = h->dSel;
     }
     PlanDev* pd = nullptr;
-    RCCHK(build_plan_dev(h, Ls, &pd));
+    RCCHK(build_plan_dev(h, Ls, h->precision, &pd));
     const int64_t compElems = (int64_t)Ls * mh * mw * 3;
     if (n_areas > 1 && h->compAreasCap < compElems * n_areas) {
         if (h->compAreas) HIPCHK(hipFree(h->compAreas));
@@ -546,6 +585,8 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
     const int64_t frameStride = (int64_t)H * W * 3;
     // pass 1: every strip is cropped from the ORIGINAL frames and inpainted (reference
     // sttn_auto_inpaint.py:257-283 / sttn_det_inpaint.py:66-82), pass 2 writes the strips back in order
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    RCCHK(guard_begin(h, stream));
     for (int k = 0; k < n_areas; ++k) {
         const int ymin = areas[4 * k], ymax = areas[4 * k + 1];
         const int sh = ymax - ymin;
@@ -563,6 +604,11 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
         if (n_areas > 1)
             HIPCHK(hipMemcpyAsync(h->compAreas + compElems * k, h->bufs[BUF_COMP], (size_t)compElems * sizeof(float),
                                   hipMemcpyDeviceToDevice, stream));
+    }
+    bool fired = false;
+    if (attempt == 0) RCCHK(guard_end(h, stream, &fired));
+    if (!fired) break;
+    RCCHK(build_plan_dev(h, Ls, 0, &pd));          // the frames are still untouched: redo pass 1 in exact fp32
     }
     for (int k = 0; k < n_areas; ++k) {
         const int ymin = areas[4 * k], ymax = areas[4 * k + 1];
@@ -594,6 +640,15 @@ int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, 
     if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
     return strips_common(h, true, frames_dev, L, H, W, mask_dev, n_areas, areas, nullptr, 0, (hipStream_t)stream_);
 }
+
+int vsr_sttn_set_precision(vsr_sttn_t* h, int mode)
+{
+    if (!h || (mode != 0 && mode != 1)) return fail(VSR_ERR_ARG, "precision mode must be 0 (f32) or 1 (split-half f16 MFMA)");
+    h->precision = mode;
+    return 0;
+}
+
+int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h) { return h ? h->fallbacks : -1; }
 
 double vsr_sttn_flops(vsr_sttn_t* h, int L)
 {
@@ -643,7 +698,20 @@ static void tile_dims(int cfg, int& BM, int& BN)
     BN = cfg == VSR_TILE_128x128 ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
 }
 
+static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_);
+
 int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, void* stream_)
+{
+    return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, gg_variant(bmode), stream_);
+}
+
+int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
+{
+    if (variant < 1 || variant > 4) return fail(VSR_ERR_ARG, "kernel variant must be 1..4");
+    return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, variant, stream_);
+}
+
+static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
 {
     if (!probs || nprobs <= 0) return fail(VSR_ERR_ARG, "bad argument");
     if (vsr_device_count() <= 0) return fail(VSR_ERR_NOGPU, "no HIP device; there is no CPU fallback");
@@ -663,14 +731,14 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
     HIPCHK(hipMalloc((void**)&d, hp.size() * sizeof(GGProblem) + 64));   // + 8 queue counters
     HIPCHK(hipMemcpy(d, hp.data(), hp.size() * sizeof(GGProblem), hipMemcpyHostToDevice));
     unsigned int* queue = nullptr;
-    if (use_persistent()) {
+    if (variant >= 2) {
         queue = (unsigned int*)((char*)d + (hp.size() * sizeof(GGProblem) + 15) / 16 * 16);
         HIPCHK(hipMemset(queue, 0, 8 * sizeof(unsigned int)));
     }
     int nQueues = 8;
     for (const auto& p : hp)
         if (p.tilesN > 4) nQueues = 1;
-    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, gg_variant(bmode), nQueues, stream);
+    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, variant, nQueues, nullptr, stream);
     hipError_t e = hipStreamSynchronize(stream);
     (void)hipFree(d);
     if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");

@@ -14,18 +14,30 @@ static int envInt(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
-const Tuning& Tuning::get()
+const Tuning& Tuning::get(int precision)
 {
-    static const Tuning t = [] {
-        Tuning x;
-        x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
-        x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
-        x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
-        x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
-        x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
-        return x;
-    }();
-    return t;
+    // defaults = best measured on the 1080p bench (profiles/): the fp32-MFMA kernels like 128x64 tiles
+    // (more workgroups per CU), the 5x faster split-half kernels need 128x128 to stay ahead of their loads
+    static const Tuning t[2] = {
+        [] {
+            Tuning x;
+            x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
+            x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
+            x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
+            x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
+            x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
+            return x;
+        }(),
+        [] {
+            Tuning x;
+            x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x128);
+            x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x128);
+            x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x128);
+            x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
+            x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
+            return x;
+        }()};
+    return t[precision ? 1 : 0];
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -199,7 +211,7 @@ static void tileDims(int cfg, int& BM, int& BN)
     else if (cfg == VSR_TILE_256x64) { BM = 256; BN = 64; }
     else { BM = 256; BN = 32; }
 }
-static int pickTile(int N) { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : Tuning::get().convTile); }
+int Plan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : tu_.convTile); }
 
 static void checkFits(int64_t v)
 {
@@ -435,7 +447,7 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
 // would otherwise leave half the chip idle) and combined by a reduce-scatter pass.
 void Plan::addAttention(int T, const BlockW&)
 {
-    const Tuning& tu = Tuning::get();
+    const Tuning& tu = tu_;
     const int C = g.channels, dk = C / g.nscales;
     const Act att{BUF_ATT, T, g.featH, g.featW, C, 1};
     Op qk, sm, pv;
@@ -557,7 +569,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         const BlockW& bw = m_.blk[b];
         {   // fused Q/K/V 1x1 (auto_sttn.py:172-174) -> plain [T*fh*fw][3C]
             Op op;
-            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = Tuning::get().convTile; op.bmode = VSR_BMODE_NK;
+            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = tu_.convTile; op.bmode = VSR_BMODE_NK;
             int BM, BN;
             tileDims(op.tileCfg, BM, BN);
             GemmItem it{};
@@ -664,7 +676,8 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     ++nwindows;
 }
 
-Plan::Plan(const Model& model, int L_) : L(L_), g(model.g), m_(model)
+Plan::Plan(const Model& model, int L_, int precision_)
+    : L(L_), precision(precision_ ? 1 : 0), g(model.g), m_(model), tu_(Tuning::get(precision_))
 {
     if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
     if (L <= 0) throw std::runtime_error("empty frame list");

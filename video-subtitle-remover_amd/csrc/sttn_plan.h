@@ -34,7 +34,8 @@ struct Tuning {
     int pvSplitChunks;   // VSR_PV_SPLIT_CHUNKS: split the P.V contraction into slices of ~this many 32-token
                          //   chunks when it has at least twice as many (0 = never split)
     int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
-    static const Tuning& get();
+    // precision 0: exact fp32 MFMA kernels; 1: split-half f16 MFMA kernels (larger tiles pay there)
+    static const Tuning& get(int precision = 0);
 };
 
 // ---- packed weights ----
@@ -115,8 +116,9 @@ struct Act {                              // NHWC activation with a physical zer
 
 class Plan {
 public:
-    Plan(const Model& model, int L);
+    Plan(const Model& model, int L, int precision = 0);
     int L;
+    int precision;
     Geometry g;
     std::vector<int64_t> bufElems;        // BUF_COUNT entries (BUF_IN_U8 / BUF_MASK_U8 in bytes, others floats)
     std::vector<std::vector<int32_t>> tables;
@@ -126,7 +128,9 @@ public:
     int nwindows = 0;
 private:
     const Model& m_;
+    const Tuning& tu_;
     std::map<std::string, int> tableKey_;
+    int pickTile(int N) const;
     int table(const std::string& key, std::vector<int32_t>&& v);
     int tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add);
     int tColsConv(const Act& a, int ksz, int dil);

@@ -25,7 +25,7 @@ def require_gpu():
 class SttnEngine:
     """One STTN generator resident on one GPU (weights + workspace), bound to the caller's stream."""
 
-    def __init__(self, state_dict, variant="auto", device=0, neighbor_stride=None, ref_length=None):
+    def __init__(self, state_dict, variant="auto", device=0, neighbor_stride=None, ref_length=None, precision=None):
         self.variant = variant
         self._h = C.c_void_p()
         check(lib.vsr_sttn_create(_lib.VARIANT[variant], C.byref(self._h)))
@@ -39,6 +39,8 @@ class SttnEngine:
                 require_gpu()
             self.device_index = -1 if device is None else int(device)
             check(lib.vsr_sttn_finalize(self._h, self.device_index))
+            if precision is not None:       # "f32" (exact fp32 MFMA) | "split" (split-half f16 MFMA, guarded)
+                check(lib.vsr_sttn_set_precision(self._h, {"f32": 0, "split": 1}[precision]))
             if neighbor_stride is not None or ref_length is not None:
                 mw, mh, ns, rl = self.geometry()
                 check(lib.vsr_sttn_set_window(self._h, neighbor_stride or ns, ref_length or rl))
@@ -62,6 +64,12 @@ class SttnEngine:
     @property
     def handle(self):
         return self._h
+
+    def set_precision(self, precision):
+        check(lib.vsr_sttn_set_precision(self._h, {"f32": 0, "split": 1}[precision]))
+
+    def fallbacks(self):
+        return int(lib.vsr_sttn_fallbacks(self._h))
 
     def geometry(self):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
