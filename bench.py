@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--res", default="1080p", choices=sorted(RES))
     ap.add_argument("--chunk", type=int, default=50, help="frames per chunk (config.sttnMaxLoadNum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     args = ap.parse_args()
@@ -218,6 +219,33 @@ def main():
                           f"{args.cpu_sample_frames} model-resolution frames ({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s), "
                           f"scaled by FLOPs to the {flops_per_frame / 1e9:.1f} GFLOP/frame of a {L}-frame chunk"}
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"
+        if args.e2e_chunks > 0:
+            # PCIe-inclusive rate of the plugin's host loop (frames start and end in host memory: pinned staging,
+            # H2D / compute / D2H pipelined over three streams).  Reported beside `value`, never as `value`.
+            from vsr_amd.backend.inpaint.sttn_auto_inpaint import STTNAutoInpaint
+            from vsr_amd.backend.tools.video_io import ArrayVideo, CountingWriter
+
+            host_clip = np.concatenate([src.cpu().numpy()] * args.e2e_chunks)[: args.e2e_chunks * L]
+            sink = CountingWriter()
+
+            class _Host:
+                ab_sections = None
+                gui_mode = False
+                video_writer = sink
+
+                def update_progress(self, tbar, increment):
+                    pass
+
+            plug = STTNAutoInpaint(f"cuda:{local_rank}", {"netG": sd}, ArrayVideo(host_clip), clip_gap=L)
+            plug(input_mask=mask, input_sub_remover=_Host(), tbar=None)          # warm-up pass (plans, pinned buffers)
+            sink.count = 0
+            t2 = time.perf_counter()
+            plug(input_mask=mask, input_sub_remover=_Host(), tbar=None)
+            dt2 = time.perf_counter() - t2
+            out["pcie_inclusive"] = {"value": round(sink.count / dt2, 3), "unit": "frames/s", "frames": sink.count,
+                                     "note": "STTNAutoInpaint.__call__ over an in-memory 1080p clip: host frames -> pinned -> HBM -> "
+                                             "inpaint -> pinned -> writer.write(frame); decode/encode excluded"}
+            plug.sttn_inpaint.engine.close()
         if not args.no_split_half:
             # informational: the same workload with split-half operands on the f16 matrix cores (fp32 data,
             # fp32 accumulation, 22-bit operands, device-side range guard with fp32 fallback).  NOT `value`.

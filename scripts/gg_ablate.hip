@@ -7,6 +7,7 @@
 #include "../video-subtitle-remover_amd/csrc/gather_gemm.hip"
 #include "../video-subtitle-remover_amd/csrc/gather_gemm_v2.h"
 #include "../video-subtitle-remover_amd/csrc/gather_gemm_v3.h"
+#include "../video-subtitle-remover_amd/csrc/gather_gemm_v4.h"
 #include <stdio.h>
 #include <vector>
 
@@ -60,6 +61,32 @@ static float run_v2(const GGProblem* d, int blocks, int iters, int residentPerCU
     return best;
 }
 
+template <int BM, int BN, int WM, int WN, int ABL>
+static float run_v4(const GGProblem* d, int blocks, int iters)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    unsigned int* q;
+    hipMalloc(&q, 64 * 8 * sizeof(unsigned int));
+    int occ = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v4<BM, BN, WM, WN, VSR_BMODE_NK, ABL>, 256, 0);
+    const int grid = blocks < 256 * occ ? blocks : 256 * occ;
+    float best = 1e9f;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipMemset(q, 0, 64 * 8 * sizeof(unsigned int));
+        hipEventRecord(a, 0);
+        for (int i = 0; i < iters; ++i)
+            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, VSR_BMODE_NK, ABL>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8, (unsigned int*)nullptr);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms / iters < best) best = ms / iters;
+    }
+    hipFree(q);
+    return best;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int sweep(int T)
 {
@@ -110,7 +137,16 @@ static int sweep(int T)
     { float ms = run_v2<BM, BN, WM, WN, 3>(d, blocks, it, 0); printf("%6.1f TF\n", gf / ms); }
     { float ms = run_v2<BM, BN, WM, WN, 3>(d, blocks, it, 2); printf("%6.1f TF\n", gf / ms); }
     { float ms = run_v2<BM, BN, WM, WN, 3>(d, blocks, it, 1); printf("%6.1f TF\n", gf / ms); }
-    if (BM == 128 && BN == 64) {   // v3 timeline of a few workgroups: per-chunk durations, prologue, epilogue
+#define R4(abl, what) { float ms = run_v4<BM, BN, WM, WN, abl>(d, blocks, it); printf("  v4 abl=%3d %-44s %8.1f us  %6.1f TF\n", abl, what, ms * 1e3, gf / ms); }
+    R4(0, "split-half full kernel");
+    R4(128, "no split arithmetic (bit casts)");
+    R4(1, "no barriers");
+    R4(2, "no global loads in loop");
+    R4(4, "no LDS stores (and no conversion)");
+    R4(6, "no loads, no stores");
+    R4(7, "no loads/stores/barriers (LDS reads + MFMA)");
+    R4(15, "MFMA only");
+    if (BM == 128 && BN == 64 && false) {   // v3 timeline of a few workgroups: per-chunk durations, prologue, epilogue
         std::vector<unsigned long long> z(1024 * 256, 0), h(1024 * 256);
         hipMemcpyToSymbol(HIP_SYMBOL(gg_trace), z.data(), z.size() * 8);
         unsigned int* q; hipMalloc(&q, 32); hipMemset(q, 0, 32);

@@ -177,38 +177,73 @@ class STTNAutoInpaint:
             clip_gap = self.clip_gap
             engine = self.sttn_inpaint.engine
             dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(engine.device)
+            torch.cuda.synchronize(engine.device)
             total = frame_info["len"]
             rec_time = total // clip_gap if total % clip_gap == 0 else total // clip_gap + 1
-            for i in range(rec_time):
-                start_f, end_f = i * clip_gap, min((i + 1) * clip_gap, total)
-                frames_hr, sel = [], []
-                for j in range(start_f, end_f):
-                    ok, image = reader.read()
-                    if not ok:
-                        print(f"Warning: Failed to read frame {j}.")
-                        break
-                    frames_hr.append(image)
-                    if is_frame_number_in_ab_sections(j, ab_sections):
-                        sel.append(j - start_f)
-                if not frames_hr:
-                    print(f"Warning: No valid frames found in range {start_f + 1}-{end_f}. Skipping this segment.")
-                    continue
-                originals = frames_hr if (input_sub_remover is not None and getattr(input_sub_remover, "gui_mode", False)) else None
-                if inpaint_area and sel:
-                    d = torch.from_numpy(np.ascontiguousarray(np.stack(frames_hr))).to(engine.device, non_blocking=True)
-                    engine.auto_chunk(d, dmask, inpaint_area, sel=None if len(sel) == len(frames_hr) else sel)
-                    out = d.cpu().numpy()
-                else:
-                    out = frames_hr
-                for j in range(len(frames_hr)):
+            # Three-stage pipeline over the chunks (reference: read -> inpaint -> write, strictly serial,
+            # sttn_auto_inpaint.py:242-328): pinned host buffers, H2D / compute / D2H on separate HIP streams,
+            # so that chunk i computes while chunk i+1 is read + uploaded and chunk i-1 is downloaded + written.
+            dev = engine.device
+            s_h2d, s_cmp, s_d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            shape = (clip_gap, H_ori, W_ori, 3)
+            pin_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            pin_out = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            dbuf = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+            ev_up = [torch.cuda.Event() for _ in range(2)]
+            ev_cmp = [torch.cuda.Event() for _ in range(2)]
+            ev_down = [torch.cuda.Event() for _ in range(2)]
+            pending = None                                   # (slot, n_frames, originals) waiting to be written
+
+            def flush(p):
+                slot, n, originals = p
+                ev_down[slot].synchronize()
+                out = pin_out[slot].numpy()
+                for j in range(n):
                     writer.write(out[j])
                     if input_sub_remover is not None:
                         if tbar is not None:
                             input_sub_remover.update_progress(tbar, increment=1)
                         if originals is not None:
                             input_sub_remover.update_preview_with_comp(originals[j], out[j])
-                del frames_hr, out
-                gc.collect()
+
+            for i in range(rec_time):
+                start_f, end_f = i * clip_gap, min((i + 1) * clip_gap, total)
+                slot = i & 1
+                ev_down[slot].synchronize()                  # pin_out[slot] / dbuf[slot] of chunk i-2 are free again
+                host = pin_in[slot].numpy()
+                n, sel = 0, []
+                for j in range(start_f, end_f):
+                    ok, image = reader.read()
+                    if not ok:
+                        print(f"Warning: Failed to read frame {j}.")
+                        break
+                    host[n] = image
+                    if is_frame_number_in_ab_sections(j, ab_sections):
+                        sel.append(n)
+                    n += 1
+                if n == 0:
+                    print(f"Warning: No valid frames found in range {start_f + 1}-{end_f}. Skipping this segment.")
+                    continue
+                gui = input_sub_remover is not None and getattr(input_sub_remover, "gui_mode", False)
+                originals = host[:n].copy() if gui else None
+                with torch.cuda.stream(s_h2d):
+                    dbuf[slot][:n].copy_(pin_in[slot][:n], non_blocking=True)
+                    ev_up[slot].record(s_h2d)
+                with torch.cuda.stream(s_cmp):
+                    s_cmp.wait_event(ev_up[slot])
+                    if inpaint_area and sel:
+                        engine.auto_chunk(dbuf[slot][:n], dmask, inpaint_area, sel=None if len(sel) == n else sel)
+                    ev_cmp[slot].record(s_cmp)
+                with torch.cuda.stream(s_d2h):
+                    s_d2h.wait_event(ev_cmp[slot])
+                    pin_out[slot][:n].copy_(dbuf[slot][:n], non_blocking=True)
+                    ev_down[slot].record(s_d2h)
+                if pending is not None:
+                    flush(pending)                           # chunk i-1 is written while chunk i computes
+                pending = (slot, n, originals)
+            if pending is not None:
+                flush(pending)
+            gc.collect()
         except Exception as e:          # the reference swallows every error here (:329-331)
             print(f"Error during video processing: {str(e)}")
         finally:

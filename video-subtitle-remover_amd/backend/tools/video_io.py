@@ -40,7 +40,22 @@ class ArrayWriter:
     def write(self, frame):
         if frame.dtype != np.uint8:
             frame = np.clip(frame, 0, 255).astype(np.uint8)
-        self.frames.append(frame)
+        self.frames.append(frame.copy())        # the caller may hand out views of a recycled (pinned) buffer
+
+    def release(self):
+        pass
+
+
+class CountingWriter:
+    """Sink that only counts (benchmarks: the encoder is out of scope)."""
+
+    def __init__(self):
+        self.count = 0
+        self.checksum = 0
+
+    def write(self, frame):
+        self.count += 1
+        self.checksum = (self.checksum + int(frame[::97, ::89].sum())) & 0xFFFFFFFF
 
     def release(self):
         pass

@@ -199,8 +199,13 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             f16x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                h[j] = (_Float16)v[j];
-                l[j] = (_Float16)(v[j] - (float)h[j]);
+                if constexpr (GG_ABL(128)) {             // ablation: no split arithmetic (wrong values)
+                    h[j] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned, v[j]) >> 16));
+                    l[j] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned, v[j]) & 0x3fff));
+                } else {
+                    h[j] = (_Float16)v[j];
+                    l[j] = (_Float16)(v[j] - (float)h[j]);
+                }
             }
             *reinterpret_cast<f16x4*>(rowBase + stHi) = h;
             *reinterpret_cast<f16x4*>(rowBase + stLo) = l;
@@ -233,6 +238,12 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             const char* As = reinterpret_cast<const char*>(smem + buf * BUF_FLOATS);
             const char* Bs = As + AS_FLOATS * 4;
             f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+            if constexpr (GG_ABL(8)) {                   // ablation: MFMA only
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) { ah[mi] = __builtin_bit_cast(f16x8, ra[mi % A_IT]); al[mi] = ah[mi]; }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) { bh[ni] = __builtin_bit_cast(f16x8, ra[(ni + 1) % A_IT]); bl[ni] = bh[ni]; }
+            } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const char* row = As + (wm * WTM + mi * 32 + l31) * 128;
@@ -244,6 +255,7 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 const char* row = Bs + (wn * WTN + ni * 32 + l31) * 128;
                 bh[ni] = *reinterpret_cast<const f16x8*>(row + rdHi[st]);
                 bl[ni] = *reinterpret_cast<const f16x8*>(row + rdLo[st]);
+            }
             }
             // small cross terms first, the hi*hi term last
 #pragma unroll
@@ -266,8 +278,8 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 // registers hold chunk kc+1 (fp32); LDS[cur] holds chunk kc (split halves)
                 compute_step(cur, 0);
                 if (kc + 1 < kcEnd) {
-                    store_tile(cur ^ 1);           // buffer last read in iteration kc-1, fenced by its barrier
-                    if (kc + 2 < kcEnd) {
+                    if constexpr (!GG_ABL(4)) store_tile(cur ^ 1);   // buffer last read in iteration kc-1, fenced by its barrier
+                    if (kc + 2 < kcEnd && !GG_ABL(2)) {
                         if (kc + 2 - colBase >= 64) {
                             colBase += 64;
                             vcolA = vcolAn; vcolB = vcolBn;
@@ -277,7 +289,7 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     }
                 }
                 compute_step(cur, 1);
-                __syncthreads();
+                if constexpr (!GG_ABL(1)) __syncthreads();
                 cur ^= 1;
             }
         }

@@ -248,7 +248,10 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 // problem (P.V, n-contiguous B) on v1.  VSR_GG_VARIANT / VSR_PV_VARIANT override for A/B runs.
 static int gg_variant(int bmode, int precision = 0)
 {
-    if (precision) return 4;
+    if (precision) {   // split-half mode; VSR_SPLIT_PV_VARIANT lets the P.V product stay on an fp32 kernel for A/B runs
+        static const int pv = [] { const char* e = getenv("VSR_SPLIT_PV_VARIANT"); int x = e ? atoi(e) : 4; return (x < 1 || x > 4) ? 4 : x; }();
+        return bmode == VSR_BMODE_KN ? pv : 4;
+    }
     static const int nk = [] { const char* e = getenv("VSR_GG_VARIANT"); int x = e ? atoi(e) : 3; return (x < 1 || x > 4) ? 3 : x; }();
     static const int kn = [] {
         const char* e = getenv("VSR_PV_VARIANT");

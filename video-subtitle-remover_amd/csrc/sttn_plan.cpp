@@ -16,8 +16,8 @@ static int envInt(const char* name, int dflt)
 
 const Tuning& Tuning::get(int precision)
 {
-    // defaults = best measured on the 1080p bench (profiles/): the fp32-MFMA kernels like 128x64 tiles
-    // (more workgroups per CU), the 5x faster split-half kernels need 128x128 to stay ahead of their loads
+    // defaults = best measured on the 1080p bench (interleaved A/B, profiles/): 128x64 tiles (3 workgroups
+    // per CU) win in both modes; 128x128 is 8 % slower with the split-half kernels and 4 % with fp32
     static const Tuning t[2] = {
         [] {
             Tuning x;
@@ -30,9 +30,9 @@ const Tuning& Tuning::get(int precision)
         }(),
         [] {
             Tuning x;
-            x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x128);
-            x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x128);
-            x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x128);
+            x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
+            x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
+            x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
             x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
             return x;
