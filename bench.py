@@ -95,6 +95,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    # VSR_BENCH_DRYRUN_1GPU=1: exercise the N > 1 code path on a single-GPU box (every rank on cuda:0, gloo)
+    dry = os.environ.get("VSR_BENCH_DRYRUN_1GPU") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -102,7 +106,10 @@ def main():
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group(backend="nccl", device_id=device)
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     import vsr_amd  # noqa: F401
     from vsr_amd.backend.tools.inpaint_tools import create_mask, get_inpaint_area_by_mask, threshold_mask
@@ -143,7 +150,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
