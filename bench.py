@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
+    ap.add_argument("--precision", default=None, choices=["f32", "split", "split-format", "f16"],
+                    help="arithmetic of the contractions in the timed region (default: exact fp32; BASELINE.json's config 5 "
+                         "is --res 4k --precision f16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +122,9 @@ def main():
     H, W, box = RES[args.res]
     L = args.chunk
     sd = make_state_dict(0, "auto")
-    eng = SttnEngine(sd, "auto", device=local_rank)
+    eng = SttnEngine(sd, "auto", device=local_rank, precision=args.precision)
+    base_precision = args.precision or {"1": "split", "s": "split", "2": "split-format", "3": "f16"}.get(
+        os.environ.get("VSR_PRECISION", "0")[:1], "f32")
     mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
     mask01 = threshold_mask(mask)
     areas = get_inpaint_area_by_mask(W, H, int(W * 3 / 16), mask01)
@@ -164,7 +169,10 @@ def main():
         else f"inpainted frames/sec @{args.res} (STTN, 5-frame window)",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": {"f32": "f32", "split": "f32 (operands as fp16 hi/lo pairs)", "split-format": "f32 (operands as fp16 hi/lo pairs)",
+                  "f16": "f16 (fp32 accumulate)"}[base_precision],
+        "data": "synthetic",
         "config": {"workload": f"{args.res} synthetic clip, --inpaint-mode sttn-auto, {L}-frame chunks resident in HBM, "
                                f"neighbor stride 5 / refs every 10 (BASELINE.json metric; model cost is resolution-independent)",
                    "frame_size": [W, H], "strip": [W, int(W * 3 / 16)], "chunk_frames": L, "parallelism": f"chunk-parallel x{world}",
@@ -183,7 +191,7 @@ def main():
         for cfg, (bm, bn, wm, wn) in dims.items():
             for bmode in (0, 1):
                 for var, sym in ((1, "gather_gemm_f32"), (2, "gather_gemm_f32_v2"), (3, "gather_gemm_f32_v3"),
-                                 (4, "gather_gemm_f32_v4")):
+                                 (4, "gather_gemm_f32_v4"), (5, "gather_gemm_f32_v5")):
                     a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}:v{var}")
                     if b:
                         per_kernel[f"{sym}<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)
@@ -256,26 +264,30 @@ def main():
         if not args.no_split_half:
             # informational: the same workload with split-half operands on the f16 matrix cores (fp32 data,
             # fp32 accumulation, 22-bit operands, device-side range guard with fp32 fallback).  NOT `value`.
-            eng.set_precision("split")
-            for _ in range(max(1, args.warmup)):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            sp = {"value": round(args.steps * L / dt, 3), "unit": "frames/s (this rank)", "ms_per_step": round(dt / args.steps * 1e3, 3),
-                  "fp32_fallback_chunks": eng.fallbacks(),
-                  "arithmetic": "fp32 data + fp32 accumulate; operands as fp16 hi/lo pairs, a*b = a_lo*b_hi + a_hi*b_lo + a_hi*b_hi "
-                                "(3x v_mfma_f32_32x32x16_f16)"}
-            if not args.no_cpu_baseline:
-                comp2, _ = eng.inpaint(torch.from_numpy(frames).to(device))
+            for mode, key in (("split", "split_half_mode"), ("split-format", "split_format_mode"), ("f16", "fp16_mode")):
+                eng.set_precision(mode)
+                for _ in range(max(1, args.warmup)):
+                    step()
                 torch.cuda.synchronize()
-                mse2 = float(np.mean((comp2.cpu().numpy().astype(np.float64) - refa) ** 2))
-                sp["psnr_db_vs_oracle"] = "inf" if mse2 == 0 else round(20 * np.log10(255.0 / np.sqrt(mse2)), 2)
-            eng.set_precision("f32")
-            out["split_half_mode"] = sp
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                sp = {"value": round(args.steps * L / dt, 3), "unit": "frames/s (this rank)", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                      "fp32_fallback_chunks": eng.fallbacks(),
+                      "arithmetic": ("fp16 operands (hi halves of the split-format tensors), fp32 accumulate, 1x v_mfma_f32_32x32x16_f16 "
+                                     "per product; bias / activation / residual / softmax in fp32") if mode == "f16" else
+                                    ("fp32 data + fp32 accumulate; operands as fp16 hi/lo pairs, a*b = a_lo*b_hi + a_hi*b_lo + a_hi*b_hi "
+                                     "(3x v_mfma_f32_32x32x16_f16)" + ("; tensors kept in split format by their producers, "
+                                     "operands by LDS-DMA" if mode == "split-format" else "; split inside the GEMM"))}
+                if not args.no_cpu_baseline:
+                    comp2, _ = eng.inpaint(torch.from_numpy(frames).to(device))
+                    torch.cuda.synchronize()
+                    mse2 = float(np.mean((comp2.cpu().numpy().astype(np.float64) - refa) ** 2))
+                    sp["psnr_db_vs_oracle"] = "inf" if mse2 == 0 else round(20 * np.log10(255.0 / np.sqrt(mse2)), 2)
+                out[key] = sp
+            eng.set_precision(base_precision)
         print(json.dumps(out), flush=True)
 
     eng.close()

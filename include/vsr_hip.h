@@ -100,7 +100,15 @@ int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, 
  * hi = fp16(x), lo = fp16(x - hi) and a*b taken as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (22 significand bits per
  * operand; 5.3x the fp32-MFMA rate).  Operands beyond the fp16 range make a result non-finite; that is detected
  * on the device and the chunk is then recomputed with the exact kernels (vsr_sttn_fallbacks counts them).
- * Environment default: VSR_PRECISION=split. */
+ * 2: the same arithmetic with the split done once by the PRODUCER of each tensor: every GEMM operand (weights,
+ * activations, softmax probabilities) is kept in HBM in "split format" -- each aligned group of 32 fp32 slots
+ * (128 B) holds the 32 fp16 hi halves followed by the 32 fp16 lo halves -- so tiles stream into LDS by DMA and
+ * the kernel does no conversion.  Scores, split-K partial sums and the decoder output stay plain fp32.  Same
+ * range guard and fp32 fallback as mode 1.
+ * 3: fp16 operands, fp32 accumulation (BASELINE.json's "fp16 MFMA path"): mode 2's tensors and kernels with the
+ * lo halves left out of the contractions -- one v_mfma_f32_32x32x16_f16 per product, 11-bit operands; bias,
+ * activation, residual adds, softmax and the decoder output stay fp32-accurate.  Same guard and fallback.
+ * Environment default: VSR_PRECISION=split (mode 1) / VSR_PRECISION=2 / VSR_PRECISION=3. */
 int vsr_sttn_set_precision(vsr_sttn_t* h, int mode);
 int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h);
 
@@ -117,7 +125,9 @@ int vsr_sttn_timing_reset(vsr_sttn_t* h);
  * ------------------------------------------------------------------------------------- */
 #define VSR_GG_KC 32 /* K / N chunk granularity of the offset tables */
 enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
-enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1 };
+enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1,
+       VSR_ACT_OUT_SPLIT = 0x100,   /* variant 5 only: OR-ed into act, C is written in split format */
+       VSR_ACT_F16_OPERANDS = 0x200 /* variant 5 only: operands are the fp16 hi halves alone (one MFMA per product) */ };
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3 };
 
 /* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]
@@ -153,16 +163,21 @@ typedef struct SMProblem {
     int32_t M, N, ldS, ldP, nsplit;
     int32_t rowStart;
     float scale;
-    int32_t pad_;
+    int32_t flags;      /* bit 0: P is written in split format (precision mode 2) */
     int64_t splitStride;
 } SMProblem;
 
 /* probs: HOST array whose pointers are device pointers; tileStart / rowStart are filled in */
 int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, void* stream);
 /* same with an explicit kernel variant: 1 one workgroup per tile, 2 persistent (register staged), 3 persistent
- * LDS-DMA (fp32 MFMA), 4 persistent split-half operands on the f16 matrix cores (see vsr_sttn_set_precision) */
+ * LDS-DMA (fp32 MFMA), 4 persistent split-half operands on the f16 matrix cores (see vsr_sttn_set_precision),
+ * 5 the same on split-format tensors: A, B and R are read in split format; C is written in split format when
+ * act carries VSR_ACT_OUT_SPLIT, as plain fp32 otherwise */
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream);
 int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
+/* fp32 -> split format (variant 5 operands): dst[32c .. 32c+31] as bytes = fp16 hi[0..31] | fp16 lo[0..31] of
+ * src[32c .. 32c+31]; n a multiple of 32 */
+int vsr_launch_to_split(const float* src_dev, float* dst_dev, int64_t n, void* stream);
 
 /* cv2.resize(..., INTER_LINEAR) on uint8 (fixed-point path), tables from vsr_cv2_linear_tables;
  * frame_idx (device, nullable) gathers source frames (sttn_auto_inpaint.py:269-271) */

@@ -104,12 +104,27 @@ def _run_cases(_lib, device, cases, tile_cfg, bmode, variant=None):
     return [o.cpu().numpy() for o in outs]
 
 
-def _assert_close(got, ref, K, what):
+def _written_mask(case):
+    """Cells of Cbuf the descriptor writes: (m < M, n < N) of every split-K plane."""
+    m, n = np.meshgrid(np.arange(case.M), np.arange(case.N), indexing="ij")
+    cell = (case.rowC[m] + case.colC[n // 32] + n % 32).reshape(-1)
+    mask = np.zeros(case.Cbuf.shape[0], dtype=bool)
+    for s in range(case.splitK):
+        mask[cell + s * case.splitStride] = True
+    return mask
+
+
+def _assert_close(got, ref, K, what, case=None):
     err = np.abs(got - ref).max()
     tol = 2e-5 * np.sqrt(K) * 4 + 1e-5
     assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e}"
     # untouched sentinel cells must stay untouched (no out-of-tile stores)
-    assert np.array_equal(got == -7.0, ref == -7.0), f"{what}: store footprint differs"
+    if case is not None:      # exact footprint (a computed value may by chance equal the sentinel)
+        keep = ~_written_mask(case)
+        assert np.all(ref[keep] == -7.0)
+        assert np.array_equal(got[keep], ref[keep]), f"{what}: store footprint differs"
+    else:
+        assert np.array_equal(got == -7.0, ref == -7.0), f"{what}: store footprint differs"
 
 
 @pytest.mark.parametrize("M,N,K,splitK,bias,act,res", [
@@ -189,7 +204,77 @@ def test_gather_gemm_every_variant(built_lib, gpu_device, variant, cfg, bm, bn, 
     full = splitK == 1 and bmode == 0
     c = _make_gemm_case(rng, M, N, K, bm, bn, bmode, splitK, full, 1 if full else 0, full and N > 3)
     got = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), bmode, variant)[0]
-    _assert_close(got, _reference(c), K, f"v{variant} {cfg} mode{bmode} {M}x{N}x{K}")
+    _assert_close(got, _reference(c), K, f"v{variant} {cfg} mode{bmode} {M}x{N}x{K}", case=c)
+
+
+def _to_split_inplace(buf, starts):
+    """fp32 -> split format on the 32-float chunks starting at ``starts`` (see include/vsr_hip.h, precision 2)."""
+    starts = np.unique(np.asarray(starts, dtype=np.int64))
+    idx = starts[:, None] + np.arange(32)[None, :]
+    v = buf[idx]
+    hi = v.astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    buf[idx] = np.ascontiguousarray(np.concatenate([hi, lo], axis=1)).view(np.float32)
+
+
+def _starts(row, col):
+    return (np.asarray(row, np.int64)[:, None] + np.asarray(col, np.int64)[None, :]).reshape(-1)
+
+
+@pytest.mark.parametrize("out_split", [0, 1])
+@pytest.mark.parametrize("cfg,bm,bn,bmode,M,N,K,splitK", [
+    ("TILE_128x128", 128, 128, 0, 513, 257, 2304, 1), ("TILE_128x64", 128, 64, 0, 300, 256, 576, 1),
+    ("TILE_128x128", 128, 128, 0, 375, 375, 384, 3), ("TILE_256x64", 256, 64, 0, 520, 64, 576, 1),
+    ("TILE_256x32", 256, 32, 0, 700, 3, 64, 1),
+    ("TILE_128x128", 128, 128, 1, 200, 192, 96, 1), ("TILE_128x64", 128, 64, 1, 1440, 960, 320, 3),
+    ("TILE_128x64", 128, 64, 1, 129, 960, 4800 // 32 * 32, 1),
+])
+def test_gather_gemm_split_format(built_lib, gpu_device, out_split, cfg, bm, bn, bmode, M, N, K, splitK):
+    """Variant 5: A, B and R arrive in split format ([32 fp16 hi | 32 fp16 lo] per 32-float chunk); C leaves in
+    split format when act carries VSR_ACT_OUT_SPLIT, as plain fp32 otherwise (split-K planes always fp32)."""
+    if out_split and splitK > 1:
+        pytest.skip("partial planes are plain fp32")
+    rng = np.random.default_rng(5000 + M + N + K + out_split)
+    full = splitK == 1
+    c = _make_gemm_case(rng, M, N, K, bm, bn, bmode, splitK, full, 1 if full else 0, full and N > 3)
+    ref = _reference(c)
+    sentinel = c.Cbuf.copy()
+    _to_split_inplace(c.Abuf, _starts(c.rowA, c.colA))
+    _to_split_inplace(c.Bbuf, _starts(c.rowB, c.colB))
+    if c.use_res:
+        _to_split_inplace(c.Rbuf, _starts(c.rowR[:M], c.colC))
+    if out_split:
+        c.act |= 0x100                                   # VSR_ACT_OUT_SPLIT
+    got = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), bmode, 5)[0]
+    what = f"v5 {cfg} mode{bmode} {M}x{N}x{K} out_split={out_split}"
+    if not out_split:
+        _assert_close(got, ref, K, what, case=c)
+        return
+    m, n = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    chunk = c.rowC[m] + c.colC[n // 32]
+    hi_i, lo_i = 2 * chunk + n % 32, 2 * chunk + 32 + n % 32
+    g16 = got.view(np.uint16)
+    val = g16[hi_i].view(np.float16).astype(np.float32) + g16[lo_i].view(np.float16).astype(np.float32)
+    err = np.abs(val - ref[chunk + n % 32]).max()
+    tol = 2e-5 * np.sqrt(K) * 4 + 1e-5
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e}"
+    s16 = sentinel.view(np.uint16)
+    rest = g16.copy()
+    rest[hi_i] = s16[hi_i]
+    rest[lo_i] = s16[lo_i]
+    assert np.array_equal(rest, s16), f"{what}: store footprint differs"
+
+
+def test_to_split_bit_exact(built_lib, gpu_device):
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal(32 * 1000) * np.exp(rng.uniform(-8, 8, 32 * 1000))).astype(np.float32)
+    dx = _dev(x, gpu_device)
+    out = torch.empty_like(dx)
+    assert built_lib.lib.vsr_launch_to_split(_ptr(dx), _ptr(out), x.size, None) == 0
+    torch.cuda.synchronize()
+    ref = x.copy()
+    _to_split_inplace(ref, np.arange(0, x.size, 32))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
 
 
 def test_gather_gemm_grouped_launch(built_lib, gpu_device):

@@ -36,7 +36,7 @@ class GGProblem(C.Structure):
 class SMProblem(C.Structure):
     _fields_ = [("S", C.c_void_p), ("P", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldS", C.c_int32),
                 ("ldP", C.c_int32), ("nsplit", C.c_int32), ("rowStart", C.c_int32), ("scale", C.c_float),
-                ("pad_", C.c_int32), ("splitStride", C.c_int64)]
+                ("flags", C.c_int32), ("splitStride", C.c_int64)]
 
 
 class VsrOpInfo(C.Structure):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "vsr_run_gather_gemm": (_I, [C.POINTER(GGProblem), _I, _I, _I, _P]),
     "vsr_run_gather_gemm_variant": (_I, [C.POINTER(GGProblem), _I, _I, _I, _I, _P]),
     "vsr_run_softmax": (_I, [C.POINTER(SMProblem), _I, _P]),
+    "vsr_launch_to_split": (_I, [_P, _P, C.c_int64, _P]),
     "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsr_launch_norm_im2col": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_launch_reduce_scatter": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P]),

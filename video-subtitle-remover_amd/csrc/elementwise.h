@@ -5,3 +5,13 @@
 
 // d_probs: DEVICE array (rowStart filled, multiples of 4); totalRows = padded row count
 extern "C" int vsr_launch_softmax_dev(const SMProblem* d_probs, int nprobs, int totalRows, void* stream);
+
+// precision mode 2: the same kernels writing (and, for the upsampler, reading) split-format tensors
+// (gather_gemm_v5.h); *Split = 0 is the plain fp32 layout of the public entry points
+extern "C" int vsr_launch_norm_im2col_fmt(const uint8_t* img, int ih, int iw, int nframes, float* out, int premask,
+                                          const uint8_t* mask, int outSplit, void* stream);
+extern "C" int vsr_launch_reduce_scatter_fmt(const float* part, int nsplit, int64_t splitStride, int M, int N,
+                                             const int32_t* rowC, const int32_t* colC, float* out, int outSplit,
+                                             void* stream);
+extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
+                                         int nframes, int split, void* stream);

@@ -58,6 +58,36 @@ k_resize_u8(const uint8_t* __restrict__ src, int64_t srcFrameStride, int srcRowS
 }
 
 // ---------------------------------------------------------------------------------------
+// Split format (precision mode 2, see gather_gemm_v5.h): an aligned group of 32 fp32 slots holds
+// [32 fp16 hi | 32 fp16 lo] of the same 32 values.  e = float index (multiple of 4) relative to a
+// 128-byte aligned base whose chunk grid the GEMM tables address.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_fmt(float* base, int64_t e, f32x4 v, int split)
+{
+    if (!split) { *reinterpret_cast<f32x4*>(base + e) = v; return; }
+    _Float16* p = reinterpret_cast<_Float16*>(base) + 2 * (e & ~(int64_t)31) + (e & 31);
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)v[j];
+        l[j] = (_Float16)(v[j] - (float)h[j]);
+    }
+    *reinterpret_cast<f16x4*>(p) = h;
+    *reinterpret_cast<f16x4*>(p + 32) = l;
+}
+__device__ __forceinline__ f32x4 load4_fmt(const float* base, int64_t e, int split)
+{
+    if (!split) return *reinterpret_cast<const f32x4*>(base + e);
+    const _Float16* p = reinterpret_cast<const _Float16*>(base) + 2 * (e & ~(int64_t)31) + (e & 31);
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p), l = *reinterpret_cast<const f16x4*>(p + 32);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + (float)l[j];
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
 // K1b: Stack (BGR->RGB) + ToTorchFormatTensor (/255) + "*2-1" (sttn_utils.py:73,111;
 // sttn_auto_inpaint.py:128) fused with the im2col of encoder conv1 (3x3, stride 2, pad 1,
 // auto_sttn.py:76): row m = (frame, oy, ox), 32 columns: k = (ky*3+kx)*3 + c_rgb, 27..31 zero.
@@ -65,7 +95,7 @@ k_resize_u8(const uint8_t* __restrict__ src, int64_t srcFrameStride, int srcRowS
 __global__ void __launch_bounds__(256)
 k_norm_im2col_s2(const uint8_t* __restrict__ img /*[n][ih][iw][3] BGR*/, int ih, int iw, int nframes,
                  float* __restrict__ out /*[n*oh*ow][32]*/, int premask,
-                 const uint8_t* __restrict__ mask /*[n][ih][iw] resized 0..255 mask or null*/)
+                 const uint8_t* __restrict__ mask /*[n][ih][iw] resized 0..255 mask or null*/, int outSplit)
 {
     const int oh = ih / 2, ow = iw / 2;
     const int64_t total = (int64_t)nframes * oh * ow * 8;
@@ -93,7 +123,7 @@ k_norm_im2col_s2(const uint8_t* __restrict__ img /*[n][ih][iw][3] BGR*/, int ih,
             }
             v[j] = val;
         }
-        *reinterpret_cast<f32x4*>(out + m * 32 + 4 * q) = v;
+        store4_fmt(out, m * 32 + 4 * q, v, outSplit);
     }
 }
 
@@ -130,6 +160,7 @@ k_softmax_rows(const SMProblem* __restrict__ probs, int nprobs)
     const float scale = P->scale;
     const float* __restrict__ S = P->S + (int64_t)r * P->ldS;
     float* __restrict__ O = P->P + (int64_t)r * ldP;
+    const bool outSplit = (P->flags & 1) != 0;
 
     float mx = -INFINITY;
     for (int n = lane; n < N; n += 64) {
@@ -152,7 +183,14 @@ k_softmax_rows(const SMProblem* __restrict__ probs, int nprobs)
             for (int k = 1; k < nsplit; ++k) s += S[n + k * ss];
             p = expf(s * scale - mx) / sum;
         }
-        O[n] = p;
+        if (outSplit) {
+            _Float16* o = reinterpret_cast<_Float16*>(O) + 2 * (n & ~31) + (n & 31);
+            const _Float16 h = (_Float16)p;
+            o[0] = h;
+            o[32] = (_Float16)(p - (float)h);
+        } else {
+            O[n] = p;
+        }
     }
 }
 
@@ -162,7 +200,7 @@ k_softmax_rows(const SMProblem* __restrict__ probs, int nprobs)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_upsample2x_nhwc(const float* __restrict__ src, int H, int W, int C, int haloS,
-                  float* __restrict__ dst, int haloD, int nframes)
+                  float* __restrict__ dst, int haloD, int nframes, int split)
 {
     const int OH = 2 * H, OW = 2 * W, C4 = C / 4;
     const int Hs = H + 2 * haloS, Ws = W + 2 * haloS, Hd = OH + 2 * haloD, Wd = OW + 2 * haloD;
@@ -181,16 +219,16 @@ k_upsample2x_nhwc(const float* __restrict__ src, int H, int W, int C, int haloS,
         float ly = fy - (float)y0; ly = fminf(fmaxf(ly, 0.f), 1.f);
         float lx = fx - (float)x0; lx = fminf(fmaxf(lx, 0.f), 1.f);
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* b = src + (int64_t)f * Hs * Ws * C + 4 * c4;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y0 + haloS) * Ws + x0 + haloS) * C);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y0 + haloS) * Ws + x1 + haloS) * C);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y1 + haloS) * Ws + x0 + haloS) * C);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((int64_t)(y1 + haloS) * Ws + x1 + haloS) * C);
+        const int64_t b = (int64_t)f * Hs * Ws * C + 4 * c4;
+        const f32x4 v00 = load4_fmt(src, b + ((int64_t)(y0 + haloS) * Ws + x0 + haloS) * C, split);
+        const f32x4 v01 = load4_fmt(src, b + ((int64_t)(y0 + haloS) * Ws + x1 + haloS) * C, split);
+        const f32x4 v10 = load4_fmt(src, b + ((int64_t)(y1 + haloS) * Ws + x0 + haloS) * C, split);
+        const f32x4 v11 = load4_fmt(src, b + ((int64_t)(y1 + haloS) * Ws + x1 + haloS) * C, split);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
-        *reinterpret_cast<f32x4*>(dst + (((int64_t)f * Hd + oy + haloD) * Wd + ox + haloD) * C + 4 * c4) = o;
+        store4_fmt(dst, (((int64_t)f * Hd + oy + haloD) * Wd + ox + haloD) * C + 4 * c4, o, split);
     }
 }
 
@@ -290,7 +328,7 @@ k_upscale_blend(const float* __restrict__ comp /*[n][mh][mw][3] RGB*/, int mw, i
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_reduce_scatter(const float* __restrict__ part, int nsplit, int64_t splitStride, int M, int N,
-                 const int32_t* __restrict__ rowC, const int32_t* __restrict__ colC, float* __restrict__ out)
+                 const int32_t* __restrict__ rowC, const int32_t* __restrict__ colC, float* __restrict__ out, int outSplit)
 {
     const int N4 = N / 4;
     const int64_t total = (int64_t)M * N4;
@@ -304,8 +342,18 @@ k_reduce_scatter(const float* __restrict__ part, int nsplit, int64_t splitStride
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += v[j];
         }
-        *reinterpret_cast<f32x4*>(out + rowC[m] + colC[n >> 5] + (n & 31)) = acc;
+        store4_fmt(out, (int64_t)rowC[m] + colC[n >> 5] + (n & 31), acc, outSplit);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// fp32 -> split format copy (the packed weights, once)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_to_split(const float* __restrict__ src, float* __restrict__ dst, int64_t n4)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        store4_fmt(dst, 4 * i, *reinterpret_cast<const f32x4*>(src + 4 * i), 1);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -340,10 +388,15 @@ extern "C" int vsr_launch_resize_u8(const uint8_t* src, int64_t srcFrameStride, 
 extern "C" int vsr_launch_norm_im2col(const uint8_t* img, int ih, int iw, int nframes, float* out, int premask,
                                       const uint8_t* mask, void* stream)
 {
+    return vsr_launch_norm_im2col_fmt(img, ih, iw, nframes, out, premask, mask, 0, stream);
+}
+extern "C" int vsr_launch_norm_im2col_fmt(const uint8_t* img, int ih, int iw, int nframes, float* out, int premask,
+                                          const uint8_t* mask, int outSplit, void* stream)
+{
     const int64_t total = (int64_t)nframes * (ih / 2) * (iw / 2) * 8;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_norm_im2col_s2, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, ih, iw,
-                       nframes, out, premask, mask);
+                       nframes, out, premask, mask, outSplit);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
@@ -357,20 +410,30 @@ extern "C" int vsr_launch_softmax_dev(const SMProblem* d_probs, int nprobs, int 
 extern "C" int vsr_launch_reduce_scatter(const float* part, int nsplit, int64_t splitStride, int M, int N,
                                          const int32_t* rowC, const int32_t* colC, float* out, void* stream)
 {
+    return vsr_launch_reduce_scatter_fmt(part, nsplit, splitStride, M, N, rowC, colC, out, 0, stream);
+}
+extern "C" int vsr_launch_reduce_scatter_fmt(const float* part, int nsplit, int64_t splitStride, int M, int N,
+                                             const int32_t* rowC, const int32_t* colC, float* out, int outSplit, void* stream)
+{
     const int64_t total = (int64_t)M * (N / 4);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_reduce_scatter, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, part, nsplit,
-                       splitStride, M, N, rowC, colC, out);
+                       splitStride, M, N, rowC, colC, out, outSplit);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
 extern "C" int vsr_launch_upsample2x(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
                                      int nframes, void* stream)
 {
+    return vsr_launch_upsample2x_fmt(src, H, W, C, haloS, dst, haloD, nframes, 0, stream);
+}
+extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
+                                         int nframes, int split, void* stream)
+{
     const int64_t total = (int64_t)nframes * 4 * H * W * (C / 4);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_upsample2x_nhwc, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, C,
-                       haloS, dst, haloD, nframes);
+                       haloS, dst, haloD, nframes, split);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
@@ -396,5 +459,13 @@ extern "C" int vsr_launch_upscale_blend(const float* comp, int mw, int mh, const
     hipLaunchKernelGGL(k_upscale_blend, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, comp, mw, mh,
                        isFloat, frames, frameStride, rowStride, frameIdx, mask, maskRowStride, W, sh, nframes, xofs,
                        ialpha, falpha, yofs, ibeta, fbeta);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+extern "C" int vsr_launch_to_split(const float* src, float* dst, int64_t n, void* stream)
+{
+    if (n <= 0) return 0;
+    if (n % 32) return VSR_ERR_ARG;
+    hipLaunchKernelGGL(k_to_split, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }

@@ -294,6 +294,7 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #include "gather_gemm_v2.h"
 #include "gather_gemm_v3.h"
 #include "gather_gemm_v4.h"
+#include "gather_gemm_v5.h"
 
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
@@ -309,7 +310,12 @@ static int resident_blocks(K kernel)
 
 #define GG_LAUNCH(BM, BN, WM, WN, MODE)                                                                         \
     do {                                                                                                        \
-        if (queue && variant == 4) {                                                                            \
+        if (queue && variant == 5) {                                                                            \
+            static const int resident = resident_blocks(gather_gemm_f32_v5<BM, BN, WM, WN, MODE>);             \
+            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
+            hipLaunchKernelGGL((gather_gemm_f32_v5<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream,          \
+                               d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag);          \
+        } else if (queue && variant == 4) {                                                                     \
             static const int resident = resident_blocks(gather_gemm_f32_v4<BM, BN, WM, WN, MODE>);             \
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
             hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream,          \
@@ -332,11 +338,12 @@ static int resident_blocks(K kernel)
 
 // variant 1 (or queue == nullptr): one workgroup per tile.  variant 2 / 3 / 4: persistent kernels pulling tile
 // ids from queue[0..7] (must be 0): 2 = register-staged double buffer, 3 = LDS-DMA double buffer,
-// 4 = split-half operands on the f16 matrix cores.
+// 4 = split-half operands on the f16 matrix cores (fp32 tensors, split in the kernel), 5 = the same arithmetic
+// on SPLIT-FORMAT tensors (A, B, R and -- with VSR_ACT_OUT_SPLIT in act -- C; see gather_gemm_v5.h).
 // nQueues (v3): 8 = one tile range per XCD with stealing (few N tiles per A row block: neighbours share A
 // through one L2), 1 = a single global queue (many N tiles per row block: spreading them over the XCDs
 // avoids hammering one L2 with the same lines -- measured 101 vs 86 TF on the QKV GEMM).
-// rangeFlag (variant 4): device word that is OR-ed with 1 when an accumulator comes out non-finite.
+// rangeFlag (variants 4, 5): device word that is OR-ed with 1 when an accumulator comes out non-finite.
 extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
                                           int bmode, unsigned int* queue, int variant, int nQueues,
                                           unsigned int* rangeFlag, void* stream_)

@@ -59,6 +59,7 @@ struct OpDev {
     int64_t splitStride = 0;
     const int32_t* tRowC = nullptr;
     const int32_t* tColC = nullptr;
+    int split = 0;               // precision mode 2: this elementwise op reads / writes split-format tensors
     double flops = 0;
     std::string tag;
 };
@@ -106,7 +107,9 @@ struct vsr_sttn {
     int64_t compAreasCap = 0;
     int32_t* dSel = nullptr;
     int dSelCap = 0;
-    int precision = 0;                 // 0 = exact fp32 MFMA, 1 = split-half f16 MFMA with range guard + fp32 fallback
+    int precision = 0;                 // 0 = exact fp32 MFMA, 1 = split-half f16 MFMA with range guard + fp32 fallback,
+                                       // 2 = split-half on split-format tensors, 3 = fp16 operands on the same tensors
+    float* weightsSplit = nullptr;     // mode 2: the packed weights in split format (biases are read from BUF_WEIGHTS)
     unsigned int* dRangeFlag = nullptr;
     int64_t fallbacks = 0;             // chunks recomputed in fp32 because the range guard fired
     bool timing = false;
@@ -115,7 +118,7 @@ struct vsr_sttn {
     explicit vsr_sttn(int variant) : model(variant)
     {
         const char* e = getenv("VSR_PRECISION");
-        precision = (e && (e[0] == '1' || e[0] == 's')) ? 1 : 0;   // "1" / "split"
+        precision = !e ? 0 : (e[0] == '3' ? 3 : (e[0] == '2' ? 2 : ((e[0] == '1' || e[0] == 's') ? 1 : 0)));   // "1" / "split" / "2" / "3"
     }
 };
 
@@ -127,7 +130,17 @@ static int64_t bufBytes(int buf, int64_t elems) { return (buf == BUF_IN_U8 || bu
 
 static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 {
-    const int key = L * 2 + (precision ? 1 : 0);
+    const int key = L * 4 + precision;
+    const bool fmt = precision >= 2;       // split-format tensors: everything a GEMM reads (see gather_gemm_v5.h)
+    const int actMode = precision == 3 ? VSR_ACT_F16_OPERANDS : 0;
+    auto plainF32 = [](int buf) { return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
+    if (fmt && !h->weightsSplit) {
+        const int64_t n = (int64_t)h->model.packed.size();
+        HIPCHK(hipMalloc((void**)&h->weightsSplit, (size_t)n * sizeof(float)));
+        if (vsr_launch_to_split((const float*)h->bufs[BUF_WEIGHTS], h->weightsSplit, n, nullptr) != 0)
+            return fail(VSR_ERR_HIP, "weight split launch failed");
+        HIPCHK(hipDeviceSynchronize());
+    }
     auto it = h->plans.find(key);
     if (it != h->plans.end()) { *out = it->second.get(); return 0; }
     std::unique_ptr<PlanDev> pd(new PlanDev);
@@ -184,13 +197,15 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
                 const GemmItem& g = op.gemm[j];
                 GGProblem& q = hp[j];
                 q.A = F(g.bufA, g.offA); q.B = F(g.bufB, g.offB); q.C = F(g.bufC, g.offC);
+                if (fmt && g.bufB == BUF_WEIGHTS) q.B = h->weightsSplit + g.offB;
                 q.bias = g.offBias >= 0 ? F(BUF_WEIGHTS, g.offBias) : nullptr;
                 q.R = g.bufR >= 0 ? F(g.bufR, g.offR) : nullptr;
                 q.rowA = T(g.tRowA); q.colA = T(g.tColA); q.rowB = T(g.tRowB); q.colB = T(g.tColB);
                 q.rowC = T(g.tRowC); q.colC = T(g.tColC); q.rowR = T(g.tRowR);
                 q.M = g.M; q.N = g.N; q.K = g.K; q.tilesM = g.tilesM; q.tilesN = g.tilesN;
                 q.splitK = g.splitK; q.chunksPerSplit = g.chunksPerSplit; q.tileStart = tileStart;
-                q.act = g.act; q.alpha = g.alpha; q.splitStride = g.splitStride;
+                q.act = g.act | ((fmt && !plainF32(g.bufC)) ? VSR_ACT_OUT_SPLIT : 0) | actMode;
+                q.alpha = g.alpha; q.splitStride = g.splitStride;
                 tileStart += g.tilesM * g.tilesN * g.splitK;
             }
             od.dDesc = (char*)pd->dDescs + cursor;
@@ -208,7 +223,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
                 SMProblem& q = hp[j];
                 q.S = F(s.bufS, s.offS); q.P = F(s.bufP, s.offP);
                 q.M = s.M; q.N = s.N; q.ldS = s.ldS; q.ldP = s.ldP; q.nsplit = s.nsplit; q.rowStart = rowStart;
-                q.scale = s.scale; q.pad_ = 0; q.splitStride = s.splitStride;
+                q.scale = s.scale; q.flags = fmt ? 1 : 0; q.splitStride = s.splitStride;
                 rowStart += (s.M + 3) / 4 * 4;
             }
             od.dDesc = (char*)pd->dDescs + cursor;
@@ -220,7 +235,9 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
             od.dst = F(op.bufDst, op.offDst);
             od.M = op.M; od.N = op.N; od.nsplit = op.nsplit; od.splitStride = op.splitStride;
             od.tRowC = T(op.tRowC); od.tColC = T(op.tColC);
+            od.split = fmt ? 1 : 0;
         } else {
+            od.split = (fmt && op.kind != OP_DECODE_OUT) ? 1 : 0;
             od.src = op.bufSrc >= 0 ? h->bufs[op.bufSrc] : nullptr;
             od.dst = op.bufDst >= 0 ? h->bufs[op.bufDst] : nullptr;
             od.H = op.H; od.W = op.W; od.C = op.C; od.haloS = op.haloS; od.haloD = op.haloD; od.n = op.n;
@@ -248,6 +265,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 // problem (P.V, n-contiguous B) on v1.  VSR_GG_VARIANT / VSR_PV_VARIANT override for A/B runs.
 static int gg_variant(int bmode, int precision = 0)
 {
+    if (precision >= 2) return 5;   // split-format tensors: every GEMM must speak the format
     if (precision) {   // split-half mode; VSR_SPLIT_PV_VARIANT lets the P.V product stay on an fp32 kernel for A/B runs
         static const int pv = [] { const char* e = getenv("VSR_SPLIT_PV_VARIANT"); int x = e ? atoi(e) : 4; return (x < 1 || x > 4) ? 4 : x; }();
         return bmode == VSR_BMODE_KN ? pv : 4;
@@ -292,18 +310,18 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
             break;
         case OP_NORM_IM2COL:
-            rc = vsr_launch_norm_im2col((const uint8_t*)od.src, od.H, od.W, od.n, (float*)od.dst, od.premask, od.maskU8, stream);
+            rc = vsr_launch_norm_im2col_fmt((const uint8_t*)od.src, od.H, od.W, od.n, (float*)od.dst, od.premask, od.maskU8, od.split, stream);
             break;
         case OP_UPSAMPLE2X:
-            rc = vsr_launch_upsample2x((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, stream);
+            rc = vsr_launch_upsample2x_fmt((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, od.split, stream);
             break;
         case OP_DECODE_OUT:
             rc = vsr_launch_decode_out((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
                                        od.maskU8 ? od.inU8 : nullptr, od.maskU8, stream);
             break;
         case OP_REDUCE_SCATTER:
-            rc = vsr_launch_reduce_scatter((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,
-                                           (float*)od.dst, stream);
+            rc = vsr_launch_reduce_scatter_fmt((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,
+                                               (float*)od.dst, od.split, stream);
             break;
         default:
             return fail(VSR_ERR_STATE, "unknown op kind");
@@ -458,6 +476,7 @@ void vsr_sttn_destroy(vsr_sttn_t* h)
             if (kv.second.dev) (void)hipFree(kv.second.dev);
         if (h->compAreas) (void)hipFree(h->compAreas);
         if (h->dRangeFlag) (void)hipFree(h->dRangeFlag);
+        if (h->weightsSplit) (void)hipFree(h->weightsSplit);
         if (h->dSel) (void)hipFree(h->dSel);
     }
     delete h;
@@ -646,7 +665,8 @@ int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, 
 
 int vsr_sttn_set_precision(vsr_sttn_t* h, int mode)
 {
-    if (!h || (mode != 0 && mode != 1)) return fail(VSR_ERR_ARG, "precision mode must be 0 (f32) or 1 (split-half f16 MFMA)");
+    if (!h || mode < 0 || mode > 3)
+        return fail(VSR_ERR_ARG, "precision mode must be 0 (f32), 1 (split-half f16 MFMA), 2 (split-half on split-format tensors) or 3 (fp16 operands)");
     h->precision = mode;
     return 0;
 }
@@ -710,7 +730,7 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
 
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
 {
-    if (variant < 1 || variant > 4) return fail(VSR_ERR_ARG, "kernel variant must be 1..4");
+    if (variant < 1 || variant > 5) return fail(VSR_ERR_ARG, "kernel variant must be 1..5");
     return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, variant, stream_);
 }
 

@@ -677,7 +677,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
 }
 
 Plan::Plan(const Model& model, int L_, int precision_)
-    : L(L_), precision(precision_ ? 1 : 0), g(model.g), m_(model), tu_(Tuning::get(precision_))
+    : L(L_), precision(precision_), g(model.g), m_(model), tu_(Tuning::get(precision_))
 {
     if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
     if (L <= 0) throw std::runtime_error("empty frame list");

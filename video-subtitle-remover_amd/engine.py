@@ -22,6 +22,11 @@ def require_gpu():
         raise _lib.VsrError(_lib.VSR_ERR_NOGPU, "no HIP device visible: the MI355X path has no CPU fallback")
 
 
+# vsr_sttn_set_precision modes: exact fp32 MFMA | split-half f16 MFMA (guarded) | the same on split-format
+# tensors | fp16 operands + fp32 accumulation (BASELINE.json's "fp16 MFMA path")
+PRECISION_MODES = {"f32": 0, "split": 1, "split-format": 2, "f16": 3}
+
+
 class SttnEngine:
     """One STTN generator resident on one GPU (weights + workspace), bound to the caller's stream."""
 
@@ -40,7 +45,7 @@ class SttnEngine:
             self.device_index = -1 if device is None else int(device)
             check(lib.vsr_sttn_finalize(self._h, self.device_index))
             if precision is not None:       # "f32" (exact fp32 MFMA) | "split" (split-half f16 MFMA, guarded)
-                check(lib.vsr_sttn_set_precision(self._h, {"f32": 0, "split": 1}[precision]))
+                check(lib.vsr_sttn_set_precision(self._h, PRECISION_MODES[precision]))
             if neighbor_stride is not None or ref_length is not None:
                 mw, mh, ns, rl = self.geometry()
                 check(lib.vsr_sttn_set_window(self._h, neighbor_stride or ns, ref_length or rl))
@@ -66,7 +71,7 @@ class SttnEngine:
         return self._h
 
     def set_precision(self, precision):
-        check(lib.vsr_sttn_set_precision(self._h, {"f32": 0, "split": 1}[precision]))
+        check(lib.vsr_sttn_set_precision(self._h, PRECISION_MODES[precision]))
 
     def fallbacks(self):
         return int(lib.vsr_sttn_fallbacks(self._h))
