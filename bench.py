@@ -191,7 +191,7 @@ def main():
         for cfg, (bm, bn, wm, wn) in dims.items():
             for bmode in (0, 1):
                 for var, sym in ((1, "gather_gemm_f32"), (2, "gather_gemm_f32_v2"), (3, "gather_gemm_f32_v3"),
-                                 (4, "gather_gemm_f32_v4"), (5, "gather_gemm_f32_v5")):
+                                 (4, "gather_gemm_f32_v4"), (5, "gather_gemm_f32_v5"), (6, "gather_gemm_f32_v5")):
                     a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}:v{var}")
                     if b:
                         per_kernel[f"{sym}<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)

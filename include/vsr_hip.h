@@ -126,8 +126,7 @@ int vsr_sttn_timing_reset(vsr_sttn_t* h);
 #define VSR_GG_KC 32 /* K / N chunk granularity of the offset tables */
 enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
 enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1,
-       VSR_ACT_OUT_SPLIT = 0x100,   /* variant 5 only: OR-ed into act, C is written in split format */
-       VSR_ACT_F16_OPERANDS = 0x200 /* variant 5 only: operands are the fp16 hi halves alone (one MFMA per product) */ };
+       VSR_ACT_OUT_SPLIT = 0x100 /* variants 5, 6: OR-ed into act, C is written in split format */ };
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3 };
 
 /* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]
@@ -172,7 +171,8 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
 /* same with an explicit kernel variant: 1 one workgroup per tile, 2 persistent (register staged), 3 persistent
  * LDS-DMA (fp32 MFMA), 4 persistent split-half operands on the f16 matrix cores (see vsr_sttn_set_precision),
  * 5 the same on split-format tensors: A, B and R are read in split format; C is written in split format when
- * act carries VSR_ACT_OUT_SPLIT, as plain fp32 otherwise */
+ * act carries VSR_ACT_OUT_SPLIT, as plain fp32 otherwise; 6 = variant 5 with the fp16 hi halves alone as
+ * operands (fp16 x fp16 -> fp32 accumulate, one MFMA per product) */
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream);
 int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
 /* fp32 -> split format (variant 5 operands): dst[32c .. 32c+31] as bytes = fp16 hi[0..31] | fp16 lo[0..31] of

@@ -308,13 +308,52 @@ static int resident_blocks(K kernel)
     return cus * occ;
 }
 
+// operand buffers of the split-format kernel.  Measured on the bench workload (128x64 tiles): 2 buffers with 3
+// workgroups per CU beat 3 buffers with 2 workgroups and 4 buffers with 1 -- the operand stream is bound by the
+// L2 -> LDS path, which more resident workgroups keep busier than a deeper per-workgroup queue does.
+static constexpr int v5_stages(int bm, int bn, int bmode)
+{
+    return bmode == VSR_BMODE_KN ? 2 : ((bm == 128 && bn == 64) ? 2 : 3);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int ST>
+static void launch_v5_st(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, int nQueues,
+                         unsigned int* rangeFlag, bool hiOnly, hipStream_t stream)
+{
+    if (hiOnly) {
+        static const int resident = resident_blocks(gather_gemm_f32_v5<BM, BN, WM, WN, MODE, ST, true>);
+        const int g = totalBlocks < resident ? totalBlocks : resident;
+        hipLaunchKernelGGL((gather_gemm_f32_v5<BM, BN, WM, WN, MODE, ST, true>), dim3(g), dim3(256), 0, stream, d_probs,
+                           nprobs, totalBlocks, queue, nQueues, rangeFlag);
+    } else {
+        static const int resident = resident_blocks(gather_gemm_f32_v5<BM, BN, WM, WN, MODE, ST, false>);
+        const int g = totalBlocks < resident ? totalBlocks : resident;
+        hipLaunchKernelGGL((gather_gemm_f32_v5<BM, BN, WM, WN, MODE, ST, false>), dim3(g), dim3(256), 0, stream, d_probs,
+                           nprobs, totalBlocks, queue, nQueues, rangeFlag);
+    }
+}
+template <int BM, int BN, int WM, int WN, int MODE>
+static void launch_v5(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, int nQueues,
+                      unsigned int* rangeFlag, bool hiOnly, hipStream_t stream)
+{
+    // VSR_V5_STAGES = 2..4 overrides the buffer count of the 128-row NK tiles (A/B runs)
+    static const int over = [] { const char* e = getenv("VSR_V5_STAGES"); int x = e ? atoi(e) : 0; return (x < 2 || x > 4) ? 0 : x; }();
+    if constexpr (MODE == VSR_BMODE_NK && BM == 128) {
+        // fp16 operands (a third of the MFMA work per byte): the deeper queue pays, 376 vs 360 fps on the bench
+        const int st = over ? over : ((hiOnly && BN == 64) ? 3 : v5_stages(BM, BN, MODE));
+        if (st == 2) launch_v5_st<BM, BN, WM, WN, MODE, 2>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, hiOnly, stream);
+        else if (st == 3) launch_v5_st<BM, BN, WM, WN, MODE, 3>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, hiOnly, stream);
+        else launch_v5_st<BM, BN, WM, WN, MODE, 4>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, hiOnly, stream);
+    } else {
+        launch_v5_st<BM, BN, WM, WN, MODE, v5_stages(BM, BN, MODE)>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, hiOnly, stream);
+    }
+}
+
 #define GG_LAUNCH(BM, BN, WM, WN, MODE)                                                                         \
     do {                                                                                                        \
-        if (queue && variant == 5) {                                                                            \
-            static const int resident = resident_blocks(gather_gemm_f32_v5<BM, BN, WM, WN, MODE>);             \
-            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
-            hipLaunchKernelGGL((gather_gemm_f32_v5<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream,          \
-                               d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag);          \
+        if (queue && variant >= 5) {                                                                            \
+            launch_v5<BM, BN, WM, WN, MODE>(d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag,       \
+                                            variant == 6, stream);                                              \
         } else if (queue && variant == 4) {                                                                     \
             static const int resident = resident_blocks(gather_gemm_f32_v4<BM, BN, WM, WN, MODE>);             \
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
@@ -339,11 +378,12 @@ static int resident_blocks(K kernel)
 // variant 1 (or queue == nullptr): one workgroup per tile.  variant 2 / 3 / 4: persistent kernels pulling tile
 // ids from queue[0..7] (must be 0): 2 = register-staged double buffer, 3 = LDS-DMA double buffer,
 // 4 = split-half operands on the f16 matrix cores (fp32 tensors, split in the kernel), 5 = the same arithmetic
-// on SPLIT-FORMAT tensors (A, B, R and -- with VSR_ACT_OUT_SPLIT in act -- C; see gather_gemm_v5.h).
+// on SPLIT-FORMAT tensors (A, B, R and -- with VSR_ACT_OUT_SPLIT in act -- C; see gather_gemm_v5.h), 6 = variant 5
+// with the fp16 hi halves alone as operands (one MFMA per product).
 // nQueues (v3): 8 = one tile range per XCD with stealing (few N tiles per A row block: neighbours share A
 // through one L2), 1 = a single global queue (many N tiles per row block: spreading them over the XCDs
 // avoids hammering one L2 with the same lines -- measured 101 vs 86 TF on the QKV GEMM).
-// rangeFlag (variants 4, 5): device word that is OR-ed with 1 when an accumulator comes out non-finite.
+// rangeFlag (variants 4, 5, 6): device word that is OR-ed with 1 when an accumulator comes out non-finite.
 extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
                                           int bmode, unsigned int* queue, int variant, int nQueues,
                                           unsigned int* rangeFlag, void* stream_)

@@ -15,8 +15,9 @@
 #pragma once
 #include <type_traits>
 
-template <int BM, int BN, int WM, int WN, int BMODE GG_ABL_PARAM>
-__global__ void __launch_bounds__(256)
+template <int BM, int BN, int WM, int WN, int BMODE, int STAGES, bool HI_ONLY GG_ABL_PARAM>
+__global__ void __launch_bounds__(256, (STAGES == 2 && BM * BN <= 128 * 64) ? 3 : 1)   // 50 KB of LDS: 3 workgroups per CU,
+                                                                                        // so hold hipcc to 3 waves' worth of registers
 gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue, int nQueues,
                    unsigned int* __restrict__ rangeFlag)
 {
@@ -31,10 +32,13 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
     constexpr int BUF_FLOATS = AS_FLOATS + BS_FLOATS;
     static_assert(WM * WN == 4, "4 waves");
 
-    // [2 operand buffers][rowC | rowR offsets of the tile's BM rows][next tile id]
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS + 2 * BM + 4];
-    int* rowTab = reinterpret_cast<int*>(smem + 2 * BUF_FLOATS);
-    volatile int* nextTile = reinterpret_cast<volatile int*>(smem + 2 * BUF_FLOATS + 2 * BM);
+    // [STAGES operand buffers][rowC | rowR offsets of the tile's BM rows][next tile id] -- ONE __shared__ object:
+    // a second one makes hipcc drain the LDS-DMA queue (vmcnt(0)) in front of every fragment read
+    static_assert(STAGES >= 2 && STAGES <= 4, "2..4 operand buffers");
+    static_assert(BMODE == VSR_BMODE_NK || STAGES == 2, "the register-transposed KN operand is double-buffered");
+    __shared__ __attribute__((aligned(16))) float smem[STAGES * BUF_FLOATS + 2 * BM + 4];
+    int* rowTab = reinterpret_cast<int*>(smem + STAGES * BUF_FLOATS);
+    volatile int* nextTile = reinterpret_cast<volatile int*>(smem + STAGES * BUF_FLOATS + 2 * BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -145,8 +149,10 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             if constexpr (BMODE == VSR_BMODE_NK) vb = colB[idx]; else vb = 0;
         };
         int vcolA = 0, vcolB = 0, vcolAn = 0, vcolBn = 0;
-        fetchCols(colBase, vcolA, vcolB);
-        fetchCols(colBase + 64, vcolAn, vcolBn);
+        if constexpr (BMODE == VSR_BMODE_KN) {                 // NK fetches its tables per super-block (below)
+            fetchCols(colBase, vcolA, vcolB);
+            fetchCols(colBase + 64, vcolAn, vcolBn);
+        }
 
         f32x16 acc[MI][NI];
 #pragma unroll
@@ -160,15 +166,13 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const gcu16 B16 = (gcu16)P->B;
         unsigned short kh[KN_PAIRS][8], kl[KN_PAIRS][8];  // KN: halves of 8 k-values of this thread's column
         // LDS-DMA of chunk kc: A always, B when it is k-contiguous (NK)
-        auto dma_tile = [&](int kc, int buf) {
+        auto dma_tile = [&](int buf, int ca, int cb) {      // ca / cb: chunk offsets (wave-uniform) of A / B
             float* As = smem + buf * BUF_FLOATS;
             float* Bs = As + AS_FLOATS;
-            const int ca = __builtin_amdgcn_readlane(vcolA, kc - colBase);
 #pragma unroll
             for (int it = 0; it < A_IT; ++it)
                 glds16(A + (aoff[it] + ca), (lds_vptr)(As + (wave * 8 + 32 * it) * 32));
             if constexpr (BMODE == VSR_BMODE_NK) {
-                const int cb = __builtin_amdgcn_readlane(vcolB, kc - colBase);
 #pragma unroll
                 for (int it = 0; it < B_IT; ++it)
                     glds16(B + (boff[it] + cb), (lds_vptr)(Bs + (wave * 8 + 32 * it) * 32));
@@ -232,7 +236,7 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 }
         };
 
-        // fp16 mode (VSR_ACT_F16_OPERANDS): operands are the hi halves alone -- one MFMA per product instead of
+        // fp16 mode (HI_ONLY, kernel variant 6): operands are the hi halves alone -- one MFMA per product instead of
         // three, half the fragment reads; the tensors keep the split format (producers still write lo, the
         // residual add and the elementwise kernels still use it)
         auto compute_step_hi = [&](int buf, int st) {
@@ -251,41 +255,94 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
         };
-        const bool hiOnly = (P->act & VSR_ACT_F16_OPERANDS) != 0;
 
-        if (kcBeg < kcEnd) {
-            dma_tile(kcBeg, 0);
-            if constexpr (BMODE == VSR_BMODE_KN) {
-                load_B_KN(kcBeg);
-                store_B_KN(0);
+        auto compute_chunk = [&](int buf) {
+            if constexpr (HI_ONLY) {
+                compute_step_hi(buf, 0);
+                compute_step_hi(buf, 1);
+            } else {
+                compute_step(buf, 0);
+                compute_step(buf, 1);
             }
+        };
+        auto refreshCols = [&](int kc) {           // chunk kc is about to be fetched: lane (kc - colBase) must hold it
+            if (kc - colBase >= 64) {
+                colBase += 64;
+                vcolA = vcolAn; vcolB = vcolBn;
+                fetchCols(colBase + 64, vcolAn, vcolBn);
+            }
+        };
+
+        if constexpr (BMODE == VSR_BMODE_NK) {
+            // Operand pipeline, D = STAGES-1 chunks deep.  At 3 f16 MFMAs per product a chunk is ~400 MFMA cycles per
+            // wave, far less than an L2 round trip, so ONE chunk in flight per workgroup (the fp32 kernels' double
+            // buffer) leaves the matrix cores waiting on memory latency.  Each wave waits only for ITS pieces of
+            // chunk kc (counted vmcnt: the D-1 younger chunks stay in flight), the barrier then publishes the chunk
+            // and retires the buffer of chunk kc-1, which the DMA of chunk kc+D overwrites.  Raw s_barrier, not
+            // __syncthreads(): its fence would drain the DMA queue (vmcnt(0)).
+            // The loop body must not contain an ordinary (VGPR-destination) load: hipcc waits vmcnt(0) for those,
+            // which drains the pipeline every iteration.  The chunk-offset tables are therefore fetched per
+            // super-block of 128 chunks (2 VGPRs per table, lane i = chunk base+i / base+64+i); every conv / QKV /
+            // QK^T range of this network fits one super-block.
+            constexpr int D = STAGES - 1;
+            constexpr int PIECES = A_IT + B_IT;    // LDS-DMA instructions per wave and chunk
+            static_assert(PIECES * (D - 1) <= 63, "vmcnt is 6 bits");
+            for (int sb = kcBeg; sb < kcEnd; sb += 128) {
+                const int sbEnd = sb + 128 < kcEnd ? sb + 128 : kcEnd;
+                const int i0 = sb + lane < nchunksTotal ? sb + lane : nchunksTotal - 1;
+                const int i1 = sb + 64 + lane < nchunksTotal ? sb + 64 + lane : nchunksTotal - 1;
+                const int ca0 = colA[i0], ca1 = colA[i1], cb0 = colB[i0], cb1 = colB[i1];
+                // a use in front of the first DMA: the compiler's wait for these four loads lands here, not
+                // (as vmcnt(0)) behind the prologue's DMAs
+                asm volatile("" ::"v"(ca0), "v"(ca1), "v"(cb0), "v"(cb1));
+                auto issue = [&](int kc, int buf) {
+                    const int i = kc - sb;
+                    const int ca = i < 64 ? __builtin_amdgcn_readlane(ca0, i) : __builtin_amdgcn_readlane(ca1, i - 64);
+                    const int cb = i < 64 ? __builtin_amdgcn_readlane(cb0, i) : __builtin_amdgcn_readlane(cb1, i - 64);
+                    dma_tile(buf, ca, cb);
+                };
+                if (sb != kcBeg) {                 // buffers of the previous super-block are still being read
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (sb + d < sbEnd) issue(sb + d, d);
+                int cur = 0, nxt = D % STAGES;
+                for (int kc = sb; kc < sbEnd; ++kc) {
+                    const int ahead = sbEnd - 1 - kc;  // younger chunks already issued: min(ahead, D-1)
+                    if (D >= 3 && ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (D >= 3 ? 2 : 0)) : "memory");
+                    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (D >= 2 ? 1 : 0)) : "memory");
+                    else                           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads of chunk kc-1 have left the LDS
+                    __builtin_amdgcn_s_barrier();
+                    if (kc + D < sbEnd) issue(kc + D, nxt);
+                    compute_chunk(cur);
+                    cur = cur + 1 == STAGES ? 0 : cur + 1;
+                    nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+                }
+            }
+            // the tile-end barrier below keeps the next tile's DMA off the buffers still being read
+        } else if (kcBeg < kcEnd) {
+            dma_tile(0, __builtin_amdgcn_readlane(vcolA, kcBeg - colBase), 0);
+            load_B_KN(kcBeg);
+            store_B_KN(0);
             __syncthreads();                       // drains the DMA (vmcnt(0)) and publishes buffer 0
             int cur = 0;
             for (int kc = kcBeg; kc < kcEnd; ++kc) {
                 const bool more = kc + 1 < kcEnd;
                 if (more) {
-                    if (kc + 1 - colBase >= 64) {  // next 64 table entries become current
-                        colBase += 64;
-                        vcolA = vcolAn; vcolB = vcolBn;
-                        fetchCols(colBase + 64, vcolAn, vcolBn);
-                    }
-                    dma_tile(kc + 1, cur ^ 1);     // buffer last read in iteration kc-1, fenced by its barrier
-                    if constexpr (BMODE == VSR_BMODE_KN) load_B_KN(kc + 1);
+                    refreshCols(kc + 1);
+                    dma_tile(cur ^ 1, __builtin_amdgcn_readlane(vcolA, kc + 1 - colBase), 0);   // buffer last read in iteration kc-1
+                    load_B_KN(kc + 1);
                 }
-                if (hiOnly) {
-                    compute_step_hi(cur, 0);
-                    compute_step_hi(cur, 1);
-                } else {
-                    compute_step(cur, 0);
-                    compute_step(cur, 1);
-                }
-                if constexpr (BMODE == VSR_BMODE_KN) {
-                    if (more) store_B_KN(cur ^ 1);
-                }
+                compute_chunk(cur);
+                if (more) store_B_KN(cur ^ 1);
                 __syncthreads();                   // vmcnt(0) + barrier: chunk kc+1 landed, chunk kc retired
                 cur ^= 1;
             }
         }
+        __syncthreads();                           // rowTab visible even when the k range is empty; LDS-DMA queue empty
 
         // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
         // Row offsets come from LDS, the residual reads of 16 rows are issued back to back.

@@ -132,7 +132,6 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 {
     const int key = L * 4 + precision;
     const bool fmt = precision >= 2;       // split-format tensors: everything a GEMM reads (see gather_gemm_v5.h)
-    const int actMode = precision == 3 ? VSR_ACT_F16_OPERANDS : 0;
     auto plainF32 = [](int buf) { return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
     if (fmt && !h->weightsSplit) {
         const int64_t n = (int64_t)h->model.packed.size();
@@ -204,7 +203,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
                 q.rowC = T(g.tRowC); q.colC = T(g.tColC); q.rowR = T(g.tRowR);
                 q.M = g.M; q.N = g.N; q.K = g.K; q.tilesM = g.tilesM; q.tilesN = g.tilesN;
                 q.splitK = g.splitK; q.chunksPerSplit = g.chunksPerSplit; q.tileStart = tileStart;
-                q.act = g.act | ((fmt && !plainF32(g.bufC)) ? VSR_ACT_OUT_SPLIT : 0) | actMode;
+                q.act = g.act | ((fmt && !plainF32(g.bufC)) ? VSR_ACT_OUT_SPLIT : 0);
                 q.alpha = g.alpha; q.splitStride = g.splitStride;
                 tileStart += g.tilesM * g.tilesN * g.splitK;
             }
@@ -265,7 +264,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 // problem (P.V, n-contiguous B) on v1.  VSR_GG_VARIANT / VSR_PV_VARIANT override for A/B runs.
 static int gg_variant(int bmode, int precision = 0)
 {
-    if (precision >= 2) return 5;   // split-format tensors: every GEMM must speak the format
+    if (precision >= 2) return precision == 3 ? 6 : 5;   // split-format tensors: every GEMM must speak the format
     if (precision) {   // split-half mode; VSR_SPLIT_PV_VARIANT lets the P.V product stay on an fp32 kernel for A/B runs
         static const int pv = [] { const char* e = getenv("VSR_SPLIT_PV_VARIANT"); int x = e ? atoi(e) : 4; return (x < 1 || x > 4) ? 4 : x; }();
         return bmode == VSR_BMODE_KN ? pv : 4;
@@ -730,7 +729,7 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
 
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
 {
-    if (variant < 1 || variant > 5) return fail(VSR_ERR_ARG, "kernel variant must be 1..5");
+    if (variant < 1 || variant > 6) return fail(VSR_ERR_ARG, "kernel variant must be 1..6");
     return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, variant, stream_);
 }
 
