@@ -112,6 +112,36 @@ def _sample(t, n=4096, seed=123):
     return idx.astype(np.int64), flat[idx].astype(np.float32)
 
 
+def _raft_fixture():
+    """RAFT (raft/raft.py:87-146, the "things" configuration of flow_comp_raft.py:10-24) run from the reference on
+    three synthetic frames: consecutive pairs in both directions as RAFT_bi.forward does (:39-55), 20 iterations."""
+    import argparse
+
+    from vsr_amd.synth import make_flow_frames, make_raft_state_dict
+
+    for n in ("torchvision.ops", "torchvision.transforms"):
+        sys.modules.setdefault(n, _Permissive(n))
+    from backend.inpaint.video.raft.raft import RAFT
+
+    net = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)).eval()
+    sd = make_raft_state_dict(0)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    assert sum(p.numel() for p in net.parameters()) == 5257536          # SURVEY.md section 8(c)
+    frames = make_flow_frames(3, 128, 192, seed=1)
+    x = torch.from_numpy(frames).permute(0, 3, 1, 2).float().div(255) * 2 - 1   # to_tensors()(frames) * 2 - 1
+    res = {}
+    with torch.no_grad():
+        for iters in (1, 20):
+            lo_f, up_f = net(x[:-1], x[1:], iters=iters, test_mode=True)
+            lo_b, up_b = net(x[1:], x[:-1], iters=iters, test_mode=True)
+            res[f"low_f_{iters}"], res[f"up_f_{iters}"] = lo_f.numpy(), up_f[..., ::2, ::3].numpy()
+            res[f"low_b_{iters}"], res[f"up_b_{iters}"] = lo_b.numpy(), up_b[..., ::2, ::3].numpy()
+        fmap = net.fnet(x[:1])
+        cmap = net.cnet(x[:1])
+    np.savez_compressed(os.path.join(OUT, "raft.npz"), frames_seed=1, fmap_sub=fmap[:, ::8].numpy(), cmap_sub=cmap[:, ::8].numpy(),
+                        **res)
+
+
 def main():
     from vsr_amd.synth import make_state_dict
 
@@ -157,6 +187,8 @@ def main():
         pred_idx=pi, pred_val=pv, pred_sum=np.float64(pred.double().sum()), pred_sq=np.float64((pred.double() ** 2).sum()),
         out_sub=out[:, :, ::4, ::4].numpy().astype(np.float32),
         out_sum=np.float64(out.double().sum()), out_sq=np.float64((out.double() ** 2).sum()))
+
+    _raft_fixture()
 
     # ---- batch_generator (tools/inpaint_tools.py:7-29), executed from the reference ----
     cases = [(1200, 50), (300, 50), (600, 50), (1200, 70), (49, 50), (50, 50), (51, 50), (75, 50), (1, 50), (0, 50),

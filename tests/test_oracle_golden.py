@@ -77,3 +77,29 @@ def test_window_schedule_L50():
         visits[n] += 1
     assert list(np.nonzero(visits == 1)[0]) == [46, 47, 48, 49]
     assert list(np.nonzero(visits == 3)[0]) == list(range(5, 45, 5))
+
+
+def test_raft_matches_reference():
+    """oracle/raft.py against the reference RAFT module (fixture from oracle/make_golden.py): encoders, 1 and 20
+    update iterations, both directions, convex upsampling.  20 recurrent iterations amplify last-bit differences
+    between CPUs (measured: a 1e-6 input perturbation moves the flow by 8e-4 px), hence the absolute tolerance."""
+    from oracle.raft import RaftOracle
+    from vsr_amd.synth import make_flow_frames, make_raft_state_dict, raft_state_dict_spec
+
+    spec = raft_state_dict_spec()
+    assert sum(int(np.prod(s)) for k, s in spec if k.endswith(("weight", "bias")) and "norm3" not in k) == 5257536
+    g = np.load(os.path.join(GOLD, "raft.npz"))
+    o = RaftOracle(make_raft_state_dict(0))
+    frames = make_flow_frames(3, 128, 192, seed=int(g["frames_seed"]))
+    x = torch.from_numpy(frames).permute(0, 3, 1, 2).float().div(255) * 2 - 1
+    with torch.no_grad():
+        _close(o.encoder(x[:1], "fnet.", "instance")[:, ::8].numpy(), g["fmap_sub"], "fnet")
+        _close(o.encoder(x[:1], "cnet.", "batch")[:, ::8].numpy(), g["cmap_sub"], "cnet")
+    for iters, tol in ((1, 1e-4), (20, 2e-2)):
+        lo_f, up_f = o.forward(x[:-1], x[1:], iters)
+        lo_b, up_b = o.forward(x[1:], x[:-1], iters)
+        for name, t in (("low_f", lo_f), ("up_f", up_f), ("low_b", lo_b), ("up_b", up_b)):
+            ref = g[f"{name}_{iters}"]
+            t = t[..., ::2, ::3] if name.startswith("up") else t          # the fixture keeps every 2nd row / 3rd column
+            err = np.abs(t.numpy() - ref).max()
+            assert err <= tol, f"{name} after {iters} iterations: max abs err {err:.3e} px (flow range {np.abs(ref).max():.1f})"

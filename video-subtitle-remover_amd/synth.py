@@ -100,3 +100,118 @@ def make_clip(n, H, W, box, seed=0):
             x += wpx + max(gh_px // 4, 2)
         frames[i] = img
     return frames
+
+
+# ------------------------------------------------------------------------------------------------
+# RAFT (backend/inpaint/video/raft/raft.py:24-57, "things" checkpoint layout, args.small = False)
+# ------------------------------------------------------------------------------------------------
+def _raft_encoder_spec(prefix, out_dim, batch_norm):
+    """BasicEncoder (raft/extractor.py:118-160).  InstanceNorm2d has no parameters; BatchNorm2d has five entries,
+    and a stride-2 block's norm3 is ALSO registered as downsample.1 (extractor.py:46-47), so both keys exist."""
+    spec = []
+
+    def conv(name, co, ci, kh, kw):
+        spec.append((f"{prefix}{name}.weight", (co, ci, kh, kw)))
+        spec.append((f"{prefix}{name}.bias", (co,)))
+
+    def norm(name, c):
+        if batch_norm:
+            for leaf, shape in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)),
+                                ("num_batches_tracked", ())):
+                spec.append((f"{prefix}{name}.{leaf}", shape))
+
+    norm("norm1", 64)
+    conv("conv1", 64, 3, 7, 7)
+    cin = 64
+    for li, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), start=1):
+        for bi in range(2):
+            p = f"layer{li}.{bi}."
+            s = stride if bi == 0 else 1
+            conv(p + "conv1", dim, cin, 3, 3)
+            conv(p + "conv2", dim, dim, 3, 3)
+            norm(p + "norm1", dim)
+            norm(p + "norm2", dim)
+            if s != 1:
+                norm(p + "norm3", dim)
+                conv(p + "downsample.0", dim, cin, 1, 1)
+                norm(p + "downsample.1", dim)
+            cin = dim
+    conv("conv2", out_dim, 128, 1, 1)
+    return spec
+
+
+def raft_state_dict_spec():
+    spec = _raft_encoder_spec("fnet.", 256, False) + _raft_encoder_spec("cnet.", 256, True)
+    u = "update_block."
+    for name, co, ci, kh, kw in (("encoder.convc1", 256, 324, 1, 1), ("encoder.convc2", 192, 256, 3, 3),
+                                 ("encoder.convf1", 128, 2, 7, 7), ("encoder.convf2", 64, 128, 3, 3),
+                                 ("encoder.conv", 126, 256, 3, 3),
+                                 ("gru.convz1", 128, 384, 1, 5), ("gru.convr1", 128, 384, 1, 5), ("gru.convq1", 128, 384, 1, 5),
+                                 ("gru.convz2", 128, 384, 5, 1), ("gru.convr2", 128, 384, 5, 1), ("gru.convq2", 128, 384, 5, 1),
+                                 ("flow_head.conv1", 256, 128, 3, 3), ("flow_head.conv2", 2, 256, 3, 3),
+                                 ("mask.0", 256, 128, 3, 3), ("mask.2", 576, 256, 1, 1)):
+        spec.append((u + name + ".weight", (co, ci, kh, kw)))
+        spec.append((u + name + ".bias", (co,)))
+    return spec
+
+
+def make_raft_state_dict(seed=0):
+    """Stand-in for weights/raft-things.pth (missing blob): He-style conv weights, non-trivial BatchNorm statistics,
+    a damped flow head so that 20 GRU iterations stay in a few-pixel regime.  Keys as saved by the reference's
+    checkpoint minus DataParallel's "module." prefix (flow_comp_raft.py:17-19)."""
+    rng = np.random.default_rng(seed + 77)
+    sd = {}
+    for key, shape in raft_state_dict_spec():
+        leaf = key.rsplit(".", 1)[1]
+        is_norm = ".norm" in key or "downsample.1" in key
+        if key.endswith("norm3." + leaf):                 # alias of downsample.1: filled when that key comes
+            continue
+        if is_norm:
+            if leaf == "weight":
+                v = rng.uniform(0.6, 1.4, shape)
+            elif leaf == "bias":
+                v = rng.normal(0, 0.1, shape)
+            elif leaf == "running_mean":
+                v = rng.normal(0, 0.2, shape)
+            elif leaf == "running_var":
+                v = rng.uniform(0.5, 1.5, shape)
+            else:
+                v = np.zeros(shape)
+            sd[key] = np.asarray(v, dtype=np.int64 if leaf == "num_batches_tracked" else np.float32)
+            if "downsample.1" in key:
+                sd[key.replace("downsample.1", "norm3")] = sd[key]
+        elif leaf == "weight":
+            fan_in = int(np.prod(shape[1:]))
+            gain = 1.3
+            if "flow_head.conv2" in key:
+                gain = 0.25
+            elif "gru.conv" in key or "mask.2" in key:
+                gain = 0.9
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
+        else:
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
+    # the reference's state_dict order lists norm3 before downsample.*; order does not matter for loading
+    return sd
+
+
+def make_flow_frames(t, H, W, seed=0):
+    """t RGB uint8 frames [t,H,W,3] of a smooth texture translating by a few pixels per frame plus an
+    independently moving bright block -- something an optical-flow network can lock onto."""
+    rng = np.random.default_rng(seed + 4242)
+    gh, gw = H // 12 + 6, W // 12 + 6
+    base = rng.random((gh, gw, 3)).astype(np.float32)
+    pad = 48
+    ys = np.linspace(0, gh - 2, H + pad).astype(np.float32)
+    xs = np.linspace(0, gw - 2, W + pad).astype(np.float32)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    big = ((1 - fy) * (1 - fx) * base[y0][:, x0] + (1 - fy) * fx * base[y0][:, x0 + 1]
+           + fy * (1 - fx) * base[y0 + 1][:, x0] + fy * fx * base[y0 + 1][:, x0 + 1]) * 220 + 20
+    out = np.empty((t, H, W, 3), dtype=np.uint8)
+    for i in range(t):
+        dy, dx = (2 * i) % pad, (3 * i) % pad
+        img = big[dy:dy + H, dx:dx + W].copy()
+        by, bx = H // 3 + 2 * i, W // 4 + 5 * i
+        img[by:by + H // 6, bx:bx + W // 8] = 240
+        out[i] = np.clip(img, 0, 255).astype(np.uint8)
+    return out
