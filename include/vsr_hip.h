@@ -125,8 +125,9 @@ int vsr_sttn_timing_reset(vsr_sttn_t* h);
  * ------------------------------------------------------------------------------------- */
 #define VSR_GG_KC 32 /* K / N chunk granularity of the offset tables */
 enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
-enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1,
-       VSR_ACT_OUT_SPLIT = 0x100 /* variants 5, 6: OR-ed into act, C is written in split format */ };
+enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2,
+       VSR_ACT_OUT_SPLIT = 0x100, /* variants 5, 6: OR-ed into act, C is written in split format */
+       VSR_ACT_POST_RELU = 0x200  /* OR-ed into act: C = relu(act(..) + R)  (residual blocks, raft/extractor.py:48-58) */ };
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3 };
 
 /* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]
@@ -220,7 +221,7 @@ int vsr_cv2_linear_tables(int ssize, int dsize, int clamp_x, int32_t* ofs, int16
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
 typedef struct VsrOpInfo {
-    int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter */
+    int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter, 6 RAFT elementwise */
     int32_t nitems, tile_cfg, bmode;
     int32_t buf_src, buf_dst, H, W, C, halo_src, halo_dst, n, ldy, pix, t_frame_idx, t_first, premask;
     /* reduce_scatter: part = buf_src + off_src, out = buf_dst + off_dst, M, N, nsplit, tables */
@@ -229,6 +230,12 @@ typedef struct VsrOpInfo {
     int64_t off_src, off_dst, split_stride;
     double flops;
     char tag[32];
+    /* kind 6: sub-kind (VSR_EW_*) and its generic operands: buffers, element offsets, int / float parameters */
+    int32_t ew;
+    int32_t ibuf[4];
+    int64_t ioff[4];
+    int32_t ipar[16];
+    float fpar[4];
 } VsrOpInfo;
 typedef struct VsrGemmInfo {
     int32_t bufA, bufB, bufC, bufR;

@@ -46,7 +46,9 @@ class VsrOpInfo(C.Structure):
                 ("pix", C.c_int32), ("t_frame_idx", C.c_int32), ("t_first", C.c_int32), ("premask", C.c_int32),
                 ("M", C.c_int32), ("N", C.c_int32), ("nsplit", C.c_int32), ("t_rowC", C.c_int32), ("t_colC", C.c_int32),
                 ("buf_mask", C.c_int32), ("off_src", C.c_int64), ("off_dst", C.c_int64), ("split_stride", C.c_int64),
-                ("flops", C.c_double), ("tag", C.c_char * 32)]
+                ("flops", C.c_double), ("tag", C.c_char * 32),
+                ("ew", C.c_int32), ("ibuf", C.c_int32 * 4), ("ioff", C.c_int64 * 4), ("ipar", C.c_int32 * 16),
+                ("fpar", C.c_float * 4)]
 
 
 class VsrGemmInfo(C.Structure):

@@ -208,7 +208,8 @@ gather_gemm_f32_v2(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 
         // ---- epilogue (identical to v1) ----
         const float alpha = P->alpha;
-        const int act = P->act;
+        const int act = P->act & 0xff;
+        const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;   // relu(act(..) + R): residual blocks of RAFT
         const bool partial = (splitK > 1);
         const gcf32 bias = partial ? (gcf32) nullptr : (gcf32)P->bias;
         const gcf32 R = partial ? (gcf32) nullptr : (gcf32)P->R;
@@ -238,8 +239,9 @@ gather_gemm_f32_v2(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 for (int ni = 0; ni < NI; ++ni) {
                     float v = acc[mi][ni][r] * alpha + bv[ni];
                     if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+                        else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
                     if (m < M && nok[ni]) {
-                        if (R != nullptr) v += R[rr + ccol[ni]];
+                        if (R != nullptr) { v += R[rr + ccol[ni]]; if (postRelu) v = fmaxf(v, 0.f); }
                         C[rc + ccol[ni]] = v;
                     }
                 }

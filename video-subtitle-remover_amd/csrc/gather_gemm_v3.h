@@ -263,7 +263,8 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
         // Row offsets come from LDS, the residual reads of 16 rows are issued back to back.
         const float alpha = P->alpha;
-        const int act = P->act;
+        const int act = P->act & 0xff;
+        const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;   // relu(act(..) + R): residual blocks of RAFT
         const bool partial = (splitK > 1);
         const gcf32 bias = partial ? (gcf32) nullptr : (gcf32)P->bias;
         const gcf32 R = partial ? (gcf32) nullptr : (gcf32)P->R;
@@ -313,7 +314,8 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     for (int ni = 0; ni < NI; ++ni) {
                         float v = acc[mi][ni][r] * alpha + bv[ni];
                         if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-                        if constexpr (HASR) v += rv[r][ni];
+                        else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+                        if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
                         if (mok && (FULL || nok[ni])) C[rc[r] + ccol[ni]] = v;
                     }
                 }

@@ -348,6 +348,7 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         // Row offsets come from LDS, the residual reads of 16 rows are issued back to back.
         const float alpha = P->alpha;
         const int act = P->act & 0xff;
+        const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;   // relu(act(..) + R): residual blocks of RAFT
         const bool cSplit = (P->act & VSR_ACT_OUT_SPLIT) != 0;   // output in split format (a later GEMM operand)
         const float vmax = cSplit ? 65504.f : 3.0e38f;           // a split-format value must fit its fp16 hi half
         bool nonFinite = false;
@@ -408,7 +409,8 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     for (int ni = 0; ni < NI; ++ni) {
                         float v = acc[mi][ni][r] * alpha + bv[ni];
                         if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-                        if constexpr (HASR) v += rv[r][ni];
+                        else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+                        if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
                         nonFinite |= !(__builtin_fabsf(v) <= vmax);      // also catches NaN
                         if (mok && (FULL || nok[ni])) {
                             if (cSplit) {

@@ -1,0 +1,8 @@
+// The C handle behind vsr_plan_t: shared by the STTN engine (sttn_engine.hip) and the RAFT engine (raft_engine.hip).
+#pragma once
+#include <memory>
+#include "sttn_plan.h"
+
+struct vsr_plan {
+    std::unique_ptr<vsr::PlanIR> plan;
+};

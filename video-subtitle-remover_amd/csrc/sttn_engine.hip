@@ -122,9 +122,7 @@ struct vsr_sttn {
     }
 };
 
-struct vsr_plan {
-    std::unique_ptr<Plan> plan;
-};
+#include "plan_c.h"
 
 static int64_t bufBytes(int buf, int64_t elems) { return (buf == BUF_IN_U8 || buf == BUF_MASK_U8) ? elems : elems * 4; }
 
@@ -815,8 +813,8 @@ int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out)
     return 0;
 }
 void vsr_plan_destroy(vsr_plan_t* p) { delete p; }
-int vsr_plan_num_buffers(const vsr_plan_t* p) { return p ? BUF_COUNT : 0; }
-int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf) { return (p && buf >= 0 && buf < BUF_COUNT) ? p->plan->bufElems[buf] : -1; }
+int vsr_plan_num_buffers(const vsr_plan_t* p) { return p ? (int)p->plan->bufElems.size() : 0; }
+int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf) { return (p && buf >= 0 && buf < (int)p->plan->bufElems.size()) ? p->plan->bufElems[buf] : -1; }
 int vsr_plan_num_tables(const vsr_plan_t* p) { return p ? (int)p->plan->tables.size() : 0; }
 int64_t vsr_plan_table_len(const vsr_plan_t* p, int t) { return (p && t >= 0 && t < (int)p->plan->tables.size()) ? (int64_t)p->plan->tables[t].size() : -1; }
 int vsr_plan_table_copy(const vsr_plan_t* p, int t, int32_t* out)
@@ -841,6 +839,9 @@ int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* o)
     o->buf_mask = op.bufMask;
     o->off_src = op.offSrc; o->off_dst = op.offDst; o->split_stride = op.splitStride;
     o->flops = op.flops;
+    o->ew = op.ew;
+    for (int k = 0; k < 4; ++k) { o->ibuf[k] = op.ibuf[k]; o->ioff[k] = op.ioff[k]; o->fpar[k] = op.fpar[k]; }
+    for (int k = 0; k < 16; ++k) o->ipar[k] = op.ipar[k];
     strncpy(o->tag, op.tag.c_str(), sizeof(o->tag) - 1);
     return 0;
 }

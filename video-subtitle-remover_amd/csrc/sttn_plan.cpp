@@ -218,7 +218,7 @@ static void checkFits(int64_t v)
     if (v > 2147483647LL || v < -2147483648LL) throw std::runtime_error("offset table entry exceeds int32");
 }
 
-int Plan::table(const std::string& key, std::vector<int32_t>&& v)
+int PlanBuilder::table(const std::string& key, std::vector<int32_t>&& v)
 {
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
@@ -228,8 +228,9 @@ int Plan::table(const std::string& key, std::vector<int32_t>&& v)
     return id;
 }
 
-void Plan::need(int buf, int64_t elems)
+void PlanBuilder::need(int buf, int64_t elems)
 {
+    if ((int)bufElems.size() <= buf) bufElems.resize(buf + 1, 0);
     if (bufElems[buf] < elems) bufElems[buf] = elems;
 }
 
@@ -240,7 +241,7 @@ static std::string idsKey(const std::vector<int>& ids)
     return s;
 }
 
-int Plan::tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add)
+int PlanBuilder::tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add)
 {
     const std::string key = "RA:" + std::to_string(a.buf) + ":" + std::to_string(a.halo) + ":" + std::to_string(a.H) +
                             ":" + std::to_string(a.W) + ":" + std::to_string(a.C) + ":" + std::to_string(oh) + ":" +
@@ -263,31 +264,33 @@ int Plan::tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, in
     return table(key, std::move(v));
 }
 
-int Plan::tColsConv(const Act& a, int ksz, int dil)
+int PlanBuilder::tColsConvHW(const Act& a, int kh, int kw, int dil, int c0, int cin)
 {
+    if (cin < 0) cin = a.C - c0;
     const std::string key = "CC:" + std::to_string(a.halo) + ":" + std::to_string(a.W) + ":" + std::to_string(a.C) +
-                            ":" + std::to_string(ksz) + ":" + std::to_string(dil);
+                            ":" + std::to_string(kh) + "x" + std::to_string(kw) + ":" + std::to_string(dil) + ":" +
+                            std::to_string(c0) + ":" + std::to_string(cin);
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
-    if (a.halo < dil * (ksz / 2)) throw std::runtime_error("activation halo too small for conv");
-    if (a.C % VSR_GG_KC) throw std::runtime_error("conv input channels must be a multiple of 32");
+    if (a.halo < dil * (kh / 2) || a.halo < dil * (kw / 2)) throw std::runtime_error("activation halo too small for conv");
+    if (cin % VSR_GG_KC || c0 % VSR_GG_KC) throw std::runtime_error("conv input channels must be a multiple of 32");
     std::vector<int32_t> v;
-    auto off = [&](int ky, int kx, int c0) {
-        return (int32_t)(((int64_t)(ky - ksz / 2) * dil * a.Wp() + (kx - ksz / 2) * dil) * a.C + c0);
+    auto off = [&](int ky, int kx, int c) {
+        return (int32_t)(((int64_t)(ky - kh / 2) * dil * a.Wp() + (kx - kw / 2) * dil) * a.C + c0 + c);
     };
     if (Tuning::get().convChannelMajor) { // mirrors Model::pack_conv
-        for (int c0 = 0; c0 < a.C; c0 += VSR_GG_KC)
-            for (int ky = 0; ky < ksz; ++ky)
-                for (int kx = 0; kx < ksz; ++kx) v.push_back(off(ky, kx, c0));
+        for (int c = 0; c < cin; c += VSR_GG_KC)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx) v.push_back(off(ky, kx, c));
     } else {
-        for (int ky = 0; ky < ksz; ++ky)
-            for (int kx = 0; kx < ksz; ++kx)
-                for (int c0 = 0; c0 < a.C; c0 += VSR_GG_KC) v.push_back(off(ky, kx, c0));
+        for (int ky = 0; ky < kh; ++ky)
+            for (int kx = 0; kx < kw; ++kx)
+                for (int c = 0; c < cin; c += VSR_GG_KC) v.push_back(off(ky, kx, c));
     }
     return table(key, std::move(v));
 }
 
-int Plan::tRowsLinear(int count, int ld, int padTo)
+int PlanBuilder::tRowsLinear(int count, int ld, int padTo)
 {
     const std::string key = "RL:" + std::to_string(count) + ":" + std::to_string(ld) + ":" + std::to_string(padTo);
     auto it = tableKey_.find(key);
@@ -298,7 +301,7 @@ int Plan::tRowsLinear(int count, int ld, int padTo)
     return table(key, std::move(v));
 }
 
-int Plan::tColsLinear(int nchunks, int padTo)
+int PlanBuilder::tColsLinear(int nchunks, int padTo)
 {
     const std::string key = "CL:" + std::to_string(nchunks) + ":" + std::to_string(padTo);
     auto it = tableKey_.find(key);

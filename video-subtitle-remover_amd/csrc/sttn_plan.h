@@ -70,7 +70,8 @@ enum BufId {
     BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_MASK_U8, BUF_COUNT
 };
 
-enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5 };
+enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5,
+              OP_EW = 6 /* RAFT's elementwise / gather kernels, sub-kind in Op::ew (raft_plan.h) */ };
 
 struct GemmItem {
     int bufA, bufB, bufC, bufR;          // bufR = -1: no residual
@@ -103,6 +104,12 @@ struct Op {
     int64_t offSrc = 0, offDst = 0, splitStride = 0;
     double flops = 0;                    // algorithmic flops of this op (2*M*N*K, unpadded)
     std::string tag;
+    // OP_EW: sub-kind + generic operands (buffers, element offsets, integer / float parameters; meaning per sub-kind)
+    int ew = 0;
+    int ibuf[4] = {-1, -1, -1, -1};
+    int64_t ioff[4] = {0, 0, 0, 0};
+    int ipar[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float fpar[4] = {0.f, 0.f, 0.f, 0.f};
 };
 
 struct Act {                              // NHWC activation with a physical zero halo
@@ -114,33 +121,46 @@ struct Act {                              // NHWC activation with a physical zer
     int64_t elems() const { return (int64_t)n * frameElems(); }
 };
 
-class Plan {
+// What the engines materialise and what tests replay: symbolic buffers, offset tables, op list.
+struct PlanIR {
+    std::vector<int64_t> bufElems;        // one entry per buffer id (u8 buffers in bytes, others floats)
+    std::vector<std::vector<int32_t>> tables;
+    std::vector<Op> ops;
+    std::vector<int32_t> compCount;       // STTN: decodes per frame (1 => comp stays u8)
+    double flops = 0;                     // algorithmic model flops of the whole call
+    virtual ~PlanIR() {}
+};
+
+// Table / conv primitives shared by the STTN and RAFT plan builders.
+class PlanBuilder : public PlanIR {
+protected:
+    std::map<std::string, int> tableKey_;
+    int table(const std::string& key, std::vector<int32_t>&& v);
+    // element offset of pixel (ids[i], y*stride, x*stride) of `a` (+ add) for every output pixel, padded to padTo rows
+    int tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add);
+    // 32-channel chunk offsets of a kh x kw window (dilation dil) over channels [c0, c0+cin) of `a`; K order mirrors pack
+    int tColsConvHW(const Act& a, int kh, int kw, int dil, int c0 = 0, int cin = -1);
+    int tColsConv(const Act& a, int ksz, int dil) { return tColsConvHW(a, ksz, ksz, dil); }
+    int tRowsLinear(int count, int ld, int padTo);
+    int tColsLinear(int nchunks, int padTo);
+    void need(int buf, int64_t elems);
+};
+
+class Plan : public PlanBuilder {
 public:
     Plan(const Model& model, int L, int precision = 0);
     int L;
     int precision;
     Geometry g;
-    std::vector<int64_t> bufElems;        // BUF_COUNT entries (BUF_IN_U8 / BUF_MASK_U8 in bytes, others floats)
-    std::vector<std::vector<int32_t>> tables;
-    std::vector<Op> ops;
-    std::vector<int32_t> compCount;       // decodes per frame (1 => comp stays u8)
-    double flops = 0;                     // algorithmic model flops of the whole call
     int nwindows = 0;
 private:
     const Model& m_;
     const Tuning& tu_;
-    std::map<std::string, int> tableKey_;
     int pickTile(int N) const;
-    int table(const std::string& key, std::vector<int32_t>&& v);
-    int tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add);
-    int tColsConv(const Act& a, int ksz, int dil);
-    int tRowsLinear(int count, int ld, int padTo);
-    int tColsLinear(int nchunks, int padTo);
     int tRowsTokens(int T, int s, int choff, int count, int padTo);
     int tColsPatch(int s, int padTo);
     int tRowsTokensAct(const Act& a, int T, int s, int padTo);
     int tColsPatchAct(const Act& a, int s, int padTo);
-    void need(int buf, int64_t elems);
     void addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut,
                  int ksz, int stride, int dil, const ConvW& w, int act, const Act* res,
                  const std::vector<int>* resIds);
