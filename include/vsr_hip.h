@@ -217,9 +217,36 @@ int vsr_launch_reduce_scatter(const float* part_dev, int nsplit, int64_t split_s
 int vsr_cv2_linear_tables(int ssize, int dsize, int clamp_x, int32_t* ofs, int16_t* icoef, float* fcoef);
 
 /* ---------------------------------------------------------------------------------------
+ * RAFT optical flow -- the first stage of --inpaint-mode propainter.
+ * Replaces RAFT_bi (backend/inpaint/video/model/modules/flow_comp_raft.py:27-55) and the network behind it
+ * (backend/inpaint/video/raft/raft.py:24-146, extractor.py, corr.py, update.py), "things" configuration
+ * (small = False, corr_levels 4, corr_radius 4), exact fp32 (propainter_inpaint.py:230 keeps RAFT in fp32).
+ * ------------------------------------------------------------------------------------- */
+typedef struct vsr_raft vsr_raft_t;
+int vsr_raft_create(vsr_raft_t** out);
+/* one entry of torch.load('raft-things.pth') with DataParallel's "module." prefix removed (flow_comp_raft.py:17-19);
+ * fp32 contiguous (num_batches_tracked as a 0-d value); unknown keys and wrong shapes are errors */
+int vsr_raft_set_param(vsr_raft_t* h, const char* key, const float* data, const int64_t* shape, int ndim);
+/* all keys present -> BatchNorm folded, weights packed and uploaded; device < 0: host only (plan introspection) */
+int vsr_raft_finalize(vsr_raft_t* h, int device);
+void vsr_raft_destroy(vsr_raft_t* h);
+int64_t vsr_raft_packed_weights(const vsr_raft_t* h, float* out, int64_t capacity);
+/* RAFT_bi.forward(frames, iters): frames_dev uint8 [t][H][W][3] on the device (RGB, or BGR with bgr = 1), normalised
+ * as to_tensors()(frames) * 2 - 1 (propainter_inpaint.py:214); H, W multiples of 8 and >= 128.  Outputs fp32 on the
+ * device, both [t-1][2][H][W] (x then y displacement): fwd[i] = flow frame i -> i+1, bwd[i] = flow frame i+1 -> i. */
+int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W, int iters, int bgr, float* fwd_dev,
+                   float* bwd_dev, void* stream);
+/* algorithmic FLOPs of one vsr_raft_flows call (2*M*N*K over every conv and the all-pairs correlation) */
+double vsr_raft_flops(vsr_raft_t* h, int t, int H, int W, int iters);
+
+/* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
+/* sub-kinds of op kind 6 (RAFT, csrc/raft_kernels.hip) */
+enum { VSR_EW_IM2COL7_U8 = 1, VSR_EW_INORM_STATS = 2, VSR_EW_INORM_APPLY = 3, VSR_EW_CTX_SPLIT = 4, VSR_EW_FLOW_UPDATE = 5,
+       VSR_EW_IM2COL7_FLOW = 6, VSR_EW_AVGPOOL2 = 7, VSR_EW_CORR_LOOKUP = 8, VSR_EW_GRU_RH = 9, VSR_EW_GRU_UPDATE = 10,
+       VSR_EW_CONVEX_UP = 11 };
 typedef struct VsrOpInfo {
     int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter, 6 RAFT elementwise */
     int32_t nitems, tile_cfg, bmode;
@@ -254,6 +281,7 @@ typedef struct VsrSoftmaxInfo {
 } VsrSoftmaxInfo;
 
 int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
+int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out);
 void vsr_plan_destroy(vsr_plan_t* p);
 int vsr_plan_num_buffers(const vsr_plan_t* p);
 int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf);

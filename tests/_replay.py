@@ -16,11 +16,13 @@ BUF_WEIGHTS, BUF_IN_U8 = 0, 1
 
 
 class PlanView:
-    def __init__(self, _lib, engine, L):
+    def __init__(self, _lib, engine, L, plan_ptr=None):
+        """STTN: PlanView(_lib, engine, L).  Any other plan: pass the vsr_plan_t pointer (L = length of the counts array, 0 = none)."""
         self._lib = _lib
         lib = _lib.lib
-        self.p = C.c_void_p()
-        _lib.check(lib.vsr_plan_create(engine.handle, L, C.byref(self.p)))
+        self.p = plan_ptr if plan_ptr is not None else C.c_void_p()
+        if plan_ptr is None:
+            _lib.check(lib.vsr_plan_create(engine.handle, L, C.byref(self.p)))
         self.L = L
         self.buf_elems = [lib.vsr_plan_buffer_elems(self.p, b) for b in range(lib.vsr_plan_num_buffers(self.p))]
         self.tables = []
@@ -44,7 +46,8 @@ class PlanView:
                 items.append(it)
             self.ops.append((info, items))
         counts = np.zeros(L, dtype=np.int32)
-        _lib.check(lib.vsr_plan_counts(self.p, counts.ctypes.data_as(C.c_void_p)))
+        if L:
+            _lib.check(lib.vsr_plan_counts(self.p, counts.ctypes.data_as(C.c_void_p)))
         self.counts = counts
         self.flops = lib.vsr_plan_flops(self.p)
 
@@ -89,11 +92,15 @@ def gemm_reference(it, bmode, bufs, tables):
     acc = (Am @ Bm) * it.alpha
     if it.offBias >= 0:
         acc = acc + torch.from_numpy(bufs[BUF_WEIGHTS][it.offBias:it.offBias + N])[None, :]
-    if it.act == 1:
+    if it.act & 0xff == 1:
         acc = torch.nn.functional.leaky_relu(acc, 0.2)
+    elif it.act & 0xff == 2:
+        acc = torch.relu(acc)
     if it.bufR >= 0:
         rowR = tables[it.tRowR][:M]
         acc = acc + torch.from_numpy(bufs[it.bufR][it.offR + rowR[:, None] + colC[None, :]])
+        if it.act & 0x200:                 # VSR_ACT_POST_RELU
+            acc = torch.relu(acc)
     Cbuf[it.offC + rowC[:, None] + colC[None, :]] = acc.numpy()
 
 

@@ -103,6 +103,14 @@ SIGNATURES = {
     "vsr_launch_upscale_blend": (_I, [_P, _I, _I, _P, _P, _L, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsr_cv2_linear_tables": (_I, [_I, _I, _I, _P, _P, _P]),
     "vsr_plan_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "vsr_raft_plan_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
+    "vsr_raft_create": (_I, [C.POINTER(_P)]),
+    "vsr_raft_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "vsr_raft_finalize": (_I, [_P, _I]),
+    "vsr_raft_destroy": (None, [_P]),
+    "vsr_raft_packed_weights": (_L, [_P, _P, _L]),
+    "vsr_raft_flows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "vsr_raft_flops": (_D, [_P, _I, _I, _I, _I]),
     "vsr_plan_destroy": (None, [_P]),
     "vsr_plan_num_buffers": (_I, [_P]),
     "vsr_plan_buffer_elems": (_L, [_P, _I]),

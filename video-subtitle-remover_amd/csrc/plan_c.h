@@ -6,3 +6,6 @@
 struct vsr_plan {
     std::unique_ptr<vsr::PlanIR> plan;
 };
+
+// records the message returned by vsr_last_error() and returns `code`
+int vsr_internal_fail(int code, const char* msg);

@@ -27,6 +27,9 @@ static int fail(int code, const std::string& msg)
     g_err = msg;
     return code;
 }
+// error sink shared with raft_engine.hip (plan_c.h)
+int vsr_internal_fail(int code, const char* msg) { return fail(code, msg); }
+
 #define HIPCHK(expr)                                                                                       \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \

@@ -155,3 +155,63 @@ class SttnEngine:
         ms, n, fl = C.c_double(), C.c_int32(), C.c_double()
         check(lib.vsr_sttn_timing_get(self._h, prefix.encode(), C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
+
+
+class RaftEngine:
+    """RAFT ("things" configuration) resident on one GPU: the optical-flow stage of --inpaint-mode propainter
+    (reference RAFT_bi, backend/inpaint/video/model/modules/flow_comp_raft.py:27-55)."""
+
+    def __init__(self, state_dict, device=0):
+        self._h = C.c_void_p()
+        check(lib.vsr_raft_create(C.byref(self._h)))
+        try:
+            for key, val in state_dict.items():
+                key = key[7:] if key.startswith("module.") else key      # DataParallel checkpoint (flow_comp_raft.py:17-19)
+                arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                shape = (C.c_int64 * arr.ndim)(*arr.shape)
+                check(lib.vsr_raft_set_param(self._h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+            if device is not None and device >= 0:
+                require_gpu()
+            self.device_index = -1 if device is None else int(device)
+            check(lib.vsr_raft_finalize(self._h, self.device_index))
+        except Exception:
+            lib.vsr_raft_destroy(self._h)
+            self._h = None
+            raise
+        self.device = torch.device("cuda", self.device_index) if self.device_index >= 0 else torch.device("cpu")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vsr_raft_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def packed_weights(self):
+        n = lib.vsr_raft_packed_weights(self._h, None, 0)
+        out = np.empty(n, dtype=np.float32)
+        lib.vsr_raft_packed_weights(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def flops(self, t, H, W, iters=20):
+        return lib.vsr_raft_flops(self._h, t, H, W, iters)
+
+    def flows(self, frames_dev, iters=20, bgr=False):
+        """frames_dev uint8 [t,H,W,3] on the GPU -> (forward, backward) flows, fp32 [t-1,2,H,W] each."""
+        assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
+        t, H, W, _ = frames_dev.shape
+        fwd = torch.empty((t - 1, 2, H, W), dtype=torch.float32, device=frames_dev.device)
+        bwd = torch.empty_like(fwd)
+        with torch.cuda.device(frames_dev.device):
+            check(lib.vsr_raft_flows(self._h, C.c_void_p(frames_dev.data_ptr()), t, H, W, iters, 1 if bgr else 0,
+                                     C.c_void_p(fwd.data_ptr()), C.c_void_p(bwd.data_ptr()), _stream_ptr()))
+        return fwd, bwd
