@@ -236,6 +236,9 @@ int64_t vsr_raft_packed_weights(const vsr_raft_t* h, float* out, int64_t capacit
  * device, both [t-1][2][H][W] (x then y displacement): fwd[i] = flow frame i -> i+1, bwd[i] = flow frame i+1 -> i. */
 int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W, int iters, int bgr, float* fwd_dev,
                    float* bwd_dev, void* stream);
+/* test hook: copy `count` floats at `offset` of workspace buffer `buf` (ids = the plan's buffer ids) to the host,
+ * after a device synchronisation -- stage-by-stage parity against the CPU replay of the plan */
+int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, float* out_host);
 /* algorithmic FLOPs of one vsr_raft_flows call (2*M*N*K over every conv and the all-pairs correlation) */
 double vsr_raft_flops(vsr_raft_t* h, int t, int H, int W, int iters);
 

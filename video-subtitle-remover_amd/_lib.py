@@ -111,6 +111,7 @@ SIGNATURES = {
     "vsr_raft_packed_weights": (_L, [_P, _P, _L]),
     "vsr_raft_flows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vsr_raft_flops": (_D, [_P, _I, _I, _I, _I]),
+    "vsr_raft_read_buffer": (_I, [_P, _I, _L, _L, _P]),
     "vsr_plan_destroy": (None, [_P]),
     "vsr_plan_num_buffers": (_I, [_P]),
     "vsr_plan_buffer_elems": (_L, [_P, _I]),

@@ -66,6 +66,7 @@ struct vsr_raft {
     int64_t cap[RB_COUNT] = {};
     double* statAcc = nullptr;
     int64_t statAccCap = 0;
+    std::tuple<int, int, int> geom{0, 0, 0};   // (t, H, W) the halos of the workspace are currently laid out for
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<RaftPlanDev>> plans;
 };
 
@@ -294,11 +295,28 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
     hipStream_t stream = (hipStream_t)stream_;
     RaftPlanDev* pd = nullptr;
     RCCHK(raft_plan_dev(h, t, H, W, iters, &pd));
+    if (h->geom != std::make_tuple(t, H, W)) {
+        // kernels write interiors only and rely on zero halos: another frame size or count moves the halos, so the
+        // workspace is cleared when the geometry changes (never in steady state)
+        for (int b = 0; b < RB_COUNT; ++b)
+            if (b != RB_WEIGHTS && h->bufs[b]) HIPCHK(hipMemsetAsync(h->bufs[b], 0, (size_t)rbBytes(b, h->cap[b]), stream));
+        h->geom = std::make_tuple(t, H, W);
+    }
     HIPCHK(hipMemcpyAsync(h->bufs[RB_IN_U8], frames_dev, (size_t)t * H * W * 3, hipMemcpyDeviceToDevice, stream));
     RCCHK(raft_run(h, pd, bgr ? 1 : 0, stream));
     const size_t half = (size_t)(t - 1) * 2 * H * W * sizeof(float);
     HIPCHK(hipMemcpyAsync(fwd_dev, h->bufs[RB_OUT], half, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(bwd_dev, (char*)h->bufs[RB_OUT] + half, half, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, float* out_host)
+{
+    if (!h || !out_host || buf <= RB_IN_U8 || buf >= RB_COUNT || offset < 0 || count < 0) return rfail(VSR_ERR_ARG, "bad argument");
+    if (h->device < 0 || !h->bufs[buf] || offset + count > h->cap[buf]) return rfail(VSR_ERR_STATE, "buffer not allocated / range outside it");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, (const float*)h->bufs[buf] + offset, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -205,6 +205,12 @@ class RaftEngine:
     def flops(self, t, H, W, iters=20):
         return lib.vsr_raft_flops(self._h, t, H, W, iters)
 
+    def read_buffer(self, buf, count, offset=0):
+        """test hook: `count` floats of workspace buffer `buf` (plan buffer id) as a numpy array"""
+        out = np.empty(count, dtype=np.float32)
+        check(lib.vsr_raft_read_buffer(self._h, buf, offset, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def flows(self, frames_dev, iters=20, bgr=False):
         """frames_dev uint8 [t,H,W,3] on the GPU -> (forward, backward) flows, fp32 [t-1,2,H,W] each."""
         assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
