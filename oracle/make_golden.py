@@ -142,6 +142,39 @@ def _raft_fixture():
                         **res)
 
 
+def rfc_inputs(seed, t, h, w):
+    """Seeded (flows_f, flows_b [t-1,2,h,w], masks [t,1,h,w] in {0,1}) for the flow-completion fixtures and tests."""
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((2, 2, h // 8 + 2, w // 8 + 2)).astype(np.float32) * 4
+    up = torch.nn.functional.interpolate(torch.from_numpy(base), size=(h, w), mode="bilinear", align_corners=True).numpy()
+    ff = np.stack([up[0] + 0.3 * i + rng.standard_normal((2, h, w)).astype(np.float32) * 0.2 for i in range(t - 1)])
+    fb = np.stack([up[1] - 0.2 * i + rng.standard_normal((2, h, w)).astype(np.float32) * 0.2 for i in range(t - 1)])
+    masks = np.zeros((t, 1, h, w), dtype=np.float32)
+    masks[:, :, h // 2: h // 2 + h // 4, w // 8: w - w // 8] = 1
+    return ff.astype(np.float32), fb.astype(np.float32), masks
+
+
+def _rfc_fixture():
+    """RecurrentFlowCompleteNet.forward_bidirect_flow + combine_flow (recurrent_flow_completion.py:313-348) run from the
+    reference with torchvision.ops.deform_conv2d provided by oracle/deform_conv.py (torchvision is absent here)."""
+    from oracle.deform_conv import deform_conv2d
+    from vsr_amd.synth import make_rfc_state_dict
+
+    sys.modules["torchvision"].ops.deform_conv2d = deform_conv2d
+    from backend.inpaint.video.model.recurrent_flow_completion import RecurrentFlowCompleteNet
+
+    net = RecurrentFlowCompleteNet().eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in make_rfc_state_dict(0).items()}, strict=True)
+    assert sum(p.numel() for p in net.parameters()) == 5079555          # SURVEY.md section 8(c)
+    ff, fb, masks = rfc_inputs(21, 5, 64, 96)
+    tf, tb, tm = torch.from_numpy(ff)[None], torch.from_numpy(fb)[None], torch.from_numpy(masks)[None]
+    with torch.no_grad():
+        (pf, pb), _ = net.forward_bidirect_flow([tf, tb], tm)
+        cf, cb = net.combine_flow([tf, tb], [pf, pb], tm)
+    np.savez_compressed(os.path.join(OUT, "rfc.npz"), seed=21, pred_f=pf[0].numpy(), pred_b=pb[0].numpy(),
+                        comb_f=cf[0, :, :, ::2, ::2].numpy(), comb_b=cb[0, :, :, ::2, ::2].numpy())
+
+
 def main():
     from vsr_amd.synth import make_state_dict
 
@@ -189,6 +222,7 @@ def main():
         out_sum=np.float64(out.double().sum()), out_sq=np.float64((out.double() ** 2).sum()))
 
     _raft_fixture()
+    _rfc_fixture()
 
     # ---- batch_generator (tools/inpaint_tools.py:7-29), executed from the reference ----
     cases = [(1200, 50), (300, 50), (600, 50), (1200, 70), (49, 50), (50, 50), (51, 50), (75, 50), (1, 50), (0, 50),

@@ -103,3 +103,38 @@ def test_raft_matches_reference():
             t = t[..., ::2, ::3] if name.startswith("up") else t          # the fixture keeps every 2nd row / 3rd column
             err = np.abs(t.numpy() - ref).max()
             assert err <= tol, f"{name} after {iters} iterations: max abs err {err:.3e} px (flow range {np.abs(ref).max():.1f})"
+
+
+def test_rfc_matches_reference():
+    """oracle/rfc.py against the reference RecurrentFlowCompleteNet (fixture from oracle/make_golden.py, the reference
+    run with oracle/deform_conv.py standing in for the absent torchvision.ops.deform_conv2d)."""
+    from oracle.make_golden import rfc_inputs
+    from oracle.rfc import RfcOracle
+    from vsr_amd.synth import make_rfc_state_dict, rfc_state_dict_spec
+
+    assert sum(int(np.prod(s)) for _, s in rfc_state_dict_spec()) == 5079555
+    g = np.load(os.path.join(GOLD, "rfc.npz"))
+    ff, fb, masks = rfc_inputs(int(g["seed"]), 5, 64, 96)
+    cf, cb, pf, pb = RfcOracle(make_rfc_state_dict(0)).complete_bi(torch.from_numpy(ff), torch.from_numpy(fb), torch.from_numpy(masks))
+    _close(pf.numpy(), g["pred_f"], "predicted forward flows")
+    _close(pb.numpy(), g["pred_b"], "predicted backward flows")
+    _close(cf[:, :, ::2, ::2].numpy(), g["comb_f"], "combined forward flows")
+    _close(cb[:, :, ::2, ::2].numpy(), g["comb_b"], "combined backward flows")
+
+
+def test_deform_conv_restatement_reduces_to_conv2d():
+    """zero offsets + unit mask: deform_conv2d is a plain conv; integer offsets shift the sampling grid (zero outside)."""
+    from oracle.deform_conv import deform_conv2d
+
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.standard_normal((2, 32, 9, 11)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((8, 32, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(8).astype(np.float32))
+    off = torch.zeros(2, 2 * 9 * 16, 9, 11)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    assert torch.allclose(deform_conv2d(x, off, w, b, 1, 1, 1, torch.ones(2, 9 * 16, 9, 11)), ref, atol=2e-4)
+    off2 = off.clone()
+    off2[:, 1::2] = 1.0                                    # every tap samples one pixel to the right
+    xs = torch.nn.functional.pad(x, (0, 1))[..., 1:]       # shift left, zero fill
+    assert torch.allclose(deform_conv2d(x, off2, w, b, 1, 1, 1, torch.ones(2, 9 * 16, 9, 11)),
+                          torch.nn.functional.conv2d(xs, w, b, padding=1), atol=2e-4)

@@ -215,3 +215,64 @@ def make_flow_frames(t, H, W, seed=0):
         img[by:by + H // 6, bx:bx + W // 8] = 240
         out[i] = np.clip(img, 0, 255).astype(np.uint8)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# RecurrentFlowCompleteNet (backend/inpaint/video/model/recurrent_flow_completion.py:206-273)
+# ------------------------------------------------------------------------------------------------
+def rfc_state_dict_spec():
+    spec = []
+
+    def add(name, *shape):
+        spec.append((name + ".weight", tuple(shape)))
+        spec.append((name + ".bias", (shape[0],)))
+
+    add("downsample.0", 32, 3, 1, 5, 5)
+    for name, cin, cout in (("encoder1.0", 32, 32), ("encoder1.2", 32, 64), ("encoder2.0", 64, 64), ("encoder2.2", 64, 128)):
+        add(name + ".conv1.0", cout, cin, 1, 3, 3)
+        add(name + ".conv2.0", cout, cout, 3, 1, 1)
+    for i in (0, 2, 4):
+        add(f"mid_dilation.{i}", 128, 128, 1, 3, 3)
+    for mod in ("backward_", "forward_"):
+        p = f"feat_prop_module.deform_align.{mod}"
+        add(p, 128, 256, 3, 3)
+        add(p + ".conv_offset.0", 128, 384, 3, 3)
+        add(p + ".conv_offset.2", 128, 128, 3, 3)
+        add(p + ".conv_offset.4", 128, 128, 3, 3)
+        add(p + ".conv_offset.6", 432, 128, 3, 3)
+    add("feat_prop_module.backbone.backward_.0", 128, 256, 3, 3)
+    add("feat_prop_module.backbone.backward_.2", 128, 128, 3, 3)
+    add("feat_prop_module.backbone.forward_.0", 128, 384, 3, 3)
+    add("feat_prop_module.backbone.forward_.2", 128, 128, 3, 3)
+    add("feat_prop_module.fusion", 128, 256, 1, 1)
+    add("decoder2.0", 128, 128, 3, 3)
+    add("decoder2.2.conv", 64, 128, 3, 3)
+    add("decoder1.0", 64, 64, 3, 3)
+    add("decoder1.2.conv", 32, 64, 3, 3)
+    add("upsample.0", 32, 32, 3, 3)
+    add("upsample.2.conv", 2, 32, 3, 3)
+    add("edgeDetector.projection.0", 16, 2, 3, 3)      # training-only head (:298-300); present in the checkpoint
+    add("edgeDetector.mid_layer_1.0", 16, 16, 3, 3)
+    add("edgeDetector.mid_layer_2.0", 16, 16, 3, 3)
+    add("edgeDetector.out_layer", 1, 16, 1, 1)
+    return spec
+
+
+def make_rfc_state_dict(seed=0):
+    """Stand-in for weights/recurrent_flow_completion.pth (missing blob).  The offset head is NOT zero-initialised as
+    in the reference's constructor (:27-28): offsets of a few pixels and non-trivial masks exercise the deformable
+    sampling."""
+    rng = np.random.default_rng(seed + 991)
+    sd = {}
+    for key, shape in rfc_state_dict_spec():
+        if key.endswith("weight"):
+            fan_in = int(np.prod(shape[1:]))
+            gain = 1.2
+            if "conv_offset.6" in key:
+                gain = 0.4
+            elif "conv2.0" in key or "backbone" in key or "fusion" in key:
+                gain = 0.9
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
+        else:
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
+    return sd
