@@ -125,7 +125,7 @@ int vsr_sttn_timing_reset(vsr_sttn_t* h);
  * ------------------------------------------------------------------------------------- */
 #define VSR_GG_KC 32 /* K / N chunk granularity of the offset tables */
 enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
-enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2,
+enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2, VSR_ACT_LRELU01 = 3,
        VSR_ACT_OUT_SPLIT = 0x100, /* variants 5, 6: OR-ed into act, C is written in split format */
        VSR_ACT_POST_RELU = 0x200  /* OR-ed into act: C = relu(act(..) + R)  (residual blocks, raft/extractor.py:48-58) */ };
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3 };
@@ -243,13 +243,36 @@ int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, 
 double vsr_raft_flops(vsr_raft_t* h, int t, int H, int W, int iters);
 
 /* ---------------------------------------------------------------------------------------
+ * Recurrent flow completion -- the second stage of --inpaint-mode propainter.
+ * Replaces RecurrentFlowCompleteNet.forward_bidirect_flow + combine_flow
+ * (backend/inpaint/video/model/recurrent_flow_completion.py:313-348; network :206-311, BidirectionalPropagation :49-126,
+ * SecondOrderDeformableAlignment :10-46 with torchvision.ops.deform_conv2d).  Exact fp32.
+ * ------------------------------------------------------------------------------------- */
+typedef struct vsr_rfc vsr_rfc_t;
+int vsr_rfc_create(vsr_rfc_t** out);
+/* one entry of torch.load('recurrent_flow_completion.pth') (:269-272): fp32 contiguous, unknown keys / wrong shapes are errors */
+int vsr_rfc_set_param(vsr_rfc_t* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int vsr_rfc_finalize(vsr_rfc_t* h, int device);
+void vsr_rfc_destroy(vsr_rfc_t* h);
+int64_t vsr_rfc_packed_weights(const vsr_rfc_t* h, float* out, int64_t capacity);
+/* flows_f / flows_b: fp32 [t-1][2][H][W] on the device (RAFT's outputs, unmasked); masks: uint8 [t][H][W], non-zero = hole
+ * (flow_masks of propainter_inpaint.py:215).  Outputs fp32 [t-1][2][H][W]: pred * mask + flow * (1 - mask) per direction
+ * (combine_flow).  H, W multiples of 8. */
+int vsr_rfc_complete(vsr_rfc_t* h, const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_dev, int t, int H,
+                     int W, float* out_f_dev, float* out_b_dev, void* stream);
+int vsr_rfc_read_buffer(vsr_rfc_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook, see vsr_raft_read_buffer */
+double vsr_rfc_flops(vsr_rfc_t* h, int t, int H, int W);
+
+/* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
 /* sub-kinds of op kind 6 (RAFT, csrc/raft_kernels.hip) */
 enum { VSR_EW_IM2COL7_U8 = 1, VSR_EW_INORM_STATS = 2, VSR_EW_INORM_APPLY = 3, VSR_EW_CTX_SPLIT = 4, VSR_EW_FLOW_UPDATE = 5,
        VSR_EW_IM2COL7_FLOW = 6, VSR_EW_AVGPOOL2 = 7, VSR_EW_CORR_LOOKUP = 8, VSR_EW_GRU_RH = 9, VSR_EW_GRU_UPDATE = 10,
-       VSR_EW_CONVEX_UP = 11 };
+       VSR_EW_CONVEX_UP = 11,
+       /* flow completion (csrc/rfc_plan.h) */
+       VSR_EW_RFC_IM2COL5 = 20, VSR_EW_DEFORM_COLS = 21, VSR_EW_RFC_COMBINE = 22 };
 typedef struct VsrOpInfo {
     int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter, 6 RAFT elementwise */
     int32_t nitems, tile_cfg, bmode;
@@ -285,6 +308,7 @@ typedef struct VsrSoftmaxInfo {
 
 int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
 int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out);
+int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 void vsr_plan_destroy(vsr_plan_t* p);
 int vsr_plan_num_buffers(const vsr_plan_t* p);
 int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf);

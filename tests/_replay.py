@@ -96,6 +96,8 @@ def gemm_reference(it, bmode, bufs, tables):
         acc = torch.nn.functional.leaky_relu(acc, 0.2)
     elif it.act & 0xff == 2:
         acc = torch.relu(acc)
+    elif it.act & 0xff == 3:
+        acc = torch.nn.functional.leaky_relu(acc, 0.1)
     if it.bufR >= 0:
         rowR = tables[it.tRowR][:M]
         acc = acc + torch.from_numpy(bufs[it.bufR][it.offR + rowR[:, None] + colC[None, :]])

@@ -112,6 +112,15 @@ SIGNATURES = {
     "vsr_raft_flows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vsr_raft_flops": (_D, [_P, _I, _I, _I, _I]),
     "vsr_raft_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_rfc_plan_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "vsr_rfc_create": (_I, [C.POINTER(_P)]),
+    "vsr_rfc_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "vsr_rfc_finalize": (_I, [_P, _I]),
+    "vsr_rfc_destroy": (None, [_P]),
+    "vsr_rfc_packed_weights": (_L, [_P, _P, _L]),
+    "vsr_rfc_complete": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "vsr_rfc_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_rfc_flops": (_D, [_P, _I, _I, _I]),
     "vsr_plan_destroy": (None, [_P]),
     "vsr_plan_num_buffers": (_I, [_P]),
     "vsr_plan_buffer_elems": (_L, [_P, _I]),

@@ -1,0 +1,555 @@
+// Device engines + C-ABI (include/vsr_hip.h, "RAFT" and "flow completion" sections) of the optical-flow stages of
+// --inpaint-mode propainter: SURVEY.md section 8(a) rows a14 (RAFT_bi.forward, flow_comp_raft.py:39-55) and a15
+// (RecurrentFlowCompleteNet.forward_bidirect_flow + combine_flow, recurrent_flow_completion.py:313-348).
+//
+// Same structure as sttn_engine.hip: a workspace allocated and zeroed once (NHWC fp32 activations whose physical zero
+// halos are the conv padding), a plan (raft_plan.h / rfc_plan.h) materialised into device descriptors once per shape
+// and replayed on the caller's stream without host synchronisation.  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32):
+// the reference runs RAFT in fp32 even in its fp16 mode (propainter_inpaint.py:230).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "../../include/vsr_hip.h"
+#include "gather_gemm.h"
+#include "plan_c.h"
+#include "raft_kernels.h"
+#include "raft_plan.h"
+#include "rfc_plan.h"
+
+using namespace vsr;
+
+static int rfail(int code, const std::string& msg) { return vsr_internal_fail(code, msg.c_str()); }
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return rfail(VSR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define RCCHK(expr)                                                                                        \
+    do {                                                                                                   \
+        int rc_ = (expr);                                                                                  \
+        if (rc_ != 0) return rc_;                                                                          \
+    } while (0)
+
+namespace {
+
+struct FlowOpDev {
+    const Op* op = nullptr;
+    const void* dDesc = nullptr;   // GGProblem* (device)
+    int nitems = 0, total = 0, nQueues = 1;
+};
+
+// a plan on the device: tables, gather-GEMM descriptors with baked buffer pointers, tile queues
+struct FlowPlanDev {
+    std::unique_ptr<PlanIR> plan;
+    int32_t* dTables = nullptr;
+    std::vector<int64_t> toff;
+    void* dDescs = nullptr;
+    unsigned int* dQueues = nullptr;
+    std::vector<FlowOpDev> ops;
+    ~FlowPlanDev()
+    {
+        if (dTables) (void)hipFree(dTables);
+        if (dDescs) (void)hipFree(dDescs);
+        if (dQueues) (void)hipFree(dQueues);
+    }
+};
+
+// workspace of one engine: buffer ids are the plan's; `bytes` marks the ids whose size is in bytes (u8 inputs)
+struct Workspace {
+    std::vector<void*> bufs;
+    std::vector<int64_t> cap;
+    std::vector<bool> bytes;
+    int weights = 0;
+    double* statAcc = nullptr;
+    int64_t statAccCap = 0;
+    void init(int n, int weightsBuf, std::initializer_list<int> byteBufs)
+    {
+        bufs.assign(n, nullptr);
+        cap.assign(n, 0);
+        bytes.assign(n, false);
+        for (int b : byteBufs) bytes[b] = true;
+        weights = weightsBuf;
+    }
+    int64_t nbytes(int b, int64_t elems) const { return bytes[b] ? elems : elems * 4; }
+    float* f(int b, int64_t off = 0) const { return (float*)bufs[b] + off; }
+    bool needs_growth(const PlanIR& P) const
+    {
+        for (size_t b = 0; b < bufs.size(); ++b)
+            if ((int)b != weights && P.bufElems[b] > cap[b]) return true;
+        return false;
+    }
+    void release()
+    {
+        for (void*& p : bufs)
+            if (p) { (void)hipFree(p); p = nullptr; }
+        if (statAcc) { (void)hipFree(statAcc); statAcc = nullptr; }
+    }
+};
+
+} // namespace
+
+// grows the workspace to the plan's needs and bakes the plan (callers drop their cached plans first when it grows)
+static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_ptr<FlowPlanDev>* out)
+{
+    std::unique_ptr<FlowPlanDev> pd(new FlowPlanDev);
+    pd->plan = std::move(plan);
+    const PlanIR& P = *pd->plan;
+    const int nb = (int)ws.bufs.size();
+    if (ws.needs_growth(P)) {
+        for (int b = 0; b < nb; ++b) {
+            if (b == ws.weights || P.bufElems[b] <= ws.cap[b]) continue;
+            if (ws.bufs[b]) { HIPCHK(hipFree(ws.bufs[b])); ws.bufs[b] = nullptr; ws.cap[b] = 0; }
+            const int64_t bytes = ws.nbytes(b, P.bufElems[b]);
+            HIPCHK(hipMalloc(&ws.bufs[b], (size_t)bytes));
+            HIPCHK(hipMemset(ws.bufs[b], 0, (size_t)bytes));   // zero halos, once
+            ws.cap[b] = P.bufElems[b];
+        }
+        HIPCHK(hipDeviceSynchronize());
+    }
+    pd->toff.resize(P.tables.size());
+    int64_t tot = 0;
+    for (size_t i = 0; i < P.tables.size(); ++i) { pd->toff[i] = tot; tot += (int64_t)((P.tables[i].size() + 3) / 4 * 4); }
+    std::vector<int32_t> flat((size_t)tot, 0);
+    for (size_t i = 0; i < P.tables.size(); ++i)
+        memcpy(flat.data() + pd->toff[i], P.tables[i].data(), P.tables[i].size() * sizeof(int32_t));
+    HIPCHK(hipMalloc((void**)&pd->dTables, (size_t)(tot > 0 ? tot : 4) * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(pd->dTables, flat.data(), (size_t)tot * sizeof(int32_t), hipMemcpyHostToDevice));
+    auto T = [&](int id) -> const int32_t* { return id < 0 ? nullptr : pd->dTables + pd->toff[id]; };
+    auto F = [&](int buf, int64_t off) -> float* { return buf < 0 ? nullptr : ws.f(buf, off); };
+    size_t descBytes = 0;
+    for (const Op& op : P.ops) descBytes += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+    std::vector<char> hostDesc(descBytes + 64, 0);
+    HIPCHK(hipMalloc(&pd->dDescs, descBytes + 64));
+    size_t cursor = 0;
+    for (const Op& op : P.ops) {
+        FlowOpDev od;
+        od.op = &op;
+        if (op.kind == OP_GEMM) {
+            GGProblem* hp = (GGProblem*)(hostDesc.data() + cursor);
+            int tileStart = 0;
+            for (size_t j = 0; j < op.gemm.size(); ++j) {
+                const GemmItem& g = op.gemm[j];
+                GGProblem& q = hp[j];
+                q.A = F(g.bufA, g.offA); q.B = F(g.bufB, g.offB); q.C = F(g.bufC, g.offC);
+                q.bias = g.offBias >= 0 ? F(ws.weights, g.offBias) : nullptr;
+                q.R = g.bufR >= 0 ? F(g.bufR, g.offR) : nullptr;
+                q.rowA = T(g.tRowA); q.colA = T(g.tColA); q.rowB = T(g.tRowB); q.colB = T(g.tColB);
+                q.rowC = T(g.tRowC); q.colC = T(g.tColC); q.rowR = T(g.tRowR);
+                q.M = g.M; q.N = g.N; q.K = g.K; q.tilesM = g.tilesM; q.tilesN = g.tilesN;
+                q.splitK = g.splitK; q.chunksPerSplit = g.chunksPerSplit; q.tileStart = tileStart;
+                q.act = g.act; q.alpha = g.alpha; q.splitStride = g.splitStride;
+                tileStart += g.tilesM * g.tilesN * g.splitK;
+            }
+            od.dDesc = (char*)pd->dDescs + cursor;
+            od.nitems = (int)op.gemm.size();
+            od.total = tileStart;
+            od.nQueues = 8;
+            for (const GemmItem& g : op.gemm)
+                if (g.tilesN > 4) od.nQueues = 1;
+            cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+        }
+        pd->ops.push_back(od);
+    }
+    HIPCHK(hipMemcpy(pd->dDescs, hostDesc.data(), descBytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 8 * sizeof(unsigned int)));
+    *out = std::move(pd);
+    return 0;
+}
+
+// replays a materialised plan; `bgr`: channel order of RAFT's u8 input frames
+static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t stream)
+{
+    HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
+    auto B = [&](int buf, int64_t off) -> float* { return ws.f(buf, off); };
+    size_t idx = 0;
+    for (const FlowOpDev& od : pd->ops) {
+        const Op& op = *od.op;
+        unsigned int* queue = pd->dQueues + 8 * idx++;
+        int rc = 0;
+        if (op.kind == OP_GEMM) {
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, 3, od.nQueues,
+                                            nullptr, stream);
+        } else if (op.kind == OP_UPSAMPLE2X) {
+            rc = vsr_launch_upsample2x(B(op.bufSrc, 0), op.H, op.W, op.C, op.haloS, B(op.bufDst, 0), op.haloD, op.n, stream);
+        } else if (op.kind == OP_EW) {
+            const int* ip = op.ipar;
+            switch (op.ew) {
+            case EW_IM2COL7_U8:
+                rc = vsr_raft_launch_im2col7_u8((const uint8_t*)ws.bufs[op.ibuf[0]], ip[0], ip[1], ip[2], bgr, B(op.ibuf[1], 0), stream);
+                break;
+            case EW_INORM_STATS:
+                rc = vsr_raft_launch_inorm_stats(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ws.statAcc, B(op.ibuf[1], 0), stream);
+                break;
+            case EW_INORM_APPLY:
+                rc = vsr_raft_launch_inorm_apply(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], B(op.ibuf[1], 0), ip[5],
+                                                 op.ibuf[2] >= 0 ? B(op.ibuf[2], 0) : nullptr, ip[6], stream);
+                break;
+            case EW_CTX_SPLIT:
+                rc = vsr_raft_launch_ctx_split(B(op.ibuf[0], 0), pd->dTables + pd->toff[ip[5]], ip[0], ip[1], ip[2], ip[3], ip[4],
+                                               B(op.ibuf[1], 0), stream);
+                break;
+            case EW_FLOW_UPDATE:
+                rc = vsr_raft_launch_flow_update(B(op.ibuf[0], 0), ip[7], B(op.ibuf[1], 0), B(op.ibuf[2], 0), B(op.ibuf[3], 0), ip[0], ip[1],
+                                                 ip[2], ip[3], ip[4], ip[5], ip[6], stream);
+                break;
+            case EW_IM2COL7_FLOW:
+                rc = vsr_raft_launch_im2col7_flow(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], B(op.ibuf[1], 0), stream);
+                break;
+            case EW_AVGPOOL2:
+                rc = vsr_raft_launch_avgpool2(B(op.ibuf[0], op.ioff[0]), ip[0], ip[1], ip[2], B(op.ibuf[0], op.ioff[1]), stream);
+                break;
+            case EW_CORR_LOOKUP: {
+                const float* lv[4];
+                for (int l = 0; l < 4; ++l) lv[l] = B(op.ibuf[0], op.ioff[l]);
+                rc = vsr_raft_launch_corr_lookup(lv, ip + 1, ip + 5, B(op.ibuf[1], 0), ip[0], ip[9], B(op.ibuf[2], 0), stream);
+                break;
+            }
+            case EW_GRU_RH:
+                rc = vsr_raft_launch_gru_rh(B(op.ibuf[0], 0), B(op.ibuf[1], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], stream);
+                break;
+            case EW_GRU_UPDATE:
+                rc = vsr_raft_launch_gru_update(B(op.ibuf[0], 0), B(op.ibuf[1], 0), B(op.ibuf[2], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
+                                                stream);
+                break;
+            case EW_CONVEX_UP:
+                rc = vsr_raft_launch_convex_up(B(op.ibuf[0], 0), B(op.ibuf[1], 0), ip[0], ip[1], ip[2], B(op.ibuf[2], 0), stream);
+                break;
+            case EW_RFC_IM2COL5:
+                rc = vsr_rfc_launch_im2col5(B(op.ibuf[0], 0), B(op.ibuf[1], 0), (const uint8_t*)ws.bufs[op.ibuf[2]], ip[0], ip[1], ip[2],
+                                            B(op.ibuf[3], 0), stream);
+                break;
+            case EW_DEFORM_COLS:
+                rc = vsr_rfc_launch_deform_cols(B(op.ibuf[0], op.ioff[0]), B(op.ibuf[0], op.ioff[1]), B(op.ibuf[1], 0), ip[5], op.fpar[0], ip[0],
+                                                ip[1], ip[2], ip[3], ip[4], B(op.ibuf[2], 0), stream);
+                break;
+            case EW_RFC_COMBINE:
+                rc = vsr_rfc_launch_combine(B(op.ibuf[0], 0), ip[3], B(FB_IN_FLOW_F, 0), B(FB_IN_FLOW_B, 0), (const uint8_t*)ws.bufs[FB_IN_MASK],
+                                            ip[0], ip[1], ip[2], B(op.ibuf[1], 0), B(op.ibuf[2], 0), stream);
+                break;
+            default:
+                return rfail(VSR_ERR_STATE, "unknown elementwise op");
+            }
+        } else {
+            return rfail(VSR_ERR_STATE, "unexpected op kind in a flow plan");
+        }
+        if (rc != 0) return rfail(VSR_ERR_HIP, "kernel launch failed: " + op.tag + ": " + hipGetErrorString(hipGetLastError()));
+    }
+    return 0;
+}
+
+// kernels write interiors only and rely on zero halos: another frame size or count moves the halos, so the workspace
+// is cleared when the geometry changes (never in steady state)
+static int clear_workspace(Workspace& ws, hipStream_t stream)
+{
+    for (size_t b = 0; b < ws.bufs.size(); ++b)
+        if ((int)b != ws.weights && ws.bufs[b]) HIPCHK(hipMemsetAsync(ws.bufs[b], 0, (size_t)ws.nbytes((int)b, ws.cap[b]), stream));
+    return 0;
+}
+
+static int upload_weights(Workspace& ws, const std::vector<float>& packed, int device)
+{
+    if (device >= vsr_device_count()) return rfail(VSR_ERR_NOGPU, "no such HIP device; there is no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    const size_t bytes = packed.size() * sizeof(float);
+    HIPCHK(hipMalloc(&ws.bufs[ws.weights], bytes));
+    HIPCHK(hipMemcpy(ws.bufs[ws.weights], packed.data(), bytes, hipMemcpyHostToDevice));
+    ws.cap[ws.weights] = (int64_t)packed.size();
+    return 0;
+}
+
+static int read_buffer(const Workspace& ws, int device, int buf, int64_t offset, int64_t count, float* out_host)
+{
+    if (!out_host || buf < 0 || buf >= (int)ws.bufs.size() || ws.bytes[buf] || offset < 0 || count < 0) return rfail(VSR_ERR_ARG, "bad argument");
+    if (device < 0 || !ws.bufs[buf] || offset + count > ws.cap[buf]) return rfail(VSR_ERR_STATE, "buffer not allocated / range outside it");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, ws.f(buf, offset), (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// RAFT
+// ---------------------------------------------------------------------------------------
+struct vsr_raft {
+    RaftModel model;
+    int device = -1;
+    bool finalized = false;
+    Workspace ws;
+    std::tuple<int, int, int> geom{0, 0, 0};   // (t, H, W) the halos of the workspace are currently laid out for
+    std::map<std::tuple<int, int, int, int>, std::unique_ptr<FlowPlanDev>> plans;
+    vsr_raft() { ws.init(RB_COUNT, RB_WEIGHTS, {RB_IN_U8}); }
+};
+
+static int raft_plan_dev(vsr_raft* h, int t, int H, int W, int iters, FlowPlanDev** out)
+{
+    const auto key = std::make_tuple(t, H, W, iters);
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) { *out = it->second.get(); return 0; }
+    std::unique_ptr<PlanIR> plan;
+    try {
+        plan.reset(new RaftPlan(h->model, t, H, W, iters));
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("raft plan: ") + e.what());
+    }
+    const int64_t accNeed = (int64_t)t * 256 * 2;
+    if (h->ws.statAccCap < accNeed) {
+        if (h->ws.statAcc) HIPCHK(hipFree(h->ws.statAcc));
+        HIPCHK(hipMalloc((void**)&h->ws.statAcc, (size_t)accNeed * sizeof(double)));
+        h->ws.statAccCap = accNeed;
+    }
+    if (h->ws.needs_growth(*plan)) h->plans.clear();   // pointers baked into the cached plans die with the old buffers
+    std::unique_ptr<FlowPlanDev> pd;
+    RCCHK(materialize(h->ws, std::move(plan), &pd));
+    *out = pd.get();
+    h->plans[key] = std::move(pd);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// recurrent flow completion
+// ---------------------------------------------------------------------------------------
+struct vsr_rfc {
+    RfcModel model;
+    int device = -1;
+    bool finalized = false;
+    Workspace ws;
+    std::tuple<int, int, int> geom{0, 0, 0};
+    std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> plans;
+    vsr_rfc() { ws.init(FB_COUNT, FB_WEIGHTS, {FB_IN_MASK}); }
+};
+
+static int rfc_plan_dev(vsr_rfc* h, int t, int H, int W, FlowPlanDev** out)
+{
+    const auto key = std::make_tuple(t, H, W);
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) { *out = it->second.get(); return 0; }
+    std::unique_ptr<PlanIR> plan;
+    try {
+        plan.reset(new RfcPlan(h->model, t, H, W));
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("flow-completion plan: ") + e.what());
+    }
+    if (h->ws.needs_growth(*plan)) h->plans.clear();
+    std::unique_ptr<FlowPlanDev> pd;
+    RCCHK(materialize(h->ws, std::move(plan), &pd));
+    *out = pd.get();
+    h->plans[key] = std::move(pd);
+    return 0;
+}
+
+extern "C" {
+
+int vsr_raft_create(vsr_raft_t** out)
+{
+    if (!out) return rfail(VSR_ERR_ARG, "null out pointer");
+    *out = new vsr_raft();
+    return 0;
+}
+
+int vsr_raft_set_param(vsr_raft_t* h, const char* key, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h || !key || !data || (ndim > 0 && !shape)) return rfail(VSR_ERR_ARG, "bad argument");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.set_param(key, data, shape, ndim, err)) return rfail(VSR_ERR_ARG, err);
+    return 0;
+}
+
+int vsr_raft_finalize(vsr_raft_t* h, int device)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.pack(err)) return rfail(VSR_ERR_ARG, err);
+    if (device >= 0) RCCHK(upload_weights(h->ws, h->model.packed, device));
+    h->device = device;
+    h->finalized = true;
+    return 0;
+}
+
+void vsr_raft_destroy(vsr_raft_t* h)
+{
+    if (!h) return;
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        h->plans.clear();
+        h->ws.release();
+    }
+    delete h;
+}
+
+int64_t vsr_raft_packed_weights(const vsr_raft_t* h, float* out, int64_t capacity)
+{
+    if (!h || !h->model.packed_ready()) { rfail(VSR_ERR_STATE, "model not finalized"); return -1; }
+    const int64_t n = (int64_t)h->model.packed.size();
+    if (out && capacity >= n) memcpy(out, h->model.packed.data(), (size_t)n * sizeof(float));
+    return n;
+}
+
+int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W, int iters, int bgr, float* fwd_dev, float* bwd_dev,
+                   void* stream_)
+{
+    if (!h || !frames_dev || !fwd_dev || !bwd_dev) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->finalized || h->device < 0)
+        return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device (no GPU / finalize(device<0)); there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    FlowPlanDev* pd = nullptr;
+    RCCHK(raft_plan_dev(h, t, H, W, iters, &pd));
+    if (h->geom != std::make_tuple(t, H, W)) {
+        RCCHK(clear_workspace(h->ws, stream));
+        h->geom = std::make_tuple(t, H, W);
+    }
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[RB_IN_U8], frames_dev, (size_t)t * H * W * 3, hipMemcpyDeviceToDevice, stream));
+    RCCHK(run_plan(h->ws, pd, bgr ? 1 : 0, stream));
+    const size_t half = (size_t)(t - 1) * 2 * H * W * sizeof(float);
+    HIPCHK(hipMemcpyAsync(fwd_dev, h->ws.bufs[RB_OUT], half, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(bwd_dev, (char*)h->ws.bufs[RB_OUT] + half, half, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, float* out_host)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    return read_buffer(h->ws, h->device, buf, offset, count, out_host);
+}
+
+double vsr_raft_flops(vsr_raft_t* h, int t, int H, int W, int iters)
+{
+    if (!h || !h->model.packed_ready()) { rfail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        RaftPlan p(h->model, t, H, W, iters);
+        return p.flops;
+    } catch (const std::exception& e) {
+        rfail(VSR_ERR_ARG, std::string("raft plan: ") + e.what());
+        return -1.0;
+    }
+}
+
+int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out)
+{
+    if (!h || !out) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return rfail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new RaftPlan(h->model, t, H, W, iters));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("raft plan: ") + e.what());
+    }
+    return 0;
+}
+
+// ---- flow completion ----------------------------------------------------------------------------------------------
+
+int vsr_rfc_create(vsr_rfc_t** out)
+{
+    if (!out) return rfail(VSR_ERR_ARG, "null out pointer");
+    *out = new vsr_rfc();
+    return 0;
+}
+
+int vsr_rfc_set_param(vsr_rfc_t* h, const char* key, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h || !key || !data || (ndim > 0 && !shape)) return rfail(VSR_ERR_ARG, "bad argument");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.set_param(key, data, shape, ndim, err)) return rfail(VSR_ERR_ARG, err);
+    return 0;
+}
+
+int vsr_rfc_finalize(vsr_rfc_t* h, int device)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.pack(err)) return rfail(VSR_ERR_ARG, err);
+    if (device >= 0) RCCHK(upload_weights(h->ws, h->model.packed, device));
+    h->device = device;
+    h->finalized = true;
+    return 0;
+}
+
+void vsr_rfc_destroy(vsr_rfc_t* h)
+{
+    if (!h) return;
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        h->plans.clear();
+        h->ws.release();
+    }
+    delete h;
+}
+
+int64_t vsr_rfc_packed_weights(const vsr_rfc_t* h, float* out, int64_t capacity)
+{
+    if (!h || !h->model.packed_ready()) { rfail(VSR_ERR_STATE, "model not finalized"); return -1; }
+    const int64_t n = (int64_t)h->model.packed.size();
+    if (out && capacity >= n) memcpy(out, h->model.packed.data(), (size_t)n * sizeof(float));
+    return n;
+}
+
+int vsr_rfc_complete(vsr_rfc_t* h, const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_dev, int t, int H, int W,
+                     float* out_f_dev, float* out_b_dev, void* stream_)
+{
+    if (!h || !flows_f_dev || !flows_b_dev || !masks_dev || !out_f_dev || !out_b_dev) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->finalized || h->device < 0)
+        return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device (no GPU / finalize(device<0)); there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    FlowPlanDev* pd = nullptr;
+    RCCHK(rfc_plan_dev(h, t, H, W, &pd));
+    if (h->geom != std::make_tuple(t, H, W)) {
+        RCCHK(clear_workspace(h->ws, stream));
+        h->geom = std::make_tuple(t, H, W);
+    }
+    const size_t fbytes = (size_t)(t - 1) * 2 * H * W * sizeof(float);
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[FB_IN_FLOW_F], flows_f_dev, fbytes, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[FB_IN_FLOW_B], flows_b_dev, fbytes, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[FB_IN_MASK], masks_dev, (size_t)t * H * W, hipMemcpyDeviceToDevice, stream));
+    RCCHK(run_plan(h->ws, pd, 0, stream));
+    HIPCHK(hipMemcpyAsync(out_f_dev, h->ws.bufs[FB_OUT_F], fbytes, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(out_b_dev, h->ws.bufs[FB_OUT_B], fbytes, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int vsr_rfc_read_buffer(vsr_rfc_t* h, int buf, int64_t offset, int64_t count, float* out_host)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    return read_buffer(h->ws, h->device, buf, offset, count, out_host);
+}
+
+double vsr_rfc_flops(vsr_rfc_t* h, int t, int H, int W)
+{
+    if (!h || !h->model.packed_ready()) { rfail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        RfcPlan p(h->model, t, H, W);
+        return p.flops;
+    } catch (const std::exception& e) {
+        rfail(VSR_ERR_ARG, std::string("flow-completion plan: ") + e.what());
+        return -1.0;
+    }
+}
+
+int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out)
+{
+    if (!h || !out) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return rfail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new RfcPlan(h->model, t, H, W));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("flow-completion plan: ") + e.what());
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -240,6 +240,7 @@ gather_gemm_f32_v2(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     float v = acc[mi][ni][r] * alpha + bv[ni];
                     if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
                         else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
                     if (m < M && nok[ni]) {
                         if (R != nullptr) { v += R[rr + ccol[ni]]; if (postRelu) v = fmaxf(v, 0.f); }
                         C[rc + ccol[ni]] = v;

@@ -353,6 +353,7 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                         nonFinite |= !(__builtin_fabsf(v) <= 3.0e38f);
                         if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
                         else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
                         if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
                         if (mok && (FULL || nok[ni])) C[rc[r] + ccol[ni]] = v;
                     }

@@ -410,6 +410,7 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                         float v = acc[mi][ni][r] * alpha + bv[ni];
                         if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
                         else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
                         if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
                         nonFinite |= !(__builtin_fabsf(v) <= vmax);      // also catches NaN
                         if (mok && (FULL || nok[ni])) {

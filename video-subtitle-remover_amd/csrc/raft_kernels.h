@@ -22,3 +22,12 @@ int vsr_raft_launch_gru_update(const float* zr, const float* q, float* hxr, int 
                                void* stream);
 int vsr_raft_launch_convex_up(const float* flow, const float* mask, int pairs, int h, int w, float* out, void* stream);
 }
+
+// recurrent flow completion (rfc_plan.h)
+extern "C" {
+int vsr_rfc_launch_im2col5(const float* ff, const float* fb, const uint8_t* mask, int t, int H, int W, float* out, void* stream);
+int vsr_rfc_launch_deform_cols(const float* srcA, const float* srcB, const float* off, int ldOff, float maxMag, int n, int h, int w,
+                               int halo, int C, float* cols, void* stream);
+int vsr_rfc_launch_combine(const float* pred, int ld, const float* ff, const float* fb, const uint8_t* mask, int t, int H, int W,
+                           float* outF, float* outB, void* stream);
+}

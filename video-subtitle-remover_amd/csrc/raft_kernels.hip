@@ -421,3 +421,143 @@ extern "C" int vsr_raft_launch_convex_up(const float* flow, const float* mask, i
 {
     LAUNCH(k_raft_convex_up, (int64_t)pairs * h * w * 64, flow, mask, pairs, h, w, out);
 }
+
+// =======================================================================================
+// Recurrent flow completion (rfc_plan.h; reference backend/inpaint/video/model/recurrent_flow_completion.py)
+// =======================================================================================
+
+// ---------------------------------------------------------------------------------------
+// EW_RFC_IM2COL5: forward_bidirect_flow's masking (:322-333) + cat((masked_flows, masks)) (:281) fused with the im2col of
+// the stem Conv3d (1,5,5), stride (1,2,2), replicate padding (:209-211).  Two sequences of T = t-1 steps: s = 0 the
+// forward flows with masks[:-1], s = 1 the backward flows with masks[1:], both flipped in time.  Row ((i*2+s), oy, ox),
+// 96 columns, k = (ky*5+kx)*3 + c with c = (flow_x*(1-m), flow_y*(1-m), m); 75.. zero.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rfc_im2col5(const float* __restrict__ ff, const float* __restrict__ fb, const uint8_t* __restrict__ mask, int t, int H, int W,
+              float* __restrict__ out)
+{
+    const int T = t - 1, oh = H / 2, ow = W / 2;
+    const int64_t total = (int64_t)2 * T * oh * ow * 24;
+    GRID_STRIDE(i, total) {
+        const int q = (int)(i % 24);
+        const int64_t m = i / 24;
+        const int ox = (int)(m % ow), oy = (int)((m / ow) % oh);
+        const int fs = (int)(m / ((int64_t)ow * oh));
+        const int s = fs & 1, step = fs >> 1;
+        const float* fl = s == 0 ? ff + (int64_t)step * 2 * H * W : fb + (int64_t)(T - 1 - step) * 2 * H * W;
+        const uint8_t* mk = mask + (int64_t)(s == 0 ? step : T - step) * H * W;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * q + j;
+            float val = 0.f;
+            if (k < 75) {
+                const int tap = k / 3, c = k - 3 * tap;
+                const int ky = tap / 5, kx = tap - 5 * ky;
+                int y = 2 * oy - 2 + ky, x = 2 * ox - 2 + kx;
+                y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);            // padding_mode='replicate'
+                x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+                const float mv = mk[(int64_t)y * W + x] ? 1.0f : 0.0f;
+                val = c == 2 ? mv : fl[((int64_t)c * H + y) * W + x] * (1.0f - mv);
+            }
+            v[j] = val;
+        }
+        *reinterpret_cast<f32x4*>(out + m * 96 + 4 * q) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// EW_DEFORM_COLS: SecondOrderDeformableAlignment.forward (:31-46) up to the contraction: offset = 5*tanh(o[0:288]),
+// mask = sigmoid(o[288:432]); torchvision.ops.deform_conv2d's column matrix for x = cat[srcA, srcB] (2 x 128 channels,
+// 16 offset groups of 16 channels, 3x3, stride 1, pad 1): cols[m][((ci/32)*9 + k)*32 + ci%32] =
+// mask[g,k] * bilinear(x[ci], y - 1 + ky + off_y[g,k], x - 1 + kx + off_x[g,k]), zero outside the image
+// (offset channel g*18 + 2k (+1), mask channel g*9 + k).  One thread per (pixel, group, tap): 16 channels.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_deform_cols(const float* __restrict__ srcA, const float* __restrict__ srcB, const float* __restrict__ off, int ldOff, float maxMag, int n,
+              int h, int w, int halo, int C, float* __restrict__ cols)
+{
+    const int64_t total = (int64_t)n * h * w * 144;
+    const int Wp = w + 2 * halo, Hp = h + 2 * halo;
+    GRID_STRIDE(i, total) {
+        const int gk = (int)(i % 144);
+        const int64_t m = i / 144;
+        const int g = gk / 9, k = gk - 9 * g;
+        const int xx = (int)(m % w), y = (int)((m / w) % h), f = (int)(m / ((int64_t)w * h));
+        const float* o = off + m * ldOff;
+        const float dy = maxMag * tanhf(o[g * 18 + 2 * k]), dx = maxMag * tanhf(o[g * 18 + 2 * k + 1]);
+        const float mk = sigmoidf_(o[288 + g * 9 + k]);
+        const float py = (float)(y - 1 + k / 3) + dy, px = (float)(xx - 1 + k % 3) + dx;
+        const float fy0 = floorf(py), fx0 = floorf(px);
+        const int y0 = (int)fy0, x0 = (int)fx0;
+        const float ly = py - fy0, lx = px - fx0;
+        const float* src = (g < 8 ? srcA : srcB) + (int64_t)f * Hp * Wp * C + (g & 7) * 16;      // channels 16g.. of cat[srcA, srcB]
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int corner = 0; corner < 4; ++corner) {
+            const int yy = y0 + (corner >> 1), x2 = x0 + (corner & 1);
+            const float wgt = ((corner >> 1) ? ly : 1.0f - ly) * ((corner & 1) ? lx : 1.0f - lx);
+            if (yy >= 0 && yy < h && x2 >= 0 && x2 < w) {
+                const float* p = src + ((int64_t)(yy + halo) * Wp + x2 + halo) * C;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = acc[j][e] + v[e] * wgt;
+                }
+            }
+        }
+        const int ci0 = g * 16;                                     // channel of cat[srcA, srcB]
+        float* dst = cols + m * (9 * 2 * C) + ((ci0 / 32) * 9 + k) * 32 + (ci0 % 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][e] = acc[j][e] * mk;
+            *reinterpret_cast<f32x4*>(dst + 4 * j) = acc[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// EW_RFC_COMBINE: un-flip the backward sequence (:334-336) and combine_flow (:341-348):
+// out = pred * mask + flow * (1 - mask), planar [T][2][H][W]; pred [(i*2+s)][H][W][ld] (columns 0, 1)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rfc_combine(const float* __restrict__ pred, int ld, const float* __restrict__ ff, const float* __restrict__ fb,
+              const uint8_t* __restrict__ mask, int t, int H, int W, float* __restrict__ outF, float* __restrict__ outB)
+{
+    const int T = t - 1;
+    const int64_t total = (int64_t)2 * T * H * W;
+    GRID_STRIDE(i, total) {
+        const int xx = (int)(i % W), y = (int)((i / W) % H);
+        const int fs = (int)(i / ((int64_t)W * H));
+        const int s = fs & 1, step = fs >> 1;
+        const int fi = s == 0 ? step : T - 1 - step;               // flow index inside its direction
+        const float mv = mask[((int64_t)(s == 0 ? fi : fi + 1) * H + y) * W + xx] ? 1.0f : 0.0f;
+        const float* fl = (s == 0 ? ff : fb) + (int64_t)fi * 2 * H * W;
+        float* o = (s == 0 ? outF : outB) + (int64_t)fi * 2 * H * W;
+        const float* p = pred + i * ld;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t at = ((int64_t)c * H + y) * W + xx;
+            o[at] = p[c] * mv + (fl[at] * (1.0f - mv)) * (1.0f - mv);
+        }
+    }
+}
+
+extern "C" int vsr_rfc_launch_im2col5(const float* ff, const float* fb, const uint8_t* mask, int t, int H, int W, float* out, void* stream)
+{
+    LAUNCH(k_rfc_im2col5, (int64_t)2 * (t - 1) * (H / 2) * (W / 2) * 24, ff, fb, mask, t, H, W, out);
+}
+extern "C" int vsr_rfc_launch_deform_cols(const float* srcA, const float* srcB, const float* off, int ldOff, float maxMag, int n, int h, int w,
+                                          int halo, int C, float* cols, void* stream)
+{
+    LAUNCH(k_deform_cols, (int64_t)n * h * w * 144, srcA, srcB, off, ldOff, maxMag, n, h, w, halo, C, cols);
+}
+extern "C" int vsr_rfc_launch_combine(const float* pred, int ld, const float* ff, const float* fb, const uint8_t* mask, int t, int H, int W,
+                                      float* outF, float* outB, void* stream)
+{
+    LAUNCH(k_rfc_combine, (int64_t)2 * (t - 1) * H * W, pred, ld, ff, fb, mask, t, H, W, outF, outB);
+}

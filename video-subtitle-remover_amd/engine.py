@@ -221,3 +221,68 @@ class RaftEngine:
             check(lib.vsr_raft_flows(self._h, C.c_void_p(frames_dev.data_ptr()), t, H, W, iters, 1 if bgr else 0,
                                      C.c_void_p(fwd.data_ptr()), C.c_void_p(bwd.data_ptr()), _stream_ptr()))
         return fwd, bwd
+
+
+class RfcEngine:
+    """Recurrent flow completion resident on one GPU: the second stage of --inpaint-mode propainter (reference
+    RecurrentFlowCompleteNet.forward_bidirect_flow + combine_flow, recurrent_flow_completion.py:313-348)."""
+
+    def __init__(self, state_dict, device=0):
+        self._h = C.c_void_p()
+        check(lib.vsr_rfc_create(C.byref(self._h)))
+        try:
+            for key, val in state_dict.items():
+                arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                shape = (C.c_int64 * arr.ndim)(*arr.shape)
+                check(lib.vsr_rfc_set_param(self._h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+            if device is not None and device >= 0:
+                require_gpu()
+            self.device_index = -1 if device is None else int(device)
+            check(lib.vsr_rfc_finalize(self._h, self.device_index))
+        except Exception:
+            lib.vsr_rfc_destroy(self._h)
+            self._h = None
+            raise
+        self.device = torch.device("cuda", self.device_index) if self.device_index >= 0 else torch.device("cpu")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vsr_rfc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def packed_weights(self):
+        n = lib.vsr_rfc_packed_weights(self._h, None, 0)
+        out = np.empty(n, dtype=np.float32)
+        lib.vsr_rfc_packed_weights(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def flops(self, t, H, W):
+        return lib.vsr_rfc_flops(self._h, t, H, W)
+
+    def read_buffer(self, buf, count, offset=0):
+        out = np.empty(count, dtype=np.float32)
+        check(lib.vsr_rfc_read_buffer(self._h, buf, offset, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def complete(self, flows_f, flows_b, masks):
+        """flows fp32 [t-1,2,H,W] and masks uint8 [t,H,W] (non-zero = hole) on the GPU -> completed (forward, backward) flows."""
+        assert flows_f.dtype == torch.float32 and flows_f.is_cuda and flows_f.is_contiguous() and flows_b.is_contiguous()
+        assert masks.dtype == torch.uint8 and masks.is_cuda and masks.is_contiguous()
+        T, _, H, W = flows_f.shape
+        assert masks.shape == (T + 1, H, W) and flows_b.shape == flows_f.shape
+        of, ob = torch.empty_like(flows_f), torch.empty_like(flows_b)
+        with torch.cuda.device(flows_f.device):
+            check(lib.vsr_rfc_complete(self._h, C.c_void_p(flows_f.data_ptr()), C.c_void_p(flows_b.data_ptr()), C.c_void_p(masks.data_ptr()),
+                                       T + 1, H, W, C.c_void_p(of.data_ptr()), C.c_void_p(ob.data_ptr()), _stream_ptr()))
+        return of, ob
