@@ -175,6 +175,48 @@ def _rfc_fixture():
                         comb_f=cf[0, :, :, ::2, ::2].numpy(), comb_b=cb[0, :, :, ::2, ::2].numpy())
 
 
+def propainter_inputs(seed, t, lt, h, w):
+    """Seeded inputs of the ProPainter generator: frames [t,3,h,w] in [-1,1], masks [t,1,h,w] in {0,1}, completed flows
+    [lt-1,2,h,w] (smooth, a few pixels) for the lt local frames."""
+    rng = np.random.default_rng(seed)
+    base = torch.from_numpy(rng.uniform(-1, 1, (t, 3, h // 4 + 1, w // 4 + 1)).astype(np.float32))
+    frames = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=True).numpy()
+    frames = np.clip(frames + rng.normal(0, 0.05, frames.shape).astype(np.float32), -1, 1).astype(np.float32)
+    masks = np.zeros((t, 1, h, w), dtype=np.float32)
+    masks[:, :, h // 2 + 2: h - h // 8, w // 12: w - w // 12] = 1
+    fl = torch.from_numpy(rng.standard_normal((2, 2, h // 8 + 2, w // 8 + 2)).astype(np.float32) * 2.5)
+    up = torch.nn.functional.interpolate(fl, size=(h, w), mode="bilinear", align_corners=True).numpy()
+    ff = np.stack([up[0] + 0.2 * i for i in range(lt - 1)]).astype(np.float32)
+    fb = np.stack([-up[0] - 0.2 * i + 0.3 * up[1] for i in range(lt - 1)]).astype(np.float32)
+    return frames, masks, ff, fb
+
+
+def _propainter_fixture():
+    """InpaintGenerator.img_propagation + forward (propainter.py:316-378) as PropainterInpaint.inpaint chains them
+    (propainter_inpaint.py:283-341), run from the reference with oracle/deform_conv.py for torchvision.ops.deform_conv2d."""
+    from oracle.deform_conv import deform_conv2d
+    from vsr_amd.synth import make_propainter_state_dict
+
+    sys.modules["torchvision"].ops.deform_conv2d = deform_conv2d
+    from backend.inpaint.video.model.propainter import InpaintGenerator
+
+    net = InpaintGenerator(init_weights=False).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in make_propainter_state_dict(0).items()}, strict=True)
+    assert sum(p.numel() for p in net.parameters()) == 39429667          # SURVEY.md section 8(c)
+    t, lt, h, w = 7, 5, 64, 96
+    frames, masks, ff, fb = propainter_inputs(41, t, lt, h, w)
+    fr, mk, tf, tb = (torch.from_numpy(a)[None] for a in (frames, masks, ff, fb))
+    with torch.no_grad():
+        masked = fr * (1 - mk)
+        prop, upd = net.img_propagation(masked[:, :lt], (tf, tb), mk[:, :lt].clone(), "nearest")
+        upd_frames = fr[:, :lt] * (1 - mk[:, :lt]) + prop.view(1, lt, 3, h, w) * mk[:, :lt]
+        sel = torch.cat([upd_frames, masked[:, lt:]], 1)
+        sel_upd = torch.cat([upd.view(1, lt, 1, h, w), mk[:, lt:]], 1)
+        out = net(sel, (tf, tb), mk, sel_upd, lt)
+    np.savez_compressed(os.path.join(OUT, "propainter.npz"), seed=41, prop=prop.view(lt, 3, h, w)[:, :, ::2, ::2].numpy(),
+                        upd_mask=upd.view(lt, h, w).numpy().astype(np.uint8), out=out[0].numpy())
+
+
 def main():
     from vsr_amd.synth import make_state_dict
 
@@ -223,6 +265,7 @@ def main():
 
     _raft_fixture()
     _rfc_fixture()
+    _propainter_fixture()
 
     # ---- batch_generator (tools/inpaint_tools.py:7-29), executed from the reference ----
     cases = [(1200, 50), (300, 50), (600, 50), (1200, 70), (49, 50), (50, 50), (51, 50), (75, 50), (1, 50), (0, 50),

@@ -139,3 +139,26 @@ def test_deform_conv_restatement_reduces_to_conv2d():
     # (the first output column differs by construction: the shifted conv pads where the deformable one still sees x = 0)
     assert torch.allclose(deform_conv2d(x, off2, w, b, 1, 1, 1, torch.ones(2, 9 * 16, 9, 11))[..., 1:],
                           torch.nn.functional.conv2d(xs, w, b, padding=1)[..., 1:], atol=2e-4)
+
+
+def test_propainter_generator_matches_reference():
+    """oracle/propainter.py (image propagation + generator forward) against the reference InpaintGenerator (fixture from
+    oracle/make_golden.py; deform_conv2d restated)."""
+    from oracle.make_golden import propainter_inputs
+    from oracle.propainter import ProPainterOracle
+    from vsr_amd.synth import make_propainter_state_dict, propainter_state_dict_spec
+
+    assert sum(int(np.prod(s)) for k, s in propainter_state_dict_spec() if not k.endswith("valid_ind_rolled")) == 39429667
+    g = np.load(os.path.join(GOLD, "propainter.npz"))
+    t, lt, h, w = 7, 5, 64, 96
+    frames, masks, ff, fb = (torch.from_numpy(a) for a in propainter_inputs(int(g["seed"]), t, lt, h, w))
+    o = ProPainterOracle(make_propainter_state_dict(0))
+    masked = frames * (1 - masks)
+    prop, upd = o.img_propagation(masked[:lt], ff, fb, masks[:lt].clone())
+    _close(prop[:, :, ::2, ::2].numpy(), g["prop"], "propagated frames")
+    assert np.array_equal(upd[:, 0].numpy().astype(np.uint8), g["upd_mask"])
+    assert upd.sum() < masks[:lt].sum(), "image propagation must fill part of the hole"
+    upd_frames = frames[:lt] * (1 - masks[:lt]) + prop * masks[:lt]
+    out = o.forward(torch.cat([upd_frames, masked[lt:]]), ff, fb, masks, torch.cat([upd, masks[lt:]]), lt)
+    err = np.abs(out.numpy() - g["out"]).max()
+    assert err <= 2e-3, f"generator output: max abs err {err:.3e} (tanh range)"

@@ -276,3 +276,90 @@ def make_rfc_state_dict(seed=0):
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# ProPainter InpaintGenerator (backend/inpaint/video/model/propainter.py:250-314)
+# ------------------------------------------------------------------------------------------------
+def propainter_valid_ind_rolled(window=(5, 9)):
+    """SparseWindowAttention's buffer (sparse_transformer.py:141-154): indices of the rolled-window tokens that lie
+    outside the current window, over the concatenation (top-left, top-right, bottom-left, bottom-right)."""
+    wh, ww = window
+    eh, ew = (wh + 1) // 2, (ww + 1) // 2
+    m = np.ones((4, wh, ww), dtype=np.int64)
+    m[0, :-eh, :-ew] = 0
+    m[1, :-eh, ew:] = 0
+    m[2, eh:, :-ew] = 0
+    m[3, eh:, ew:] = 0
+    return np.nonzero(m.reshape(-1))[0].astype(np.int64)
+
+
+def propainter_state_dict_spec():
+    spec = []
+
+    def add(name, *shape):
+        spec.append((name + ".weight", tuple(shape)))
+        spec.append((name + ".bias", (shape[0],)))
+
+    for i, (co, ci) in zip(range(0, 18, 2), ((64, 5), (64, 64), (128, 64), (256, 128), (384, 256), (512, 320), (384, 192), (256, 80), (128, 512))):
+        add(f"encoder.layers.{i}", co, ci, 3, 3)
+    add("decoder.0.conv", 128, 128, 3, 3)
+    add("decoder.2", 64, 128, 3, 3)
+    add("decoder.4.conv", 64, 64, 3, 3)
+    add("decoder.6", 3, 64, 3, 3)
+    add("ss.embedding", 512, 6272)
+    add("sc.embedding", 6272, 512)
+    add("sc.bias_conv", 128, 128, 3, 3)
+    for mod in ("backward_1", "forward_1"):
+        p = f"feat_prop_module.deform_align.{mod}"
+        add(p, 128, 128, 3, 3)
+        add(p + ".conv_offset.0", 128, 261, 3, 3)
+        add(p + ".conv_offset.2", 128, 128, 3, 3)
+        add(p + ".conv_offset.4", 128, 128, 3, 3)
+        add(p + ".conv_offset.6", 432, 128, 3, 3)
+    for mod in ("backward_1", "forward_1"):
+        add(f"feat_prop_module.backbone.{mod}.0", 128, 258, 3, 3)
+        add(f"feat_prop_module.backbone.{mod}.2", 128, 128, 3, 3)
+    add("feat_prop_module.fuse.0", 128, 258, 3, 3)
+    add("feat_prop_module.fuse.2", 128, 128, 3, 3)
+    for i in range(8):
+        p = f"transformers.transformer.{i}."
+        spec.append((p + "attention.valid_ind_rolled", (148,)))
+        for name in ("key", "query", "value", "proj"):
+            add(p + "attention." + name, 512, 512)
+        add(p + "attention.pool_layer", 512, 1, 4, 4)
+        for name in ("norm1", "norm2"):
+            add(p + name, 512)
+        add(p + "mlp.fc1.0", 1960, 512)
+        add(p + "mlp.fc2.1", 512, 1960)
+    return spec
+
+
+def make_propainter_state_dict(seed=0):
+    """Stand-in for weights/ProPainter.pth (missing blob): variance-preserving weights, non-trivial LayerNorm affine and
+    deformable offsets (the reference zero-initialises the offset head, propainter.py:56-57)."""
+    rng = np.random.default_rng(seed + 313)
+    sd = {}
+    for key, shape in propainter_state_dict_spec():
+        leaf = key.rsplit(".", 1)[1]
+        if leaf == "valid_ind_rolled":
+            sd[key] = propainter_valid_ind_rolled()
+        elif ".norm" in key:
+            sd[key] = (rng.uniform(0.7, 1.3, shape) if leaf == "weight" else rng.normal(0, 0.1, shape)).astype(np.float32)
+        elif "pool_layer" in key:
+            sd[key] = (np.full(shape, 1.0 / 16) if leaf == "weight" else np.zeros(shape)).astype(np.float32)
+        elif leaf == "weight":
+            fan_in = int(np.prod(shape[1:]))
+            gain = 1.2
+            if "conv_offset.6" in key:
+                gain = 0.4
+            elif "attention.query" in key or "attention.key" in key:
+                gain = 1.6
+            elif "mlp.fc2" in key or "attention.proj" in key or "sc.embedding" in key:
+                gain = 0.7
+            elif key.startswith("decoder.6"):
+                gain = 0.7
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
+        else:
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
+    return sd
