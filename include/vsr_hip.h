@@ -264,6 +264,19 @@ int vsr_rfc_read_buffer(vsr_rfc_t* h, int buf, int64_t offset, int64_t count, fl
 double vsr_rfc_flops(vsr_rfc_t* h, int t, int H, int W);
 
 /* ---------------------------------------------------------------------------------------
+ * ProPainter generator, built stage by stage.
+ * vsr_pp_img_propagation = InpaintGenerator.img_propagation(masked_frames, completed_flows, masks, 'nearest')
+ * (backend/inpaint/video/model/propainter.py:316-319; BidirectionalPropagation(3, learnable=False) :104-193).
+ * ------------------------------------------------------------------------------------- */
+typedef struct vsr_pp vsr_pp_t;
+int vsr_pp_create(int device, vsr_pp_t** out);
+void vsr_pp_destroy(vsr_pp_t* h);
+/* masked_frames fp32 [t][3][H][W] in [-1,1] (frames * (1 - mask)), flows fp32 [t-1][2][H][W] (completed), masks uint8 [t][H][W]
+ * (non-zero = hole), all on the device.  Outputs: propagated frames fp32 [t][3][H][W] and updated masks uint8 [t][H][W] {0,1}. */
+int vsr_pp_img_propagation(vsr_pp_t* h, const float* masked_frames_dev, const float* flows_f_dev, const float* flows_b_dev,
+                           const uint8_t* masks_dev, int t, int H, int W, float* out_frames_dev, uint8_t* out_masks_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
@@ -272,7 +285,9 @@ enum { VSR_EW_IM2COL7_U8 = 1, VSR_EW_INORM_STATS = 2, VSR_EW_INORM_APPLY = 3, VS
        VSR_EW_IM2COL7_FLOW = 6, VSR_EW_AVGPOOL2 = 7, VSR_EW_CORR_LOOKUP = 8, VSR_EW_GRU_RH = 9, VSR_EW_GRU_UPDATE = 10,
        VSR_EW_CONVEX_UP = 11,
        /* flow completion (csrc/rfc_plan.h) */
-       VSR_EW_RFC_IM2COL5 = 20, VSR_EW_DEFORM_COLS = 21, VSR_EW_RFC_COMBINE = 22 };
+       VSR_EW_RFC_IM2COL5 = 20, VSR_EW_DEFORM_COLS = 21, VSR_EW_RFC_COMBINE = 22,
+       /* ProPainter generator (csrc/pp_plan.h) */
+       VSR_EW_PP_MASK_F32 = 30, VSR_EW_PP_IMGPROP = 31, VSR_EW_PP_COPY = 32 };
 typedef struct VsrOpInfo {
     int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter, 6 RAFT elementwise */
     int32_t nitems, tile_cfg, bmode;
@@ -309,6 +324,7 @@ typedef struct VsrSoftmaxInfo {
 int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
 int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out);
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
+int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);
 void vsr_plan_destroy(vsr_plan_t* p);
 int vsr_plan_num_buffers(const vsr_plan_t* p);
 int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf);

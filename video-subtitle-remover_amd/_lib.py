@@ -121,6 +121,10 @@ SIGNATURES = {
     "vsr_rfc_complete": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vsr_rfc_read_buffer": (_I, [_P, _I, _L, _L, _P]),
     "vsr_rfc_flops": (_D, [_P, _I, _I, _I]),
+    "vsr_pp_create": (_I, [_I, C.POINTER(_P)]),
+    "vsr_pp_destroy": (None, [_P]),
+    "vsr_pp_img_propagation": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "vsr_pp_imgprop_plan_create": (_I, [_I, _I, _I, C.POINTER(_P)]),
     "vsr_plan_destroy": (None, [_P]),
     "vsr_plan_num_buffers": (_I, [_P]),
     "vsr_plan_buffer_elems": (_L, [_P, _I]),

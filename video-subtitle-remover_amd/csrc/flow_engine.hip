@@ -20,6 +20,8 @@
 #include "raft_kernels.h"
 #include "raft_plan.h"
 #include "rfc_plan.h"
+#include "pp_kernels.h"
+#include "pp_plan.h"
 
 using namespace vsr;
 
@@ -231,6 +233,18 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
                 rc = vsr_rfc_launch_combine(B(op.ibuf[0], 0), ip[3], B(FB_IN_FLOW_F, 0), B(FB_IN_FLOW_B, 0), (const uint8_t*)ws.bufs[FB_IN_MASK],
                                             ip[0], ip[1], ip[2], B(op.ibuf[1], 0), B(op.ibuf[2], 0), stream);
                 break;
+            case EW_PP_MASK_F32:
+                rc = vsr_pp_launch_mask_f32((const uint8_t*)ws.bufs[op.ibuf[0]], ip[0], B(op.ibuf[1], 0), stream);
+                break;
+            case EW_PP_IMGPROP: {
+                // ipar: C, h, w, first, frame, previous frame, flow index, direction (pp_plan.cpp)
+                const int64_t hw = (int64_t)ip[1] * ip[2], fe = (int64_t)ip[0] * hw;
+                const float* fprop = B(ip[7] == 0 ? PB_IN_FLOW_F : PB_IN_FLOW_B, (int64_t)ip[6] * 2 * hw);
+                const float* fcheck = B(ip[7] == 0 ? PB_IN_FLOW_B : PB_IN_FLOW_F, (int64_t)ip[6] * 2 * hw);
+                rc = vsr_pp_launch_imgprop(B(op.ibuf[2], ip[5] * fe), B(op.ibuf[3], ip[5] * hw), B(op.ibuf[0], ip[4] * fe), B(op.ibuf[1], ip[4] * hw),
+                                           fprop, fcheck, ip[0], ip[1], ip[2], ip[3], B(op.ibuf[2], ip[4] * fe), B(op.ibuf[3], ip[4] * hw), stream);
+                break;
+            }
             default:
                 return rfail(VSR_ERR_STATE, "unknown elementwise op");
             }
@@ -341,6 +355,17 @@ static int rfc_plan_dev(vsr_rfc* h, int t, int H, int W, FlowPlanDev** out)
     h->plans[key] = std::move(pd);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// ProPainter generator
+// ---------------------------------------------------------------------------------------
+struct vsr_pp {
+    int device = -1;
+    Workspace ws;
+    std::tuple<int, int, int> geom{0, 0, 0};
+    std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> imgPlans;
+    vsr_pp() { ws.init(PB_COUNT, PB_WEIGHTS, {PB_IN_MASK_U8, PB_IN_MASK_UPD_U8, PB_OUT_MASK_U8}); }
+};
 
 extern "C" {
 
@@ -548,6 +573,81 @@ int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** ou
         *out = p.release();
     } catch (const std::exception& e) {
         return rfail(VSR_ERR_ARG, std::string("flow-completion plan: ") + e.what());
+    }
+    return 0;
+}
+
+// ---- ProPainter generator --------------------------------------------------------------------------------------------
+
+int vsr_pp_create(int device, vsr_pp_t** out)
+{
+    if (!out) return rfail(VSR_ERR_ARG, "null out pointer");
+    if (device >= 0 && device >= vsr_device_count()) return rfail(VSR_ERR_NOGPU, "no such HIP device; there is no CPU fallback");
+    *out = new vsr_pp();
+    (*out)->device = device;
+    return 0;
+}
+
+void vsr_pp_destroy(vsr_pp_t* h)
+{
+    if (!h) return;
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        h->imgPlans.clear();
+        h->ws.release();
+    }
+    delete h;
+}
+
+int vsr_pp_img_propagation(vsr_pp_t* h, const float* masked_frames_dev, const float* flows_f_dev, const float* flows_b_dev,
+                           const uint8_t* masks_dev, int t, int H, int W, float* out_frames_dev, uint8_t* out_masks_dev, void* stream_)
+{
+    if (!h || !masked_frames_dev || !masks_dev || !out_frames_dev || !out_masks_dev || (t > 1 && (!flows_f_dev || !flows_b_dev)))
+        return rfail(VSR_ERR_ARG, "bad argument");
+    if (h->device < 0) return rfail(VSR_ERR_NOGPU, "handle was created without a HIP device; there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const auto key = std::make_tuple(t, H, W);
+    FlowPlanDev* pd = nullptr;
+    auto it = h->imgPlans.find(key);
+    if (it != h->imgPlans.end()) {
+        pd = it->second.get();
+    } else {
+        std::unique_ptr<PlanIR> plan;
+        try {
+            plan.reset(new PpImgPropPlan(t, H, W));
+        } catch (const std::exception& e) {
+            return rfail(VSR_ERR_ARG, std::string("image-propagation plan: ") + e.what());
+        }
+        if (h->ws.needs_growth(*plan)) h->imgPlans.clear();
+        std::unique_ptr<FlowPlanDev> npd;
+        RCCHK(materialize(h->ws, std::move(plan), &npd));
+        pd = npd.get();
+        h->imgPlans[key] = std::move(npd);
+    }
+    const size_t hw = (size_t)H * W;
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FRAMES], masked_frames_dev, (size_t)t * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));
+    if (t > 1) {
+        HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_F], flows_f_dev, (size_t)(t - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_B], flows_b_dev, (size_t)(t - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    RCCHK(run_plan(h->ws, pd, 0, stream));
+    HIPCHK(hipMemcpyAsync(out_frames_dev, h->ws.bufs[PB_FW], (size_t)t * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (vsr_pp_launch_mask_u8(h->ws.f(PB_FWM), (int64_t)t * hw, out_masks_dev, stream) != 0) return rfail(VSR_ERR_HIP, "mask conversion launch failed");
+    return 0;
+}
+
+int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out)
+{
+    if (!out) return rfail(VSR_ERR_ARG, "bad argument");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new PpImgPropPlan(t, H, W));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("image-propagation plan: ") + e.what());
     }
     return 0;
 }

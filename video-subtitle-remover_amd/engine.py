@@ -286,3 +286,40 @@ class RfcEngine:
             check(lib.vsr_rfc_complete(self._h, C.c_void_p(flows_f.data_ptr()), C.c_void_p(flows_b.data_ptr()), C.c_void_p(masks.data_ptr()),
                                        T + 1, H, W, C.c_void_p(of.data_ptr()), C.c_void_p(ob.data_ptr()), _stream_ptr()))
         return of, ob
+
+
+class PpEngine:
+    """ProPainter generator stages on one GPU (reference InpaintGenerator, backend/inpaint/video/model/propainter.py)."""
+
+    def __init__(self, device=0):
+        if device is not None and device >= 0:
+            require_gpu()
+        self.device_index = -1 if device is None else int(device)
+        self._h = C.c_void_p()
+        check(lib.vsr_pp_create(self.device_index, C.byref(self._h)))
+        self.device = torch.device("cuda", self.device_index) if self.device_index >= 0 else torch.device("cpu")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vsr_pp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def img_propagation(self, masked_frames, flows_f, flows_b, masks):
+        """InpaintGenerator.img_propagation(..., 'nearest'): masked_frames fp32 [t,3,H,W], flows fp32 [t-1,2,H,W], masks uint8
+        [t,H,W] on the GPU -> (propagated frames fp32 [t,3,H,W], updated masks uint8 [t,H,W])."""
+        assert masked_frames.dtype == torch.float32 and masked_frames.is_cuda and masked_frames.is_contiguous()
+        assert masks.dtype == torch.uint8 and masks.is_contiguous() and flows_f.is_contiguous() and flows_b.is_contiguous()
+        t, _, H, W = masked_frames.shape
+        out = torch.empty_like(masked_frames)
+        om = torch.empty_like(masks)
+        with torch.cuda.device(masked_frames.device):
+            check(lib.vsr_pp_img_propagation(self._h, C.c_void_p(masked_frames.data_ptr()), C.c_void_p(flows_f.data_ptr()),
+                                             C.c_void_p(flows_b.data_ptr()), C.c_void_p(masks.data_ptr()), t, H, W,
+                                             C.c_void_p(out.data_ptr()), C.c_void_p(om.data_ptr()), _stream_ptr()))
+        return out, om
