@@ -275,6 +275,24 @@ void vsr_pp_destroy(vsr_pp_t* h);
  * (non-zero = hole), all on the device.  Outputs: propagated frames fp32 [t][3][H][W] and updated masks uint8 [t][H][W] {0,1}. */
 int vsr_pp_img_propagation(vsr_pp_t* h, const float* masked_frames_dev, const float* flows_f_dev, const float* flows_b_dev,
                            const uint8_t* masks_dev, int t, int H, int W, float* out_frames_dev, uint8_t* out_masks_dev, void* stream);
+/* InpaintGenerator weights: one entry of torch.load('ProPainter.pth') (propainter.py:308-311) per call, then finalize
+ * (packs the grouped encoder convs, pads the 261 / 258-channel propagation convs, fuses q/k/v; uploads when the handle
+ * has a device) */
+int vsr_pp_set_param(vsr_pp_t* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int vsr_pp_finalize(vsr_pp_t* h);
+int64_t vsr_pp_packed_weights(const vsr_pp_t* h, float* out, int64_t capacity);
+/* host helper: one flag per 5x9 attention window (row-major), SparseWindowAttention's "window touches the hole" test
+ * (sparse_transformer.py:229-236) from the HOST copy of the local frames' masks_in, uint8 [lt][H][W]; returns the number
+ * of windows (or < 0).  The flags select the key set of every window and are part of the plan. */
+int vsr_pp_window_flags(const uint8_t* masks_host, int lt, int H, int W, uint8_t* flags, int capacity);
+/* InpaintGenerator.forward(masked_frames, completed_flows, masks_in, masks_updated, num_local_frames) in eval mode
+ * (propainter.py:321-378): frames fp32 [t][3][H][W] (the first lt are the local ones), flows fp32 [lt-1][2][H][W], masks uint8
+ * [t][H][W], all on the device; window_flags from vsr_pp_window_flags.  Output: tanh image fp32 [lt][3][H][W]. */
+int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev,
+                   const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t, int lt, int H, int W,
+                   const uint8_t* window_flags, int nflags, float* out_dev, void* stream);
+int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook */
+double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags);
 
 /* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
@@ -287,7 +305,9 @@ enum { VSR_EW_IM2COL7_U8 = 1, VSR_EW_INORM_STATS = 2, VSR_EW_INORM_APPLY = 3, VS
        /* flow completion (csrc/rfc_plan.h) */
        VSR_EW_RFC_IM2COL5 = 20, VSR_EW_DEFORM_COLS = 21, VSR_EW_RFC_COMBINE = 22,
        /* ProPainter generator (csrc/pp_plan.h) */
-       VSR_EW_PP_MASK_F32 = 30, VSR_EW_PP_IMGPROP = 31, VSR_EW_PP_COPY = 32 };
+       VSR_EW_PP_MASK_F32 = 30, VSR_EW_PP_IMGPROP = 31, VSR_EW_PP_COPY = 32, VSR_EW_PP_IM2COL3 = 33, VSR_EW_PP_DS_FLOW = 34,
+       VSR_EW_PP_DS_MASK = 35, VSR_EW_PP_FEATPROP_PREP = 36, VSR_EW_PP_DEFORM_COLS = 37, VSR_EW_PP_LAYERNORM = 38, VSR_EW_PP_POOL = 39,
+       VSR_EW_PP_FOLD = 40, VSR_EW_PP_UNFOLD_GELU = 41, VSR_EW_PP_TANH_OUT = 42 };
 typedef struct VsrOpInfo {
     int32_t kind; /* 0 norm_im2col, 1 gemm, 2 softmax, 3 upsample2x, 4 decode_out, 5 reduce_scatter, 6 RAFT elementwise */
     int32_t nitems, tile_cfg, bmode;
@@ -325,6 +345,7 @@ int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
 int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out);
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);
+int vsr_pp_gen_plan_create(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, vsr_plan_t** out);
 void vsr_plan_destroy(vsr_plan_t* p);
 int vsr_plan_num_buffers(const vsr_plan_t* p);
 int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf);

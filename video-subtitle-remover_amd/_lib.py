@@ -125,6 +125,14 @@ SIGNATURES = {
     "vsr_pp_destroy": (None, [_P]),
     "vsr_pp_img_propagation": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vsr_pp_imgprop_plan_create": (_I, [_I, _I, _I, C.POINTER(_P)]),
+    "vsr_pp_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "vsr_pp_finalize": (_I, [_P]),
+    "vsr_pp_packed_weights": (_L, [_P, _P, _L]),
+    "vsr_pp_window_flags": (_I, [_P, _I, _I, _I, _P, _I]),
+    "vsr_pp_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "vsr_pp_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_pp_flops": (_D, [_P, _I, _I, _I, _I, _P, _I]),
+    "vsr_pp_gen_plan_create": (_I, [_P, _I, _I, _I, _I, _P, _I, C.POINTER(_P)]),
     "vsr_plan_destroy": (None, [_P]),
     "vsr_plan_num_buffers": (_I, [_P]),
     "vsr_plan_buffer_elems": (_L, [_P, _I]),

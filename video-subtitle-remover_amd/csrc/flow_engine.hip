@@ -15,6 +15,7 @@
 #include <tuple>
 #include <vector>
 #include "../../include/vsr_hip.h"
+#include "elementwise.h"
 #include "gather_gemm.h"
 #include "plan_c.h"
 #include "raft_kernels.h"
@@ -124,7 +125,8 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
     auto T = [&](int id) -> const int32_t* { return id < 0 ? nullptr : pd->dTables + pd->toff[id]; };
     auto F = [&](int buf, int64_t off) -> float* { return buf < 0 ? nullptr : ws.f(buf, off); };
     size_t descBytes = 0;
-    for (const Op& op : P.ops) descBytes += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+    for (const Op& op : P.ops)
+        descBytes += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64 + (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
     std::vector<char> hostDesc(descBytes + 64, 0);
     HIPCHK(hipMalloc(&pd->dDescs, descBytes + 64));
     size_t cursor = 0;
@@ -154,6 +156,21 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
             for (const GemmItem& g : op.gemm)
                 if (g.tilesN > 4) od.nQueues = 1;
             cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+        } else if (op.kind == OP_SOFTMAX) {
+            SMProblem* hp = (SMProblem*)(hostDesc.data() + cursor);
+            int rowStart = 0;
+            for (size_t j = 0; j < op.softmax.size(); ++j) {
+                const SoftmaxItem& sm = op.softmax[j];
+                SMProblem& q = hp[j];
+                q.S = F(sm.bufS, sm.offS); q.P = F(sm.bufP, sm.offP);
+                q.M = sm.M; q.N = sm.N; q.ldS = sm.ldS; q.ldP = sm.ldP; q.nsplit = sm.nsplit; q.rowStart = rowStart;
+                q.scale = sm.scale; q.flags = 0; q.splitStride = sm.splitStride;
+                rowStart += (sm.M + 3) / 4 * 4;
+            }
+            od.dDesc = (char*)pd->dDescs + cursor;
+            od.nitems = (int)op.softmax.size();
+            od.total = rowStart;
+            cursor += (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
         }
         pd->ops.push_back(od);
     }
@@ -176,6 +193,8 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         if (op.kind == OP_GEMM) {
             rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, 3, od.nQueues,
                                             nullptr, stream);
+        } else if (op.kind == OP_SOFTMAX) {
+            rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
         } else if (op.kind == OP_UPSAMPLE2X) {
             rc = vsr_launch_upsample2x(B(op.bufSrc, 0), op.H, op.W, op.C, op.haloS, B(op.bufDst, 0), op.haloD, op.n, stream);
         } else if (op.kind == OP_EW) {
@@ -245,6 +264,46 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
                                            fprop, fcheck, ip[0], ip[1], ip[2], ip[3], B(op.ibuf[2], ip[4] * fe), B(op.ibuf[3], ip[4] * hw), stream);
                 break;
             }
+            case EW_PP_IM2COL3:
+                rc = vsr_pp_launch_im2col3(B(op.ibuf[0], 0), (const uint8_t*)ws.bufs[op.ibuf[1]], (const uint8_t*)ws.bufs[op.ibuf[2]], ip[0], ip[1],
+                                           ip[2], B(op.ibuf[3], 0), stream);
+                break;
+            case EW_PP_DS_FLOW:
+                rc = vsr_pp_launch_ds_flow(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], B(op.ibuf[1], 0), stream);
+                break;
+            case EW_PP_DS_MASK:
+                rc = vsr_pp_launch_ds_mask((const uint8_t*)ws.bufs[op.ibuf[0]], (const uint8_t*)ws.bufs[op.ibuf[1]], ip[0], ip[1], ip[2],
+                                           B(op.ibuf[2], op.ioff[2]), ip[3], ip[4], stream);
+                break;
+            case EW_PP_FEATPROP_PREP: {
+                // ipar: h, w, halo, C, warped slot, misc slot ; ioff: propagated feature, flow (prop), flow (check), mask slot
+                const int64_t fe = (int64_t)(ip[0] + 2 * ip[2]) * (ip[1] + 2 * ip[2]) * ip[3];
+                rc = vsr_pp_launch_featprop_prep(B(op.ibuf[0], op.ioff[0]), B(op.ibuf[1], op.ioff[1]), B(op.ibuf[2], op.ioff[2]),
+                                                 B(op.ibuf[0], op.ioff[3]), ip[0], ip[1], ip[2], ip[3], B(op.ibuf[0], ip[4] * fe),
+                                                 B(op.ibuf[0], ip[5] * fe), stream);
+                break;
+            }
+            case EW_PP_DEFORM_COLS:
+                rc = vsr_pp_launch_deform_cols(B(op.ibuf[0], op.ioff[0]), B(op.ibuf[1], 0), ip[4], B(op.ibuf[2], op.ioff[2]), op.fpar[0], ip[0], ip[1],
+                                               ip[2], ip[3], B(op.ibuf[3], 0), stream);
+                break;
+            case EW_PP_LAYERNORM:
+                rc = vsr_pp_launch_layernorm(B(op.ibuf[0], 0), B(ws.weights, op.ioff[0]), B(ws.weights, op.ioff[1]), ip[0], ip[1], ip[2], ip[3], ip[4],
+                                             ip[5], B(op.ibuf[1], 0), stream);
+                break;
+            case EW_PP_POOL:
+                rc = vsr_pp_launch_pool(B(op.ibuf[0], 0), B(ws.weights, op.ioff[2]), B(ws.weights, op.ioff[3]), ip[0], ip[1], ip[2], ip[3], ip[4],
+                                        ip[5], B(op.ibuf[0], op.ioff[1]), stream);
+                break;
+            case EW_PP_FOLD:
+                rc = vsr_pp_launch_fold(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], ip[8], B(op.ibuf[1], 0), stream);
+                break;
+            case EW_PP_UNFOLD_GELU:
+                rc = vsr_pp_launch_unfold_gelu(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], B(op.ibuf[1], 0), stream);
+                break;
+            case EW_PP_TANH_OUT:
+                rc = vsr_pp_launch_tanh_out(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], B(op.ibuf[1], 0), stream);
+                break;
             default:
                 return rfail(VSR_ERR_STATE, "unknown elementwise op");
             }
@@ -360,10 +419,13 @@ static int rfc_plan_dev(vsr_rfc* h, int t, int H, int W, FlowPlanDev** out)
 // ProPainter generator
 // ---------------------------------------------------------------------------------------
 struct vsr_pp {
+    PpModel model;
+    bool finalized = false;
     int device = -1;
     Workspace ws;
-    std::tuple<int, int, int> geom{0, 0, 0};
+    std::string geom;                          // shape key the halos of the workspace are currently laid out for
     std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> imgPlans;
+    std::map<std::string, std::unique_ptr<FlowPlanDev>> genPlans;
     vsr_pp() { ws.init(PB_COUNT, PB_WEIGHTS, {PB_IN_MASK_U8, PB_IN_MASK_UPD_U8, PB_OUT_MASK_U8}); }
 };
 
@@ -595,9 +657,141 @@ void vsr_pp_destroy(vsr_pp_t* h)
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
         h->imgPlans.clear();
+        h->genPlans.clear();
         h->ws.release();
     }
     delete h;
+}
+
+int vsr_pp_set_param(vsr_pp_t* h, const char* key, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h || !key || !data || (ndim > 0 && !shape)) return rfail(VSR_ERR_ARG, "bad argument");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.set_param(key, data, shape, ndim, err)) return rfail(VSR_ERR_ARG, err);
+    return 0;
+}
+
+int vsr_pp_finalize(vsr_pp_t* h)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.pack(err)) return rfail(VSR_ERR_ARG, err);
+    if (h->device >= 0) RCCHK(upload_weights(h->ws, h->model.packed, h->device));
+    h->finalized = true;
+    return 0;
+}
+
+int64_t vsr_pp_packed_weights(const vsr_pp_t* h, float* out, int64_t capacity)
+{
+    if (!h || !h->model.packed_ready()) { rfail(VSR_ERR_STATE, "model not finalized"); return -1; }
+    const int64_t n = (int64_t)h->model.packed.size();
+    if (out && capacity >= n) memcpy(out, h->model.packed.data(), (size_t)n * sizeof(float));
+    return n;
+}
+
+// SparseWindowAttention's masked-window test (sparse_transformer.py:229-236) from host masks: nearest 1/4 downsampling
+// (propainter.py:345), MaxPool2d(7, 3, 3) (:351-356), zero padding to whole windows, window max, any local frame
+int vsr_pp_window_flags(const uint8_t* masks_host, int lt, int H, int W, uint8_t* flags, int capacity)
+{
+    if (!masks_host || !flags || lt < 1 || H % 4 || W % 4) return rfail(VSR_ERR_ARG, "bad argument");
+    int fh, fw, gh, gw;
+    PpGenPlan::token_grid(H, W, fh, fw, gh, gw);
+    const int nwh = gh / 5, nww = gw / 9, h = H / 4, w = W / 4;
+    if (capacity < nwh * nww) return rfail(VSR_ERR_ARG, "flag buffer too small");
+    memset(flags, 0, (size_t)nwh * nww);
+    for (int f = 0; f < lt; ++f)
+        for (int ty = 0; ty < fh; ++ty)
+            for (int tx = 0; tx < fw; ++tx) {
+                bool any = false;
+                for (int ky = 0; ky < 7 && !any; ++ky)
+                    for (int kx = 0; kx < 7 && !any; ++kx) {
+                        const int y = 3 * ty - 3 + ky, x = 3 * tx - 3 + kx;
+                        if (y >= 0 && y < h && x >= 0 && x < w && masks_host[((int64_t)f * H + 4 * y) * W + 4 * x]) any = true;
+                    }
+                if (any) flags[(ty / 5) * nww + tx / 9] = 1;
+            }
+    return nwh * nww;
+}
+
+int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_in_dev,
+                   const uint8_t* masks_updated_dev, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, float* out_dev,
+                   void* stream_)
+{
+    if (!h || !frames_dev || !masks_in_dev || !masks_updated_dev || !window_flags || !out_dev || (lt > 1 && (!flows_f_dev || !flows_b_dev)))
+        return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->finalized || h->device < 0)
+        return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device; there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    std::string key = std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W) + ":";
+    key.append((const char*)window_flags, (size_t)nflags);
+    FlowPlanDev* pd = nullptr;
+    auto it = h->genPlans.find(key);
+    if (it != h->genPlans.end()) {
+        pd = it->second.get();
+    } else {
+        std::unique_ptr<PlanIR> plan;
+        try {
+            plan.reset(new PpGenPlan(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags)));
+        } catch (const std::exception& e) {
+            return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+        }
+        if (h->ws.needs_growth(*plan)) { h->genPlans.clear(); h->imgPlans.clear(); }
+        std::unique_ptr<FlowPlanDev> npd;
+        RCCHK(materialize(h->ws, std::move(plan), &npd));
+        pd = npd.get();
+        h->genPlans[key] = std::move(npd);
+    }
+    const std::string geom = "gen:" + std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W);
+    if (h->geom != geom) {
+        RCCHK(clear_workspace(h->ws, stream));
+        h->geom = geom;
+    }
+    const size_t hw = (size_t)H * W;
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FRAMES], frames_dev, (size_t)t * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_in_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_UPD_U8], masks_updated_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));
+    if (lt > 1) {
+        HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_F], flows_f_dev, (size_t)(lt - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_B], flows_b_dev, (size_t)(lt - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    RCCHK(run_plan(h->ws, pd, 0, stream));
+    HIPCHK(hipMemcpyAsync(out_dev, h->ws.bufs[PG_OUT], (size_t)lt * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    return read_buffer(h->ws, h->device, buf, offset, count, out_host);
+}
+
+double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags)
+{
+    if (!h || !h->model.packed_ready() || !window_flags) { rfail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        PpGenPlan p(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags));
+        return p.flops;
+    } catch (const std::exception& e) {
+        rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+        return -1.0;
+    }
+}
+
+int vsr_pp_gen_plan_create(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, vsr_plan_t** out)
+{
+    if (!h || !out || !window_flags) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return rfail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new PpGenPlan(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags)));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+    }
+    return 0;
 }
 
 int vsr_pp_img_propagation(vsr_pp_t* h, const float* masked_frames_dev, const float* flows_f_dev, const float* flows_b_dev,
@@ -620,12 +814,13 @@ int vsr_pp_img_propagation(vsr_pp_t* h, const float* masked_frames_dev, const fl
         } catch (const std::exception& e) {
             return rfail(VSR_ERR_ARG, std::string("image-propagation plan: ") + e.what());
         }
-        if (h->ws.needs_growth(*plan)) h->imgPlans.clear();
+        if (h->ws.needs_growth(*plan)) { h->imgPlans.clear(); h->genPlans.clear(); }
         std::unique_ptr<FlowPlanDev> npd;
         RCCHK(materialize(h->ws, std::move(plan), &npd));
         pd = npd.get();
         h->imgPlans[key] = std::move(npd);
     }
+    h->geom = "img";                                        // planar buffers only, no halos: nothing to clear, but the generator must re-clear
     const size_t hw = (size_t)H * W;
     HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FRAMES], masked_frames_dev, (size_t)t * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));

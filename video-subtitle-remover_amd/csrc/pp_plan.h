@@ -8,14 +8,28 @@ namespace vsr {
 
 // OP_EW sub-kinds (numbering continues raft_plan.h / rfc_plan.h)
 enum PpEwKind {
-    EW_PP_MASK_F32 = 30,   // u8 masks -> fp32 {0,1}
-    EW_PP_IMGPROP = 31,    // one step of the non-learnable bidirectional image propagation
-    EW_PP_COPY = 32        // plain copy (buffer, offset, count)
+    EW_PP_MASK_F32 = 30,      // u8 masks -> fp32 {0,1}
+    EW_PP_IMGPROP = 31,       // one step of the non-learnable bidirectional image propagation
+    EW_PP_COPY = 32,          // (reserved)
+    EW_PP_IM2COL3 = 33,       // cat[frames, masks_in, masks_updated] -> im2col of the encoder's first conv
+    EW_PP_DS_FLOW = 34,       // flows at 1/4 resolution
+    EW_PP_DS_MASK = 35,       // masks at 1/4 resolution into the per-frame mask slots
+    EW_PP_FEATPROP_PREP = 36, // consistency mask + feature warp + small condition channels of a propagation step
+    EW_PP_DEFORM_COLS = 37,   // flow-guided modulated deformable-conv columns
+    EW_PP_LAYERNORM = 38,
+    EW_PP_POOL = 39,          // depthwise 4x4 stride-4 pooling tokens
+    EW_PP_FOLD = 40,          // overlapping-patch fold (optionally normalised)
+    EW_PP_UNFOLD_GELU = 41,
+    EW_PP_TANH_OUT = 42
 };
 
 enum PpBuf {
     PB_WEIGHTS = 0, PB_IN_FRAMES, PB_IN_MASK_U8, PB_IN_MASK_UPD_U8, PB_IN_FLOW_F, PB_IN_FLOW_B,
     PB_MASK_F, PB_BK, PB_BKM, PB_FW, PB_FWM, PB_OUT_MASK_U8,
+    // generator
+    PG_IM2COL, PG_E0, PG_E1, PG_E2, PG_ENC, PG_FEAT, PG_DSF_F, PG_DSF_B, PG_PROP, PG_T1, PG_T2, PG_T3, PG_OFF, PG_COLS, PG_BB, PG_FU,
+    PG_X, PG_YQ, PG_QKV, PG_S, PG_P, PG_ATT, PG_Y2, PG_F1, PG_FMAP, PG_F2, PG_SC, PG_SCF, PG_DIN, PG_UP0, PG_D0, PG_D1, PG_UP1, PG_D2, PG_D3,
+    PG_OUT,
     PB_COUNT
 };
 
@@ -25,6 +39,62 @@ class PpImgPropPlan : public PlanBuilder {
 public:
     PpImgPropPlan(int t, int H, int W);
     int t, H, W;
+};
+
+struct PpBlockW {
+    ConvW qkv, proj, fc1, fc2;
+    int64_t ln1g, ln1b, ln2g, ln2b, poolW, poolB;    // element offsets into the packed buffer
+};
+
+class PpModel {
+public:
+    PpModel() {}
+    bool set_param(const std::string& name, const float* data, const int64_t* shape, int ndim, std::string& err);
+    bool pack(std::string& err);
+    bool packed_ready() const { return ready_; }
+    static std::vector<std::string> expected_keys();
+    ConvW enc0, enc2, enc4, enc6, enc8, enc10[2], enc12[4], enc14[8], enc16;
+    ConvW off[2][4], deform[2], bb1[2], bb2[2], fuse1, fuse2;      // [0] = backward_1, [1] = forward_1
+    ConvW ss, sc, scConv, dec0, dec2, dec4, dec6;
+    PpBlockW blk[8];
+    std::vector<float> packed;
+private:
+    struct Raw { std::vector<float> v; std::vector<int64_t> shape; };
+    std::map<std::string, Raw> raw_;
+    bool ready_ = false;
+    // general packer: rows [r0, r0+nrows) of weight `key` ([cout][cin][taps]); ciPos[ci] = position of input channel ci in the
+    // padded channel axis of length cinPad (a multiple of 32); outPos[n] = row of output n in the padded row axis of length nPad
+    bool pack_conv(const std::string& key, ConvW& cw, int cout, int cin, int taps, int r0, int nrows, const std::vector<int>& ciPos, int cinPad,
+                   const std::vector<int>& outPos, int nPad, std::string& err);
+    bool pack_plain(const std::string& key, ConvW& cw, int cout, int cin, int taps, std::string& err);
+    int64_t push_vec(const std::string& key, int n, std::string& err);
+};
+
+// InpaintGenerator.forward(masked_frames, completed_flows, masks_in, masks_updated, num_local_frames) in eval mode:
+// t frames (the first lt are the local ones) of H x W (multiples of 4 with (H/4, W/4) giving at least one token).
+// windowMasked: one flag per attention window (row-major over ceil(fh/5) x ceil(fw/9)): SparseWindowAttention's
+// "mask.sum > 0" test (:229-236), computed by the caller from the masks (host side, see flow_engine.hip).
+class PpGenPlan : public PlanBuilder {
+public:
+    PpGenPlan(const PpModel& model, int t, int lt, int H, int W, const std::vector<uint8_t>& windowMasked);
+    int t, lt, H, W;
+    int h, w;            // H/4, W/4
+    int fh, fw;          // token grid (soft split 7/3/3)
+    int gh, gw;          // token grid padded to whole 5x9 windows
+    int ph, pw;          // pooled tokens per frame
+    static void token_grid(int H, int W, int& fh, int& fw, int& gh, int& gw);
+private:
+    const PpModel& m_;
+    int pickTile(int N) const;
+    int tColsChunks(const Act& a, int kh, int kw, int dil, const std::vector<int>& chunkCh);
+    void gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tColA, int K, int M, int bufC, int64_t offC, int tRowC, int tColC,
+              const ConvW& w, int act, int bufR, int64_t offR, int tRowR, int tile, Op* appendTo = nullptr);
+    void conv(const char* tag, const Act& in, const std::vector<int>& inIds, const std::vector<int>& chunkCh, int kh, int kw, int stride, int dil,
+              const Act& out, const std::vector<int>& outIds, int c0out, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds,
+              Op* appendTo = nullptr);
+    void upsample(const Act& in, const Act& out);
+    Op& ew(int kind, const char* tag);
+    void attention(int blk, const std::vector<uint8_t>& windowMasked);
 };
 
 } // namespace vsr

@@ -291,13 +291,67 @@ class RfcEngine:
 class PpEngine:
     """ProPainter generator stages on one GPU (reference InpaintGenerator, backend/inpaint/video/model/propainter.py)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, state_dict=None):
+        """state_dict: torch.load('ProPainter.pth') -- needed by forward(), not by img_propagation()."""
         if device is not None and device >= 0:
             require_gpu()
         self.device_index = -1 if device is None else int(device)
         self._h = C.c_void_p()
         check(lib.vsr_pp_create(self.device_index, C.byref(self._h)))
         self.device = torch.device("cuda", self.device_index) if self.device_index >= 0 else torch.device("cpu")
+        if state_dict is not None:
+            try:
+                for key, val in state_dict.items():
+                    arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+                    arr = np.ascontiguousarray(arr, dtype=np.float32)
+                    shape = (C.c_int64 * arr.ndim)(*arr.shape)
+                    check(lib.vsr_pp_set_param(self._h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+                check(lib.vsr_pp_finalize(self._h))
+            except Exception:
+                lib.vsr_pp_destroy(self._h)
+                self._h = None
+                raise
+
+    @property
+    def handle(self):
+        return self._h
+
+    def packed_weights(self):
+        n = lib.vsr_pp_packed_weights(self._h, None, 0)
+        out = np.empty(n, dtype=np.float32)
+        lib.vsr_pp_packed_weights(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    @staticmethod
+    def window_flags(masks_local_host):
+        """masks_in of the local frames, uint8 numpy [lt,H,W] -> one flag per attention window (numpy uint8)"""
+        m = np.ascontiguousarray(masks_local_host, dtype=np.uint8)
+        lt, H, W = m.shape
+        flags = np.zeros(4096, dtype=np.uint8)
+        n = lib.vsr_pp_window_flags(m.ctypes.data_as(C.c_void_p), lt, H, W, flags.ctypes.data_as(C.c_void_p), flags.size)
+        if n < 0:
+            check(n)
+        return flags[:n].copy()
+
+    def read_buffer(self, buf, count, offset=0):
+        out = np.empty(count, dtype=np.float32)
+        check(lib.vsr_pp_read_buffer(self._h, buf, offset, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def forward(self, frames, flows_f, flows_b, masks_in, masks_updated, lt, flags=None):
+        """InpaintGenerator.forward in eval mode: frames fp32 [t,3,H,W], flows fp32 [lt-1,2,H,W], masks uint8 [t,H,W] on the GPU
+        -> tanh output fp32 [lt,3,H,W]."""
+        assert frames.dtype == torch.float32 and frames.is_cuda and frames.is_contiguous()
+        assert masks_in.dtype == torch.uint8 and masks_in.is_contiguous() and masks_updated.is_contiguous()
+        t, _, H, W = frames.shape
+        if flags is None:
+            flags = self.window_flags(masks_in[:lt].cpu().numpy())
+        out = torch.empty((lt, 3, H, W), dtype=torch.float32, device=frames.device)
+        with torch.cuda.device(frames.device):
+            check(lib.vsr_pp_forward(self._h, C.c_void_p(frames.data_ptr()), C.c_void_p(flows_f.data_ptr()), C.c_void_p(flows_b.data_ptr()),
+                                     C.c_void_p(masks_in.data_ptr()), C.c_void_p(masks_updated.data_ptr()), t, lt, H, W,
+                                     flags.ctypes.data_as(C.c_void_p), flags.size, C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
 
     def close(self):
         if getattr(self, "_h", None):
