@@ -31,3 +31,57 @@ def test_image_propagation_bit_exact(engine, gpu_device, t, H, W):
     print(f"imgprop {t}x{H}x{W}: mask mismatches {mism:.2e}, pixel mismatches {diff:.2e}, filled {1 - rm.sum().item() / masks.sum():.3f}")
     # thresholded decisions (flow consistency, nearest rounding) can flip on last-bit differences of the sampling coordinates
     assert mism <= 1e-4 and diff <= 1e-4
+
+
+@pytest.fixture(scope="module")
+def pp_sd():
+    from vsr_amd.synth import make_propainter_state_dict
+
+    return make_propainter_state_dict(0)
+
+
+@pytest.fixture(scope="module")
+def gen_engine(pp_sd, built_lib, gpu_device):
+    e = PpEngine(device=0, state_dict=pp_sd)
+    yield e
+    e.close()
+
+
+def _generator_case(seed, t, lt, H, W, sd):
+    frames, masks, ff, fb = propainter_inputs(seed, t, lt, H, W)
+    o = ProPainterOracle(sd)
+    fr, mk = torch.from_numpy(frames), torch.from_numpy(masks)
+    masked = fr * (1 - mk)
+    prop, upd = o.img_propagation(masked[:lt], torch.from_numpy(ff), torch.from_numpy(fb), mk[:lt].clone())
+    sel = torch.cat([fr[:lt] * (1 - mk[:lt]) + prop * mk[:lt], masked[lt:]])
+    sel_upd = torch.cat([upd, mk[lt:]])
+    ref = o.forward(sel, torch.from_numpy(ff), torch.from_numpy(fb), mk, sel_upd, lt)
+    return sel.numpy(), ff, fb, masks[:, 0].astype(np.uint8), sel_upd[:, 0].numpy().astype(np.uint8), ref.numpy()
+
+
+@pytest.mark.parametrize("t,lt,H,W", [(7, 5, 64, 96), (5, 3, 128, 192), (6, 4, 240, 432)])
+def test_generator_matches_oracle(gen_engine, pp_sd, gpu_device, t, lt, H, W):
+    sel, ff, fb, m_in, m_upd, ref = _generator_case(80 + t, t, lt, H, W, pp_sd)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+    out = gen_engine.forward(d(sel), d(ff), d(fb), d(m_in), d(m_upd), lt)
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - ref).max()
+    print(f"generator {t}/{lt} x {H}x{W}: max abs err {err:.3e} (tanh output)")
+    assert torch.isfinite(out).all()
+    assert err <= 2e-3
+
+
+def test_generator_strip_size_smoke(gen_engine, gpu_device):
+    """1080p strip (1920x360), 11 local + 4 reference frames: finite, deterministic, survives a plan change."""
+    t, lt, H, W = 15, 11, 360, 1920
+    frames, masks, ff, fb = propainter_inputs(91, t, lt, H, W)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+    m8 = masks[:, 0].astype(np.uint8)
+    args = (d(frames * (1 - masks)), d(ff), d(fb), d(m8), d(m8), lt)
+    a = gen_engine.forward(*args)
+    small = propainter_inputs(92, 3, 2, 64, 96)
+    gen_engine.forward(d(small[0]), d(small[2]), d(small[3]), d(small[1][:, 0].astype(np.uint8)), d(small[1][:, 0].astype(np.uint8)), 2)
+    b = gen_engine.forward(*args)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and a.abs().max() <= 1.0
+    assert torch.equal(a, b)

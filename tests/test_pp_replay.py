@@ -24,3 +24,58 @@ def test_image_propagation_replay_matches_oracle(built_lib, t, H, W):
     if t > 1:
         assert gm.sum() < masks.sum(), "some hole pixels must get filled from neighbouring frames"
     view.close()
+
+
+def _generator_case(seed, t, lt, H, W, sd):
+    """inputs chained as PropainterInpaint.inpaint does (propainter_inpaint.py:283-341) + the oracle's output"""
+    frames, masks, ff, fb = propainter_inputs(seed, t, lt, H, W)
+    o = ProPainterOracle(sd)
+    fr, mk = torch.from_numpy(frames), torch.from_numpy(masks)
+    masked = fr * (1 - mk)
+    prop, upd = o.img_propagation(masked[:lt], torch.from_numpy(ff), torch.from_numpy(fb), mk[:lt].clone())
+    sel = torch.cat([fr[:lt] * (1 - mk[:lt]) + prop * mk[:lt], masked[lt:]])
+    sel_upd = torch.cat([upd, mk[lt:]])
+    ref = o.forward(sel, torch.from_numpy(ff), torch.from_numpy(fb), mk, sel_upd, lt)
+    return sel.numpy(), ff, fb, masks[:, 0].astype(np.uint8), sel_upd[:, 0].numpy().astype(np.uint8), ref.numpy()
+
+
+@pytest.fixture(scope="module")
+def pp_sd():
+    return make_propainter_state_dict(0)
+
+
+@pytest.fixture(scope="module")
+def pp_host_engine(pp_sd, built_lib):
+    from vsr_amd.engine import PpEngine
+
+    e = PpEngine(device=-1, state_dict=pp_sd)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("t,lt,H,W,expect_unmasked", [(7, 5, 64, 96, False), (5, 3, 128, 192, True)])
+def test_generator_replay_matches_oracle(pp_host_engine, pp_sd, t, lt, H, W, expect_unmasked):
+    """Every packed weight (grouped / padded-channel convs, fused qkv), table, descriptor and elementwise op of
+    InpaintGenerator.forward; the second case has attention windows outside the hole (per-frame attention) and a token
+    grid that needs window padding."""
+    sel, ff, fb, m_in, m_upd, ref = _generator_case(70 + t, t, lt, H, W, pp_sd)
+    flags = pp_host_engine.window_flags(m_in[:lt])
+    assert (0 in flags) == expect_unmasked and 1 in flags
+    view = rp.gen_plan_view(_lib, pp_host_engine, t, lt, H, W, flags)
+    out, _ = rp.replay_gen(view, pp_host_engine.packed_weights(), sel, ff, fb, m_in, m_upd, lt)
+    err = np.abs(out - ref).max()
+    assert err <= 5e-4, f"generator output: max abs err {err:.3e} (tanh range)"
+    view.close()
+
+
+def test_generator_strict_state_dict(pp_sd, built_lib):
+    from vsr_amd.engine import PpEngine
+
+    bad = dict(pp_sd)
+    bad.pop("sc.bias_conv.bias")
+    with pytest.raises(_lib.VsrError, match="missing key"):
+        PpEngine(device=-1, state_dict=bad)
+    bad = dict(pp_sd)
+    bad["encoder.layers.14.weight"] = np.zeros((256, 96, 3, 3), np.float32)
+    with pytest.raises(_lib.VsrError, match="shape mismatch"):
+        PpEngine(device=-1, state_dict=bad)

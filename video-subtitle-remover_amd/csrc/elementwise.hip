@@ -149,9 +149,12 @@ k_softmax_rows(const SMProblem* __restrict__ probs, int nprobs)
 {
     const int lane = threadIdx.x & 63;
     const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (grow >= probs[i].rowStart) pi = i;
+    int pi = 0;          // last problem whose first row is <= grow (binary search over the non-decreasing rowStart)
+    for (int lo_ = 0, hi_ = nprobs - 1; lo_ < hi_;) {
+        const int mid_ = (lo_ + hi_ + 1) >> 1;
+        if (grow >= probs[mid_].rowStart) lo_ = mid_; else hi_ = mid_ - 1;
+        pi = lo_;
+    }
     const SMProblem* __restrict__ P = probs + pi;
     const int r = grow - P->rowStart;
     if (r >= P->M) return;

@@ -89,9 +89,14 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         if (bid >= totalTiles) break;
         if (tid == 0) *nextTile = fetchTile();
 
+        // last problem whose first tile id is <= bid (tileStart is non-decreasing; binary search: a grouped launch
+        // can carry thousands of problems, e.g. ProPainter's per-window / per-frame attention)
         int pi = 0;
-        for (int i = 1; i < nprobs; ++i)
-            if (bid >= probs[i].tileStart) pi = i;
+        for (int lo_ = 0, hi_ = nprobs - 1; lo_ < hi_;) {
+            const int mid_ = (lo_ + hi_ + 1) >> 1;
+            if (bid >= probs[mid_].tileStart) lo_ = mid_; else hi_ = mid_ - 1;
+            pi = lo_;
+        }
         const GGProblem* __restrict__ P = probs + pi;
         const int M = P->M, N = P->N;
         const int tilesN = P->tilesN, splitK = P->splitK;

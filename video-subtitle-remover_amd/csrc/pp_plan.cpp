@@ -373,50 +373,19 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
     const int eh = 3, ew_ = 5;                                    // expand_size = ((5+1)/2, (9+1)/2)
     const int64_t pooledBase = (int64_t)t * gh * gw;
     int64_t sOff = 0;
-    for (int win = 0; win < nwh * nww; ++win) {
-        const int wy = win / nww, wx = win % nww;
-        const bool masked = windowMasked[win] != 0;
-        const std::string wkey = std::to_string(win);
-        auto tokRow = [&](int f, int y, int x) { return ((int64_t)f * gh + y) * gw + x; };
-        // query rows / output rows
-        std::vector<int32_t> qrow, arow;
-        for (int f = 0; f < t; ++f)
-            for (int i = 0; i < 5; ++i)
-                for (int j = 0; j < 9; ++j) {
-                    const int64_t r = tokRow(f, wy * 5 + i, wx * 9 + j);
-                    qrow.push_back((int32_t)(r * Q3));
-                    arow.push_back((int32_t)(r * C));
-                }
-        const int M = (int)qrow.size();
-        while (qrow.size() % BM) { qrow.push_back(qrow[0]); arow.push_back(arow[0]); }
-        const int tQ = table("QROW:" + wkey, std::move(qrow)), tA = table("AROW:" + wkey, std::move(arow));
-        // key rows
-        std::vector<int32_t> krow;
-        for (int f = 0; f < t; ++f) {
-            if (masked && f % 2 != parity) continue;
-            for (int i = 0; i < 5; ++i)
-                for (int j = 0; j < 9; ++j) krow.push_back((int32_t)(tokRow(f, wy * 5 + i, wx * 9 + j) * Q3));
-            if (!masked) continue;
-            // rolled windows (:189-209): torch.roll(k, shifts=(sh, sw)) puts k[(y - sh) mod gh][(x - sw) mod gw] at (y, x);
-            // of each rolled window only the tokens outside the current one are kept (mask_tl/tr/bl/br, :143-154)
-            const int sh[4] = {-eh, -eh, eh, eh}, sw[4] = {-ew_, ew_, -ew_, ew_};
-            for (int s = 0; s < 4; ++s)
-                for (int i = 0; i < 5; ++i)
-                    for (int j = 0; j < 9; ++j) {
-                        const bool rowKeep = (s < 2) ? (i >= 5 - eh) : (i < eh);
-                        const bool colKeep = (s % 2 == 0) ? (j >= 9 - ew_) : (j < ew_);
-                        if (!(rowKeep || colKeep)) continue;
-                        const int y = ((wy * 5 + i - sh[s]) % gh + gh) % gh, x = ((wx * 9 + j - sw[s]) % gw + gw) % gw;
-                        krow.push_back((int32_t)(tokRow(f, y, x) * Q3));
-                    }
-            for (int p = 0; p < ph * pw; ++p) krow.push_back((int32_t)((pooledBase + (int64_t)f * ph * pw + p) * Q3));
-        }
-        const int nk = (int)krow.size();
+    auto tokRow = [&](int f, int y, int x) { return ((int64_t)f * gh + y) * gw + x; };
+    // one problem: queries qTok (token rows) x keys kTok, for every head
+    auto addProblem = [&](const std::string& qkey, const std::vector<int64_t>& qTok, const std::string& kkey, const std::vector<int64_t>& kTok) {
+        const int M = (int)qTok.size(), nk = (int)kTok.size();
         const int ldS = (int)rup(nk, VSR_GG_KC);
-        std::vector<int32_t> krowN = krow, krowK = krow;
-        while (krowN.size() % BN) krowN.push_back(krow[0]);
-        while ((int)krowK.size() < ldS) krowK.push_back(krow[0]);     // P's padded columns are zero
-        const std::string kkey = wkey + (masked ? ":m" + std::to_string(parity) : ":u");
+        std::vector<int32_t> qrow, arow, krowN, krowK;
+        for (int64_t r : qTok) { qrow.push_back((int32_t)(r * Q3)); arow.push_back((int32_t)(r * C)); }
+        while (qrow.size() % BM) { qrow.push_back(qrow[0]); arow.push_back(arow[0]); }
+        for (int64_t r : kTok) krowN.push_back((int32_t)(r * Q3));
+        krowK = krowN;
+        while (krowN.size() % BN) krowN.push_back(krowN[0]);
+        while ((int)krowK.size() < ldS) krowK.push_back(krowK[0]);          // P's padded columns are zero
+        const int tQ = table("QROW:" + qkey, std::move(qrow)), tA = table("AROW:" + qkey, std::move(arow));
         const int tKn = table("KROWN:" + kkey, std::move(krowN)), tKk = table("KROWK:" + kkey, std::move(krowK));
         for (int head = 0; head < 4; ++head) {
             GemmItem a{};
@@ -429,12 +398,12 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
             a.tColC = tColsLinear(a.tilesN * BN / VSR_GG_KC, a.tilesN * BN / VSR_GG_KC);
             a.bufR = -1; a.tRowR = -1; a.offBias = -1;
             qk.gemm.push_back(a);
-            SoftmaxItem s{};
-            s.bufS = PG_S; s.offS = sOff; s.splitStride = 0; s.nsplit = 1;
-            s.bufP = PG_P; s.offP = sOff;
-            s.M = M; s.N = nk; s.ldS = ldS; s.ldP = ldS;
-            s.scale = (float)(1.0 / sqrt((double)CH));
-            sm.softmax.push_back(s);
+            SoftmaxItem sI{};
+            sI.bufS = PG_S; sI.offS = sOff; sI.splitStride = 0; sI.nsplit = 1;
+            sI.bufP = PG_P; sI.offP = sOff;
+            sI.M = M; sI.N = nk; sI.ldS = ldS; sI.ldP = ldS;
+            sI.scale = (float)(1.0 / sqrt((double)CH));
+            sm.softmax.push_back(sI);
             GemmItem b{};
             b.M = M; b.N = CH; b.K = ldS;
             b.tilesM = cdiv(M, BM); b.tilesN = cdiv(CH, BN);
@@ -448,6 +417,45 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
             qk.flops += fl; pv.flops += fl;
             sOff += rup((int64_t)M * ldS, 32);
         }
+    };
+    for (int win = 0; win < nwh * nww; ++win) {
+        const int wy = win / nww, wx = win % nww;
+        const std::string wkey = std::to_string(win);
+        if (!windowMasked[win]) {
+            // unmasked window (:253-262): every frame's 45 queries attend to the same frame's 45 window tokens (t is a batch dimension)
+            for (int f = 0; f < t; ++f) {
+                std::vector<int64_t> tok;
+                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < 9; ++j) tok.push_back(tokRow(f, wy * 5 + i, wx * 9 + j));
+                const std::string key = wkey + ":f" + std::to_string(f);
+                addProblem(key, tok, key, tok);
+            }
+            continue;
+        }
+        // masked window (:238-251): all frames' queries; keys on the frames of this block's temporal stride: the window tokens,
+        // the rolled-window tokens outside the window, all pooled tokens
+        std::vector<int64_t> qTok, kTok;
+        for (int f = 0; f < t; ++f)
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j < 9; ++j) qTok.push_back(tokRow(f, wy * 5 + i, wx * 9 + j));
+        for (int f = parity; f < t; f += 2) {
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j < 9; ++j) kTok.push_back(tokRow(f, wy * 5 + i, wx * 9 + j));
+            // rolled windows (:189-209): torch.roll(k, shifts=(sh, sw)) puts k[(y - sh) mod gh][(x - sw) mod gw] at (y, x);
+            // of each rolled window only the tokens outside the current one are kept (mask_tl/tr/bl/br, :143-154)
+            const int sh[4] = {-eh, -eh, eh, eh}, sw[4] = {-ew_, ew_, -ew_, ew_};
+            for (int s = 0; s < 4; ++s)
+                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < 9; ++j) {
+                        const bool rowKeep = (s < 2) ? (i >= 5 - eh) : (i < eh);
+                        const bool colKeep = (s % 2 == 0) ? (j >= 9 - ew_) : (j < ew_);
+                        if (!(rowKeep || colKeep)) continue;
+                        const int y = ((wy * 5 + i - sh[s]) % gh + gh) % gh, x = ((wx * 9 + j - sw[s]) % gw + gw) % gw;
+                        kTok.push_back(tokRow(f, y, x));
+                    }
+            for (int p = 0; p < ph * pw; ++p) kTok.push_back(pooledBase + (int64_t)f * ph * pw + p);
+        }
+        addProblem(wkey, qTok, wkey + ":m" + std::to_string(parity), kTok);
     }
     need(PG_S, sOff);
     need(PG_P, sOff);
