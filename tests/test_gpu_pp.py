@@ -85,3 +85,37 @@ def test_generator_strip_size_smoke(gen_engine, gpu_device):
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and a.abs().max() <= 1.0
     assert torch.equal(a, b)
+
+
+def test_propainter_plugin_matches_oracle(built_lib, gpu_device, pp_sd):
+    """PropainterInpaint.__call__ (row a13) end to end -- crop, mask dilation, RAFT, flow completion, image propagation,
+    sliding neighbour / reference windows of the generator, u8 overlap blending -- against the restated reference wrapper
+    built from the three CPU oracles.  RAFT runs 3 iterations on both sides to bound the CPU time."""
+    from oracle.propainter_wrapper import PropainterOracle
+    from oracle.raft import RaftOracle
+    from oracle.rfc import RfcOracle
+    from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+    from vsr_amd.backend.tools.inpaint_tools import create_mask
+    from vsr_amd.synth import make_clip, make_raft_state_dict, make_rfc_state_dict
+
+    H, W, n = 288, 704, 7
+    box = (236, 268, 120, 600)                                      # ymin, ymax, xmin, xmax
+    frames = list(make_clip(n, H, W, box, seed=5))
+    mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
+    sds = {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": pp_sd}
+    plug = PropainterInpaint("cuda:0", sds)
+    plug.raft_iter = 3
+    got = plug(frames, mask)
+    plug.close()
+    ora = PropainterOracle(RaftOracle(sds["raft"]), RfcOracle(sds["rfc"]), ProPainterOracle(pp_sd), raft_iter=3)
+    ref = ora(frames, mask)
+    assert len(got) == n
+    g, r = np.stack(got).astype(np.float64), np.stack(ref).astype(np.float64)
+    changed = (np.stack(ref) != np.stack(frames)).any(axis=(0, 3))
+    assert changed.any(), "the plugin must repaint the masked strip"
+    assert np.array_equal(np.stack(got)[:, ~changed], np.stack(frames)[:, ~changed]), "pixels the reference leaves alone stay bit-identical"
+    mse = ((g - r)[:, changed] ** 2).mean()
+    psnr = 99.0 if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
+    dmax = np.abs(g - r).max()
+    print(f"propainter plugin: PSNR vs oracle on repainted pixels {psnr:.1f} dB, max |d| {dmax:.0f}, repainted {changed.mean():.3f} of the frame")
+    assert psnr >= 50.0

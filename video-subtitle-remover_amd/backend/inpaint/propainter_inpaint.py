@@ -1,0 +1,166 @@
+"""ProPainter plugin with the reference's signature, running on the MI355X engines.
+
+Mirrors backend/inpaint/propainter_inpaint.py:
+  PropainterInpaint(device, model_dir, sub_video_length=80, use_fp16=True)   :139-188
+      __call__(input_frames, input_mask) -> frames                            :363-418  (the generic plugin contract)
+      inpaint(frames, mask) -> comp frames                                    :190-361
+  read_mask :32-77 (numpy-mask branch), get_ref_index :122-136
+All network arithmetic happens in libvsr_hip.so (RAFT, flow completion, image propagation, generator: vsr_raft_* /
+vsr_rfc_* / vsr_pp_*), in exact fp32 -- `use_fp16` is accepted for signature compatibility and ignored.  This file is the
+host loop: mask dilation, sub-video / neighbour / reference schedules, the u8 blend of overlapping windows.  The masked /
+composed frame tensors are elementwise torch ops on the GPU (plumbing).  `model_dir` may also be a dict
+{"raft": sd, "rfc": sd, "propainter": sd} of already loaded state_dicts (the shipped checkpoints are missing blobs).
+"""
+import os
+
+import numpy as np
+import scipy.ndimage
+import torch
+
+from ..tools.inpaint_tools import get_inpaint_area_by_mask
+from ...engine import PpEngine, RaftEngine, RfcEngine
+from .sttn_auto_inpaint import _device_index
+
+
+def read_mask(mask, length, flow_mask_dilates=8, mask_dilates=5):
+    """numpy-mask branch of the reference's read_mask: -> (flow_mask, mask_dilated) uint8 {0,1} arrays [H,W] (used for every frame)"""
+    m = np.asarray(mask)
+    if m.ndim == 3 and m.shape[2] == 1:
+        m = m[:, :, 0]
+    elif m.ndim == 3 and m.shape[2] == 3:
+        # cv2.COLOR_BGR2GRAY: (B*1868 + G*9617 + R*4899 + 8192) >> 14 on uint8
+        m = ((m[:, :, 0].astype(np.int32) * 1868 + m[:, :, 1].astype(np.int32) * 9617 + m[:, :, 2].astype(np.int32) * 4899 + 8192) >> 14).astype(np.uint8)
+
+    def dil(it):
+        return scipy.ndimage.binary_dilation(m, iterations=it).astype(np.uint8) if it > 0 else (m > 0.1).astype(np.uint8)
+
+    return dil(flow_mask_dilates), dil(mask_dilates)
+
+
+def get_ref_index(mid_neighbor_id, neighbor_ids, length, ref_stride=10, ref_num=-1):
+    ref_index = []
+    if ref_num == -1:
+        for i in range(0, length, ref_stride):
+            if i not in neighbor_ids:
+                ref_index.append(i)
+    else:
+        start_idx = max(0, mid_neighbor_id - ref_stride * (ref_num // 2))
+        end_idx = min(length, mid_neighbor_id + ref_stride * (ref_num // 2))
+        for i in range(start_idx, end_idx, ref_stride):
+            if i not in neighbor_ids:
+                if len(ref_index) > ref_num:
+                    break
+                ref_index.append(i)
+    return ref_index
+
+
+def _load(model_dir, name, file):
+    if isinstance(model_dir, dict):
+        return model_dir[name]
+    return torch.load(os.path.join(model_dir, file), map_location="cpu")
+
+
+class PropainterInpaint:
+    def __init__(self, device, model_dir, sub_video_length=80, use_fp16=True):
+        self.device = device
+        self.model_dir = model_dir
+        self.use_fp16 = use_fp16           # ignored: exact fp32 kernels
+        self.sub_video_length = sub_video_length
+        self.neighbor_length = 10
+        self.mask_dilation = 4
+        self.ref_stride = 10
+        self.raft_iter = 20
+        di = _device_index(device)
+        self.fix_raft = RaftEngine(_load(model_dir, "raft", "raft-things.pth"), device=di)
+        self.fix_flow_complete = RfcEngine(_load(model_dir, "rfc", "recurrent_flow_completion.pth"), device=di)
+        self.model = PpEngine(device=di, state_dict=_load(model_dir, "propainter", "ProPainter.pth"))
+        self.dev = self.model.device
+
+    def close(self):
+        for e in (self.fix_raft, self.fix_flow_complete, self.model):
+            e.close()
+
+    def inpaint(self, frames, mask):
+        """frames: list of HxWx3 uint8 BGR crops (H, W multiples of 8), mask: HxW(x1) uint8 -> list of HxWx3 uint8 BGR"""
+        n = len(frames)
+        dev = self.dev
+        frames_inp = np.stack([np.asarray(f)[:, :, ::-1] for f in frames])                  # cv2.COLOR_BGR2RGB
+        h, w = frames_inp.shape[1:3]
+        fm, md = read_mask(mask, n, self.mask_dilation, self.mask_dilation)
+        u8 = torch.from_numpy(np.ascontiguousarray(frames_inp)).to(dev)                     # [n,h,w,3] RGB
+        frames_t = u8.permute(0, 3, 1, 2).float().div(255) * 2 - 1                          # to_tensors()(frames) * 2 - 1
+        fm_dev = torch.from_numpy(fm).to(dev)[None].repeat(n, 1, 1).contiguous()            # uint8 [n,h,w]
+        md_dev = torch.from_numpy(md).to(dev)[None].repeat(n, 1, 1).contiguous()
+        md_f = md_dev[:, None].float()
+        # ---- flows (:217-247): every consecutive pair in both directions, fp32
+        gt_f, gt_b = self.fix_raft.flows(u8.contiguous(), iters=self.raft_iter)
+        # ---- flow completion (:253-281)
+        flow_length, svl = n - 1, self.sub_video_length
+        if flow_length > svl:
+            pf, pb = [], []
+            for f in range(0, flow_length, svl):
+                s_f, e_f = max(0, f - 5), min(flow_length, f + svl + 5)
+                ps, pe = max(0, f) - s_f, e_f - min(flow_length, f + svl)
+                cf, cb = self.fix_flow_complete.complete(gt_f[s_f:e_f].contiguous(), gt_b[s_f:e_f].contiguous(), fm_dev[s_f:e_f + 1].contiguous())
+                pf.append(cf[ps:e_f - s_f - pe])
+                pb.append(cb[ps:e_f - s_f - pe])
+            pred_f, pred_b = torch.cat(pf).contiguous(), torch.cat(pb).contiguous()
+        else:
+            pred_f, pred_b = self.fix_flow_complete.complete(gt_f, gt_b, fm_dev)
+        # ---- image propagation (:283-315)
+        masked_frames = (frames_t * (1 - md_f)).contiguous()
+        sip = min(100, svl)
+        if n > sip:
+            uf, um = [], []
+            for f in range(0, n, sip):
+                s_f, e_f = max(0, f - 10), min(n, f + sip + 10)
+                ps, pe = max(0, f) - s_f, e_f - min(n, f + sip)
+                prop, upd = self.model.img_propagation(masked_frames[s_f:e_f].contiguous(), pred_f[s_f:e_f - 1].contiguous(),
+                                                       pred_b[s_f:e_f - 1].contiguous(), md_dev[s_f:e_f].contiguous())
+                sub = frames_t[s_f:e_f] * (1 - md_f[s_f:e_f]) + prop * md_f[s_f:e_f]
+                uf.append(sub[ps:e_f - s_f - pe])
+                um.append(upd[ps:e_f - s_f - pe])
+            updated_frames, updated_masks = torch.cat(uf).contiguous(), torch.cat(um).contiguous()
+        else:
+            prop, updated_masks = self.model.img_propagation(masked_frames, pred_f, pred_b, md_dev)
+            updated_frames = (frames_t * (1 - md_f) + prop * md_f).contiguous()
+        # ---- feature propagation + transformer over sliding neighbour windows (:317-358)
+        comp = [None] * n
+        stride = self.neighbor_length // 2
+        ref_num = svl // self.ref_stride if n > svl else -1
+        binary = md[:, :, None].astype(np.uint8)
+        flags_cache = {}
+        for f in range(0, n, stride):
+            nb = [i for i in range(max(0, f - stride), min(n, f + stride + 1))]
+            ref = get_ref_index(f, nb, n, self.ref_stride, ref_num)
+            ids = nb + ref
+            l_t = len(nb)
+            if l_t not in flags_cache:                                                      # the same mask on every frame
+                flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
+            pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
+                                      md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t])
+            pred = ((pred + 1) / 2).permute(0, 2, 3, 1).cpu().numpy() * 255
+            for i, idx in enumerate(nb):
+                img = np.array(pred[i]).astype(np.uint8) * binary + frames_inp[idx] * (1 - binary)
+                if comp[idx] is None:
+                    comp[idx] = img
+                else:
+                    comp[idx] = comp[idx].astype(np.float32) * 0.5 + img.astype(np.float32) * 0.5
+                comp[idx] = comp[idx].astype(np.uint8)
+        return [np.ascontiguousarray(c[:, :, ::-1]) for c in comp]                          # cv2.COLOR_RGB2BGR
+
+    def __call__(self, input_frames, input_mask):
+        mask = input_mask[:, :, None]
+        H_ori, W_ori = mask.shape[:2]
+        split_h = int(W_ori * 3 / 16)
+        inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask, multiple=8)
+        frames_hr = [f.copy() for f in input_frames]
+        if not inpaint_area:
+            return frames_hr
+        comps = {}
+        for k, (y0, y1, x0, x1) in enumerate(inpaint_area):
+            comps[k] = self.inpaint([f[y0:y1, x0:x1, :] for f in frames_hr], mask[y0:y1, x0:x1, :])
+        for j, frame in enumerate(frames_hr):
+            for k, (y0, y1, x0, x1) in enumerate(inpaint_area):
+                frame[y0:y1, x0:x1, :] = comps[k][j]
+        return frames_hr
