@@ -68,6 +68,68 @@ class SubtitleRemover:
         sttn_video_inpaint = STTNAutoInpaint(self.device, self.model_path, self.video_path)
         sttn_video_inpaint(input_mask=mask, input_sub_remover=self, tbar=tbar)
 
+    @staticmethod
+    def is_current_frame_no_start(frame_no, continuous_frame_no_list):          # main.py:90-97
+        return any(start_no == frame_no for start_no, _ in continuous_frame_no_list)
+
+    @staticmethod
+    def find_frame_no_end(frame_no, continuous_frame_no_list):                   # main.py:100-107
+        for start_no, end_no in continuous_frame_no_list:
+            if start_no <= frame_no <= end_no:
+                return end_no
+        return -1
+
+    def propainter_mode(self, tbar, propainter_inpaint=None, text_detector=None, scene_div_points=None, single_frame_inpaint=None):
+        """backend/main.py:159-245.  Intervals of frames with the same mask, cut at scene changes, are read whole and
+        handed to the plugin in batch_generator batches of propainterMaxLoadNum.  The detector, the scene-change frame
+        numbers (reference: scenedetect's ContentDetector, subtitle_detect.py:158-170) and the single-frame fallback
+        (reference: LaMa, whose network is a missing blob) are injected; without a fallback single frames pass through."""
+        detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
+        sub_list = detector.find_subtitle_frame_no(sub_remover=self)
+        if len(sub_list) == 0:
+            raise Exception(f"No subtitle detected in {self.video_path}")
+        ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
+        ranges = detector.split_range_by_scene(ranges, list(scene_div_points or []))
+        if propainter_inpaint is None:
+            from .inpaint.propainter_inpaint import PropainterInpaint
+
+            model_dir = os.environ.get("PROPAINTER_MODEL_DIR", os.path.join(os.path.dirname(__file__), "models", "propainter"))
+            propainter_inpaint = PropainterInpaint(self.device, model_dir, config.propainterMaxLoadNum.value)
+        reader = open_video(self.video_path)
+        index = 0
+        while True:
+            ok, frame = reader.read()
+            if not ok:
+                break
+            index += 1
+            if index not in sub_list:
+                self.video_writer.write(frame)
+                self.update_progress(tbar, increment=1)
+                continue
+            if not self.is_current_frame_no_start(index, ranges):
+                continue
+            start_frame_no = index
+            end_frame_no = self.find_frame_no_end(index, ranges)
+            if end_frame_no == -1:
+                continue
+            temp_frames = [frame]
+            while index < end_frame_no:
+                ok, frame = reader.read()
+                if not ok:
+                    break
+                index += 1
+                temp_frames.append(frame)
+            mask = create_mask(self.mask_size, sub_list[start_frame_no])
+            for batch in ([temp_frames] if len(temp_frames) == 1 else batch_generator(temp_frames, config.propainterMaxLoadNum.value)):
+                if len(batch) == 1:
+                    out = single_frame_inpaint(batch[0], mask) if single_frame_inpaint is not None else batch[0]
+                    self.video_writer.write(out)
+                else:
+                    for out in propainter_inpaint(batch, mask):
+                        self.video_writer.write(out)
+                self.update_progress(tbar, increment=len(batch))
+        reader.release()
+
     def video_inpaint(self, tbar, model, text_detector=None):
         """backend/main.py:260-333 -- detector pass, interval construction, then `model(batch, mask)` per batch.
         Frame numbers are 1-based here exactly as in the reference."""
@@ -127,6 +189,9 @@ class SubtitleRemover:
 
             det_path = os.environ.get("STTN_DET_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-det", "sttn.pth"))
             self.video_inpaint(None, STTNDetInpaint(self.device, det_path), text_detector=getattr(self, "text_detector", None))
+        elif mode == InpaintMode.PROPAINTER:
+            self.propainter_mode(None, propainter_inpaint=getattr(self, "propainter_inpaint", None),
+                                 text_detector=getattr(self, "text_detector", None), scene_div_points=getattr(self, "scene_div_points", None))
         else:
             raise Exception(f"inpaint mode: {mode} not implemented")     # main.py:386
         self.isFinished = True

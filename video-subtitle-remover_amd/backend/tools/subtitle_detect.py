@@ -131,6 +131,19 @@ class SubtitleDetect:
         return ranges
 
     @staticmethod
+    def split_range_by_scene(intervals, points):
+        """tools/subtitle_detect.py:135-155: cut every (start, end) interval at the scene-change frame numbers inside it."""
+        points = sorted(points)
+        out = []
+        for start, end in intervals:
+            for p in [q for q in points if start <= q <= end]:
+                if start < p:
+                    out.append((start, p - 1))
+                start = p
+            out.append((start, end))
+        return out
+
+    @staticmethod
     def filter_and_merge_intervals(intervals, target_length):
         """:261-293 -- single-frame intervals grow to target_length where neighbours allow; short touching ones merge."""
         if not intervals:
