@@ -295,6 +295,28 @@ int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, floa
 double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags);
 
 /* ---------------------------------------------------------------------------------------
+ * Text detector: the operators of the PP-OCRv5 detection inference programs the reference
+ * loads through paddleocr (backend/tools/subtitle_detect.py:41-58, backend/models/V5/{ch_det,ch_det_fast}/inference.json).
+ * NCHW fp32 device tensors; the host runner (backend/tools/ocr_det.py) walks the program and calls one launcher per op.
+ * act: 0 none, 1 relu, 2 hardswish.  Paddle operator definitions: conv2d / depthwise_conv2d (zero padding (pt, pl) before,
+ * output Ho x Wo), conv2d_transpose 2x2 stride 2 (weight [Cin][Cout][2][2], depthwise: [C][1][2][2]), elementwise add (op 0) /
+ * multiply (op 1) with b of the same shape (bmode 0), [C] (1) or [N*C] (2), unary relu 0 / hardswish 1 / hardsigmoid(p0, p1) 2 /
+ * sigmoid 3 / x*p0+p1 4, inference batch_norm as x*scale[c]+shift[c], adaptive average pool to 1x1, max pool, nearest_interp
+ * (integer scale), and the inference.yml pre-processing NormalizeImage + ToCHWImage on a BGR uint8 image.
+ * ------------------------------------------------------------------------------------- */
+int vsr_det_launch_conv2d(const float* x, const float* w, const float* bias, int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                          int sh, int sw, int pt, int pl, int Ho, int Wo, int depthwise, int act, float* out, void* stream);
+int vsr_det_launch_deconv2x2(const float* x, const float* w, int N, int Cin, int H, int W, int Cout, int depthwise, float* out, void* stream);
+int vsr_det_launch_binary(const float* a, const float* b, int op, int64_t total, int C, int64_t HW, int bmode, float* out, void* stream);
+int vsr_det_launch_unary(const float* x, int64_t total, int kind, float p0, float p1, float* out, void* stream);
+int vsr_det_launch_affine(const float* x, const float* scale, const float* shift, int64_t total, int C, int64_t HW, float* out, void* stream);
+int vsr_det_launch_gap(const float* x, int64_t planes, int64_t HW, float* out, void* stream);
+int vsr_det_launch_maxpool(const float* x, int64_t planes, int H, int W, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo,
+                           float* out, void* stream);
+int vsr_det_launch_nearest(const float* x, int64_t planes, int H, int W, int s, float* out, void* stream);
+int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_chw, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */

@@ -217,6 +217,17 @@ def _propainter_fixture():
                         upd_mask=upd.view(lt, h, w).numpy().astype(np.uint8), out=out[0].numpy())
 
 
+def _detector_graph_fixtures():
+    """The PP-OCRv5 detection programs (backend/models/V5/{ch_det_fast,ch_det}/inference.json) condensed by
+    vsr_amd.backend.tools.paddle_graph (op list + parameter shapes only): the GPU box has no reference mount."""
+    from vsr_amd.backend.tools.paddle_graph import load_graph
+
+    for name, out in (("ch_det_fast", "ppocr_det_fast_graph.json"), ("ch_det", "ppocr_det_graph.json")):
+        g = load_graph(os.path.join(REF, "backend", "models", "V5", name, "inference.json"))
+        with open(os.path.join(OUT, out), "w") as f:
+            json.dump(g.to_json(), f, separators=(",", ":"))
+
+
 def main():
     from vsr_amd.synth import make_state_dict
 
@@ -266,6 +277,7 @@ def main():
     _raft_fixture()
     _rfc_fixture()
     _propainter_fixture()
+    _detector_graph_fixtures()
 
     # ---- batch_generator (tools/inpaint_tools.py:7-29), executed from the reference ----
     cases = [(1200, 50), (300, 50), (600, 50), (1200, 70), (49, 50), (50, 50), (51, 50), (75, 50), (1, 50), (0, 50),

@@ -1,0 +1,107 @@
+"""CPU interpreter of the text detector's inference program (test infrastructure only) -- SURVEY.md 8(a) row a20.
+
+The reference runs PP-OCRv5 detection through paddleocr==3.4.0 / paddlepaddle 3.0.0 (requirements.txt:9, docker/Dockerfile:17;
+call site backend/tools/subtitle_detect.py:41-58).  Neither package nor the weights (*.pdiparams) are in the image or the
+mount; only the program (backend/models/V5/*/inference.json) is.  This file executes that program op by op with torch-CPU
+functional ops following Paddle's operator definitions (phi kernels: conv2d, depthwise_conv2d, conv2d_transpose,
+batch_norm (inference), pool2d, nearest_interp (align_corners=False), hardswish = x*relu6(x+3)/6,
+hardsigmoid = clip(slope*x + offset, 0, 1), elementwise add / multiply with numpy broadcasting, concat, reshape, scale).
+PARITY UNPINNED: no Paddle binary or golden output exists to check the operator semantics against.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def synthetic_weights(graph, seed=0):
+    """{param name: fp32 array} with plausible statistics; BatchNorm variances (4th input of batch_norm_) are positive"""
+    rng = np.random.default_rng(seed + 2718)
+    role = {}
+    for kind, ins, _, _ in graph.ops:
+        if kind == "batch_norm_":
+            role[ins[1]], role[ins[2]], role[ins[3]], role[ins[4]] = "mean", "var", "scale", "shift"
+        elif kind in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
+            role[ins[1]] = "weight"
+    out = {}
+    for vid, (name, shape) in graph.params.items():
+        r = role.get(vid, "bias" if len(shape) == 1 else "weight")
+        if r == "weight" and len(shape) == 4:
+            fan_in = int(np.prod(shape[1:]))
+            v = rng.standard_normal(shape) * (1.3 / np.sqrt(fan_in))
+        elif r == "var":
+            v = rng.uniform(0.5, 1.5, shape)
+        elif r == "scale":
+            v = rng.uniform(0.7, 1.3, shape)
+        elif r in ("mean", "shift"):
+            v = rng.normal(0, 0.1, shape)
+        else:
+            v = rng.normal(0, 0.1, shape) if len(shape) == 1 else rng.uniform(0.5, 1.5, shape)
+        out[name] = np.asarray(v, dtype=np.float32)
+    return out
+
+
+def run_graph(graph, weights, x):
+    """x: torch [N,3,H,W] fp32 (normalised image) -> probability map [N,1,H,W]"""
+    val = {vid: torch.from_numpy(np.asarray(weights[name], dtype=np.float32)) for vid, (name, _) in graph.params.items()}
+    val[graph.input_id] = x
+    with torch.no_grad():
+        for kind, ins, outs, a in graph.ops:
+            g = lambda i: val[ins[i]]
+            if kind in ("conv2d", "depthwise_conv2d"):
+                w = g(1)
+                pad = a["paddings"]
+                xin = g(0)
+                if a.get("padding_algorithm") == "SAME":          # stride 1 on this path: total pad k-1, the extra pixel after
+                    kh, kw = w.shape[2:]
+                    xin = F.pad(xin, ((kw - 1) // 2, kw - 1 - (kw - 1) // 2, (kh - 1) // 2, kh - 1 - (kh - 1) // 2))
+                    pad = [0, 0]
+                val[outs[0]] = F.conv2d(xin, w, None, stride=a["strides"], padding=pad, dilation=a["dilations"], groups=a["groups"])
+            elif kind == "conv2d_transpose":
+                val[outs[0]] = F.conv_transpose2d(g(0), g(1), None, stride=a["strides"], padding=a["paddings"], groups=a["groups"])
+            elif kind == "batch_norm_":
+                val[outs[0]] = F.batch_norm(g(0), g(1), g(2), g(3), g(4), training=False, eps=a["epsilon"])
+            elif kind == "full_int_array":
+                val[outs[0]] = [int(v) for v in a["value"]]
+            elif kind == "full":
+                val[outs[0]] = a["value"]
+            elif kind == "reshape":
+                val[outs[0]] = g(0).reshape(g(1))
+            elif kind == "add":
+                val[outs[0]] = g(0) + g(1)
+            elif kind == "multiply":
+                val[outs[0]] = g(0) * g(1)
+            elif kind == "relu":
+                val[outs[0]] = torch.relu(g(0))
+            elif kind == "hardswish":
+                val[outs[0]] = g(0) * torch.clamp(g(0) + 3.0, 0.0, 6.0) / 6.0
+            elif kind == "hardsigmoid":
+                val[outs[0]] = torch.clamp(g(0) * a["slope"] + a["offset"], 0.0, 1.0)
+            elif kind == "sigmoid":
+                val[outs[0]] = torch.sigmoid(g(0))
+            elif kind == "scale":
+                s = val[ins[1]] if len(ins) > 1 and ins[1] in val else a.get("scale", 1.0)
+                s = float(s if not isinstance(s, torch.Tensor) else s.item())
+                b = float(a.get("bias", 0.0))
+                val[outs[0]] = g(0) * s + b if a.get("bias_after_scale", True) else (g(0) + b) * s
+            elif kind == "pool2d":
+                ks = g(1)
+                if a["adaptive"]:
+                    assert list(ks) == [1, 1] and a["pooling_type"] == "avg"
+                    val[outs[0]] = g(0).mean(dim=(2, 3), keepdim=True)
+                else:
+                    assert a["pooling_type"] == "max"
+                    xin, pad = g(0), a["paddings"]
+                    if a.get("padding_algorithm") == "SAME":          # stride 1: k-1 extra pixels, after; padding never wins a max
+                        xin = F.pad(xin, ((ks[1] - 1) // 2, ks[1] - 1 - (ks[1] - 1) // 2, (ks[0] - 1) // 2, ks[0] - 1 - (ks[0] - 1) // 2),
+                                    value=float("-inf"))
+                        pad = [0, 0]
+                    val[outs[0]] = F.max_pool2d(xin, ks, stride=a["strides"], padding=pad, ceil_mode=a["ceil_mode"])
+            elif kind == "nearest_interp":
+                val[outs[0]] = F.interpolate(g(0), scale_factor=tuple(a["scale"]), mode="nearest")
+            elif kind == "combine":
+                val[outs[0]] = [val[i] for i in ins]
+            elif kind == "concat":
+                val[outs[0]] = torch.cat(g(0), dim=int(g(1)))
+            else:
+                raise NotImplementedError(f"detector op {kind}")
+    return val[graph.output_id]

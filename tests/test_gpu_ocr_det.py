@@ -1,0 +1,45 @@
+"""Text detector on the MI355X: the program executed by csrc/det_kernels.hip against the CPU interpreter
+(oracle/ppocr_det.py; parity with Paddle's binary is unpinned -- no Paddle, no weights in the reference mount)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cv2_restate as cv2r
+from oracle.ppocr_det import run_graph, synthetic_weights
+from vsr_amd.backend.tools import ocr_det
+from vsr_amd.backend.tools.paddle_graph import load_graph
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("fixture,H,W", [("ppocr_det_fast_graph.json", 96, 160), ("ppocr_det_fast_graph.json", 544, 960),
+                                         ("ppocr_det_graph.json", 96, 160), ("ppocr_det_graph.json", 224, 352)])
+def test_program_matches_interpreter(built_lib, gpu_device, fixture, H, W):
+    g = load_graph(os.path.join(GOLD, fixture))
+    w = synthetic_weights(g)
+    x = torch.from_numpy(np.random.default_rng(H + W).standard_normal((1, 3, H, W)).astype(np.float32))
+    ref = run_graph(g, w, x)
+    got = ocr_det.PaddleGraphRunner(g, w, device=0).run(x.to(gpu_device).contiguous())
+    torch.cuda.synchronize()
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"{fixture} {H}x{W}: max abs err of the probability map {err:.2e}")
+    assert got.shape == ref.shape and err <= 2e-4
+
+
+def test_predict_preprocessing_and_plumbing(built_lib, gpu_device):
+    """resize_long 960 (cv2 INTER_LINEAR, bit-exact vs the restated cv2) + NormalizeImage; predict() returns paddleocr's dict"""
+    g = load_graph(os.path.join(GOLD, "ppocr_det_fast_graph.json"))
+    det = ocr_det.TextDetection(g, synthetic_weights(g), device=0)
+    img = np.random.default_rng(3).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    prob, rh, rw = det.probability_map(img)
+    assert (rh, rw) == (544, 960) and tuple(prob.shape) == (544, 960)
+    small = cv2r.resize_linear(img, rw, rh)
+    x = ((small.astype(np.float32) * np.float32(1.0 / 255.0) - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32))
+    ref = run_graph(g, synthetic_weights(g), torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None])
+    assert (prob.cpu() - ref[0, 0]).abs().max().item() <= 2e-4
+    res = det.predict(img)
+    assert isinstance(res, list) and res[0]["dt_polys"].ndim == 3 and res[0]["dt_polys"].shape[1:] == (4, 2)
+    assert len(res[0]["dt_scores"]) == res[0]["dt_polys"].shape[0]

@@ -1,0 +1,66 @@
+"""Text detector, host side: program reader, oracle interpreter on the condensed fixtures, DB post-process."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.ppocr_det import run_graph, synthetic_weights
+from vsr_amd import _lib
+from vsr_amd.backend.tools import ocr_det
+from vsr_amd.backend.tools.ocr import get_coordinates
+from vsr_amd.backend.tools.paddle_graph import load_graph
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("fixture,nparams,nconv", [("ppocr_det_fast_graph.json", 1171721, 62), ("ppocr_det_graph.json", 21979682, 142)])
+def test_program_reader_and_oracle(fixture, nparams, nconv):
+    g = load_graph(os.path.join(GOLD, fixture))
+    assert sum(int(np.prod(s)) for _, s in g.params.values()) == nparams
+    assert sum(1 for k, *_ in g.ops if k in ("conv2d", "depthwise_conv2d")) == nconv
+    y = run_graph(g, synthetic_weights(g), torch.randn(1, 3, 64, 96))
+    assert y.shape == (1, 1, 64, 96) and float(y.min()) >= 0 and float(y.max()) <= 1
+    assert load_graph(json.loads(json.dumps(g.to_json()))).ops == g.ops            # the condensed form round-trips
+
+
+def test_min_area_rect_and_box_order():
+    th = np.deg2rad(25.0)
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    rect = np.array([[0, 0], [60, 0], [60, 20], [0, 20]], dtype=np.float64) @ R.T + [100, 50]
+    pts = np.round(np.concatenate([rect, (rect[:, None] * 0.5 + rect[None] * 0.5).reshape(-1, 2)])).astype(int)
+    corners, w, h = ocr_det.min_area_rect(pts)
+    assert sorted([round(w), round(h)]) == pytest.approx([20, 60], abs=2)
+    box = ocr_det._order_box(corners)
+    assert box[0][0] <= box[1][0] and box[3][0] <= box[2][0] and box[0][1] <= box[3][1] and box[1][1] <= box[2][1]
+
+
+def test_db_postprocess_on_a_synthetic_map():
+    """two text lines at high probability, a weak blob (below box_thresh) and a speck (below min_size): boxes come back in
+    source-image pixels, grown by area * 1.5 / perimeter, ordered tl, tr, br, bl -- and feed get_coordinates (tools/ocr.py)."""
+    prob = np.zeros((136, 240), dtype=np.float32)
+    prob[20:30, 40:160] = 0.9
+    prob[60:72, 30:200] = 0.8
+    prob[100:110, 50:90] = 0.45          # mean 0.45 < 0.6
+    prob[120:122, 10:12] = 0.95          # too small
+    boxes, scores = ocr_det.db_postprocess(prob, src_h=1088, src_w=1920)
+    assert boxes.shape == (2, 4, 2) and len(scores) == 2
+    sx, sy = 1920 / 240, 1088 / 136
+    for b, (y0, y1, x0, x1) in zip(sorted(boxes.tolist(), key=lambda q: q[0][1]), ((20, 29, 40, 159), (60, 71, 30, 199))):
+        w, h = x1 - x0, y1 - y0
+        d = w * h * 1.5 / (2 * (w + h))
+        exp = [(x0 - d) * sx, (x1 + d) * sx, (y0 - d) * sy, (y1 + d) * sy]
+        xmin, xmax, ymin, ymax = get_coordinates([b])[0]
+        assert [xmin, xmax, ymin, ymax] == pytest.approx(exp, abs=9)
+    empty, _ = ocr_det.db_postprocess(np.zeros((64, 64), np.float32), 64, 64)
+    assert empty.shape == (0, 4, 2)
+
+
+def test_runner_needs_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU box")
+    g = load_graph(os.path.join(GOLD, "ppocr_det_fast_graph.json"))
+    with pytest.raises(_lib.VsrError) as ei:
+        ocr_det.PaddleGraphRunner(g, synthetic_weights(g))
+    assert ei.value.code == _lib.VSR_ERR_NOGPU

@@ -121,6 +121,15 @@ SIGNATURES = {
     "vsr_rfc_complete": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vsr_rfc_read_buffer": (_I, [_P, _I, _L, _L, _P]),
     "vsr_rfc_flops": (_D, [_P, _I, _I, _I]),
+    "vsr_det_launch_conv2d": (_I, [_P, _P, _P] + [_I] * 15 + [_P, _P]),
+    "vsr_det_launch_deconv2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vsr_det_launch_binary": (_I, [_P, _P, _I, _L, _I, _L, _I, _P, _P]),
+    "vsr_det_launch_unary": (_I, [_P, _L, _I, C.c_float, C.c_float, _P, _P]),
+    "vsr_det_launch_affine": (_I, [_P, _P, _P, _L, _I, _L, _P, _P]),
+    "vsr_det_launch_gap": (_I, [_P, _L, _L, _P, _P]),
+    "vsr_det_launch_maxpool": (_I, [_P, _L] + [_I] * 10 + [_P, _P]),
+    "vsr_det_launch_nearest": (_I, [_P, _L, _I, _I, _I, _P, _P]),
+    "vsr_det_launch_normalize": (_I, [_P, _I, _I, _P, _P]),
     "vsr_pp_create": (_I, [_I, C.POINTER(_P)]),
     "vsr_pp_destroy": (None, [_P]),
     "vsr_pp_img_propagation": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

@@ -1,0 +1,328 @@
+"""Text detector on the MI355X: the `text_detector` object the reference builds in backend/tools/subtitle_detect.py:41-54
+(paddleocr.TextDetection over backend/models/V5/{ch_det,ch_det_fast}: PP-OCRv5 server / mobile detection) -- SURVEY.md 8(a) a20.
+
+  TextDetection(model_dir | graph, weights, device).predict(img) -> [{"dt_polys": int32 [n,4,2], "dt_scores": [n]}]
+
+Pre-processing follows the model's inference.yml (DetResizeForTest resize_long 960, NormalizeImage ImageNet mean / std on the
+BGR image, CHW), the forward pass executes the PaddlePaddle inference program (inference.json) operator by operator with the
+HIP kernels of csrc/det_kernels.hip (walked here, on the host, the way Paddle's executor walks it), post-processing is
+DBPostProcess (thresh 0.3, box_thresh 0.6, max_candidates 1000, unclip_ratio 1.5) on the host like in the reference.
+There is no CPU path: the runner needs a HIP device.  paddleocr / paddlepaddle and the *.pdiparams weights are absent from the
+reference mount, so `weights` is a {parameter name: array} dict (tests use synthetic ones) -- parity with Paddle's binary
+is unpinned.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.ndimage
+import torch
+
+from ... import _lib
+from ..._lib import check, lib
+from .paddle_graph import load_graph
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PaddleGraphRunner:
+    """Executes a detection program on one GPU; values are NCHW fp32 torch tensors (device memory only)."""
+
+    def __init__(self, graph, weights, device=0):
+        if lib.vsr_device_count() <= 0 or not torch.cuda.is_available():
+            raise _lib.VsrError(_lib.VSR_ERR_NOGPU, "no HIP device visible: the text detector has no CPU fallback")
+        self.graph = graph
+        self.device = torch.device("cuda", device)
+        self.params = {}
+        for vid, (name, shape) in graph.params.items():
+            if name not in weights:
+                raise KeyError(f"missing detector parameter: {name}")
+            a = np.ascontiguousarray(np.asarray(weights[name], dtype=np.float32))
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError(f"shape mismatch for {name}: {a.shape} vs {shape}")
+            self.params[vid] = torch.from_numpy(a).to(self.device)
+        # inference batch_norm as a per-channel affine (inputs: x, mean, variance, scale, bias)
+        self.bn = {}
+        for i, (kind, ins, outs, a) in enumerate(graph.ops):
+            if kind == "batch_norm_":
+                mean, var, gamma, beta = (self.params[j].double() for j in ins[1:5])
+                s = gamma / torch.sqrt(var + a["epsilon"])
+                self.bn[i] = (s.float().contiguous(), (beta - mean * s).float().contiguous())
+
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _binary(self, a, b, op):
+        if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.numel() < b.numel():
+            a, b = b, a                                            # add / multiply commute: keep the full tensor first
+        n, c = a.shape[0], a.shape[1]
+        hw = a.numel() // (n * c)
+        if tuple(b.shape) == tuple(a.shape):
+            mode = 0
+        elif b.numel() == c:
+            mode = 1
+        elif b.numel() == n * c:
+            mode = 2
+        else:
+            raise NotImplementedError(f"broadcast {tuple(a.shape)} with {tuple(b.shape)}")
+        out = self._new(*a.shape)
+        check(lib.vsr_det_launch_binary(_p(a), _p(b.contiguous()), op, a.numel(), c, hw, mode, _p(out), _stream()))
+        return out
+
+    def _unary(self, x, kind, p0=0.0, p1=0.0):
+        out = self._new(*x.shape)
+        check(lib.vsr_det_launch_unary(_p(x), x.numel(), kind, C.c_float(p0), C.c_float(p1), _p(out), _stream()))
+        return out
+
+    def run(self, x):
+        """x: fp32 [N,3,H,W] on the device -> probability map [N,1,H,W]"""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        val = dict(self.params)
+        val[self.graph.input_id] = x
+        with torch.cuda.device(self.device):
+            for i, (kind, ins, outs, a) in enumerate(self.graph.ops):
+                g = lambda j: val[ins[j]]
+                if kind in ("conv2d", "depthwise_conv2d"):
+                    xin, w = g(0).contiguous(), g(1)
+                    n, cin, h, wd = xin.shape
+                    cout, _, kh, kw = w.shape
+                    sh, sw = a["strides"]
+                    pt, pl = a["paddings"][0], a["paddings"][1]
+                    if a.get("padding_algorithm") == "SAME":              # stride 1 here: the extra pixel goes after
+                        pt, pl = (kh - 1) // 2, (kw - 1) // 2
+                        ho, wo = -(-h // sh), -(-wd // sw)
+                    else:
+                        ho, wo = (h + 2 * pt - kh) // sh + 1, (wd + 2 * pl - kw) // sw + 1
+                    dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
+                    if not dw and a["groups"] != 1:
+                        raise NotImplementedError("grouped conv")
+                    out = self._new(n, cout, ho, wo)
+                    check(lib.vsr_det_launch_conv2d(_p(xin), _p(w), None, n, cin, h, wd, cout, kh, kw, sh, sw, pt, pl, ho, wo, dw, 0, _p(out), _stream()))
+                    val[outs[0]] = out
+                elif kind == "conv2d_transpose":
+                    xin, w = g(0).contiguous(), g(1)
+                    n, cin, h, wd = xin.shape
+                    if tuple(w.shape[2:]) != (2, 2) or list(a["strides"]) != [2, 2] or list(a["paddings"]) != [0, 0]:
+                        raise NotImplementedError("conv2d_transpose other than 2x2 / stride 2")
+                    dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
+                    cout = cin if dw else w.shape[1]
+                    out = self._new(n, cout, 2 * h, 2 * wd)
+                    check(lib.vsr_det_launch_deconv2x2(_p(xin), _p(w), n, cin, h, wd, cout, dw, _p(out), _stream()))
+                    val[outs[0]] = out
+                elif kind == "batch_norm_":
+                    xin = g(0).contiguous()
+                    s, t = self.bn[i]
+                    out = self._new(*xin.shape)
+                    check(lib.vsr_det_launch_affine(_p(xin), _p(s), _p(t), xin.numel(), xin.shape[1], xin.shape[2] * xin.shape[3], _p(out), _stream()))
+                    val[outs[0]] = out
+                elif kind == "full_int_array":
+                    val[outs[0]] = [int(v) for v in a["value"]]
+                elif kind == "full":
+                    val[outs[0]] = a["value"]
+                elif kind == "reshape":
+                    val[outs[0]] = g(0).reshape(g(1))
+                elif kind == "add":
+                    val[outs[0]] = self._binary(g(0), g(1), 0)
+                elif kind == "multiply":
+                    val[outs[0]] = self._binary(g(0), g(1), 1)
+                elif kind == "relu":
+                    val[outs[0]] = self._unary(g(0).contiguous(), 0)
+                elif kind == "hardswish":
+                    val[outs[0]] = self._unary(g(0).contiguous(), 1)
+                elif kind == "hardsigmoid":
+                    val[outs[0]] = self._unary(g(0).contiguous(), 2, a["slope"], a["offset"])
+                elif kind == "sigmoid":
+                    val[outs[0]] = self._unary(g(0).contiguous(), 3)
+                elif kind == "scale":
+                    s = val[ins[1]] if len(ins) > 1 and ins[1] in val else a.get("scale", 1.0)
+                    s, b = float(s), float(a.get("bias", 0.0))
+                    val[outs[0]] = self._unary(g(0).contiguous(), 4, s, b if a.get("bias_after_scale", True) else b * s)
+                elif kind == "pool2d":
+                    xin, ks = g(0).contiguous(), g(1)
+                    n, c, h, wd = xin.shape
+                    if a["adaptive"]:
+                        if list(ks) != [1, 1] or a["pooling_type"] != "avg":
+                            raise NotImplementedError("adaptive pool other than global average")
+                        out = self._new(n, c, 1, 1)
+                        check(lib.vsr_det_launch_gap(_p(xin), n * c, h * wd, _p(out), _stream()))
+                    else:
+                        if a["pooling_type"] != "max":
+                            raise NotImplementedError("average pool")
+                        sh, sw = a["strides"]
+                        pt, pl = a["paddings"][0], a["paddings"][1]
+                        if a.get("padding_algorithm") == "SAME":
+                            pt, pl = (ks[0] - 1) // 2, (ks[1] - 1) // 2
+                            ho, wo = -(-h // sh), -(-wd // sw)
+                        elif a["ceil_mode"]:
+                            ho, wo = -(-(h + 2 * pt - ks[0]) // sh) + 1, -(-(wd + 2 * pl - ks[1]) // sw) + 1
+                        else:
+                            ho, wo = (h + 2 * pt - ks[0]) // sh + 1, (wd + 2 * pl - ks[1]) // sw + 1
+                        out = self._new(n, c, ho, wo)
+                        check(lib.vsr_det_launch_maxpool(_p(xin), n * c, h, wd, ks[0], ks[1], sh, sw, pt, pl, ho, wo, _p(out), _stream()))
+                    val[outs[0]] = out
+                elif kind == "nearest_interp":
+                    xin = g(0).contiguous()
+                    n, c, h, wd = xin.shape
+                    s = int(a["scale"][0])
+                    if a["scale"][0] != a["scale"][1] or s != a["scale"][0]:
+                        raise NotImplementedError("non-integer nearest_interp scale")
+                    out = self._new(n, c, h * s, wd * s)
+                    check(lib.vsr_det_launch_nearest(_p(xin), n * c, h, wd, s, _p(out), _stream()))
+                    val[outs[0]] = out
+                elif kind == "combine":
+                    val[outs[0]] = [val[j] for j in ins]
+                elif kind == "concat":
+                    val[outs[0]] = torch.cat(g(0), dim=int(g(1)))           # pure data movement
+                else:
+                    raise NotImplementedError(f"detector op {kind}")
+        return val[self.graph.output_id]
+
+
+# ------------------------------------------------------------------------------------------------
+# DBPostProcess (inference.yml PostProcess; paddleocr's DBPostProcess: boxes_from_bitmap, get_mini_boxes, box_score_fast, unclip)
+# ------------------------------------------------------------------------------------------------
+def _convex_hull(pts):
+    pts = sorted(set(map(tuple, pts)))
+    if len(pts) <= 2:
+        return np.array(pts, dtype=np.float64)
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lower, upper = [], []
+    for p in pts:
+        while len(lower) >= 2 and cross(lower[-2], lower[-1], p) <= 0:
+            lower.pop()
+        lower.append(p)
+    for p in reversed(pts):
+        while len(upper) >= 2 and cross(upper[-2], upper[-1], p) <= 0:
+            upper.pop()
+        upper.append(p)
+    return np.array(lower[:-1] + upper[:-1], dtype=np.float64)
+
+
+def min_area_rect(points):
+    """minimum-area enclosing rectangle of integer points (cv2.minAreaRect's definition) -> (4 corners [4,2], width, height)"""
+    hull = _convex_hull(points)
+    if len(hull) == 1:
+        return np.repeat(hull, 4, axis=0), 0.0, 0.0
+    best = None
+    for i in range(len(hull)):
+        e = hull[(i + 1) % len(hull)] - hull[i]
+        nrm = np.hypot(*e)
+        if nrm == 0:
+            continue
+        u = e / nrm
+        v = np.array([-u[1], u[0]])
+        pu, pv = hull @ u, hull @ v
+        w, h = pu.max() - pu.min(), pv.max() - pv.min()
+        if best is None or w * h < best[0]:
+            c = [pu.min() * u + pv.min() * v, pu.max() * u + pv.min() * v, pu.max() * u + pv.max() * v, pu.min() * u + pv.max() * v]
+            best = (w * h, np.array(c), w, h)
+    return best[1], best[2], best[3]
+
+
+def _order_box(c):
+    """get_mini_boxes: corners ordered top-left, top-right, bottom-right, bottom-left"""
+    p = sorted(c.tolist(), key=lambda q: q[0])
+    (a, b), (d, e) = sorted(p[:2], key=lambda q: q[1]), sorted(p[2:], key=lambda q: q[1])
+    return np.array([a, d, e, b], dtype=np.float64)
+
+
+def _box_score(prob, box):
+    """box_score_fast: mean probability over the pixels inside the box polygon"""
+    h, w = prob.shape
+    x0, x1 = int(np.clip(np.floor(box[:, 0].min()), 0, w - 1)), int(np.clip(np.ceil(box[:, 0].max()), 0, w - 1))
+    y0, y1 = int(np.clip(np.floor(box[:, 1].min()), 0, h - 1)), int(np.clip(np.ceil(box[:, 1].max()), 0, h - 1))
+    ys, xs = np.mgrid[y0:y1 + 1, x0:x1 + 1]
+    inside = np.ones(ys.shape, dtype=bool)
+    for i in range(4):
+        p, q = box[i], box[(i + 1) % 4]
+        inside &= (q[0] - p[0]) * (ys - p[1]) - (q[1] - p[1]) * (xs - p[0]) >= -1e-6
+    if not inside.any():
+        return 0.0
+    return float(prob[y0:y1 + 1, x0:x1 + 1][inside].mean())
+
+
+def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
+    """prob [H,W] -> (boxes int32 [n,4,2] in source-image pixels, scores [n])"""
+    H, W = prob.shape
+    labels, n = scipy.ndimage.label(prob > thresh, structure=np.ones((3, 3), dtype=int))        # 8-connected, like findContours
+    boxes, scores = [], []
+    for lab, sl in enumerate(scipy.ndimage.find_objects(labels)[:max_candidates], start=1):
+        comp = labels[sl] == lab
+        edge = comp & ~scipy.ndimage.binary_erosion(comp, structure=np.ones((3, 3), dtype=bool), border_value=0)
+        ys, xs = np.nonzero(edge)
+        pts = np.stack([xs + sl[1].start, ys + sl[0].start], 1)
+        corners, w, h = min_area_rect(pts)
+        if min(w, h) < min_size:
+            continue
+        box = _order_box(corners)
+        score = _box_score(prob, box)
+        if score < box_thresh:
+            continue
+        d = (w * h) * unclip_ratio / (2 * (w + h))                     # unclip: offset the rectangle by area * ratio / perimeter
+        ctr = box.mean(0)
+        u = (box[1] - box[0]) / max(np.hypot(*(box[1] - box[0])), 1e-9)
+        v = (box[3] - box[0]) / max(np.hypot(*(box[3] - box[0])), 1e-9)
+        hw_, hh_ = np.hypot(*(box[1] - box[0])) / 2 + d, np.hypot(*(box[3] - box[0])) / 2 + d
+        if min(2 * hw_, 2 * hh_) < min_size + 2:
+            continue
+        big = np.array([ctr - hw_ * u - hh_ * v, ctr + hw_ * u - hh_ * v, ctr + hw_ * u + hh_ * v, ctr - hw_ * u + hh_ * v])
+        big[:, 0] = np.clip(np.round(big[:, 0] / W * src_w), 0, src_w)
+        big[:, 1] = np.clip(np.round(big[:, 1] / H * src_h), 0, src_h)
+        boxes.append(_order_box(big).astype(np.int32))
+        scores.append(score)
+    return (np.stack(boxes) if boxes else np.zeros((0, 4, 2), np.int32)), scores
+
+
+class TextDetection:
+    def __init__(self, model, weights, device=0, resize_long=960):
+        """model: directory holding inference.json (as backend/models/V5/ch_det), a path to it, or a loaded / condensed graph dict"""
+        if isinstance(model, (str, os.PathLike)) and os.path.isdir(model):
+            model = os.path.join(model, "inference.json")
+        self.graph = model if hasattr(model, "ops") else load_graph(model)
+        self.runner = PaddleGraphRunner(self.graph, weights, device)
+        self.resize_long = resize_long
+        self.device = self.runner.device
+        self._tables = {}
+
+    def _resize(self, img_dev, H, W, rh, rw):
+        """cv2.resize(img, (rw, rh)) INTER_LINEAR on uint8 -- the fixed-point kernel of the inpainting path"""
+        key = (H, W, rh, rw)
+        if key not in self._tables:
+            tabs = []
+            for ssize, dsize, clamp in ((W, rw, 1), (H, rh, 0)):
+                ofs, ic, fc = np.zeros(dsize, np.int32), np.zeros(2 * dsize, np.int16), np.zeros(2 * dsize, np.float32)
+                check(lib.vsr_cv2_linear_tables(ssize, dsize, clamp, ofs.ctypes.data_as(C.c_void_p), ic.ctypes.data_as(C.c_void_p), fc.ctypes.data_as(C.c_void_p)))
+                tabs += [torch.from_numpy(ofs).to(self.device), torch.from_numpy(ic).to(self.device)]
+            self._tables[key] = tabs
+        xofs, ialpha, yofs, ibeta = self._tables[key]
+        out = torch.empty((rh, rw, 3), dtype=torch.uint8, device=self.device)
+        check(lib.vsr_launch_resize_u8(_p(img_dev), H * W * 3, W * 3, W, H, _p(out), rw, rh, 1, 3, None, _p(xofs), _p(ialpha), _p(yofs), _p(ibeta), _stream()))
+        return out
+
+    def probability_map(self, img):
+        """img: HxWx3 uint8 BGR (numpy) -> (probability map [rh, rw] torch tensor on the device, rh, rw)"""
+        H, W = img.shape[:2]
+        ratio = float(self.resize_long) / max(H, W)                        # DetResizeForTest(resize_long): longer side -> 960,
+        rh = max(int(round(H * ratio / 32) * 32), 32)                      # both sides to multiples of 32
+        rw = max(int(round(W * ratio / 32) * 32), 32)
+        with torch.cuda.device(self.device):
+            d = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+            small = self._resize(d, H, W, rh, rw)
+            x = torch.empty((1, 3, rh, rw), dtype=torch.float32, device=self.device)
+            check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x), _stream()))
+            prob = self.runner.run(x)
+        return prob[0, 0], rh, rw
+
+    def predict(self, img):
+        prob, _, _ = self.probability_map(img)
+        boxes, scores = db_postprocess(prob.cpu().numpy(), img.shape[0], img.shape[1])
+        return [{"dt_polys": boxes, "dt_scores": scores}]
