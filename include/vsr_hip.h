@@ -300,7 +300,7 @@ double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* win
  * NCHW fp32 device tensors; the host runner (backend/tools/ocr_det.py) walks the program and calls one launcher per op.
  * act: 0 none, 1 relu, 2 hardswish.  Paddle operator definitions: conv2d / depthwise_conv2d (zero padding (pt, pl) before,
  * output Ho x Wo), conv2d_transpose 2x2 stride 2 (weight [Cin][Cout][2][2], depthwise: [C][1][2][2]), elementwise add (op 0) /
- * multiply (op 1) with b of the same shape (bmode 0), [C] (1) or [N*C] (2), unary relu 0 / hardswish 1 / hardsigmoid(p0, p1) 2 /
+ * multiply (op 1) with b of the same shape (bmode 0), [C] (1), [N*C] (2) or one scalar (3), unary relu 0 / hardswish 1 / hardsigmoid(p0, p1) 2 /
  * sigmoid 3 / x*p0+p1 4, inference batch_norm as x*scale[c]+shift[c], adaptive average pool to 1x1, max pool, nearest_interp
  * (integer scale), and the inference.yml pre-processing NormalizeImage + ToCHWImage on a BGR uint8 image.
  * ------------------------------------------------------------------------------------- */

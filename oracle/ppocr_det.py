@@ -40,10 +40,11 @@ def synthetic_weights(graph, seed=0):
     return out
 
 
-def run_graph(graph, weights, x):
-    """x: torch [N,3,H,W] fp32 (normalised image) -> probability map [N,1,H,W]"""
-    val = {vid: torch.from_numpy(np.asarray(weights[name], dtype=np.float32)) for vid, (name, _) in graph.params.items()}
-    val[graph.input_id] = x
+def run_graph(graph, weights, x, dtype=torch.float32):
+    """x: torch [N,3,H,W] (normalised image) -> probability map [N,1,H,W]; dtype=torch.float64 gives the reference against
+    which fp32 rounding of a ~150-layer program can be judged"""
+    val = {vid: torch.from_numpy(np.asarray(weights[name], dtype=np.float32)).to(dtype) for vid, (name, _) in graph.params.items()}
+    val[graph.input_id] = x.to(dtype)
     with torch.no_grad():
         for kind, ins, outs, a in graph.ops:
             g = lambda i: val[ins[i]]

@@ -177,6 +177,15 @@ class SubtitleRemover:
                 self.update_progress(tbar, increment=len(batch))
         reader.release()
 
+    def _default_detector(self):
+        """the injected detector if any, else the MI355X TextDetection configured through the environment (tools/ocr_det.py)"""
+        det = getattr(self, "text_detector", None)
+        if det is None:
+            from .tools import ocr_det
+
+            det = ocr_det.from_env(0 if not isinstance(self.device, str) or ":" not in self.device else int(self.device.split(":")[1]))
+        return det
+
     def run(self):
         start_time = time.time()
         if len(self.sub_areas) == 0:
@@ -188,10 +197,10 @@ class SubtitleRemover:
             from .inpaint.sttn_det_inpaint import STTNDetInpaint
 
             det_path = os.environ.get("STTN_DET_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-det", "sttn.pth"))
-            self.video_inpaint(None, STTNDetInpaint(self.device, det_path), text_detector=getattr(self, "text_detector", None))
+            self.video_inpaint(None, STTNDetInpaint(self.device, det_path), text_detector=self._default_detector())
         elif mode == InpaintMode.PROPAINTER:
             self.propainter_mode(None, propainter_inpaint=getattr(self, "propainter_inpaint", None),
-                                 text_detector=getattr(self, "text_detector", None), scene_div_points=getattr(self, "scene_div_points", None))
+                                 text_detector=self._default_detector(), scene_div_points=getattr(self, "scene_div_points", None))
         else:
             raise Exception(f"inpaint mode: {mode} not implemented")     # main.py:386
         self.isFinished = True

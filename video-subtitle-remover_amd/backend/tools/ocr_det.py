@@ -65,6 +65,8 @@ class PaddleGraphRunner:
         hw = a.numel() // (n * c)
         if tuple(b.shape) == tuple(a.shape):
             mode = 0
+        elif b.numel() == 1:
+            mode = 3                                               # LearnableAffineBlock's scalar scale / bias
         elif b.numel() == c:
             mode = 1
         elif b.numel() == n * c:
@@ -326,3 +328,15 @@ class TextDetection:
         prob, _, _ = self.probability_map(img)
         boxes, scores = db_postprocess(prob.cpu().numpy(), img.shape[0], img.shape[1])
         return [{"dt_polys": boxes, "dt_scores": scores}]
+
+
+def from_env(device=0):
+    """TextDetection from VSR_DET_MODEL_DIR (a directory like backend/models/V5/ch_det holding inference.json) and
+    VSR_DET_WEIGHTS (an .npz of {parameter name: array} converted from the model's inference.pdiparams, whose reader needs
+    Paddle); None when either is unset -- callers then need an injected detector, exactly as before."""
+    model_dir, wpath = os.environ.get("VSR_DET_MODEL_DIR"), os.environ.get("VSR_DET_WEIGHTS")
+    if not model_dir or not wpath:
+        return None
+    with np.load(wpath) as z:
+        weights = {k: z[k] for k in z.files}
+    return TextDetection(model_dir, weights, device=device)

@@ -116,7 +116,7 @@ k_det_binary(const float* __restrict__ a, const float* __restrict__ b, int op, i
 {
     GRID_STRIDE(i, total) {
         const int64_t nc = i / HW;
-        const float bv = bmode == 0 ? b[i] : (bmode == 1 ? b[nc % C] : b[nc]);
+        const float bv = bmode == 0 ? b[i] : (bmode == 1 ? b[nc % C] : (bmode == 2 ? b[nc] : b[0]));   // 3: one scalar
         out[i] = op == 0 ? a[i] + bv : a[i] * bv;
     }
 }
