@@ -320,7 +320,7 @@ int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_ch
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
-/* sub-kinds of op kind 6 (RAFT, csrc/raft_kernels.hip) */
+/* sub-kinds of op kind 6 (RAFT, csrc/flow_kernels.hip) */
 enum { VSR_EW_IM2COL7_U8 = 1, VSR_EW_INORM_STATS = 2, VSR_EW_INORM_APPLY = 3, VSR_EW_CTX_SPLIT = 4, VSR_EW_FLOW_UPDATE = 5,
        VSR_EW_IM2COL7_FLOW = 6, VSR_EW_AVGPOOL2 = 7, VSR_EW_CORR_LOOKUP = 8, VSR_EW_GRU_RH = 9, VSR_EW_GRU_UPDATE = 10,
        VSR_EW_CONVEX_UP = 11,

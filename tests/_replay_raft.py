@@ -1,5 +1,5 @@
 """CPU replay of the RAFT plan (test infrastructure): the OP_EW sub-kinds of csrc/raft_plan.h executed with numpy /
-torch-CPU exactly as csrc/raft_kernels.hip defines them, GEMMs through tests/_replay.gemm_reference."""
+torch-CPU exactly as csrc/flow_kernels.hip defines them, GEMMs through tests/_replay.gemm_reference."""
 import ctypes as C
 
 import numpy as np

@@ -1,5 +1,5 @@
 """CPU replay of the flow-completion plan (test infrastructure): OP_EW sub-kinds of csrc/rfc_plan.h executed with numpy /
-torch-CPU exactly as csrc/raft_kernels.hip defines them; GEMMs and the 2x upsampling through tests/_replay."""
+torch-CPU exactly as csrc/flow_kernels.hip defines them; GEMMs and the 2x upsampling through tests/_replay."""
 import ctypes as C
 
 import numpy as np

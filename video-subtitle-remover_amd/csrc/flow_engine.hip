@@ -18,7 +18,7 @@
 #include "elementwise.h"
 #include "gather_gemm.h"
 #include "plan_c.h"
-#include "raft_kernels.h"
+#include "flow_kernels.h"
 #include "raft_plan.h"
 #include "rfc_plan.h"
 #include "pp_kernels.h"

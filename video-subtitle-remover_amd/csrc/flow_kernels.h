@@ -1,4 +1,4 @@
-// Launchers of the RAFT elementwise / gather kernels (raft_kernels.hip); one per OP_EW sub-kind of raft_plan.h.
+// Launchers of the RAFT elementwise / gather kernels (flow_kernels.hip); one per OP_EW sub-kind of raft_plan.h.
 // All pointers are device pointers; return 0 or -1 (launch error).
 #pragma once
 #include <stdint.h>

@@ -1,9 +1,10 @@
-// HBM-bound kernels of the RAFT path (plan ops of kind OP_EW, raft_plan.h).  Each one cites the reference lines it
+// HBM-bound kernels of the optical-flow stages: RAFT (plan ops of kind OP_EW, raft_plan.h) and, further down, the recurrent
+// flow completion (rfc_plan.h).  Each one cites the reference lines it
 // stands for (backend/inpaint/video/raft/*).  Plain expressions under "fp contract(off)": the sampling coordinates
 // follow torch's op order (normalise to [-1,1], un-normalise) so that the CPU oracle and this file round alike.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "raft_kernels.h"
+#include "flow_kernels.h"
 
 #pragma clang fp contract(off)
 

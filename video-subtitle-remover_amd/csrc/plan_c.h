@@ -1,4 +1,4 @@
-// The C handle behind vsr_plan_t: shared by the STTN engine (sttn_engine.hip) and the RAFT engine (raft_engine.hip).
+// The C handle behind vsr_plan_t: shared by the STTN engine (sttn_engine.hip) and the RAFT engine (flow_engine.hip).
 #pragma once
 #include <memory>
 #include "sttn_plan.h"

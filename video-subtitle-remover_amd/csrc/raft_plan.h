@@ -2,8 +2,8 @@
 // network backend/inpaint/video/raft/{raft,extractor,corr,update}.py) as a flat op list over symbolic buffers and
 // offset tables -- SURVEY.md section 8(a) row a14.  Same IR as the STTN plan (sttn_plan.h): every conv and the
 // all-pairs correlation are gather-GEMM problems; normalisation, the correlation pyramid / lookup, the GRU gate
-// arithmetic, the flow bookkeeping and the convex upsampling are OP_EW ops (raft_kernels.hip).  Pure C++: the
-// engine (raft_engine.hip) materialises it, tests replay it on the CPU against oracle/raft.py.
+// arithmetic, the flow bookkeeping and the convex upsampling are OP_EW ops (flow_kernels.hip).  Pure C++: the
+// engine (flow_engine.hip) materialises it, tests replay it on the CPU against oracle/raft.py.
 #pragma once
 #include "sttn_plan.h"
 

@@ -27,7 +27,7 @@ static int fail(int code, const std::string& msg)
     g_err = msg;
     return code;
 }
-// error sink shared with raft_engine.hip (plan_c.h)
+// error sink shared with flow_engine.hip (plan_c.h)
 int vsr_internal_fail(int code, const char* msg) { return fail(code, msg); }
 
 #define HIPCHK(expr)                                                                                       \
