@@ -64,3 +64,73 @@ def test_runner_needs_a_gpu():
     with pytest.raises(_lib.VsrError) as ei:
         ocr_det.PaddleGraphRunner(g, synthetic_weights(g))
     assert ei.value.code == _lib.VSR_ERR_NOGPU
+
+
+def _pb_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _write_pdiparams(path, arrays, packed=False, lod=False):
+    """writer of the save_combine layout paddle_graph.read_pdiparams restates (test helper)"""
+    import struct
+    code = {"float32": 5, "float16": 4, "int64": 3, "float64": 6}
+    with open(path, "wb") as f:
+        for a in arrays:
+            f.write(struct.pack("<I", 0))
+            if lod:
+                f.write(struct.pack("<QQ", 1, 16) + struct.pack("<QQ", 0, 3))
+            else:
+                f.write(struct.pack("<Q", 0))
+            desc = b"\x08" + _pb_varint(code[str(a.dtype)])
+            if packed:
+                body = b"".join(_pb_varint(d) for d in a.shape)
+                desc += b"\x12" + _pb_varint(len(body)) + body
+            else:
+                desc += b"".join(b"\x10" + _pb_varint(d) for d in a.shape)
+            f.write(struct.pack("<Ii", 0, len(desc)) + desc + np.ascontiguousarray(a).tobytes())
+
+
+@pytest.mark.parametrize("order,packed,lod", [("name", False, False), ("program", True, True)])
+def test_pdiparams_reader_round_trip(tmp_path, order, packed, lod):
+    from vsr_amd.backend.tools import paddle_graph
+    g = paddle_graph.load_graph(os.path.join(GOLD, "ppocr_det_fast_graph.json"))
+    w = synthetic_weights(g)
+    plist = [g.params[k] for k in sorted(g.params)]
+    if order == "name":
+        plist = sorted(plist, key=lambda nv: nv[0])
+    arrays = [np.asarray(w[name], dtype=np.float32) for name, _ in plist]
+    arrays[3] = arrays[3].astype(np.float16)                         # a half-precision tensor is widened on read
+    path = str(tmp_path / "inference.pdiparams")
+    _write_pdiparams(path, arrays, packed=packed, lod=lod)
+    got = paddle_graph.read_pdiparams(path, g)
+    assert set(got) == {name for name, _ in plist}
+    for (name, shape), a in zip(plist, arrays):
+        assert got[name].dtype == np.float32 and got[name].shape == tuple(shape)
+        np.testing.assert_array_equal(got[name], a.astype(np.float32))
+    # a truncated stream and a wrong parameter count fail loudly
+    with open(path, "rb") as f:
+        raw = f.read()
+    bad = str(tmp_path / "bad.pdiparams")
+    with open(bad, "wb") as f:
+        f.write(raw[: len(raw) // 2])
+    with pytest.raises(ValueError):
+        paddle_graph.read_pdiparams(bad, g)
+    _write_pdiparams(bad, arrays[:-1])
+    with pytest.raises(ValueError, match="parameters"):
+        paddle_graph.read_pdiparams(bad, g)
+
+
+def test_from_env_without_weights_is_none(monkeypatch, tmp_path):
+    from vsr_amd.backend.tools import ocr_det
+    monkeypatch.delenv("VSR_DET_WEIGHTS", raising=False)
+    monkeypatch.delenv("VSR_DET_MODEL_DIR", raising=False)
+    assert ocr_det.from_env() is None
+    monkeypatch.setenv("VSR_DET_MODEL_DIR", str(tmp_path))            # directory without inference.pdiparams
+    assert ocr_det.from_env() is None

@@ -20,7 +20,7 @@ import torch
 
 from ... import _lib
 from ..._lib import check, lib
-from .paddle_graph import load_graph
+from .paddle_graph import load_graph, read_pdiparams
 
 
 def _p(t):
@@ -331,12 +331,23 @@ class TextDetection:
 
 
 def from_env(device=0):
-    """TextDetection from VSR_DET_MODEL_DIR (a directory like backend/models/V5/ch_det holding inference.json) and
-    VSR_DET_WEIGHTS (an .npz of {parameter name: array} converted from the model's inference.pdiparams, whose reader needs
-    Paddle); None when either is unset -- callers then need an injected detector, exactly as before."""
+    """TextDetection from VSR_DET_MODEL_DIR (a directory like backend/models/V5/ch_det holding inference.json) and its weights:
+    VSR_DET_WEIGHTS (an .npz of {parameter name: array}, or a .pdiparams file) or, when unset, inference.pdiparams inside the
+    model directory (what paddleocr reads, subtitle_detect.py:41-54).  None when the directory or the weights are missing --
+    callers then need an injected detector."""
     model_dir, wpath = os.environ.get("VSR_DET_MODEL_DIR"), os.environ.get("VSR_DET_WEIGHTS")
-    if not model_dir or not wpath:
+    if not model_dir:
         return None
-    with np.load(wpath) as z:
-        weights = {k: z[k] for k in z.files}
-    return TextDetection(model_dir, weights, device=device)
+    if not wpath:
+        wpath = os.path.join(model_dir, "inference.pdiparams")
+    if not os.path.isfile(wpath):
+        return None
+    return TextDetection(model_dir, load_weights(wpath, model_dir), device=device)
+
+
+def load_weights(wpath, model_dir):
+    if wpath.endswith(".npz"):
+        with np.load(wpath) as z:
+            return {k: z[k] for k in z.files}
+    graph = load_graph(os.path.join(model_dir, "inference.json")) if os.path.isdir(model_dir) else load_graph(model_dir)
+    return read_pdiparams(wpath, graph)
