@@ -79,63 +79,92 @@ class SubtitleRemover:
                 return end_no
         return -1
 
+    @staticmethod
+    def _distributed():
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+        return None
+
+    def _run_items(self, tbar, items, process):
+        """Drive the (pass-through frame | batch + mask) items of one video: on one GPU in order, on several dealt
+        round-robin by tools/batch_parallel.py (rank 0 reads, detects and writes; peers only run `process`)."""
+        from .tools.batch_parallel import run_batch_parallel
+
+        def write(frame):
+            self.video_writer.write(frame)
+            self.update_progress(tbar, increment=1)
+
+        run_batch_parallel(items, process, write, dist=self._distributed(), device=self.device if self._distributed() else "cpu")
+
     def propainter_mode(self, tbar, propainter_inpaint=None, text_detector=None, scene_div_points=None, single_frame_inpaint=None):
         """backend/main.py:159-245.  Intervals of frames with the same mask, cut at scene changes, are read whole and
         handed to the plugin in batch_generator batches of propainterMaxLoadNum.  The detector, the scene-change frame
         numbers (reference: scenedetect's ContentDetector, subtitle_detect.py:158-170) and the single-frame fallback
         (reference: LaMa, whose network is a missing blob) are injected; without a fallback single frames pass through."""
-        detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
-        sub_list = detector.find_subtitle_frame_no(sub_remover=self)
-        if len(sub_list) == 0:
-            raise Exception(f"No subtitle detected in {self.video_path}")
-        ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
-        ranges = detector.split_range_by_scene(ranges, list(scene_div_points or []))
         if propainter_inpaint is None:
             from .inpaint.propainter_inpaint import PropainterInpaint
 
             model_dir = os.environ.get("PROPAINTER_MODEL_DIR", os.path.join(os.path.dirname(__file__), "models", "propainter"))
             propainter_inpaint = PropainterInpaint(self.device, model_dir, config.propainterMaxLoadNum.value)
+        dist = self._distributed()
+        if dist is not None and dist.get_rank() != 0:
+            return self._run_items(tbar, (), propainter_inpaint)
+        detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
+        sub_list = detector.find_subtitle_frame_no(sub_remover=self)
+        if len(sub_list) == 0:
+            self._run_items(tbar, (), propainter_inpaint)                  # releases the peers before failing
+            raise Exception(f"No subtitle detected in {self.video_path}")
+        ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
+        ranges = detector.split_range_by_scene(ranges, list(scene_div_points or []))
         reader = open_video(self.video_path)
-        index = 0
-        while True:
-            ok, frame = reader.read()
-            if not ok:
-                break
-            index += 1
-            if index not in sub_list:
-                self.video_writer.write(frame)
-                self.update_progress(tbar, increment=1)
-                continue
-            if not self.is_current_frame_no_start(index, ranges):
-                continue
-            start_frame_no = index
-            end_frame_no = self.find_frame_no_end(index, ranges)
-            if end_frame_no == -1:
-                continue
-            temp_frames = [frame]
-            while index < end_frame_no:
+
+        def items():
+            index = 0
+            while True:
                 ok, frame = reader.read()
                 if not ok:
                     break
                 index += 1
-                temp_frames.append(frame)
-            mask = create_mask(self.mask_size, sub_list[start_frame_no])
-            for batch in ([temp_frames] if len(temp_frames) == 1 else batch_generator(temp_frames, config.propainterMaxLoadNum.value)):
-                if len(batch) == 1:
-                    out = single_frame_inpaint(batch[0], mask) if single_frame_inpaint is not None else batch[0]
-                    self.video_writer.write(out)
-                else:
-                    for out in propainter_inpaint(batch, mask):
-                        self.video_writer.write(out)
-                self.update_progress(tbar, increment=len(batch))
-        reader.release()
+                if index not in sub_list:
+                    yield ("pass", frame)
+                    continue
+                if not self.is_current_frame_no_start(index, ranges):
+                    continue
+                start_frame_no = index
+                end_frame_no = self.find_frame_no_end(index, ranges)
+                if end_frame_no == -1:
+                    continue
+                temp_frames = [frame]
+                while index < end_frame_no:
+                    ok, frame = reader.read()
+                    if not ok:
+                        break
+                    index += 1
+                    temp_frames.append(frame)
+                mask = create_mask(self.mask_size, sub_list[start_frame_no])
+                for batch in ([temp_frames] if len(temp_frames) == 1 else batch_generator(temp_frames, config.propainterMaxLoadNum.value)):
+                    if len(batch) == 1:
+                        yield ("pass", single_frame_inpaint(batch[0], mask) if single_frame_inpaint is not None else batch[0])
+                    else:
+                        yield ("work", batch, mask)
+
+        try:
+            self._run_items(tbar, items(), propainter_inpaint)
+        finally:
+            reader.release()
 
     def video_inpaint(self, tbar, model, text_detector=None):
         """backend/main.py:260-333 -- detector pass, interval construction, then `model(batch, mask)` per batch.
         Frame numbers are 1-based here exactly as in the reference."""
+        dist = self._distributed()
+        if dist is not None and dist.get_rank() != 0:
+            return self._run_items(tbar, (), model)
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
         sub_list = detector.find_subtitle_frame_no(sub_remover=self)
         if len(sub_list) == 0:
+            self._run_items(tbar, (), model)
             raise Exception(f"No subtitle detected in {self.video_path}")
         ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
         ranges = expand_frame_ranges(ranges, config.subtitleTimelineBackwardFrameCount.value,
@@ -143,39 +172,42 @@ class SubtitleRemover:
         ranges = detector.filter_and_merge_intervals(ranges, config.sttnReferenceLength.value)
         start_end = {s: min(e, self.frame_count) for s, e in ranges}
         reader = open_video(self.video_path)
-        idx = 0
-        while True:
-            ok, frame = reader.read()
-            if not ok:
-                break
-            idx += 1
-            if idx not in start_end:
-                self.video_writer.write(frame)
-                self.update_progress(tbar, increment=1)
-                continue
-            first, last = idx, start_end[idx]
-            frames = [frame]
-            for _ in range(last - first):
+
+        def items():
+            idx = 0
+            while True:
                 ok, frame = reader.read()
                 if not ok:
                     break
                 idx += 1
-                frames.append(frame)
-            coords = []
-            for no in range(first, last):                      # NB: the reference's range excludes `last` (:310)
-                for area in sub_list.get(no, []):
-                    xmin, xmax, ymin, ymax = area
-                    if (ymax - ymin) - (xmax - xmin) > config.subtitleYXAxisDifferencePixel.value:
-                        continue                               # taller than wide: treated as a false detection
-                    if area not in coords:
-                        coords.append(area)
-            mask = create_mask(self.mask_size, coords)
-            for batch in batch_generator(frames, config.getSttnMaxLoadNum()):
-                if len(batch) >= 1:
-                    for out in model(batch, mask):
-                        self.video_writer.write(out)
-                self.update_progress(tbar, increment=len(batch))
-        reader.release()
+                if idx not in start_end:
+                    yield ("pass", frame)
+                    continue
+                first, last = idx, start_end[idx]
+                frames = [frame]
+                for _ in range(last - first):
+                    ok, frame = reader.read()
+                    if not ok:
+                        break
+                    idx += 1
+                    frames.append(frame)
+                coords = []
+                for no in range(first, last):                      # NB: the reference's range excludes `last` (:310)
+                    for area in sub_list.get(no, []):
+                        xmin, xmax, ymin, ymax = area
+                        if (ymax - ymin) - (xmax - xmin) > config.subtitleYXAxisDifferencePixel.value:
+                            continue                               # taller than wide: treated as a false detection
+                        if area not in coords:
+                            coords.append(area)
+                mask = create_mask(self.mask_size, coords)
+                for batch in batch_generator(frames, config.getSttnMaxLoadNum()):
+                    if len(batch) >= 1:
+                        yield ("work", batch, mask)
+
+        try:
+            self._run_items(tbar, items(), model)
+        finally:
+            reader.release()
 
     def _default_detector(self):
         """the injected detector if any, else the MI355X TextDetection configured through the environment (tools/ocr_det.py)"""
