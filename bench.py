@@ -182,6 +182,8 @@ def main():
     }
 
     eng.timing(False)
+    if world > 1:          # the CPU baseline and the informational legs belong to the N = 1 line only
+        args.no_cpu_baseline, args.no_split_half, args.e2e_chunks = True, True, 0
     if rank == 0:
         # ---- roofline of the dominant kernel from the HIP events of the timed region
         # dominant kernel symbol = the gather-GEMM instantiation with the largest total time; every
