@@ -317,6 +317,18 @@ int vsr_det_launch_nearest(const float* x, int64_t planes, int H, int W, int s, 
 int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_chw, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Scene cuts: the per-frame arithmetic of the ContentDetector pass that
+ * --inpaint-mode propainter runs over the whole video (backend/tools/subtitle_detect.py:158-170 ->
+ * backend/scenedetect/detectors/content_detector.py:138-172; frames down-scaled first by
+ * scene_manager.py:499-504 = vsr_launch_resize_u8).  Integer, bit-exact.
+ * ------------------------------------------------------------------------------------- */
+/* cv2.cvtColor(img, COLOR_BGR2HSV) on uint8 (H in [0,180)), interleaved in, interleaved out (content_detector.py:147) */
+int vsr_launch_bgr2hsv_u8(const uint8_t* bgr_dev, uint8_t* hsv_dev, int64_t npix, void* stream);
+/* sums[i][c] = sum over pixels |hsv[i+1][p][c] - hsv[i][p][c]|, i < npairs, over npairs+1 consecutive interleaved frames
+ * (_mean_pixel_distance before its division, content_detector.py:28-35); sums_dev is overwritten */
+int vsr_launch_absdiff_sums_u8x3(const uint8_t* hsv_dev, int npairs, int64_t pix_per_frame, uint64_t* sums_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */
