@@ -228,6 +228,115 @@ def _detector_graph_fixtures():
             json.dump(g.to_json(), f, separators=(",", ":"))
 
 
+def scene_clip(seed=5, n=90, H=120, W=780):
+    """synthetic clip with hard cuts (some closer than min_scene_len to the previous one) and slow drift in between"""
+    rng = np.random.default_rng(seed)
+    cuts_at = {18, 25, 33, 50, 51, 70, 88}
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    base = None
+    for i in range(n):
+        if base is None or i in cuts_at:
+            base = rng.integers(0, 256, (H // 12 + 1, W // 12 + 1, 3)).astype(np.float64)
+            shade = rng.uniform(0.3, 1.0)
+        img = base[yy // 12, xx // 12] * shade + 6.0 * np.sin(0.3 * i + xx / 40.0)[..., None]
+        frames.append(np.clip(img, 0, 255).astype(np.uint8))
+    return np.stack(frames)
+
+
+def _scene_cut_fixture():
+    """backend/scenedetect's own SceneManager + ContentDetector (scene_manager.py, detectors/content_detector.py) and
+    SubtitleDetect.get_scene_div_frame_no's conversion (subtitle_detect.py:158-170) run over an in-memory stream; the two cv2
+    calls on the way (resize, cvtColor) are the restatements of oracle/cv2_restate.py and oracle/scene_cuts.py."""
+    import importlib.util
+
+    from . import cv2_restate, scene_cuts
+
+    cv2 = sys.modules["cv2"]
+    saved = {k: cv2.__dict__.get(k) for k in ("cvtColor", "split", "resize", "COLOR_BGR2HSV", "INTER_LINEAR")}
+    cv2.COLOR_BGR2HSV, cv2.INTER_LINEAR = 40, 1
+    cv2.cvtColor = lambda img, code: scene_cuts.bgr2hsv_u8(img)
+    cv2.split = lambda img: [img[..., k] for k in range(img.shape[-1])]
+
+    def _resize(img, dsize, interpolation=None):
+        assert interpolation == 1
+        return cv2_restate.resize_linear(img, dsize)
+
+    cv2.resize = _resize
+    sys.modules.setdefault("tqdm", _Permissive("tqdm"))
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "backend", "scenedetect", rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    keep = {k: sys.modules.get(k) for k in ("backend.scenedetect", "backend.scenedetect.detectors")}
+    pkg = types.ModuleType("backend.scenedetect")
+    pkg.__path__ = []
+    sys.modules["backend.scenedetect"] = pkg
+    tp = types.ModuleType("backend.scenedetect._thirdparty")
+    tp.__path__ = []
+    sys.modules["backend.scenedetect._thirdparty"] = tp
+    for mod in ("platform", "frame_timecode", "_thirdparty.simpletable", "video_stream", "stats_manager", "scene_detector", "scene_manager"):
+        load("backend.scenedetect." + mod, mod.replace(".", "/") + ".py")
+    cd = load("backend.scenedetect.detectors.content_detector", "detectors/content_detector.py")
+    sm = sys.modules["backend.scenedetect.scene_manager"]
+    FrameTimecode = sys.modules["backend.scenedetect.frame_timecode"].FrameTimecode
+
+    class ArrayStream:                      # position semantics of VideoStreamCv2 (backends/opencv.py:189-217)
+        def __init__(self, frames):
+            self.frames, self.n = frames, 0
+            self.frame_rate = 25.0
+            self.base_timecode = FrameTimecode(0, 25.0)
+            self.frame_size = (frames.shape[2], frames.shape[1])
+            self.duration = self.base_timecode + frames.shape[0]
+
+        @property
+        def frame_number(self):
+            return self.n
+
+        @property
+        def position(self):
+            return self.base_timecode if self.n < 1 else self.base_timecode + (self.n - 1)
+
+        def read(self, decode=True, advance=True):
+            if self.n >= self.frames.shape[0]:
+                return False
+            f = self.frames[self.n]
+            self.n += 1
+            return f if decode else True
+
+    out = {}
+    for tag, kw in (("a", dict(seed=5, n=90, H=120, W=780)), ("b", dict(seed=6, n=40, H=90, W=200)), ("c", dict(seed=7, n=60, H=270, W=1030))):
+        clip = scene_clip(**kw)
+        det = cd.ContentDetector()
+        scores = []
+        orig = det.process_frame
+
+        def spy(frame_num, frame_img, _orig=orig, _det=det, _scores=scores):
+            r = _orig(frame_num, frame_img)
+            _scores.append(float(_det._frame_score))
+            return r
+
+        det.process_frame = spy
+        mgr = sm.SceneManager(None)
+        mgr.add_detector(det)
+        mgr.detect_scenes(video=ArrayStream(clip), show_progress=False)
+        div = [s.frame_num + 1 for s, _ in mgr.get_scene_list(start_in_scene=False) if s.frame_num != 0]     # subtitle_detect.py:163-169
+        out[tag] = {"clip": kw, "factor": int(sm.compute_downscale_factor(clip.shape[2])), "scores": scores, "div": div}
+        print("scene cuts", tag, out[tag]["factor"], div)
+    with open(os.path.join(OUT, "scene_cuts.json"), "w") as f:
+        json.dump(out, f)
+    for k, v in saved.items():
+        if v is not None:
+            setattr(cv2, k, v)
+    for k, v in keep.items():
+        if v is not None:
+            sys.modules[k] = v
+
+
 def main():
     from vsr_amd.synth import make_state_dict
 
@@ -278,6 +387,7 @@ def main():
     _rfc_fixture()
     _propainter_fixture()
     _detector_graph_fixtures()
+    _scene_cut_fixture()
 
     # ---- batch_generator (tools/inpaint_tools.py:7-29), executed from the reference ----
     cases = [(1200, 50), (300, 50), (600, 50), (1200, 70), (49, 50), (50, 50), (51, 50), (75, 50), (1, 50), (0, 50),

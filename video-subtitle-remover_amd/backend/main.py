@@ -100,9 +100,10 @@ class SubtitleRemover:
 
     def propainter_mode(self, tbar, propainter_inpaint=None, text_detector=None, scene_div_points=None, single_frame_inpaint=None):
         """backend/main.py:159-245.  Intervals of frames with the same mask, cut at scene changes, are read whole and
-        handed to the plugin in batch_generator batches of propainterMaxLoadNum.  The detector, the scene-change frame
-        numbers (reference: scenedetect's ContentDetector, subtitle_detect.py:158-170) and the single-frame fallback
-        (reference: LaMa, whose network is a missing blob) are injected; without a fallback single frames pass through."""
+        handed to the plugin in batch_generator batches of propainterMaxLoadNum.  The scene-change frame numbers come
+        from tools/scene_detect.py (reference: scenedetect's ContentDetector, subtitle_detect.py:158-170) unless given; the
+        detector and the single-frame fallback (reference: LaMa, whose network is a missing blob) are injected; without a
+        fallback single frames pass through."""
         if propainter_inpaint is None:
             from .inpaint.propainter_inpaint import PropainterInpaint
 
@@ -117,7 +118,10 @@ class SubtitleRemover:
             self._run_items(tbar, (), propainter_inpaint)                  # releases the peers before failing
             raise Exception(f"No subtitle detected in {self.video_path}")
         ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
-        ranges = detector.split_range_by_scene(ranges, list(scene_div_points or []))
+        if scene_div_points is None:                 # main.py:165: self.sub_detector.get_scene_div_frame_no(self.video_path)
+            dev = self.device
+            scene_div_points = detector.get_scene_div_frame_no(self.video_path, device=int(dev.split(":")[1]) if isinstance(dev, str) and ":" in dev else 0)
+        ranges = detector.split_range_by_scene(ranges, list(scene_div_points))
         reader = open_video(self.video_path)
 
         def items():

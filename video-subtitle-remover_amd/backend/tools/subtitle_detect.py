@@ -131,6 +131,14 @@ class SubtitleDetect:
         return ranges
 
     @staticmethod
+    def get_scene_div_frame_no(v_path, device=0):
+        """subtitle_detect.py:158-170 -- frame numbers (1-based) where a new scene starts; the ContentDetector pass runs on the GPU
+        (tools/scene_detect.py)"""
+        from . import scene_detect
+
+        return scene_detect.get_scene_div_frame_no(v_path, device=device)
+
+    @staticmethod
     def split_range_by_scene(intervals, points):
         """tools/subtitle_detect.py:135-155: cut every (start, end) interval at the scene-change frame numbers inside it."""
         points = sorted(points)
