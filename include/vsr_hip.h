@@ -238,6 +238,11 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
                    float* bwd_dev, void* stream);
 /* test hook: copy `count` floats at `offset` of workspace buffer `buf` (ids = the plan's buffer ids) to the host,
  * after a device synchronisation -- stage-by-stage parity against the CPU replay of the plan */
+/* arithmetic of the contractions: 0 (default) exact fp32 MFMA; 1 split-half fp16 operands (22 significand bits) with fp32 accumulation,
+ * range-guarded: a call whose operands leave the fp16 range is redone in fp32 and counted by *_fallbacks.  The reference runs RAFT in
+ * fp32 and the other two networks in fp16 on a GPU (propainter_inpaint.py:140-146,230,249-251); mode 1 is closer to fp32 than either. */
+int vsr_raft_set_precision(vsr_raft_t* h, int mode);
+int64_t vsr_raft_fallbacks(const vsr_raft_t* h);
 int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, float* out_host);
 /* algorithmic FLOPs of one vsr_raft_flows call (2*M*N*K over every conv and the all-pairs correlation) */
 double vsr_raft_flops(vsr_raft_t* h, int t, int H, int W, int iters);
@@ -260,6 +265,8 @@ int64_t vsr_rfc_packed_weights(const vsr_rfc_t* h, float* out, int64_t capacity)
  * (combine_flow).  H, W multiples of 8. */
 int vsr_rfc_complete(vsr_rfc_t* h, const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_dev, int t, int H,
                      int W, float* out_f_dev, float* out_b_dev, void* stream);
+int vsr_rfc_set_precision(vsr_rfc_t* h, int mode);        /* see vsr_raft_set_precision */
+int64_t vsr_rfc_fallbacks(const vsr_rfc_t* h);
 int vsr_rfc_read_buffer(vsr_rfc_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook, see vsr_raft_read_buffer */
 double vsr_rfc_flops(vsr_rfc_t* h, int t, int H, int W);
 
@@ -291,6 +298,8 @@ int vsr_pp_window_flags(const uint8_t* masks_host, int lt, int H, int W, uint8_t
 int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev,
                    const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t, int lt, int H, int W,
                    const uint8_t* window_flags, int nflags, float* out_dev, void* stream);
+int vsr_pp_set_precision(vsr_pp_t* h, int mode);          /* see vsr_raft_set_precision; applies to vsr_pp_forward */
+int64_t vsr_pp_fallbacks(const vsr_pp_t* h);
 int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook */
 double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags);
 

@@ -21,6 +21,7 @@ ap.add_argument("--height", type=int, default=360)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--precision", default="f32", choices=["f32", "split"])
 args = ap.parse_args()
 
 H, W, n = args.height, args.width, args.frames
@@ -28,7 +29,7 @@ box = (H // 2, H - H // 6, W // 6, W - W // 6)
 frames = list(make_clip(n, H, W, box, seed=4))
 mask = np.zeros((H, W), np.uint8)
 mask[box[0]:box[1], box[2]:box[3]] = 255
-plug = PropainterInpaint("cuda:0", {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": make_propainter_state_dict(0)})
+plug = PropainterInpaint("cuda:0", {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": make_propainter_state_dict(0)}, precision=args.precision)
 for _ in range(args.warmup):
     plug.inpaint(frames, mask)
 torch.cuda.synchronize()
@@ -38,7 +39,16 @@ for _ in range(args.steps):
     out = plug.inpaint(frames, mask)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
+extra = {}
+if args.precision != "f32":
+    extra["fp32_fallback_calls"] = sum(e.fallbacks() for e in (plug.fix_raft, plug.fix_flow_complete, plug.model))
+    for e in (plug.fix_raft, plug.fix_flow_complete, plug.model):
+        e.set_precision("f32")
+    ref = plug.inpaint(frames, mask)
+    mse = float(np.mean((np.stack(out).astype(np.float64) - np.stack(ref).astype(np.float64)) ** 2))
+    extra["psnr_db_vs_exact_mode"] = "inf" if mse == 0 else round(20 * np.log10(255.0 / np.sqrt(mse)), 2)
 print(json.dumps({"metric": "propainter frames/s (1920x360 strip crops, host arrays in / out)", "value": round(n / dt, 3), "unit": "frames/s",
-                  "frames": n, "s_per_call": round(dt, 3), "dtype": "f32", "raft_iters": plug.raft_iter,
+                  "frames": n, "s_per_call": round(dt, 3),
+                  "dtype": "f32" if args.precision == "f32" else "f32 (operands as fp16 hi/lo pairs)", **extra, "raft_iters": plug.raft_iter,
                   "note": "one PropainterInpaint.inpaint call; includes H2D / D2H of the crops and the host-side u8 blending"}))
 plug.close()

@@ -112,6 +112,8 @@ SIGNATURES = {
     "vsr_raft_flows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "vsr_raft_flops": (_D, [_P, _I, _I, _I, _I]),
     "vsr_raft_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_raft_set_precision": (_I, [_P, _I]),
+    "vsr_raft_fallbacks": (_L, [_P]),
     "vsr_rfc_plan_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
     "vsr_rfc_create": (_I, [C.POINTER(_P)]),
     "vsr_rfc_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
@@ -120,6 +122,8 @@ SIGNATURES = {
     "vsr_rfc_packed_weights": (_L, [_P, _P, _L]),
     "vsr_rfc_complete": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vsr_rfc_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_rfc_set_precision": (_I, [_P, _I]),
+    "vsr_rfc_fallbacks": (_L, [_P]),
     "vsr_rfc_flops": (_D, [_P, _I, _I, _I]),
     "vsr_det_launch_conv2d": (_I, [_P, _P, _P] + [_I] * 15 + [_P, _P]),
     "vsr_det_launch_deconv2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
@@ -142,6 +146,8 @@ SIGNATURES = {
     "vsr_pp_window_flags": (_I, [_P, _I, _I, _I, _P, _I]),
     "vsr_pp_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_pp_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_pp_set_precision": (_I, [_P, _I]),
+    "vsr_pp_fallbacks": (_L, [_P]),
     "vsr_pp_flops": (_D, [_P, _I, _I, _I, _I, _P, _I]),
     "vsr_pp_gen_plan_create": (_I, [_P, _I, _I, _I, _I, _P, _I, C.POINTER(_P)]),
     "vsr_plan_destroy": (None, [_P]),

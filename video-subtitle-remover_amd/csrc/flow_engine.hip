@@ -70,6 +70,11 @@ struct Workspace {
     int weights = 0;
     double* statAcc = nullptr;
     int64_t statAccCap = 0;
+    // arithmetic of the contractions: 0 = exact fp32 MFMA (gather_gemm_v3), 1 = split-half fp16 operands with fp32 accumulation
+    // (gather_gemm_v4) guarded by dRangeFlag: a call whose operands leave the fp16 range is redone in fp32 (`fallbacks` counts them)
+    int precision = 0;
+    unsigned int* dRangeFlag = nullptr;
+    int64_t fallbacks = 0;
     void init(int n, int weightsBuf, std::initializer_list<int> byteBufs)
     {
         bufs.assign(n, nullptr);
@@ -91,6 +96,7 @@ struct Workspace {
         for (void*& p : bufs)
             if (p) { (void)hipFree(p); p = nullptr; }
         if (statAcc) { (void)hipFree(statAcc); statAcc = nullptr; }
+        if (dRangeFlag) { (void)hipFree(dRangeFlag); dRangeFlag = nullptr; }
     }
 };
 
@@ -183,6 +189,8 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
 // replays a materialised plan; `bgr`: channel order of RAFT's u8 input frames
 static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t stream)
 {
+    const int variant = ws.precision == 1 ? 4 : 3;
+    unsigned int* rangeFlag = ws.precision == 1 ? ws.dRangeFlag : nullptr;
     HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
     auto B = [&](int buf, int64_t off) -> float* { return ws.f(buf, off); };
     size_t idx = 0;
@@ -191,8 +199,8 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         unsigned int* queue = pd->dQueues + 8 * idx++;
         int rc = 0;
         if (op.kind == OP_GEMM) {
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, 3, od.nQueues,
-                                            nullptr, stream);
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, variant, od.nQueues,
+                                            rangeFlag, stream);
         } else if (op.kind == OP_SOFTMAX) {
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
         } else if (op.kind == OP_UPSAMPLE2X) {
@@ -321,6 +329,33 @@ static int clear_workspace(Workspace& ws, hipStream_t stream)
 {
     for (size_t b = 0; b < ws.bufs.size(); ++b)
         if ((int)b != ws.weights && ws.bufs[b]) HIPCHK(hipMemsetAsync(ws.bufs[b], 0, (size_t)ws.nbytes((int)b, ws.cap[b]), stream));
+    return 0;
+}
+
+static int range_guard_arm(Workspace& ws, hipStream_t stream)
+{
+    if (ws.precision != 1) return 0;
+    if (!ws.dRangeFlag) HIPCHK(hipMalloc(&ws.dRangeFlag, sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(ws.dRangeFlag, 0, sizeof(unsigned int), stream));
+    return 0;
+}
+
+// split-half mode only: waits for the plan and reports whether a contraction saw a non-finite accumulator
+static int range_guard_fired(Workspace& ws, hipStream_t stream, bool* fired)
+{
+    *fired = false;
+    if (ws.precision != 1) return 0;
+    unsigned int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, ws.dRangeFlag, sizeof(v), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (v) { *fired = true; ws.fallbacks++; }
+    return 0;
+}
+
+static int set_precision(Workspace& ws, int mode)
+{
+    if (mode != 0 && mode != 1) return rfail(VSR_ERR_ARG, "precision must be 0 (exact fp32) or 1 (split-half fp16 operands, fp32 accumulate)");
+    ws.precision = mode;
     return 0;
 }
 
@@ -493,13 +528,25 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
         RCCHK(clear_workspace(h->ws, stream));
         h->geom = std::make_tuple(t, H, W);
     }
+    RCCHK(range_guard_arm(h->ws, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[RB_IN_U8], frames_dev, (size_t)t * H * W * 3, hipMemcpyDeviceToDevice, stream));
     RCCHK(run_plan(h->ws, pd, bgr ? 1 : 0, stream));
+    bool fired = false;
+    RCCHK(range_guard_fired(h->ws, stream, &fired));
+    if (fired) {                                  // redo the call with exact fp32 contractions
+        h->ws.precision = 0;
+        const int rc = vsr_raft_flows(h, frames_dev, t, H, W, iters, bgr, fwd_dev, bwd_dev, stream_);
+        h->ws.precision = 1;
+        return rc;
+    }
     const size_t half = (size_t)(t - 1) * 2 * H * W * sizeof(float);
     HIPCHK(hipMemcpyAsync(fwd_dev, h->ws.bufs[RB_OUT], half, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(bwd_dev, (char*)h->ws.bufs[RB_OUT] + half, half, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
+
+int vsr_raft_set_precision(vsr_raft_t* h, int mode) { return h ? set_precision(h->ws, mode) : rfail(VSR_ERR_ARG, "null handle"); }
+int64_t vsr_raft_fallbacks(const vsr_raft_t* h) { return h ? h->ws.fallbacks : -1; }
 
 int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, float* out_host)
 {
@@ -601,11 +648,23 @@ int vsr_rfc_complete(vsr_rfc_t* h, const float* flows_f_dev, const float* flows_
     HIPCHK(hipMemcpyAsync(h->ws.bufs[FB_IN_FLOW_F], flows_f_dev, fbytes, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[FB_IN_FLOW_B], flows_b_dev, fbytes, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[FB_IN_MASK], masks_dev, (size_t)t * H * W, hipMemcpyDeviceToDevice, stream));
+    RCCHK(range_guard_arm(h->ws, stream));
     RCCHK(run_plan(h->ws, pd, 0, stream));
+    bool fired = false;
+    RCCHK(range_guard_fired(h->ws, stream, &fired));
+    if (fired) {
+        h->ws.precision = 0;
+        const int rc = vsr_rfc_complete(h, flows_f_dev, flows_b_dev, masks_dev, t, H, W, out_f_dev, out_b_dev, stream_);
+        h->ws.precision = 1;
+        return rc;
+    }
     HIPCHK(hipMemcpyAsync(out_f_dev, h->ws.bufs[FB_OUT_F], fbytes, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(out_b_dev, h->ws.bufs[FB_OUT_B], fbytes, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
+
+int vsr_rfc_set_precision(vsr_rfc_t* h, int mode) { return h ? set_precision(h->ws, mode) : rfail(VSR_ERR_ARG, "null handle"); }
+int64_t vsr_rfc_fallbacks(const vsr_rfc_t* h) { return h ? h->ws.fallbacks : -1; }
 
 int vsr_rfc_read_buffer(vsr_rfc_t* h, int buf, int64_t offset, int64_t count, float* out_host)
 {
@@ -757,10 +816,23 @@ int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_de
         HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_F], flows_f_dev, (size_t)(lt - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_B], flows_b_dev, (size_t)(lt - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     }
+    RCCHK(range_guard_arm(h->ws, stream));
     RCCHK(run_plan(h->ws, pd, 0, stream));
+    bool fired = false;
+    RCCHK(range_guard_fired(h->ws, stream, &fired));
+    if (fired) {
+        h->ws.precision = 0;
+        const int rc = vsr_pp_forward(h, frames_dev, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t, lt, H, W, window_flags, nflags,
+                                      out_dev, stream_);
+        h->ws.precision = 1;
+        return rc;
+    }
     HIPCHK(hipMemcpyAsync(out_dev, h->ws.bufs[PG_OUT], (size_t)lt * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return 0;
 }
+
+int vsr_pp_set_precision(vsr_pp_t* h, int mode) { return h ? set_precision(h->ws, mode) : rfail(VSR_ERR_ARG, "null handle"); }
+int64_t vsr_pp_fallbacks(const vsr_pp_t* h) { return h ? h->ws.fallbacks : -1; }
 
 int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host)
 {

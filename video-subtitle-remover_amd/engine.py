@@ -186,6 +186,16 @@ class RaftEngine:
             lib.vsr_raft_destroy(self._h)
             self._h = None
 
+    def set_precision(self, mode):
+        """'f32' (default): exact fp32 contractions; 'split': fp16 hi/lo operand pairs with fp32 accumulation, range-guarded
+        (a call that leaves the fp16 range is redone in fp32, see fallbacks())"""
+        if mode not in ("f32", "split"):
+            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
+        check(lib.vsr_raft_set_precision(self._h, 1 if mode == "split" else 0))
+
+    def fallbacks(self):
+        return int(lib.vsr_raft_fallbacks(self._h))
+
     def __del__(self):
         try:
             self.close()
@@ -250,6 +260,16 @@ class RfcEngine:
         if getattr(self, "_h", None):
             lib.vsr_rfc_destroy(self._h)
             self._h = None
+
+    def set_precision(self, mode):
+        """'f32' (default): exact fp32 contractions; 'split': fp16 hi/lo operand pairs with fp32 accumulation, range-guarded
+        (a call that leaves the fp16 range is redone in fp32, see fallbacks())"""
+        if mode not in ("f32", "split"):
+            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
+        check(lib.vsr_rfc_set_precision(self._h, 1 if mode == "split" else 0))
+
+    def fallbacks(self):
+        return int(lib.vsr_rfc_fallbacks(self._h))
 
     def __del__(self):
         try:
@@ -357,6 +377,16 @@ class PpEngine:
         if getattr(self, "_h", None):
             lib.vsr_pp_destroy(self._h)
             self._h = None
+
+    def set_precision(self, mode):
+        """'f32' (default): exact fp32 contractions; 'split': fp16 hi/lo operand pairs with fp32 accumulation, range-guarded
+        (a call that leaves the fp16 range is redone in fp32, see fallbacks())"""
+        if mode not in ("f32", "split"):
+            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
+        check(lib.vsr_pp_set_precision(self._h, 1 if mode == "split" else 0))
+
+    def fallbacks(self):
+        return int(lib.vsr_pp_fallbacks(self._h))
 
     def __del__(self):
         try:
