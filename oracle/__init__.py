@@ -17,4 +17,13 @@ Pinning status
   * cv2.resize / cv2.threshold / cv2.connectedComponentsWithStats / cv2.rectangle:
     PARITY UNPINNED -- opencv-python==4.11.0.86 (requirements.txt:2) is absent from the image
     and the mount; restated from the published OpenCV 4.11 algorithm (imgproc/resize.cpp).
+  * RAFT (raft.py), flow completion (rfc.py), ProPainter generator (propainter.py): PINNED to the
+    reference's modules the same way (fixtures raft.npz / rfc.npz / propainter.npz), except
+    ``torchvision.ops.deform_conv2d`` (deform_conv.py): torchvision is absent, PARITY UNPINNED for
+    that operator.  propainter_wrapper.py restates the plugin loop on top of them.
+  * scene cuts (scene_cuts.py): PINNED to the reference's own SceneManager + ContentDetector
+    (fixture scene_cuts.json: scores equal to the last bit) except ``cv2.cvtColor(BGR2HSV)``
+    and ``cv2.resize`` inside it, restated from OpenCV's integer algorithms.
+  * text detector (ppocr_det.py): PARITY UNPINNED -- Paddle and the weights are absent; an
+    interpreter of the shipped inference programs.
 """
