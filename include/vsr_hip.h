@@ -156,6 +156,14 @@ typedef struct GGProblem {
     int64_t splitStride;
 } GGProblem;
 
+/* resident launch list of gather-GEMM problems (fp32 tensors, kernel variants 1..4): descriptors and tile queues are uploaded
+ * once; vsr_gemm_plan_run is asynchronous on `stream` (one memset + one launch).  The pointers inside the problems must stay
+ * valid for the life of the plan.  Used by the text detector's convolutions (backend/tools/ocr_det.py). */
+typedef struct vsr_gemm_plan vsr_gemm_plan_t;
+int vsr_gemm_plan_create(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, vsr_gemm_plan_t** out);
+int vsr_gemm_plan_run(vsr_gemm_plan_t* p, void* stream);
+void vsr_gemm_plan_destroy(vsr_gemm_plan_t* p);
+
 /* P = softmax(scale * sum_splits S) row-wise (auto_sttn.py:141-143) */
 typedef struct SMProblem {
     const float* S;
@@ -324,6 +332,11 @@ int vsr_det_launch_maxpool(const float* x, int64_t planes, int H, int W, int kh,
                            float* out, void* stream);
 int vsr_det_launch_nearest(const float* x, int64_t planes, int H, int W, int s, float* out, void* stream);
 int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_chw, void* stream);
+/* layout changes around the dense convolutions that run as gather-GEMMs (vsr_gemm_plan_*): one NCHW image -> zero-padded NHWC
+ * [Hp][Wp][Cp] (image origin at (pt, pl), Cp a multiple of 32), and GEMM output [P pixels][Np] -> NCHW [C][P] with an optional
+ * per-channel affine (the batch_norm or bias add that follows the conv) and activation (act 1 relu, 2 hardswish) */
+int vsr_det_launch_nchw_to_nhwc(const float* x, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* out, void* stream);
+int vsr_det_launch_nhwc_to_nchw(const float* in, int C, int64_t P, int Np, const float* scale, const float* shift, int act, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Scene cuts: the per-frame arithmetic of the ContentDetector pass that

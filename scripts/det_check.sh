@@ -12,9 +12,11 @@ for fx in ("ppocr_det_fast_graph.json", "ppocr_det_graph.json"):
     g = load_graph(os.path.join('/root/repo/tests/golden', fx))
     det = ocr_det.TextDetection(g, synthetic_weights(g), device=0)
     img = np.random.default_rng(3).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
-    det.probability_map(img); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5): det.probability_map(img)
-    torch.cuda.synchronize()
-    print(fx, "forward at 1080p (960x544 net input): %.1f ms/frame" % ((time.perf_counter() - t0) / 5 * 1e3))
+    for gemm in (True, False):
+        det.runner.use_gemm = gemm
+        det.probability_map(img); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5): det.probability_map(img)
+        torch.cuda.synchronize()
+        print(fx, "forward at 1080p (960x544 net input), dense convs on the %s: %.1f ms/frame" % ("gather-GEMM" if gemm else "direct kernel", (time.perf_counter() - t0) / 5 * 1e3))
 PY

@@ -134,3 +134,65 @@ def test_from_env_without_weights_is_none(monkeypatch, tmp_path):
     assert ocr_det.from_env() is None
     monkeypatch.setenv("VSR_DET_MODEL_DIR", str(tmp_path))            # directory without inference.pdiparams
     assert ocr_det.from_env() is None
+
+
+def test_conv_gemm_layout_against_conv2d():
+    """the gather-GEMM description of a dense conv (offset tables + packed weights, ocr_det.conv_gemm_layout) replayed on the CPU with
+    the descriptor semantics the kernels are tested against (tests/_replay.gemm_reference) equals F.conv2d"""
+    import sys
+    from types import SimpleNamespace
+
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _replay
+
+    cases = [(65, 20, 28, 64, 3, 3, 1, False, (1, 1)), (40, 18, 25, 64, 9, 9, 1, True, None), (200, 9, 14, 256, 1, 1, 1, False, (0, 0)),
+             (33, 21, 30, 48, 3, 3, 2, False, (1, 1)), (32, 15, 16, 32, 2, 2, 1, True, None), (96, 10, 12, 130, 3, 3, 1, False, (1, 1))]
+    for cin, h, w, cout, kh, kw, st, same, pad in cases:
+        rng = np.random.default_rng(cin + h)
+        x = rng.standard_normal((1, cin, h, w)).astype(np.float32)
+        wt = rng.standard_normal((cout, cin, kh, kw)).astype(np.float32)
+        if same:
+            pt, pl, ho, wo = (kh - 1) // 2, (kw - 1) // 2, -(-h // st), -(-w // st)
+            ref = F.conv2d(F.pad(torch.from_numpy(x), (pl, kw - 1 - pl, pt, kh - 1 - pt)), torch.from_numpy(wt), stride=st)
+        else:
+            pt, pl = pad
+            ho, wo = (h + 2 * pt - kh) // st + 1, (w + 2 * pl - kw) // st + 1
+            ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), stride=st, padding=pad)
+        lay = ocr_det.conv_gemm_layout(cin, h, w, wt.shape, (st, st), pt, pl, ho, wo)
+        a = np.zeros((lay["hp"], lay["wp"], lay["cp"]), np.float32)              # what k_det_nchw_to_nhwc writes
+        a[pt:pt + h, pl:pl + w, :cin] = x[0].transpose(1, 2, 0)
+        t = lay["tables"]
+        assert int(t["rowA"][:lay["M"]].max()) + int(t["colA"].max()) + 31 < a.size and lay["K"] % 32 == 0
+        bufs = {1: a.reshape(-1), 2: ocr_det.pack_conv_weights(wt, lay["cp"]).reshape(-1), 3: np.zeros(lay["M"] * lay["ncs"], np.float32)}
+        tables = [t[k].astype(np.int64) for k in ("rowA", "colA", "rowB", "colB", "rowC", "colC")]
+        it = SimpleNamespace(M=lay["M"], N=lay["N"], K=lay["K"], bufA=1, bufB=2, bufC=3, bufR=-1, offA=0, offB=0, offC=0, offR=0, offBias=-1,
+                             tRowA=0, tColA=1, tRowB=2, tColB=3, tRowC=4, tColC=5, tRowR=-1, splitK=1, chunksPerSplit=lay["K"] // 32,
+                             splitStride=0, alpha=1.0, act=0)
+        _replay.gemm_reference(it, 0, bufs, tables)
+        out = bufs[3].reshape(lay["M"], lay["ncs"])[:, :cout].T.reshape(1, cout, ho, wo)     # what k_det_nhwc_to_nchw reads
+        assert np.abs(out - ref.numpy()).max() <= 2e-5 * np.abs(ref.numpy()).max(), (cin, h, w, cout, kh, kw)
+
+
+@pytest.mark.parametrize("fixture,nconv,min_affine", [("ppocr_det_fast_graph.json", 48, 40), ("ppocr_det_graph.json", 115, 100)])
+def test_conv_fusion_analysis(fixture, nconv, min_affine):
+    g = load_graph(os.path.join(GOLD, fixture))
+    fuse = ocr_det.conv_fusions(g)
+    assert len(fuse) == nconv == sum(1 for k, *_ in g.ops if k == "conv2d")
+    readers = {}
+    for kind, ins, outs, a in g.ops:
+        for v in ins:
+            readers[v] = readers.get(v, 0) + 1
+    n_aff = 0
+    for ci, (aff, act) in fuse.items():
+        if aff is None:
+            assert act is None
+            continue
+        n_aff += 1
+        j = aff[1]
+        assert g.ops[ci][2][0] in g.ops[j][1] and readers[g.ops[ci][2][0]] == 1
+        assert (aff[0] == "bn" and g.ops[j][0] == "batch_norm_") or (aff[0] == "bias" and g.ops[j][0] == "add" and aff[2] in g.params
+                                                                      and int(np.prod(g.params[aff[2]][1])) == g.params[g.ops[ci][1][1]][1][0])
+        if act is not None:
+            assert g.ops[act[0]][0] == {1: "relu", 2: "hardswish"}[act[1]] and g.ops[act[0]][1][0] == g.ops[j][2][0] and readers[g.ops[j][2][0]] == 1
+    assert n_aff >= min_affine

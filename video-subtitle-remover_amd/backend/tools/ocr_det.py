@@ -24,15 +24,107 @@ from .paddle_graph import load_graph, read_pdiparams
 
 
 def _p(t):
-    return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+TILE_128x128, TILE_128x64, BMODE_NK = 0, 3, 0      # include/vsr_hip.h: VSR_TILE_*, VSR_BMODE_NK
 
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+GEMM_MIN_K = 64          # dense convs with cin * kh * kw below this stay on the direct kernel (the 3-channel stem)
+
+
+def conv_gemm_layout(cin, h, w, wshape, strides, pt, pl, ho, wo):
+    """Host-side description of one dense convolution as a gather-GEMM problem (include/vsr_hip.h GGProblem, NK mode):
+    A = the input as zero-padded NHWC [Hp][Wp][Cp] (image origin at (pt, pl), Cp = cin rounded up to the 32-float K chunk),
+    rows = output pixels, K = (ky, kx, channel); B = the weights re-packed [cout][kh*kw*Cp]; C = [pixels][Ncs] row-major.
+    Returns the dims and the int32 offset tables (padded to whole tiles as the kernels expect)."""
+    cout, wcin, kh, kw = wshape
+    assert wcin == cin
+    sh, sw = strides
+    cp = -(-cin // 32) * 32
+    hp, wp = max(h + pt, (ho - 1) * sh + kh), max(w + pl, (wo - 1) * sw + kw)
+    K, M, N = kh * kw * cp, ho * wo, cout
+    bm, bn, cfg = (128, 128, TILE_128x128) if cout >= 128 else (128, 64, TILE_128x64)
+    tiles_m, tiles_n = -(-M // bm), -(-N // bn)
+    ncs = tiles_n * bn
+    if hp * wp * cp >= 2 ** 31 or M * ncs >= 2 ** 31 or N * K >= 2 ** 31:
+        raise ValueError("convolution too large for 32-bit offset tables")
+    oy, ox = np.divmod(np.arange(M, dtype=np.int64), wo)
+    row_a = np.zeros(tiles_m * bm, np.int64)
+    row_a[:M] = ((oy * sh) * wp + ox * sw) * cp
+    row_a[M:] = row_a[0]
+    tap, cc = np.divmod(np.arange(K // 32, dtype=np.int64), cp // 32)
+    col_a = ((tap // kw) * wp + tap % kw) * cp + cc * 32
+    row_b = np.zeros(tiles_n * bn, np.int64)
+    row_b[:N] = np.arange(N, dtype=np.int64) * K
+    col_b = np.arange(K // 32, dtype=np.int64) * 32
+    row_c = np.zeros(tiles_m * bm, np.int64)
+    row_c[:M] = np.arange(M, dtype=np.int64) * ncs
+    col_c = np.arange(ncs // 32, dtype=np.int64) * 32
+    t = {k: v.astype(np.int32) for k, v in dict(rowA=row_a, colA=col_a, rowB=row_b, colB=col_b, rowC=row_c, colC=col_c).items()}
+    return dict(cp=cp, hp=hp, wp=wp, K=K, M=M, N=N, ncs=ncs, tile_cfg=cfg, tiles_m=tiles_m, tiles_n=tiles_n, tables=t)
+
+
+def conv_fusions(graph):
+    """Per conv2d op, what can be folded into the pass that writes its output: {conv op index: (affine, act)} with
+    affine = None | ("bn", op index) | ("bias", op index, id of the bias parameter)   -- a batch_norm_ or the add of a reshaped
+    parameter reading the conv's result, act = None | (op index, 1 relu / 2 hardswish) reading that; every folded intermediate
+    has exactly one reader."""
+    uses, consumer, producer = {}, {}, {}
+    for i, (kind, ins, outs, a) in enumerate(graph.ops):
+        for v in ins:
+            uses[v] = uses.get(v, 0) + 1
+            consumer.setdefault(v, []).append(i)
+        for v in outs:
+            producer[v] = i
+    uses[graph.output_id] = uses.get(graph.output_id, 0) + 1
+
+    def sole_reader(v):
+        c = consumer.get(v, [])
+        return c[0] if uses.get(v, 0) == 1 and len(c) == 1 else None
+
+    def param_behind(v):                      # the parameter a bias operand is (a reshape of), else None
+        if v in graph.params:
+            return v
+        j = producer.get(v)
+        return graph.ops[j][1][0] if j is not None and graph.ops[j][0] == "reshape" and graph.ops[j][1][0] in graph.params else None
+
+    fuse = {}
+    for i, (kind, ins, outs, a) in enumerate(graph.ops):
+        if kind != "conv2d":
+            continue
+        affine = act = None
+        j = sole_reader(outs[0])
+        if j is not None:
+            k2, i2, o2, _ = graph.ops[j]
+            if k2 == "batch_norm_" and i2[0] == outs[0]:
+                affine = ("bn", j)
+            elif k2 == "add" and len(i2) == 2 and param_behind(i2[1] if i2[0] == outs[0] else i2[0]) is not None:
+                affine = ("bias", j, param_behind(i2[1] if i2[0] == outs[0] else i2[0]))
+            if affine is not None:
+                r = sole_reader(o2[0])
+                if r is not None and graph.ops[r][0] in ("relu", "hardswish"):
+                    act = (r, 1 if graph.ops[r][0] == "relu" else 2)
+        fuse[i] = (affine, act)
+    return fuse
+
+
+def pack_conv_weights(w, cp):
+    """[cout][cin][kh][kw] -> [cout][(ky, kx, channel padded to cp)], the K order of conv_gemm_layout"""
+    cout, cin, kh, kw = w.shape
+    out = np.zeros((cout, kh * kw, cp), np.float32)
+    out[:, :, :cin] = np.asarray(w, np.float32).transpose(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    return out.reshape(cout, kh * kw * cp)
+
+
 class PaddleGraphRunner:
-    """Executes a detection program on one GPU; values are NCHW fp32 torch tensors (device memory only)."""
+    """Executes a detection program on one GPU; values are NCHW fp32 torch tensors (device memory only).  Dense convolutions run
+    on the gather-GEMM (exact fp32 MFMA) between two layout kernels, with the batch_norm (+ ReLU) that follows folded into the
+    second one; depthwise and the 3-channel stem stay on the direct kernel."""
 
     def __init__(self, graph, weights, device=0):
         if lib.vsr_device_count() <= 0 or not torch.cuda.is_available():
@@ -54,6 +146,68 @@ class PaddleGraphRunner:
                 mean, var, gamma, beta = (self.params[j].double() for j in ins[1:5])
                 s = gamma / torch.sqrt(var + a["epsilon"])
                 self.bn[i] = (s.float().contiguous(), (beta - mean * s).float().contiguous())
+        self._fuse = conv_fusions(graph)      # conv op index -> (bn op index or None, relu op index or None)
+        self._one = {}
+        self._gemm = {}                       # (conv op index, input shape) -> resident plan, tables, buffers
+        self.use_gemm = os.environ.get("VSR_DET_GEMM", "1") != "0"
+
+    def close(self):
+        for st in self._gemm.values():
+            lib.vsr_gemm_plan_destroy(st["plan"])
+        self._gemm.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _conv_gemm(self, i, xin, w, strides, pt, pl, ho, wo):
+        """one dense conv (batch 1) through the gather-GEMM; returns (output NCHW, set of op indices folded into it)"""
+        _, cin, h, wd = xin.shape
+        key = (i, tuple(xin.shape))
+        st = self._gemm.get(key)
+        if st is None:
+            lay = conv_gemm_layout(cin, h, wd, tuple(w.shape), strides, pt, pl, ho, wo)
+            dev = self.device
+            st = dict(lay=lay, tabs={k: torch.from_numpy(v).to(dev) for k, v in lay["tables"].items()},
+                      wp=torch.from_numpy(pack_conv_weights(w.cpu().numpy(), lay["cp"])).to(dev),
+                      a=torch.empty(lay["hp"] * lay["wp"] * lay["cp"], dtype=torch.float32, device=dev),
+                      c=torch.empty(lay["M"] * lay["ncs"], dtype=torch.float32, device=dev))
+            pr = (_lib.GGProblem * 1)()
+            q, t = pr[0], st["tabs"]
+            q.A, q.B, q.C, q.bias, q.R = st["a"].data_ptr(), st["wp"].data_ptr(), st["c"].data_ptr(), None, None
+            q.rowA, q.colA, q.rowB, q.colB = t["rowA"].data_ptr(), t["colA"].data_ptr(), t["rowB"].data_ptr(), t["colB"].data_ptr()
+            q.rowC, q.colC, q.rowR = t["rowC"].data_ptr(), t["colC"].data_ptr(), None
+            q.M, q.N, q.K, q.tilesM, q.tilesN = lay["M"], lay["N"], lay["K"], lay["tiles_m"], lay["tiles_n"]
+            q.splitK, q.chunksPerSplit, q.act, q.alpha, q.splitStride = 1, lay["K"] // 32, 0, 1.0, 0
+            plan = C.c_void_p()
+            check(lib.vsr_gemm_plan_create(pr, 1, lay["tile_cfg"], BMODE_NK, 3, C.byref(plan)))
+            st["plan"] = plan
+            self._gemm[key] = st
+        lay = st["lay"]
+        check(lib.vsr_det_launch_nchw_to_nhwc(_p(xin), cin, h, wd, pt, pl, lay["hp"], lay["wp"], lay["cp"], _p(st["a"]), _stream()))
+        check(lib.vsr_gemm_plan_run(st["plan"], _stream()))
+        affine, act = self._fuse.get(i, (None, None))
+        scale = shift = None
+        if affine is not None and affine[0] == "bn":
+            scale, shift = self.bn[affine[1]]
+        elif affine is not None:
+            shift = self.params[affine[2]].reshape(-1)
+            if shift.numel() != lay["N"]:
+                affine = act = None
+                shift = None
+            else:
+                scale = self._ones(lay["N"])
+        out = self._new(1, lay["N"], ho, wo)
+        check(lib.vsr_det_launch_nhwc_to_nchw(_p(st["c"]), lay["N"], lay["M"], lay["ncs"], _p(scale), _p(shift), act[1] if act is not None else 0,
+                                              _p(out), _stream()))
+        return out, [j for j in (affine[1] if affine is not None else None, act[0] if act is not None else None) if j is not None]
+
+    def _ones(self, n):
+        if n not in self._one:
+            self._one[n] = torch.ones(n, dtype=torch.float32, device=self.device)
+        return self._one[n]
 
     def _new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -87,9 +241,13 @@ class PaddleGraphRunner:
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         val = dict(self.params)
         val[self.graph.input_id] = x
+        folded = {}
         with torch.cuda.device(self.device):
             for i, (kind, ins, outs, a) in enumerate(self.graph.ops):
                 g = lambda j: val[ins[j]]
+                if i in folded:                  # batch_norm / bias add / activation already applied by the conv's output pass
+                    val[outs[0]] = folded[i]
+                    continue
                 if kind in ("conv2d", "depthwise_conv2d"):
                     xin, w = g(0).contiguous(), g(1)
                     n, cin, h, wd = xin.shape
@@ -104,6 +262,11 @@ class PaddleGraphRunner:
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
                     if not dw and a["groups"] != 1:
                         raise NotImplementedError("grouped conv")
+                    if (self.use_gemm and not dw and n == 1 and cin * kh * kw >= GEMM_MIN_K and list(a.get("dilations", [1, 1])) == [1, 1]):
+                        out, done = self._conv_gemm(i, xin, w, (sh, sw), pt, pl, ho, wo)
+                        folded.update({j: out for j in done})
+                        val[outs[0]] = out
+                        continue
                     out = self._new(n, cout, ho, wo)
                     check(lib.vsr_det_launch_conv2d(_p(xin), _p(w), None, n, cin, h, wd, cout, kh, kw, sh, sw, pt, pl, ho, wo, dw, 0, _p(out), _stream()))
                     val[outs[0]] = out

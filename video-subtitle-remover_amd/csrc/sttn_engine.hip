@@ -734,6 +734,65 @@ int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg
     return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, variant, stream_);
 }
 
+// ---- resident gather-GEMM launch lists (vsr_gemm_plan_*): descriptors and tile queues stay on the device, a run is one
+// memset + one launch on the caller's stream, nothing synchronises ----
+struct vsr_gemm_plan {
+    GGProblem* d = nullptr;
+    unsigned int* queue = nullptr;
+    int nprobs = 0, total = 0, tileCfg = 0, bmode = 0, variant = 3, nQueues = 8, device = 0;
+};
+
+int vsr_gemm_plan_create(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, vsr_gemm_plan_t** out)
+{
+    if (!probs || nprobs <= 0 || !out) return fail(VSR_ERR_ARG, "bad argument");
+    if (variant < 1 || variant > 4) return fail(VSR_ERR_ARG, "kernel variant must be 1..4 (fp32 tensors)");
+    if (vsr_device_count() <= 0) return fail(VSR_ERR_NOGPU, "no HIP device; there is no CPU fallback");
+    std::vector<GGProblem> hp(probs, probs + nprobs);
+    int BM, BN;
+    tile_dims(tile_cfg, BM, BN);
+    std::unique_ptr<vsr_gemm_plan> p(new vsr_gemm_plan);
+    for (auto& q : hp) {
+        if (q.K % VSR_GG_KC) return fail(VSR_ERR_ARG, "K must be a multiple of 32");
+        if (q.tilesM != (q.M + BM - 1) / BM || q.tilesN != (q.N + BN - 1) / BN) return fail(VSR_ERR_ARG, "tile counts do not match the tile config");
+        if (q.splitK < 1 || (int64_t)q.splitK * q.chunksPerSplit < q.K / VSR_GG_KC) return fail(VSR_ERR_ARG, "bad split-K");
+        q.tileStart = p->total;
+        p->total += q.tilesM * q.tilesN * q.splitK;
+        if (q.tilesN > 4) p->nQueues = 1;
+    }
+    HIPCHK(hipGetDevice(&p->device));
+    const size_t descBytes = (hp.size() * sizeof(GGProblem) + 15) / 16 * 16;
+    HIPCHK(hipMalloc((void**)&p->d, descBytes + 8 * sizeof(unsigned int)));
+    if (hipMemcpy(p->d, hp.data(), hp.size() * sizeof(GGProblem), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p->d);
+        return fail(VSR_ERR_HIP, "gemm plan: descriptor upload failed");
+    }
+    p->queue = (unsigned int*)((char*)p->d + descBytes);
+    p->nprobs = nprobs;
+    p->tileCfg = tile_cfg;
+    p->bmode = bmode;
+    p->variant = variant;
+    *out = p.release();
+    return 0;
+}
+
+int vsr_gemm_plan_run(vsr_gemm_plan_t* p, void* stream_)
+{
+    if (!p || !p->d) return fail(VSR_ERR_ARG, "null plan");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (p->variant >= 2) HIPCHK(hipMemsetAsync(p->queue, 0, 8 * sizeof(unsigned int), stream));
+    const int rc = vsr_launch_gather_gemm_dev(p->d, p->nprobs, p->total, p->tileCfg, p->bmode, p->variant >= 2 ? p->queue : nullptr, p->variant,
+                                              p->nQueues, nullptr, stream);
+    if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");
+    return 0;
+}
+
+void vsr_gemm_plan_destroy(vsr_gemm_plan_t* p)
+{
+    if (!p) return;
+    if (p->d) (void)hipFree(p->d);
+    delete p;
+}
+
 static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
 {
     if (!probs || nprobs <= 0) return fail(VSR_ERR_ARG, "bad argument");
