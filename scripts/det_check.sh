@@ -12,11 +12,11 @@ for fx in ("ppocr_det_fast_graph.json", "ppocr_det_graph.json"):
     g = load_graph(os.path.join('/root/repo/tests/golden', fx))
     det = ocr_det.TextDetection(g, synthetic_weights(g), device=0)
     img = np.random.default_rng(3).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
-    for gemm in (True, False):
-        det.runner.use_gemm = gemm
+    for gemm, graph in ((True, False), (False, False)) + (((True, True),) if os.environ.get('VSR_DET_GRAPH') == '1' else ()):
+        det.runner.use_gemm, det.use_graph = gemm, graph
         det.probability_map(img); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5): det.probability_map(img)
         torch.cuda.synchronize()
-        print(fx, "forward at 1080p (960x544 net input), dense convs on the %s: %.1f ms/frame" % ("gather-GEMM" if gemm else "direct kernel", (time.perf_counter() - t0) / 5 * 1e3))
+        print(fx, "forward at 1080p (960x544 net input), dense convs on the %s, %s: %.1f ms/frame" % ("gather-GEMM" if gemm else "direct kernel", "HIP graph replay" if graph else "launch by launch", (time.perf_counter() - t0) / 5 * 1e3))
 PY
