@@ -5,15 +5,13 @@ import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-from oracle.sttn_auto import STTNInpaintOracle, calculate_psnr
 from vsr_amd.synth import make_state_dict
 
-from _replay import PlanView, replay
+from _replay import PlanView
 
 
 @pytest.fixture(scope="module")
