@@ -163,3 +163,39 @@ def test_gpu_propainter_mode_cuts_intervals_at_detected_scenes(built_lib, gpu_de
     assert 18 in starts and 33 in starts, seen                      # 0-based first frames of the scenes inside the text interval
     assert all(not (b[0] < 18 <= b[-1]) and not (b[0] < 33 <= b[-1]) for b in seen), seen
     assert len(sr.video_writer.frames) == 60
+
+
+def test_propainter_mode_asks_for_scene_cuts_when_none_are_given(monkeypatch):
+    """host wiring (reference main.py:165-167) without a device: get_scene_div_frame_no stands in through the oracle"""
+    from vsr_amd.backend.main import SubtitleRemover
+    from vsr_amd.backend.tools.subtitle_detect import SubtitleDetect
+    from vsr_amd.backend.tools.video_io import ArrayVideo
+
+    clip = scene_clip(seed=5, n=60, H=120, W=780).copy()
+    clip[:, 0, 0, 0] = np.arange(60)
+    asked = []
+
+    def fake(v_path, device=0):
+        asked.append(device)
+        return sc.scene_div_frame_no(v_path.frames)
+
+    monkeypatch.setattr(SubtitleDetect, "get_scene_div_frame_no", staticmethod(fake))
+    quad = np.array([[[300, 80], [480, 80], [480, 100], [300, 100]]])
+
+    class Det:
+        def predict(self, img):
+            return [{"dt_polys": quad if 10 <= int(img[0, 0, 0]) < 45 else np.zeros((0, 4, 2))}]
+
+    seen = []
+    sr = SubtitleRemover(ArrayVideo(clip, fps=25.0), device="cuda:3", model_path="unused")
+    sr.sub_areas = [(0, 120, 0, 780)]
+    sr.propainter_mode(None, propainter_inpaint=lambda b, m: seen.append((int(b[0][0, 0, 0]), int(b[-1][0, 0, 0]))) or [f.copy() for f in b],
+                       text_detector=Det())
+    assert asked == [3]                                        # the device index of "cuda:3"
+    assert seen == [(10, 17), (18, 32), (33, 44)]              # the text interval cut at the scenes starting at frames 18 and 33
+    assert len(sr.video_writer.frames) == 60
+    seen.clear()
+    sr2 = SubtitleRemover(ArrayVideo(clip, fps=25.0), device="cuda:3", model_path="unused")
+    sr2.sub_areas = [(0, 120, 0, 780)]
+    sr2.propainter_mode(None, propainter_inpaint=lambda b, m: seen.append(len(b)) or [f.copy() for f in b], text_detector=Det(), scene_div_points=[])
+    assert asked == [3] and seen == [35]                       # given (even empty) scene points are used as they are
