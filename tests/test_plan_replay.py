@@ -32,6 +32,15 @@ def test_plan_replay_matches_oracle(built_lib):
     assert res["counts"] == [2, 2, 2, 1]
 
 
+def test_plan_replay_degenerate_chunks(built_lib):
+    """a 1-frame and a 2-frame chunk with the reference's default stride 5 / references every 10 (the ragged tail of a video,
+    sttn_auto_inpaint.py:240-245): one window of T = 1 / T = 2, every frame visited once and returned as uint8"""
+    import _replay_check
+
+    assert _replay_check.run(L=1, ns=5, rl=10, seed=3)["counts"] == [1]
+    assert _replay_check.run(L=2, ns=5, rl=10, seed=4)["counts"] == [1, 1]
+
+
 def test_plan_replay_sttn_det(built_lib):
     """sttn-det geometry (432x240, patch table of network_sttn.py:69), pre-masked input, model-res blend."""
     import _replay_check
