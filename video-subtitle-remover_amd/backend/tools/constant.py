@@ -1,17 +1,10 @@
-"""Enum names and values of backend/tools/constant.py:4-19 (the --inpaint-mode plugin selector)."""
-from enum import Enum, unique
+"""The selector enums the command line and the config speak (reference backend/tools/constant.py:4-19): member names and
+values are the reference's, because `--inpaint-mode` parses `InpaintMode[NAME]` and the config file stores the values."""
+from enum import Enum
 
+# --inpaint-mode plugin selector: command-line spelling -> member name
+_INPAINT_MODES = ("sttn-auto", "sttn-det", "lama", "propainter", "opencv")
+InpaintMode = Enum("InpaintMode", {v.upper().replace("-", "_"): v for v in _INPAINT_MODES}, module=__name__)
 
-@unique
-class InpaintMode(Enum):
-    STTN_AUTO = "sttn-auto"
-    STTN_DET = "sttn-det"
-    LAMA = "lama"
-    PROPAINTER = "propainter"
-    OPENCV = "opencv"
-
-
-@unique
-class SubtitleDetectMode(Enum):
-    PP_OCRv5_MOBILE = "PP_OCRv5_MOBILE"
-    PP_OCRv5_SERVER = "PP_OCRv5_SERVER"
+# text detection program (PP-OCRv5 mobile / server); the value is the member name
+SubtitleDetectMode = Enum("SubtitleDetectMode", {n: n for n in ("PP_OCRv5_MOBILE", "PP_OCRv5_SERVER")}, module=__name__)
