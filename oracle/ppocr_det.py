@@ -40,6 +40,11 @@ def synthetic_weights(graph, seed=0):
     return out
 
 
+def _same_total(size, k, s, d=1):
+    """total padding of Paddle's padding_algorithm == "SAME" along one axis"""
+    return max((-(-size // s) - 1) * s + (k - 1) * d + 1 - size, 0)
+
+
 def run_graph(graph, weights, x, dtype=torch.float32):
     """x: torch [N,3,H,W] (normalised image) -> probability map [N,1,H,W]; dtype=torch.float64 gives the reference against
     which fp32 rounding of a ~150-layer program can be judged"""
@@ -52,9 +57,11 @@ def run_graph(graph, weights, x, dtype=torch.float32):
                 w = g(1)
                 pad = a["paddings"]
                 xin = g(0)
-                if a.get("padding_algorithm") == "SAME":          # stride 1 on this path: total pad k-1, the extra pixel after
+                if a.get("padding_algorithm") == "SAME":          # total pad so that out = ceil(in / stride); the odd pixel after
                     kh, kw = w.shape[2:]
-                    xin = F.pad(xin, ((kw - 1) // 2, kw - 1 - (kw - 1) // 2, (kh - 1) // 2, kh - 1 - (kh - 1) // 2))
+                    th, tw = (_same_total(xin.shape[2], kh, a["strides"][0], a["dilations"][0]),
+                              _same_total(xin.shape[3], kw, a["strides"][1], a["dilations"][1]))
+                    xin = F.pad(xin, (tw // 2, tw - tw // 2, th // 2, th - th // 2))
                     pad = [0, 0]
                 val[outs[0]] = F.conv2d(xin, w, None, stride=a["strides"], padding=pad, dilation=a["dilations"], groups=a["groups"])
             elif kind == "conv2d_transpose":
@@ -92,9 +99,9 @@ def run_graph(graph, weights, x, dtype=torch.float32):
                 else:
                     assert a["pooling_type"] == "max"
                     xin, pad = g(0), a["paddings"]
-                    if a.get("padding_algorithm") == "SAME":          # stride 1: k-1 extra pixels, after; padding never wins a max
-                        xin = F.pad(xin, ((ks[1] - 1) // 2, ks[1] - 1 - (ks[1] - 1) // 2, (ks[0] - 1) // 2, ks[0] - 1 - (ks[0] - 1) // 2),
-                                    value=float("-inf"))
+                    if a.get("padding_algorithm") == "SAME":          # padding never wins a max
+                        th, tw = _same_total(xin.shape[2], ks[0], a["strides"][0]), _same_total(xin.shape[3], ks[1], a["strides"][1])
+                        xin = F.pad(xin, (tw // 2, tw - tw // 2, th // 2, th - th // 2), value=float("-inf"))
                         pad = [0, 0]
                     val[outs[0]] = F.max_pool2d(xin, ks, stride=a["strides"], padding=pad, ceil_mode=a["ceil_mode"])
             elif kind == "nearest_interp":

@@ -65,6 +65,16 @@ class STTNInpaintOracle:
         mask_area = mask01[ymin:ymax, :]
         frame[ymin:ymax, :, :] = mask_area * comp + (1 - mask_area) * frame[ymin:ymax, :, :]
 
+    def __call__(self, input_frames, input_mask):
+        """STTNInpaint.__call__ (:43-97), the generic list-in / list-out plugin contract: threshold the 0/255 mask, find the
+        strips, then exactly the chunk body below over all frames."""
+        mask01 = cv2r.threshold_binary(input_mask, 127, 1)[:, :, None]
+        H_ori, W_ori = mask01.shape[:2]
+        inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, int(W_ori * 3 / 16), mask01)
+        if not inpaint_area:
+            return [f.copy() for f in input_frames]
+        return self.chunk(input_frames, mask01, inpaint_area)
+
     def chunk(self, frames_hr, mask01, inpaint_area, sel=None):
         """Body of the chunk loop of STTNAutoInpaint.__call__ (:242-317): returns the written frames.
 

@@ -5,7 +5,6 @@
 // purpose): what do barriers / global loads / LDS stores / LDS reads / table s_loads cost?
 #define GG_ABLATE 1
 #include "../video-subtitle-remover_amd/csrc/gather_gemm.hip"
-#include "../video-subtitle-remover_amd/csrc/gather_gemm_v2.h"
 #include "../video-subtitle-remover_amd/csrc/gather_gemm_v3.h"
 #include "../video-subtitle-remover_amd/csrc/gather_gemm_v4.h"
 #include <stdio.h>
@@ -39,8 +38,7 @@ static float run_v2(const GGProblem* d, int blocks, int iters, int residentPerCU
     unsigned int* q;
     hipMalloc(&q, 64 * 8 * sizeof(unsigned int));
     int occ = 0;
-    if (V == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>, 256, 0);
-    else hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v2<BM, BN, WM, WN, VSR_BMODE_NK, 0>, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>, 256, 0);
     if (residentPerCU > 0 && residentPerCU < occ) occ = residentPerCU;
     const int grid = blocks < 256 * occ ? blocks : 256 * occ;
     float best = 1e9f;
@@ -48,8 +46,7 @@ static float run_v2(const GGProblem* d, int blocks, int iters, int residentPerCU
         hipMemset(q, 0, 64 * 8 * sizeof(unsigned int));
         hipEventRecord(a, 0);
         for (int i = 0; i < iters; ++i)
-            if (V == 3) hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8);
-            else hipLaunchKernelGGL((gather_gemm_f32_v2<BM, BN, WM, WN, VSR_BMODE_NK, 0>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i);
+            hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;
@@ -133,7 +130,6 @@ static int sweep(int T)
     printf("tile %dx%d T=%d: %d workgroups, %.1f GFLOP\n", BM, BN, T, blocks, gf);
 #define R(abl, what) { float ms = run<BM, BN, WM, WN, abl>(d, blocks, it); printf("  abl=%2d %-46s %8.1f us  %6.1f TF\n", abl, what, ms * 1e3, gf / ms); }
     R(0, "full kernel");
-    { float ms = run_v2<BM, BN, WM, WN, 2>(d, blocks, it, 0); printf("%6.1f TF\n", gf / ms); }
     { float ms = run_v2<BM, BN, WM, WN, 3>(d, blocks, it, 0); printf("%6.1f TF\n", gf / ms); }
     { float ms = run_v2<BM, BN, WM, WN, 3>(d, blocks, it, 2); printf("%6.1f TF\n", gf / ms); }
     { float ms = run_v2<BM, BN, WM, WN, 3>(d, blocks, it, 1); printf("%6.1f TF\n", gf / ms); }

@@ -187,7 +187,7 @@ def test_gather_gemm_narrow_tiles(built_lib, gpu_device, cfg, bn, M, N, K):
     _assert_close(got, _reference(c), K, f"{cfg} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 @pytest.mark.parametrize("cfg,bm,bn,bmode,M,N,K,splitK", [
     ("TILE_128x128", 128, 128, 0, 513, 257, 2304, 1), ("TILE_128x64", 128, 64, 0, 300, 256, 576, 1),
     ("TILE_128x128", 128, 128, 0, 375, 375, 384, 3), ("TILE_256x64", 256, 64, 0, 520, 64, 576, 1),
@@ -198,8 +198,6 @@ def test_gather_gemm_narrow_tiles(built_lib, gpu_device, cfg, bn, M, N, K):
 def test_gather_gemm_every_variant(built_lib, gpu_device, variant, cfg, bm, bn, bmode, M, N, K, splitK):
     """All four kernel variants implement the same descriptor semantics (v4 = split-half f16 MFMA: operands
     here are O(1), far inside the fp16 range; its error is ~2^-22 relative per product)."""
-    if variant == 2 and bmode == 1 and False:
-        pytest.skip("n/a")
     rng = np.random.default_rng(variant * 1000 + M + N + K)
     full = splitK == 1 and bmode == 0
     c = _make_gemm_case(rng, M, N, K, bm, bn, bmode, splitK, full, 1 if full else 0, full and N > 3)

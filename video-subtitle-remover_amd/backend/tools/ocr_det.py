@@ -279,9 +279,9 @@ class PaddleGraphRunner:
                     cout, _, kh, kw = w.shape
                     sh, sw = a["strides"]
                     pt, pl = a["paddings"][0], a["paddings"][1]
-                    if a.get("padding_algorithm") == "SAME":              # stride 1 here: the extra pixel goes after
-                        pt, pl = (kh - 1) // 2, (kw - 1) // 2
-                        ho, wo = -(-h // sh), -(-wd // sw)
+                    if a.get("padding_algorithm") == "SAME":
+                        dil = list(a.get("dilations", [1, 1]))
+                        (pt, ho), (pl, wo) = same_padding(h, kh, sh, dil[0]), same_padding(wd, kw, sw, dil[1])
                     else:
                         ho, wo = (h + 2 * pt - kh) // sh + 1, (wd + 2 * pl - kw) // sw + 1
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
@@ -347,8 +347,7 @@ class PaddleGraphRunner:
                         sh, sw = a["strides"]
                         pt, pl = a["paddings"][0], a["paddings"][1]
                         if a.get("padding_algorithm") == "SAME":
-                            pt, pl = (ks[0] - 1) // 2, (ks[1] - 1) // 2
-                            ho, wo = -(-h // sh), -(-wd // sw)
+                            (pt, ho), (pl, wo) = same_padding(h, ks[0], sh), same_padding(wd, ks[1], sw)
                         elif a["ceil_mode"]:
                             ho, wo = -(-(h + 2 * pt - ks[0]) // sh) + 1, -(-(wd + 2 * pl - ks[1]) // sw) + 1
                         else:
@@ -472,14 +471,47 @@ def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidate
     return (np.stack(boxes) if boxes else np.zeros((0, 4, 2), np.int32)), scores
 
 
+def det_resize_shape(H, W, limit_side_len=960, limit_type="max", max_side_limit=4000):
+    """Net input size (rh, rw) of DetResizeForTest for an HxW image.
+
+    inference.yml:31-32 only says `DetResizeForTest: resize_long: 960`.  paddleocr 3.4's TextDetection (PaddleX
+    text_detection/predictor.py `build_resize`) maps that key, for the PP-OCRv5 det models, to
+    `limit_side_len = resize_long`, `limit_type = "max"` and runs processors.DetResizeForTest.resize_image_type0:
+    the image is only SHRUNK when its longer side exceeds the limit (ratio 1 otherwise), sides are truncated with int()
+    and then rounded to multiples of 32 (minimum 32).  [external: PaddleX is not in the reference mount; restated from its
+    published source, unverifiable here -- parity unpinned.]  `limit_type="long"` gives round 1's behaviour (longer side
+    always scaled to the limit)."""
+    if limit_type == "max":
+        ratio = float(limit_side_len) / max(H, W) if max(H, W) > limit_side_len else 1.0
+    elif limit_type == "min":
+        ratio = float(limit_side_len) / min(H, W) if min(H, W) < limit_side_len else 1.0
+    elif limit_type == "long":
+        ratio = float(limit_side_len) / max(H, W)
+    else:
+        raise ValueError(f"limit_type {limit_type!r}")
+    rh, rw = int(H * ratio), int(W * ratio)
+    if max(rh, rw) > max_side_limit:
+        r2 = float(max_side_limit) / max(rh, rw)
+        rh, rw = int(rh * r2), int(rw * r2)
+    return max(int(round(rh / 32) * 32), 32), max(int(round(rw / 32) * 32), 32)
+
+
+def same_padding(size, k, s, d=1):
+    """Paddle's padding_algorithm == "SAME" along one axis: (pad_before, out_size); the odd pixel goes after."""
+    out = -(-size // s)
+    total = max((out - 1) * s + (k - 1) * d + 1 - size, 0)
+    return total // 2, out
+
+
 class TextDetection:
-    def __init__(self, model, weights, device=0, resize_long=960):
+    def __init__(self, model, weights, device=0, resize_long=960, limit_type="max"):
         """model: directory holding inference.json (as backend/models/V5/ch_det), a path to it, or a loaded / condensed graph dict"""
         if isinstance(model, (str, os.PathLike)) and os.path.isdir(model):
             model = os.path.join(model, "inference.json")
         self.graph = model if hasattr(model, "ops") else load_graph(model)
         self.runner = PaddleGraphRunner(self.graph, weights, device)
         self.resize_long = resize_long
+        self.limit_type = limit_type
         # VSR_DET_GRAPH=1 replays the forward from a captured HIP graph.  OFF by default: the first capture attempt on the MI355X
         # ended in a GPU memory access fault at replay and has not been debugged yet (see DESIGN.md section 8).
         self.use_graph = os.environ.get("VSR_DET_GRAPH", "0") == "1"
@@ -504,9 +536,7 @@ class TextDetection:
     def probability_map(self, img):
         """img: HxWx3 uint8 BGR (numpy) -> (probability map [rh, rw] torch tensor on the device, rh, rw)"""
         H, W = img.shape[:2]
-        ratio = float(self.resize_long) / max(H, W)                        # DetResizeForTest(resize_long): longer side -> 960,
-        rh = max(int(round(H * ratio / 32) * 32), 32)                      # both sides to multiples of 32
-        rw = max(int(round(W * ratio / 32) * 32), 32)
+        rh, rw = det_resize_shape(H, W, self.resize_long, self.limit_type)
         with torch.cuda.device(self.device):
             d = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
             small = self._resize(d, H, W, rh, rw)

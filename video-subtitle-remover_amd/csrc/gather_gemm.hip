@@ -299,7 +299,6 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
     }
 }
 
-#include "gather_gemm_v2.h"
 #include "gather_gemm_v3.h"
 #include "gather_gemm_v4.h"
 #include "gather_gemm_v5.h"
@@ -367,24 +366,19 @@ static void launch_v5(const GGProblem* d_probs, int nprobs, int totalBlocks, uns
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
             hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream,          \
                                d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag);          \
-        } else if (queue && variant >= 3) {                                                                            \
+        } else if (queue) {                                                                                     \
             static const int resident = resident_blocks(gather_gemm_f32_v3<BM, BN, WM, WN, MODE>);             \
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
             hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream, d_probs, \
                                nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1);                              \
-        } else if (queue) {                                                                                     \
-            static const int resident = resident_blocks(gather_gemm_f32_v2<BM, BN, WM, WN, MODE>);             \
-            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
-            hipLaunchKernelGGL((gather_gemm_f32_v2<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream, d_probs, \
-                               nprobs, totalBlocks, queue);                                                    \
         } else {                                                                                                \
             hipLaunchKernelGGL((gather_gemm_f32<BM, BN, WM, WN, MODE>), dim3(totalBlocks), block, 0, stream,   \
                                d_probs, nprobs);                                                               \
         }                                                                                                       \
     } while (0)
 
-// variant 1 (or queue == nullptr): one workgroup per tile.  variant 2 / 3 / 4: persistent kernels pulling tile
-// ids from queue[0..7] (must be 0): 2 = register-staged double buffer, 3 = LDS-DMA double buffer,
+// variant 1 (or queue == nullptr): one workgroup per tile.  variant 3 / 4 / 5 / 6: persistent kernels pulling tile
+// ids from queue[0..7] (must be 0): 3 = LDS-DMA double buffer (2 is accepted as an alias of 3),
 // 4 = split-half operands on the f16 matrix cores (fp32 tensors, split in the kernel), 5 = the same arithmetic
 // on SPLIT-FORMAT tensors (A, B, R and -- with VSR_ACT_OUT_SPLIT in act -- C; see gather_gemm_v5.h), 6 = variant 5
 // with the fp16 hi halves alone as operands (one MFMA per product).
