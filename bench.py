@@ -7,15 +7,20 @@ One "step" = one pass of the hot path over one chunk: ``clip_gap`` (50) syntheti
 already resident in HBM go through vsr_sttn_auto_chunk (crop strip -> cv2-style resize to 640x120
 -> encoder -> 10 sliding windows x 8 transformer blocks -> decoder -> tanh/u8/overlap average ->
 resize back -> mask blend, in place).  Chunks are independent (sttn_auto_inpaint.py:242-328), so
-with N GPUs every rank runs its own chunks and no data-path collective exists ("weak" scaling:
-per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+with N GPUs the chunks are dealt round-robin and no data-path collective exists ("weak" scaling:
+per-GPU work is fixed).  N > 1 times the north-star data path: all N chunks of a step are resident in
+rank 0's HBM, the strip rows of chunk k travel to rank k over xGMI (RCCL send / recv, grouped, pipelined
+under the compute: backend/tools/chunk_parallel.py), are inpainted there and return to rank 0's HBM;
+`value` = N x 50 x K frames / max-over-ranks time.  The replica rate (every rank on its own resident
+chunk, nothing exchanged) is reported beside it as `replicas`.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline     -- the dominant kernel (gather_gemm_f32<128,128,NK> running the 3x3 256->256 convs:
                   59 % of the model FLOPs), algorithmic FLOPs / HIP-event time on the launch stream
                   against the 157.3 TFLOP/s fp32 MFMA peak of MI355X_MICROARCH.md.
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference modules, "port") timed on
-                  this box's host cores on a bounded sample, scaled to frames/s of the same workload.
+                  this box's host cores on ONE full 50-frame chunk of the same clip, end to end (crop,
+                  cv2-style resize, network, resize back, blend) with the network-only time beside it.
 """
 import argparse
 import json
@@ -45,8 +50,19 @@ def make_chunk_on_device(L, H, W, box, seed, device):
     return torch.cat(reps, 0)[:L].contiguous()
 
 
-def cpu_baseline(sd, flops_per_frame, sample_frames):
-    """Oracle timed on the host cores: STTNInpaint.inpaint on `sample_frames` model-res frames."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, clip, mask01, areas):
+    """The oracle's chunk body (STTNAutoInpaint.__call__ :242-317 restated) on one full chunk of host frames, timed on the host
+    cores: end to end, and the network part (STTNInpaint.inpaint) on its own."""
     from oracle.sttn_auto import STTNInpaintOracle
 
     # pick the thread count that suits this host (oneDNN collapses when 256 threads fight over a
@@ -54,7 +70,7 @@ def cpu_baseline(sd, flops_per_frame, sample_frames):
     ncpu = os.cpu_count() or 1
     x = torch.randn(8, 256, 30, 160)
     w = torch.randn(256, 256, 3, 3)
-    best, threads = None, 1
+    best, threads, tried = None, 1, {}
     for cand in sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu}):
         torch.set_num_threads(cand)
         with torch.no_grad():
@@ -63,15 +79,25 @@ def cpu_baseline(sd, flops_per_frame, sample_frames):
             for _ in range(3):
                 torch.nn.functional.conv2d(x, w, padding=1)
             dt = time.perf_counter() - t0
+        tried[cand] = round(dt / 3 * 1e3, 2)
         if best is None or dt < best:
             best, threads = dt, cand
     torch.set_num_threads(threads)
     o = STTNInpaintOracle(sd, "auto")
-    frames = np.random.default_rng(0).integers(0, 256, size=(sample_frames, 120, 640, 3), dtype=np.uint8)
+    net = {"s": 0.0}
+    inner = o.inpaint
+
+    def timed_inpaint(frames):
+        t = time.perf_counter()
+        r = inner(frames)
+        net["s"] += time.perf_counter() - t
+        return r
+
+    o.inpaint = timed_inpaint
     t0 = time.perf_counter()
-    ref = o.inpaint(list(frames))
+    ref = o.chunk(list(clip), mask01, areas)
     dt = time.perf_counter() - t0
-    return o, frames, ref, dt, threads
+    return np.stack(ref), dt, net["s"], threads, tried
 
 
 def main():
@@ -84,7 +110,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
-    ap.add_argument("--cpu-sample-frames", type=int, default=20)
     ap.add_argument("--precision", default=None, choices=["f32", "split", "split-format", "f16"],
                     help="arithmetic of the contractions in the timed region (default: exact fp32; BASELINE.json's config 5 "
                          "is --res 4k --precision f16)")
@@ -136,28 +161,68 @@ def main():
         work.copy_(src)                          # device-to-device restore of the in-place chunk
         eng.auto_chunk(work, dmask, areas)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # per-op HIP events on the launch stream during the timed region (one record pair per launch;
-    # ~1300 launches per chunk, read back once per chunk) -- feeds the roofline object
-    eng.timing(True)
-    eng.timing_reset()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn):
+        """barrier + synchronize on both sides of fn(); max over ranks"""
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    replicas = None
+    if world == 1:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        # per-op HIP events on the launch stream during the timed region (one record pair per launch;
+        # ~1300 launches per chunk, read back once per chunk) -- feeds the roofline object
+        eng.timing(True)
+        eng.timing_reset()
+        elapsed = timed(lambda: [step() for _ in range(args.steps)])
+    else:
+        # N > 1: the north-star data path.  A step = one round of N chunks: all resident in rank 0's HBM, the rows between the
+        # first and the last strip of chunk k go to rank k (RCCL send / recv over xGMI), are inpainted there in place and come
+        # back into rank 0's HBM.  backend/tools/chunk_parallel.py pipelines scatter / compute / gather over the rounds.
+        from vsr_amd.backend.tools import chunk_parallel as cp
+
+        y_lo, y_hi = min(a[0] for a in areas), max(a[1] for a in areas)
+        local_areas = [(a[0] - y_lo, a[1] - y_lo, a[2], a[3]) for a in areas]
+        dmask_rows = dmask[y_lo:y_hi].contiguous()
+        if rank == 0:
+            srcs = [src] + [make_chunk_on_device(L, H, W, box, seed=1 + k, device=device) for k in range(1, world)]
+            dsts = [torch.empty((L, y_hi - y_lo, W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+
+        def run_rounds(n_rounds):
+            ranges = [(i * L, (i + 1) * L) for i in range(n_rounds * world)]
+            cp.run_chunk_parallel(ranges, (y_hi - y_lo, W, 3),
+                                  lambda i, out: out.copy_(srcs[i % world][:, y_lo:y_hi]),
+                                  lambda i, rows: eng.auto_chunk(rows, dmask_rows, local_areas),
+                                  lambda i, rows: dsts[i % world].copy_(rows),
+                                  dist=dist, device=device, io="device")
+
+        run_rounds(max(1, args.warmup))
+        eng.timing(True)
+        eng.timing_reset()
+        elapsed = timed(lambda: run_rounds(args.steps))
+        eng.timing(False)
+        for _ in range(max(1, args.warmup)):
+            step()
+        dt_rep = timed(lambda: [step() for _ in range(args.steps)])
+        replicas = {"value": round(args.steps * L * world / dt_rep, 3), "unit": "frames/s", "ms_per_step": round(dt_rep / args.steps * 1e3, 3),
+                    "note": "every rank on its own HBM-resident chunk, nothing exchanged (upper bound of the scatter / gather path)"}
+        if rank == 0:
+            checksum = int(sum(int(d[::7, ::5, ::11].sum().item()) for d in dsts))
+            replicas["scatter_gather_result_checksum"] = checksum
 
     total_frames = args.steps * L * world
     fps = total_frames / elapsed
@@ -175,13 +240,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.res} synthetic clip, --inpaint-mode sttn-auto, {L}-frame chunks resident in HBM, "
                                f"neighbor stride 5 / refs every 10 (BASELINE.json metric; model cost is resolution-independent)",
-                   "frame_size": [W, H], "strip": [W, int(W * 3 / 16)], "chunk_frames": L, "parallelism": f"chunk-parallel x{world}",
+                   "frame_size": [W, H], "strip": [W, int(W * 3 / 16)], "chunk_frames": L,
+                   "parallelism": f"chunk-parallel x{world}" + ("" if world == 1 else
+                                  " (all chunks resident on rank 0, strip rows scattered / gathered point-to-point over RCCL, pipelined)"),
                    "weights": "synthetic variance-preserving (no checkpoint in the reference mount)"},
         "model_tflops": round(flops_per_frame * fps / 1e12, 3),
         "gflop_per_frame": round(flops_per_frame / 1e9, 2),
     }
 
     eng.timing(False)
+    if replicas is not None:
+        out["replicas"] = replicas
     if world > 1:          # the CPU baseline and the informational legs belong to the N = 1 line only
         args.no_cpu_baseline, args.no_split_half, args.e2e_chunks = True, True, 0
     if rank == 0:
@@ -221,21 +290,31 @@ def main():
         out["kernel_breakdown_timed_region"] = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_launch_ms": round(v[0] / v[1], 4),
                                                    "tflops": round(v[2] / v[0] / 1e9, 2)} for k, v in per_kernel.items()}
 
+        refa = None
         if not args.no_cpu_baseline:
-            o, frames, ref, dt, threads = cpu_baseline(sd, flops_per_frame, args.cpu_sample_frames)
-            sample_flops = eng.flops(args.cpu_sample_frames)
-            cpu_fps = (sample_flops / dt) / flops_per_frame
-            comp, counts = eng.inpaint(torch.from_numpy(frames).to(device))
+            # one full chunk of the timed clip through the oracle on the host cores, and the same chunk through the HIP path
+            host_clip1 = src.cpu().numpy()
+            ref, dt, dt_net, threads, tried = cpu_baseline(sd, host_clip1, mask01, areas)
+            got = src.clone()
+            eng.auto_chunk(got, dmask, areas)
             torch.cuda.synchronize()
-            refa = np.stack([r.astype(np.float32) for r in ref])
-            mse = float(np.mean((comp.cpu().numpy().astype(np.float64) - refa) ** 2))
+            got = got.cpu().numpy()
+            m = mask01[:, :, 0].astype(bool)
+            mse = float(np.mean((got[:, m].astype(np.float64) - ref[:, m].astype(np.float64)) ** 2))
             psnr = float("inf") if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
             out["cpu_baseline"] = {
-                "value": round(cpu_fps, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-                "sample": f"oracle STTNInpaint.inpaint (torch-CPU fp32 restatement of the reference modules) on "
-                          f"{args.cpu_sample_frames} model-resolution frames ({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s), "
-                          f"scaled by FLOPs to the {flops_per_frame / 1e9:.1f} GFLOP/frame of a {L}-frame chunk"}
+                "value": round(L / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+                "model_only": {"value": round(L / dt_net, 4), "unit": "frames/s", "tflops": round(flops_chunk / dt_net / 1e12, 3)},
+                "host": {"cpu_count": os.cpu_count(), "cpu_model": cpu_model_name(), "torch_threads": threads,
+                         "conv_probe_ms_by_threads": tried},
+                "sample": f"oracle chunk body (torch-CPU fp32 restatement of the reference modules + restated cv2 resize / blend) on ONE full "
+                          f"{L}-frame {args.res} chunk of the timed clip, end to end in {dt:.1f} s of which STTNInpaint.inpaint "
+                          f"(the network, {flops_chunk / 1e12:.2f} TFLOP) {dt_net:.1f} s; thread count picked by a conv probe"}
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"
+            out["psnr_note"] = (f"masked strip pixels of the full {L}-frame chunk, HIP path vs CPU oracle; max |d| "
+                                f"{int(np.abs(got[:, m].astype(np.int16) - ref[:, m].astype(np.int16)).max())}, "
+                                f"pixels outside the mask bit-identical: {bool(np.array_equal(got[:, ~m], host_clip1[:, ~m]))}")
+            refa = ref[:, m].astype(np.float64)
         if args.e2e_chunks > 0:
             # PCIe-inclusive rate of the plugin's host loop (frames start and end in host memory: pinned staging,
             # H2D / compute / D2H pipelined over three streams).  Reported beside `value`, never as `value`.
@@ -283,10 +362,11 @@ def main():
                                     ("fp32 data + fp32 accumulate; operands as fp16 hi/lo pairs, a*b = a_lo*b_hi + a_hi*b_lo + a_hi*b_hi "
                                      "(3x v_mfma_f32_32x32x16_f16)" + ("; tensors kept in split format by their producers, "
                                      "operands by LDS-DMA" if mode == "split-format" else "; split inside the GEMM"))}
-                if not args.no_cpu_baseline:
-                    comp2, _ = eng.inpaint(torch.from_numpy(frames).to(device))
+                if refa is not None:
+                    got2 = src.clone()
+                    eng.auto_chunk(got2, dmask, areas)
                     torch.cuda.synchronize()
-                    mse2 = float(np.mean((comp2.cpu().numpy().astype(np.float64) - refa) ** 2))
+                    mse2 = float(np.mean((got2.cpu().numpy()[:, m].astype(np.float64) - refa) ** 2))
                     sp["psnr_db_vs_oracle"] = "inf" if mse2 == 0 else round(20 * np.log10(255.0 / np.sqrt(mse2)), 2)
                 out[key] = sp
             eng.set_precision(base_precision)

@@ -10,6 +10,26 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "baseline_oracle: compares against a BASELINE-size CPU oracle run (tests/_baseline_oracle.py)")
+
+
+def pytest_collection_finish(session):
+    """Start the BASELINE-size oracle runs in background processes as soon as it is known that a selected test needs them."""
+    wanted = set()
+    for item in session.items:
+        if item.get_closest_marker("baseline_oracle") is None:
+            continue
+        cs = getattr(item, "callspec", None)
+        name = cs.params.get("name") if cs is not None else None
+        wanted.add(name or {"test_det_batch_L47_vs_oracle": "det_1080p", "test_propainter_batch_L20_vs_oracle": "pp_1080p"}.get(item.originalname))
+    wanted.discard(None)
+    if wanted and not session.config.option.collectonly:
+        import torch
+
+        if torch.cuda.is_available():
+            from tests import _baseline_oracle
+
+            _baseline_oracle.launch(sorted(wanted))
 
 
 @pytest.fixture(scope="session")

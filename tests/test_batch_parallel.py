@@ -101,3 +101,67 @@ def test_driver_orders_passthrough_and_work_items():
     out = []
     run_batch_parallel(iter([]), None, out.append)
     assert out == []
+
+
+def _bounded_worker(rank, world, port, fail, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import vsr_amd  # noqa: F401
+    from vsr_amd.backend.tools.batch_parallel import run_batch_parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    written, seen, owners = [], [], []
+    fr = lambda v: np.full((2, 3, 3), v, np.uint8)
+
+    def items():
+        yield ("work", [fr(1), fr(2)], np.zeros((2, 3), np.uint8))          # batch 0 -> rank 0
+        for i in range(150):                                              # a long subtitle-free stretch
+            if i == 149:
+                seen.append(len(written))                                 # how much was flushed before the stretch ended
+            yield ("pass", fr(10))
+        if fail:
+            raise ValueError("reader died")
+        yield ("work", [fr(3)], np.zeros((2, 3), np.uint8))                # batch 1 -> rank 1 (ownership survives the partial round)
+        yield ("pass", fr(11))
+
+    def process(frames, mask):
+        owners.append(rank)
+        return [f + 100 for f in frames]
+
+    err = None
+    try:
+        run_batch_parallel(items() if rank == 0 else (), process, lambda f: written.append(int(f[0, 0, 0])), dist=dist,
+                           max_pending=64, prefetch_frames=0)
+    except ValueError as e:
+        err = str(e)
+    q.put((rank, written, seen, owners, err))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_partial_round_is_flushed_and_peers_are_released(fail):
+    """(a) a batch followed by a long pass-through stretch must not buffer the stretch; (b) an exception on rank 0
+    must not leave the peers blocked in recv."""
+    world = 2
+    port = 33500 + (os.getpid() % 2000) + (3 if fail else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bounded_worker, args=(r, world, port, fail, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = {m[0]: m for m in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0, "no rank may hang or die"
+    _, written, seen, owners0, err = msgs[0]
+    assert seen and seen[0] >= 2 + 64, "the queued batch and the first 64 pass-through frames are out before the stretch ends"
+    if fail:
+        assert err == "reader died" and msgs[1][3] == []
+        assert written[:2] == [101, 102] and written[2:] == [10] * (len(written) - 2)
+    else:
+        assert err is None
+        assert written == [101, 102] + [10] * 150 + [103, 11]
+        assert owners0 == [0] and msgs[1][3] == [1]

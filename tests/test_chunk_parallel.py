@@ -1,13 +1,17 @@
-"""N > 1 path on CPU: two gloo processes deal the chunks of one clip and rank 0 reassembles them in order."""
+"""N > 1 path on CPU: two gloo processes deal the chunks of one clip (pipelined scatter / compute / gather of
+tools/chunk_parallel.py) and rank 0 reassembles them in order."""
 import os
 import sys
 
 import numpy as np
 import pytest
-import torch
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clip(total):
+    return (np.arange(total * 4 * 6 * 3) % 251).astype(np.uint8).reshape(total, 4, 6, 3)
 
 
 def _worker(rank, world, port, total, gap, q):
@@ -20,36 +24,39 @@ def _worker(rank, world, port, total, gap, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    clip = (np.arange(total * 4 * 6 * 3) % 251).astype(np.uint8).reshape(total, 4, 6, 3)
-    written = {}
-    processed = []
+    clip = _clip(total)
+    ranges = cp.chunk_ranges(total, gap)
+    written, processed, loaded = {}, [], []
 
-    def read_chunk(s, e):
-        return clip[s:e]
+    def load(i, out):
+        assert rank == 0
+        s, e = ranges[i]
+        loaded.append(i)
+        out[:e - s] = clip[s:e]
 
-    def process_chunk(i, frames):          # stand-in for engine.auto_chunk: mark which rank / chunk touched it
+    def process(i, frames):                # stand-in for engine.auto_chunk (in place): mark which rank / chunk touched it
         processed.append(i)
-        out = frames.clone()
-        out[:, 0, 0, 0] = 100 + rank
-        out[:, 0, 0, 1] = i
-        return out
+        assert frames.shape[0] == ranges[i][1] - ranges[i][0]
+        frames[:, 0, 0, 0] = 100 + rank
+        frames[:, 0, 0, 1] = i
 
-    def write_chunk(i, arr):
-        written[i] = arr
+    def store(i, arr):
+        assert rank == 0 and i == len(written), "results are written in chunk order"
+        written[i] = np.array(arr, copy=True)
 
-    cp.run_chunk_parallel(total, gap, (4, 6, 3), read_chunk, process_chunk, write_chunk, dist=dist)
+    cp.run_chunk_parallel(ranges, (4, 6, 3), load, process, store, dist=dist)
     if rank == 0:
-        q.put(("written", {k: v.copy() for k, v in written.items()}))
+        assert loaded == list(range(len(ranges))), "the source is read once, in order"
+        q.put(("written", written))
     q.put(("processed", rank, processed))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total,gap", [(23, 5), (20, 5), (3, 5)])
-def test_two_rank_chunk_parallel(total, gap):
+@pytest.mark.parametrize("world,total,gap", [(2, 23, 5), (2, 20, 5), (2, 3, 5), (3, 41, 4), (2, 0, 5)])
+def test_chunk_parallel_over_gloo_ranks(world, total, gap):
     from vsr_amd.backend.tools import chunk_parallel as cp
 
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + total
+    port = 29500 + (os.getpid() % 2000) + total + 7 * world
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, gap, q)) for r in range(world)]
@@ -63,7 +70,7 @@ def test_two_rank_chunk_parallel(total, gap):
     done = {m[1]: m[2] for m in msgs if m[0] == "processed"}
     ranges = cp.chunk_ranges(total, gap)
     assert sorted(written) == list(range(len(ranges)))
-    clip = (np.arange(total * 4 * 6 * 3) % 251).astype(np.uint8).reshape(total, 4, 6, 3)
+    clip = _clip(total)
     for i, (s, e) in enumerate(ranges):
         got = written[i]
         assert got.shape[0] == e - s
@@ -74,6 +81,18 @@ def test_two_rank_chunk_parallel(total, gap):
         assert np.array_equal(got, ref), "frames must come back unpermuted"
     for r in range(world):
         assert done[r] == cp.chunks_of(r, len(ranges), world), "round-robin ownership, reference chunk boundaries"
+
+
+def test_single_process_path():
+    """dist=None: the same driver degenerates to load -> process -> store per chunk."""
+    from vsr_amd.backend.tools import chunk_parallel as cp
+
+    clip = _clip(11)
+    ranges = cp.chunk_ranges(11, 4)
+    out = {}
+    cp.run_chunk_parallel(ranges, (4, 6, 3), lambda i, o: o.__setitem__(slice(0, ranges[i][1] - ranges[i][0]), clip[ranges[i][0]:ranges[i][1]]),
+                          lambda i, t: t.add_(1), lambda i, a: out.__setitem__(i, np.array(a, copy=True)))
+    assert np.array_equal(np.concatenate([out[i] for i in range(3)]), clip + 1)
 
 
 def test_chunk_ranges_match_reference_loop():

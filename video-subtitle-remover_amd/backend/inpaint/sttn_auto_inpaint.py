@@ -106,7 +106,9 @@ class STTNAutoInpaint:
     def _call_chunk_parallel(self, dist, input_mask, input_sub_remover, tbar):
         """One process per GPU: the chunks are dealt round-robin, rank 0 owns the frame source and sink
         (backend/tools/chunk_parallel.py).  Chunk boundaries are the reference's (clip_gap), so every frame
-        sees exactly the temporal context it sees in the single-GPU run."""
+        sees exactly the temporal context it sees in the single-GPU run.  Only the rows between the first and the
+        last strip travel to the GPUs (nothing else can change, :314-315); rank 0 keeps the decoded frames and
+        patches the returned rows in before writing."""
         from ..tools import chunk_parallel as cp
 
         rank = dist.get_rank()
@@ -119,35 +121,54 @@ class STTNAutoInpaint:
         self.writer = writer
         mask = self.sttn_inpaint.read_mask(self.mask_path) if input_mask is None else threshold_mask(input_mask)
         inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, int(W_ori * 3 / 16), mask)
-        dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(engine.device)
         ranges = cp.chunk_ranges(frame_info["len"], self.clip_gap)
+        y_lo = min((a[0] for a in inpaint_area), default=0)
+        y_hi = max((a[1] for a in inpaint_area), default=0)
+        local_areas = [(a[0] - y_lo, a[1] - y_lo, a[2], a[3]) for a in inpaint_area]
+        dmask = torch.from_numpy(np.ascontiguousarray(mask[y_lo:y_hi, :, 0])).to(engine.device) if inpaint_area else None
+        kept = {}
 
-        def read_chunk(s, e):
+        def tick():
+            if input_sub_remover is not None and tbar is not None:
+                input_sub_remover.update_progress(tbar, increment=1)
+
+        def load(i, out):
+            s, e = ranges[i]
             frames = []
             for j in range(s, e):
                 ok, image = reader.read()
                 if not ok:
                     raise RuntimeError(f"Failed to read frame {j}.")
+                if not image.flags.owndata or not image.flags.writeable:
+                    image = image.copy()                 # an in-memory source hands out views of the clip
+                out[j - s] = image[y_lo:y_hi]
                 frames.append(image)
-            return np.stack(frames)
+            kept[i] = frames
 
-        def process_chunk(i, frames):
+        def process(i, rows):
             s, e = ranges[i]
             sel = [j - s for j in range(s, e) if is_frame_number_in_ab_sections(j, ab_sections)]
-            if inpaint_area and sel:
-                engine.auto_chunk(frames, dmask, inpaint_area, sel=None if len(sel) == e - s else sel)
-                torch.cuda.synchronize(engine.device)
-            return frames
+            if sel:
+                engine.auto_chunk(rows, dmask, local_areas, sel=None if len(sel) == e - s else sel)
 
-        def write_chunk(i, arr):
-            for j in range(arr.shape[0]):
-                writer.write(arr[j])
-                if input_sub_remover is not None and tbar is not None:
-                    input_sub_remover.update_progress(tbar, increment=1)
+        def store(i, rows):
+            for j, frame in enumerate(kept.pop(i)):
+                frame[y_lo:y_hi] = rows[j]
+                writer.write(frame)
+                tick()
 
         try:
-            cp.run_chunk_parallel(frame_info["len"], self.clip_gap, (H_ori, W_ori, 3), read_chunk, process_chunk,
-                                  write_chunk, dist=dist, device=engine.device)
+            if not inpaint_area:                         # nothing to inpaint anywhere: rank 0 copies the video through
+                if rank == 0:
+                    while True:
+                        ok, image = reader.read()
+                        if not ok:
+                            break
+                        writer.write(image)
+                        tick()
+                dist.barrier()
+            else:
+                cp.run_chunk_parallel(ranges, (y_hi - y_lo, W_ori, 3), load, process, store, dist=dist, device=engine.device)
         finally:
             reader.release()
             if writer:

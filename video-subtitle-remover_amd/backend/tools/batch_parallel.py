@@ -30,9 +30,60 @@ def _serve(process, dist, device):
         dist.send(torch.from_numpy(np.ascontiguousarray(np.stack(out))).to(device), dst=0)
 
 
-def run_batch_parallel(items, process, write, dist=None, device="cpu"):
+class _Prefetch:
+    """Runs the `items` generator (reader + mask construction) in a thread, at most `max_frames` frames ahead -- the role the
+    reference gives FramePrefetcher (tools/video_io.py:12-47): reading the next round overlaps the current round's compute."""
+
+    def __init__(self, items, max_frames):
+        import queue
+        import threading
+
+        self.q = queue.Queue()
+        self.room = threading.Semaphore(max(1, int(max_frames)))
+        self.stop = False
+        self.t = threading.Thread(target=self._run, args=(items,), daemon=True)
+        self.t.start()
+
+    @staticmethod
+    def _cost(item):
+        return 1 if item[0] == PASS else max(1, len(item[1]))
+
+    def _run(self, items):
+        try:
+            for item in items:
+                for _ in range(self._cost(item)):
+                    self.room.acquire()
+                if self.stop:
+                    return
+                self.q.put(("item", item))
+            self.q.put(("end", None))
+        except BaseException as e:          # surfaces in the consumer
+            self.q.put(("error", e))
+
+    def __iter__(self):
+        while True:
+            kind, v = self.q.get()
+            if kind == "end":
+                return
+            if kind == "error":
+                raise v
+            yield v
+            for _ in range(self._cost(v)):
+                self.room.release()
+
+    def close(self):
+        self.stop = True
+        for _ in range(1 << 12):
+            self.room.release()
+
+
+def run_batch_parallel(items, process, write, dist=None, device="cpu", max_pending=64, prefetch_frames=256):
     """items: iterable consumed on rank 0 only, in video order, of (PASS, frame) or (WORK, [frames], mask [H,W] u8);
-    process([frames], mask) -> [frames] runs on the batch's owner; write(frame) runs on rank 0 in video order."""
+    process([frames], mask) -> [frames] runs on the batch's owner; write(frame) runs on rank 0 in video order.
+
+    A round is flushed when every rank has a batch, and also -- so that a long subtitle-free stretch after a batch neither
+    buffers the video in host memory nor leaves the queued batch unprocessed -- once `max_pending` pass-through frames wait
+    behind an incomplete round.  Whatever happens on rank 0 (reader, detector or plugin raising), the peers are released."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     if rank != 0:
@@ -40,12 +91,15 @@ def run_batch_parallel(items, process, write, dist=None, device="cpu"):
         dist.barrier()
         return
     pending, work = [], []                    # output slots of the current round; its batches
+    dealt = [0]                               # batches dealt so far: batch b belongs to rank b % world, partial rounds included
 
     def flush():
         if not work:
             return
+        base = dealt[0]
+        dealt[0] += len(work)
         for k, (frames, mask) in enumerate(work):            # peers first, so that they compute while rank 0 does
-            o = k % world
+            o = (base + k) % world
             if o:
                 arr = np.stack(frames)
                 dist.send(torch.tensor([arr.shape[0], arr.shape[1], arr.shape[2]], dtype=torch.int64, device=device), dst=o)
@@ -53,10 +107,10 @@ def run_batch_parallel(items, process, write, dist=None, device="cpu"):
                 dist.send(torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(device), dst=o)
         results = {}
         for k, (frames, mask) in enumerate(work):
-            if k % world == 0:
+            if (base + k) % world == 0:
                 results[k] = process(frames, mask)
         for k, (frames, mask) in enumerate(work):
-            o = k % world
+            o = (base + k) % world
             if o:
                 buf = torch.empty((len(frames),) + tuple(frames[0].shape), dtype=torch.uint8, device=device)
                 dist.recv(buf, src=o)
@@ -70,22 +124,36 @@ def run_batch_parallel(items, process, write, dist=None, device="cpu"):
         pending.clear()
         work.clear()
 
-    for item in items:
-        if item[0] == PASS:
-            if work:
-                pending.append((PASS, item[1]))
+    source = _Prefetch(items, prefetch_frames) if prefetch_frames else None
+    try:
+        n_pass = 0
+        for item in (source if source is not None else items):
+            if item[0] == PASS:
+                if work:
+                    pending.append((PASS, item[1]))
+                    n_pass += 1
+                    if n_pass >= max_pending:
+                        flush()
+                        n_pass = 0
+                else:
+                    write(item[1])
             else:
-                write(item[1])
-        else:
-            _, frames, mask = item
-            if mask.ndim == 3:
-                mask = mask[:, :, 0]
-            pending.append((WORK, len(work)))
-            work.append((list(frames), mask))
-            if len(work) == world:
-                flush()
-    flush()
-    if dist is not None:
-        for o in range(1, world):
-            dist.send(torch.zeros(3, dtype=torch.int64, device=device), dst=o)
-        dist.barrier()
+                _, frames, mask = item
+                if mask.ndim == 3:
+                    mask = mask[:, :, 0]
+                pending.append((WORK, len(work)))
+                work.append((list(frames), mask))
+                if len(work) == world:
+                    flush()
+                    n_pass = 0
+        flush()
+    finally:
+        if source is not None:
+            source.close()
+        if dist is not None:
+            for o in range(1, world):           # always release the peers, also when rank 0 is unwinding an exception
+                try:
+                    dist.send(torch.zeros(3, dtype=torch.int64, device=device), dst=o)
+                except Exception:
+                    pass
+            dist.barrier()

@@ -4,11 +4,30 @@ The chunks of STTNAutoInpaint.__call__ (reference backend/inpaint/sttn_auto_inpa
 every chunk re-reads, re-encodes and re-decodes its own `clip_gap` frames.  They are therefore dealt round-robin to
 the ranks (one process per GPU) with the reference's own chunk boundaries -- never re-chunked, because the boundaries
 define the temporal context of every frame -- and there is no data-path collective: rank 0 owns the frame source and
-sink and exchanges raw uint8 frames with each peer point-to-point (a flat star: on xGMI every peer has its own link
-to rank 0, a ring would only add hops).  torch.distributed: backend "nccl" (= RCCL) on GPUs, "gloo" in CPU tests.
+sink and exchanges raw uint8 frame rows with each peer point-to-point (a flat star: on xGMI every peer has its own
+link to rank 0, a ring would only add hops).  torch.distributed: backend "nccl" (= RCCL) on GPUs, "gloo" in CPU tests.
+
+Pipeline.  Chunk i belongs to round i // world and to rank i % world.  All ranks walk the rounds in lock step and
+meet in one grouped point-to-point exchange per step (dist.batch_isend_irecv -> one ncclGroup on RCCL, so the order
+of sends and receives inside a step cannot deadlock):
+
+    exchange X[e] = { rank 0 -> owner : the chunks of round e        (scatter)
+                      owner -> rank 0 : the results of round e - 2   (gather)  }
+
+    step r, every rank:  launch compute(round r)  |  post X[r+1]  |  rank 0: write round r-2, read + upload round r+2
+
+X[r+1] is posted right after compute(r) has been launched and from another stream, so the transfer of the next chunk
+and of the previous result runs under the compute of the current one -- on the peers as well as on rank 0, whose host
+thread meanwhile drains round r-2 to the writer and reads round r+2 into pinned memory.  Device buffers form a ring
+of four rounds (288 GB of HBM: a 50-frame 4K strip chunk is 415 MB).  Only the rows that can change (the strips, see
+STTNAutoInpaint._call_chunk_parallel) travel; rank 0 keeps the decoded frames and patches the rows back in.
 """
+import contextlib
+
 import numpy as np
 import torch
+
+RING = 4
 
 
 def chunk_ranges(total_frames, clip_gap):
@@ -25,54 +44,185 @@ def chunks_of(rank, n_chunks, world_size):
     return [i for i in range(n_chunks) if owner_of(i, world_size) == rank]
 
 
-def run_chunk_parallel(total_frames, clip_gap, frame_shape, read_chunk, process_chunk, write_chunk, dist=None,
-                       device="cpu"):
-    """Drive all chunks of one video over the ranks of `dist` (None = single process).
+class _Streams:
+    """two HIP streams + events on a GPU; plain synchronous execution on the CPU (gloo tests)"""
 
-    read_chunk(start, end) -> uint8 ndarray [n,H,W,3]      (called on rank 0 only, in order)
-    process_chunk(index, frames_tensor) -> uint8 tensor     (called on the owner, frames on `device`)
-    write_chunk(index, ndarray)                              (called on rank 0 only, in chunk order)
+    def __init__(self, device):
+        self.gpu = torch.device(device).type == "cuda"
+        self.device = torch.device(device)
+        if self.gpu:
+            self.io = torch.cuda.Stream(self.device)
+            self.cmp = torch.cuda.Stream(self.device)
+
+    def on(self, which):
+        return torch.cuda.stream(self.io if which == "io" else self.cmp) if self.gpu else contextlib.nullcontext()
+
+    def event(self, which):
+        """record an event at the tail of a stream (None on the CPU)"""
+        if not self.gpu:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.io if which == "io" else self.cmp)
+        return ev
+
+    def wait(self, which, ev):
+        if self.gpu and ev is not None:
+            (self.io if which == "io" else self.cmp).wait_event(ev)
+
+
+class _HostStaged:
+    """gloo moves host memory only: a dry run of the N > 1 path on GPUs without RCCL (several ranks on one GPU, where RCCL
+    refuses to build a communicator) bounces every transfer through a host copy.  Never the production path."""
+
+    def __init__(self, dist, ops):
+        self.pairs = [(kind, t, t.cpu() if kind == "send" else torch.empty(t.shape, dtype=t.dtype)) for kind, t, _ in ops]
+        self.works = dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, c, peer)
+                                             for (kind, _, c), (_, _, peer) in zip(self.pairs, ops)])
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for kind, t, c in self.pairs:
+            if kind == "recv":
+                t.copy_(c)
+
+
+def _exchange(dist, ops):
+    """post one grouped exchange; returns the work handles"""
+    if not ops:
+        return []
+    if dist.get_backend() == "gloo" and ops[0][1].is_cuda:
+        return [_HostStaged(dist, ops)]
+    return dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops])
+
+
+def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, device="cpu", io="host"):
+    """Drive the chunks `ranges` = [(start, end)] of one video over the ranks of `dist` (None = single process).
+
+    row_shape = (h, W, C): the rows of a frame that travel.
+    load(i, out)      rank 0 only, in chunk order: fill out[:n] (uint8 [n,h,W,C]: a pinned numpy array for io="host", a
+                      device tensor for io="device") with the rows of chunk i.
+    process(i, t)     on the owner of chunk i: work in place on the device tensor t uint8 [n,h,W,C]; may return while
+                      its kernels are still running on the current stream.
+    store(i, arr)     rank 0 only, in chunk order: the processed rows (same kind of array as load's).
     """
-    ranges = chunk_ranges(total_frames, clip_gap)
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    H, W, C = frame_shape
-    # processed in rounds of `world` chunks so that rank 0 never holds more than one round of results
-    for base in range(0, len(ranges), world):
-        idxs = list(range(base, min(base + world, len(ranges))))
-        mine = None
-        # scatter: rank 0 reads the round in order and ships each chunk to its owner
+    h, W, C = row_shape
+    n_rounds = (len(ranges) + world - 1) // world
+    maxn = max((e - s for s, e in ranges), default=0)
+    st = _Streams(device)
+    dev = st.device
+    host_io = io == "host"
+
+    def chunk_of(r, k):
+        i = r * world + k
+        return i if 0 <= r and i < len(ranges) else None
+
+    def nframes(i):
+        return ranges[i][1] - ranges[i][0]
+
+    if maxn == 0:
+        if dist is not None:
+            dist.barrier()
+        return
+    owners = range(world) if rank == 0 else [rank]
+    dbuf = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8, device=dev) for q in range(RING) for k in owners}
+    if rank == 0 and host_io and st.gpu:
+        pin_in = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8).pin_memory() for q in range(RING) for k in range(world)}
+        pin_out = {k: torch.empty((maxn, h, W, C), dtype=torch.uint8).pin_memory() for k in range(world)}
+    staged, computed = {}, {}                 # (round) -> event after upload of the own chunk / after its compute
+
+    def stage(r):                              # rank 0: read round r and bring it to the device (io stream)
+        for k in range(world):
+            i = chunk_of(r, k)
+            if i is None:
+                continue
+            n, d = nframes(i), dbuf[(r % RING, k)]
+            if not host_io:
+                with st.on("io"):
+                    load(i, d[:n])
+            elif st.gpu:
+                p = pin_in[(r % RING, k)]
+                load(i, p.numpy()[:n])
+                with st.on("io"):
+                    d[:n].copy_(p[:n], non_blocking=True)
+            else:
+                load(i, d.numpy()[:n])
+        staged[r] = st.event("io")
+
+    def drain(r):                              # rank 0: results of round r -> sink, in chunk order
+        for k in range(world):
+            i = chunk_of(r, k)
+            if i is None:
+                continue
+            n, d = nframes(i), dbuf[(r % RING, k)]
+            if k == 0:
+                st.wait("io", computed.get(r))
+            if not host_io:
+                with st.on("io"):
+                    store(i, d[:n])
+            elif st.gpu:
+                with st.on("io"):
+                    pin_out[k][:n].copy_(d[:n], non_blocking=True)
+                st.event("io").synchronize()
+                store(i, pin_out[k].numpy()[:n])
+            else:
+                store(i, d.numpy()[:n])
+
+    def compute(r):
+        i = chunk_of(r, rank)
+        if i is None:
+            return
+        st.wait("cmp", staged.get(r))
+        with st.on("cmp"):
+            process(i, dbuf[(r % RING, rank)][:nframes(i)])
+        computed[r] = st.event("cmp")
+
+    def post(e):                               # X[e]: scatter round e, gather round e - 2
+        ops = []
+        peers = range(1, world) if rank == 0 else [rank]
+        for k in peers:
+            i, j = chunk_of(e, k), chunk_of(e - 2, k)
+            if rank == 0:
+                if i is not None:
+                    ops.append(("send", dbuf[(e % RING, k)][:nframes(i)], k))
+                if j is not None:
+                    ops.append(("recv", dbuf[((e - 2) % RING, k)][:nframes(j)], k))
+            else:
+                if i is not None:
+                    ops.append(("recv", dbuf[(e % RING, k)][:nframes(i)], 0))
+                if j is not None:
+                    st.wait("io", computed.get(e - 2))
+                    ops.append(("send", dbuf[((e - 2) % RING, k)][:nframes(j)], 0))
+        with st.on("io"):
+            works = _exchange(dist, ops) if dist is not None else []
+        return works
+
+    def finish(works, r_recv):                 # the io stream (GPU) or the host (CPU) waits for the exchange
+        with st.on("io"):
+            for w in works:
+                w.wait()
+        if rank != 0 and r_recv is not None and chunk_of(r_recv, rank) is not None:
+            staged[r_recv] = st.event("io")    # the peer's chunk of round r_recv has arrived
+
+    if rank == 0:
+        stage(0)
+        stage(1)
+    finish(post(0), 0)
+    for r in range(n_rounds + 2):
+        compute(r)
+        works = post(r + 1)
         if rank == 0:
-            for i in idxs:
-                s, e = ranges[i]
-                frames = torch.from_numpy(np.ascontiguousarray(read_chunk(s, e)))
-                o = owner_of(i, world)
-                if o == 0:
-                    mine = (i, frames.to(device))
-                else:
-                    dist.send(frames.to(device), dst=o)
-        else:
-            for i in idxs:
-                if owner_of(i, world) == rank:
-                    s, e = ranges[i]
-                    buf = torch.empty((e - s, H, W, C), dtype=torch.uint8, device=device)
-                    dist.recv(buf, src=0)
-                    mine = (i, buf)
-        out = None
-        if mine is not None:
-            out = process_chunk(mine[0], mine[1])
-        # gather: results return to rank 0 and are written in chunk order
-        if rank == 0:
-            for i in idxs:
-                o = owner_of(i, world)
-                if o == 0:
-                    write_chunk(i, out.cpu().numpy())
-                else:
-                    s, e = ranges[i]
-                    buf = torch.empty((e - s, H, W, C), dtype=torch.uint8, device=device)
-                    dist.recv(buf, src=o)
-                    write_chunk(i, buf.cpu().numpy())
-        elif out is not None:
-            dist.send(out.contiguous(), dst=0)
+            drain(r - 2)
+            stage(r + 2)
+        finish(works, r + 1)
+        ev = computed.get(r)
+        if ev is not None:
+            ev.synchronize()                   # paces the host: at most one round of launches ahead of the GPU
+        staged.pop(r - RING, None)
+        computed.pop(r - RING, None)
+    if st.gpu:
+        torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
