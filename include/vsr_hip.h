@@ -312,6 +312,31 @@ int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, floa
 double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags);
 
 /* ---------------------------------------------------------------------------------------
+ * LaMa.  Replaces `self.model = torch.jit.load(model_path)` and `self.model(image, mask)` of
+ * backend/inpaint/lama_inpaint.py:13,24,55 together with the array work around them (lama_util.get_image /
+ * pad_img_to_modulo / the (mask > 0) * 1 tensor :48-52, clip(x * 255).astype(uint8) and the crop :56-60).  The network is the
+ * published big-LaMa generator (csrc/lama_plan.h); its weights arrive as the state_dict entries of the exported module's
+ * generator (`model.N...`, an optional `generator.` prefix is dropped, `num_batches_tracked` ignored).
+ * ------------------------------------------------------------------------------------- */
+typedef struct vsr_lama vsr_lama_t;
+int vsr_lama_create(vsr_lama_t** out);
+int vsr_lama_set_param(vsr_lama_t* h, const char* key, const float* data, const int64_t* shape, int ndim);
+int vsr_lama_finalize(vsr_lama_t* h, int device);       /* device < 0: pack only (host-side plan tests) */
+void vsr_lama_destroy(vsr_lama_t* h);
+int vsr_lama_blocks(const vsr_lama_t* h);               /* FFC residual blocks found in the state_dict (18 for big-lama) */
+int64_t vsr_lama_packed_weights(const vsr_lama_t* h, float* out, int64_t capacity);
+/* B images uint8 [H][W][3] (channel order as given: the reference feeds BGR frames) with masks uint8 [H][W] (non-zero = hole),
+ * rows contiguous: image b at img_dev + b * img_frame_stride bytes, mask b at mask_dev + b * mask_frame_stride (0: one mask for
+ * all), result b at out_dev + b * out_frame_stride (may alias the input).  Any H, W >= 16: padded to multiples of 8 exactly as
+ * lama_util.pad_img_to_modulo does (bottom / right, symmetric) and cropped back.  The whole image is rewritten (lama_inpaint.py:106). */
+int vsr_lama_inpaint(vsr_lama_t* h, const uint8_t* img_dev, int64_t img_frame_stride, const uint8_t* mask_dev, int64_t mask_frame_stride,
+                     int B, int H, int W, uint8_t* out_dev, int64_t out_frame_stride, void* stream);
+int vsr_lama_set_precision(vsr_lama_t* h, int mode);    /* see vsr_raft_set_precision */
+int64_t vsr_lama_fallbacks(const vsr_lama_t* h);
+int vsr_lama_read_buffer(vsr_lama_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook */
+double vsr_lama_flops(vsr_lama_t* h, int B, int H, int W);
+
+/* ---------------------------------------------------------------------------------------
  * Text detector: the operators of the PP-OCRv5 detection inference programs the reference
  * loads through paddleocr (backend/tools/subtitle_detect.py:41-58, backend/models/V5/{ch_det,ch_det_fast}/inference.json).
  * NCHW fp32 device tensors; the host runner (backend/tools/ocr_det.py) walks the program and calls one launcher per op.
@@ -402,6 +427,8 @@ int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vs
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_gen_plan_create(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, vsr_plan_t** out);
+int vsr_lama_plan_create(const vsr_lama_t* h, int B, int H, int W, vsr_plan_t** out);
+int64_t vsr_plan_consts(const vsr_plan_t* p, float* out, int64_t capacity);   /* fp32 plan constants (buffer id -2), returns the count */
 void vsr_plan_destroy(vsr_plan_t* p);
 int vsr_plan_num_buffers(const vsr_plan_t* p);
 int64_t vsr_plan_buffer_elems(const vsr_plan_t* p, int buf);

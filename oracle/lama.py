@@ -116,3 +116,68 @@ class StandInLama(torch.nn.Module):
         x = torch.cat([masked, mask.to(image.dtype)], dim=1)
         y = torch.sigmoid(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), self.w, self.b))
         return mask * y + (1 - mask) * image
+
+
+# ---- the published big-LaMa generator ---------------------------------------------------------------------------------
+class BigLamaNet:
+    """forward(image f32 [B,3,h,w] in [0,1], mask {0,1} [B,1,h,w]) -> inpainted f32 [B,3,h,w]; h, w multiples of 8.
+    State-dict keys: `model.N...` of FFCResNetGenerator (an optional `generator.` prefix is dropped)."""
+
+    def __init__(self, state_dict, n_blocks=18):
+        self.sd = {(k[10:] if k.startswith("generator.") else k): torch.as_tensor(np.asarray(v)).float() for k, v in state_dict.items()}
+        self.n_blocks = n_blocks
+
+    def _bn(self, x, p):
+        sd = self.sd
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+    def _rconv(self, x, key, stride=1, pad=1):
+        """nn.Conv2d(..., padding=pad, padding_mode='reflect', bias=False) of FFC (ffc.py FFC.__init__)"""
+        return F.conv2d(F.pad(x, (pad,) * 4, mode="reflect") if pad else x, self.sd[key + ".weight"], None, stride)
+
+    def _fourier_unit(self, x, p):
+        """FourierUnit.forward: rfftn(norm='ortho') -> 1x1 conv on stacked (re, im) channels + BN + ReLU -> irfftn"""
+        b, c, h, w = x.shape
+        f = torch.fft.rfftn(x, dim=(-2, -1), norm="ortho")
+        f = torch.stack((f.real, f.imag), dim=-1).permute(0, 1, 4, 2, 3).contiguous().view(b, 2 * c, h, w // 2 + 1)
+        f = F.relu(self._bn(F.conv2d(f, self.sd[p + ".conv_layer.weight"]), p + ".bn"))
+        f = f.view(b, c, 2, h, w // 2 + 1).permute(0, 1, 3, 4, 2).contiguous()
+        return torch.fft.irfftn(torch.complex(f[..., 0], f[..., 1]), s=(h, w), dim=(-2, -1), norm="ortho")
+
+    def _spectral(self, x, p):
+        """SpectralTransform.forward, stride 1, enable_lfu False"""
+        x = F.relu(self._bn(F.conv2d(x, self.sd[p + ".conv1.0.weight"]), p + ".conv1.1"))
+        return F.conv2d(x + self._fourier_unit(x, p + ".fu"), self.sd[p + ".conv2.weight"])
+
+    def _ffc_block(self, x_l, x_g, p):
+        """FFC_BN_ACT with ratio_gin = ratio_gout = 0.75, 3x3, reflect padding 1"""
+        out_l = self._rconv(x_l, p + ".ffc.convl2l") + self._rconv(x_g, p + ".ffc.convg2l")
+        out_g = self._rconv(x_l, p + ".ffc.convl2g") + self._spectral(x_g, p + ".ffc.convg2g")
+        return F.relu(self._bn(out_l, p + ".bn_l")), F.relu(self._bn(out_g, p + ".bn_g"))
+
+    def generator(self, x):
+        sd = self.sd
+        x = F.relu(self._bn(self._rconv(x, "model.1.ffc.convl2l", 1, 3), "model.1.bn_l"))
+        x = F.relu(self._bn(self._rconv(x, "model.2.ffc.convl2l", 2, 1), "model.2.bn_l"))
+        x = F.relu(self._bn(self._rconv(x, "model.3.ffc.convl2l", 2, 1), "model.3.bn_l"))
+        x_l = F.relu(self._bn(self._rconv(x, "model.4.ffc.convl2l", 2, 1), "model.4.bn_l"))
+        x_g = F.relu(self._bn(self._rconv(x, "model.4.ffc.convl2g", 2, 1), "model.4.bn_g"))
+        for i in range(self.n_blocks):
+            p = f"model.{5 + i}"
+            y_l, y_g = self._ffc_block(x_l, x_g, p + ".conv1")
+            y_l, y_g = self._ffc_block(y_l, y_g, p + ".conv2")
+            x_l, x_g = x_l + y_l, x_g + y_g
+        x = torch.cat([x_l, x_g], dim=1)
+        base = 5 + self.n_blocks + 1
+        for j in range(3):
+            k = f"model.{base + 3 * j}"
+            x = F.conv_transpose2d(x, sd[k + ".weight"], sd[k + ".bias"], stride=2, padding=1, output_padding=1)
+            x = F.relu(self._bn(x, f"model.{base + 3 * j + 1}"))
+        k = f"model.{base + 10}"
+        return torch.sigmoid(F.conv2d(F.pad(x, (3,) * 4, mode="reflect"), sd[k + ".weight"], sd[k + ".bias"]))
+
+    def __call__(self, image, mask):
+        with torch.no_grad():
+            masked = image * (1 - mask)
+            pred = self.generator(torch.cat([masked, mask.to(image.dtype)], dim=1))
+            return mask * pred + (1 - mask) * image

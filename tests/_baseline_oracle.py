@@ -139,7 +139,7 @@ def launch(names=None):
     if not names:
         return
     ncpu = os.cpu_count() or 8
-    threads = max(4, min(48, ncpu // max(1, len(names))))
+    threads = max(4, min(32, ncpu // max(1, len(names))))      # oneDNN on 30x160 / 60x108 maps stops scaling around 32 threads
     tmp = tempfile.mkdtemp(prefix="vsr_baseline_")
     for n in names:
         out = os.path.join(tmp, n + ".npy")

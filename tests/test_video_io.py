@@ -1,0 +1,148 @@
+"""Frame sources / sinks of tools/video_io.py and the CLI's output contract (`-i IN -o OUT` must write OUT or fail)."""
+import os
+
+import numpy as np
+import pytest
+
+from vsr_amd.backend.tools import video_io as v
+
+
+def _clip(n=9, H=38, W=52, seed=0):
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * 2 + 90) % 256], axis=-1)
+    return np.stack([np.roll(base, i, axis=1) for i in range(n)]).astype(np.uint8)
+
+
+def test_npy_container_is_lossless(tmp_path):
+    clip = _clip()
+    for frames in (None, len(clip), len(clip) + 3, len(clip) - 2):          # unknown, exact, over- and under-estimated frame count
+        p = str(tmp_path / f"a{frames}.npy")
+        w = v.AsyncWriter(v.open_writer(p, 25.0, (clip.shape[2], clip.shape[1]), frames=frames))
+        for f in clip:
+            w.write(f)
+        w.release()
+        w.release()                                                        # plugin and run() both release: idempotent
+        r = v.open_video(p)
+        assert r.info() == {"W_ori": 52, "H_ori": 38, "fps": 25.0, "len": len(clip)}
+        got = []
+        while True:
+            ok, f = r.read()
+            if not ok:
+                break
+            got.append(f)
+        assert np.array_equal(np.stack(got), clip)
+        r.release()
+
+
+@pytest.mark.parametrize("chroma,tol", [("444", 2), ("420", 40)])
+def test_y4m_round_trip(tmp_path, chroma, tol):
+    clip = _clip(H=37, W=51)                                                # odd sizes: chroma planes are rounded up
+    p = str(tmp_path / "c.y4m")
+    w = v.Y4mWriter(p, 30000 / 1001, (51, 37), chroma=chroma)
+    for f in clip:
+        w.write(f)
+    w.release()
+    head = open(p, "rb").readline()
+    assert head.startswith(b"YUV4MPEG2 W51 H37 F30000:1001 Ip") and (b"C444" in head) == (chroma == "444")
+    r = v.FramePrefetcher(v.open_video(p), buffer_size=3)                   # the reference's threaded reader contract
+    info = r.info()
+    assert (info["W_ori"], info["H_ori"], info["len"]) == (51, 37, len(clip)) and abs(info["fps"] - 29.97) < 0.01
+    got = np.stack([r.read()[1] for _ in range(len(clip))])
+    assert r.read()[0] is False
+    r.release()
+    err = np.abs(got.astype(int) - clip.astype(int))
+    assert err.max() <= tol and (chroma == "420" or err.mean() < 0.6)
+
+
+def test_writer_for_a_codec_container_fails_loudly_without_a_tool(tmp_path, monkeypatch):
+    monkeypatch.delenv("VSR_FFMPEG", raising=False)
+    if v.ffmpeg_path() is not None:
+        pytest.skip("an ffmpeg binary exists on this machine")
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("opencv exists on this machine")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="cannot write"):
+        v.open_writer(str(tmp_path / "x.mp4"), 25, (52, 38))
+    with pytest.raises(RuntimeError, match="cannot read"):
+        v.open_video(str(tmp_path / "x.mp4"))
+
+
+def test_async_writer_surfaces_sink_errors():
+    class Bad:
+        def write(self, f):
+            raise IOError("disk full")
+
+        def release(self):
+            pass
+
+    w = v.AsyncWriter(Bad(), buffer_size=2)
+    w.write(np.zeros((2, 2, 3), np.uint8))
+    with pytest.raises(IOError):
+        for _ in range(50):
+            w.write(np.zeros((2, 2, 3), np.uint8))
+        w.release()
+
+
+@pytest.mark.parametrize("out_ext", [".npy", ".y4m"])
+def test_run_writes_the_output_file(tmp_path, out_ext):
+    """SubtitleRemover(path).run() streams to `video_out_path` (here in lama mode with a stand-in plugin on the CPU: the driver
+    and the IO are what is under test)"""
+    from vsr_amd.backend.config import config
+    from vsr_amd.backend.main import SubtitleRemover
+    from vsr_amd.backend.tools.constant import InpaintMode
+
+    clip = _clip(n=24, H=90, W=160)
+    src = str(tmp_path / "in.npy")
+    np.save(src, clip)
+    quad = np.array([[[40, 60], [120, 60], [120, 75], [40, 75]]])
+
+    class Det:
+        def predict(self, img):
+            return [{"dt_polys": quad}]
+
+    def plugin(frames, mask):
+        return [np.where(mask[:, :, None] > 0, 255 - f, f) for f in frames]
+
+    old = config.inpaintMode.value
+    config.inpaintMode.value = InpaintMode.LAMA
+    try:
+        sr = SubtitleRemover(src, device="cpu")
+        assert sr.video_out_path.endswith("in_no_sub.npy")
+        sr.video_out_path = str(tmp_path / ("out" + out_ext))
+        sr.sub_areas = [(0, 90, 0, 160)]
+        sr.text_detector = Det()
+        sr.lama_inpaint = plugin
+        sr.run()
+    finally:
+        config.inpaintMode.value = old
+    assert os.path.exists(sr.video_out_path)
+    r = v.open_video(sr.video_out_path)
+    assert r.info()["len"] == 24
+    got = np.stack([r.read()[1] for _ in range(24)])
+    from vsr_amd.backend.tools.inpaint_tools import create_mask
+
+    m = create_mask((90, 160), [(40, 120, 60, 75)]) > 0
+    want = np.where(m[None, :, :, None], 255 - clip, clip)
+    if out_ext == ".npy":
+        assert np.array_equal(got, want)
+    else:
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 2
+
+
+def test_lama_mode_without_weights_is_an_error(tmp_path, monkeypatch):
+    from vsr_amd.backend.config import config
+    from vsr_amd.backend.main import SubtitleRemover
+    from vsr_amd.backend.tools.constant import InpaintMode
+    from vsr_amd.backend.tools.video_io import ArrayVideo
+
+    monkeypatch.delenv("LAMA_MODEL_PATH", raising=False)
+    old = config.inpaintMode.value
+    config.inpaintMode.value = InpaintMode.LAMA
+    try:
+        sr = SubtitleRemover(ArrayVideo(_clip()), device="cpu")
+        with pytest.raises(Exception, match="lama needs its weights"):
+            sr.run()
+    finally:
+        config.inpaintMode.value = old

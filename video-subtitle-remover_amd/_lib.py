@@ -155,6 +155,19 @@ SIGNATURES = {
     "vsr_pp_fallbacks": (_L, [_P]),
     "vsr_pp_flops": (_D, [_P, _I, _I, _I, _I, _P, _I]),
     "vsr_pp_gen_plan_create": (_I, [_P, _I, _I, _I, _I, _P, _I, C.POINTER(_P)]),
+    "vsr_lama_create": (_I, [C.POINTER(_P)]),
+    "vsr_lama_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "vsr_lama_finalize": (_I, [_P, _I]),
+    "vsr_lama_destroy": (None, [_P]),
+    "vsr_lama_blocks": (_I, [_P]),
+    "vsr_lama_packed_weights": (_L, [_P, _P, _L]),
+    "vsr_lama_inpaint": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _L, _P]),
+    "vsr_lama_set_precision": (_I, [_P, _I]),
+    "vsr_lama_fallbacks": (_L, [_P]),
+    "vsr_lama_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_lama_flops": (_D, [_P, _I, _I, _I]),
+    "vsr_lama_plan_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "vsr_plan_consts": (_L, [_P, _P, _L]),
     "vsr_plan_destroy": (None, [_P]),
     "vsr_plan_num_buffers": (_I, [_P]),
     "vsr_plan_buffer_elems": (_L, [_P, _I]),

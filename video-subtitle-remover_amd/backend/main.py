@@ -3,9 +3,11 @@
     python -m vsr_amd.backend.main -i IN -o OUT [-c YMIN YMAX XMIN XMAX]... [--inpaint-mode sttn-auto]
 
 Same flags, enum names and call order as the reference (backend/main.py:473-488, tools/args_handler.py:6-30):
-SubtitleRemover(path).sub_areas / .ab_sections / .video_out_path / .run().  Only what the sttn-auto hot path needs
-is kept: mask construction (create_mask, +10 px), the plugin call and a frame sink.  Audio muxing, temp files,
-the GUI hooks' transport and the other modes stay with the reference (surface only, not accelerated).
+SubtitleRemover(path).sub_areas / .ab_sections / .video_out_path / .run() with the modes sttn-auto, sttn-det, lama and
+propainter on the MI355X engines.  Frames are read and written through tools/video_io.py (raw containers, an ffmpeg pipe
+when a binary exists; `-o OUT` is written or the run fails -- there is no silent in-memory sink for a file input); audio is
+muxed with the reference's two ffmpeg commands when ffmpeg exists (main.py:418-460).  GUI transport, temp files and the
+opencv mode stay with the reference (surface only, not accelerated).
 """
 import os
 import sys
@@ -18,7 +20,7 @@ from .tools.args_handler import parse_args
 from .tools.constant import InpaintMode
 from .tools.inpaint_tools import batch_generator, create_mask, expand_frame_ranges
 from .tools.subtitle_detect import SubtitleDetect
-from .tools.video_io import ArrayWriter, open_video
+from .tools.video_io import IMAGE_EXTS, ArrayWriter, AsyncWriter, ffmpeg_path, open_video, open_writer
 
 
 class SubtitleRemover:
@@ -37,16 +39,37 @@ class SubtitleRemover:
         self.fps = info["fps"]
         self.frame_height, self.frame_width = info["H_ori"], info["W_ori"]
         self.mask_size = (self.frame_height, self.frame_width)
-        self.video_writer = video_writer if video_writer is not None else ArrayWriter()
-        if isinstance(vd_path, (str, os.PathLike)):
+        self.is_path = isinstance(vd_path, (str, os.PathLike))
+        self.is_picture = False
+        # in-memory input: in-memory sink.  File input: the sink is opened on first use for `video_out_path` (the caller may
+        # still change it, main.py:486) and streams -- the reference writes through FFmpegVideoWriter as it goes (main.py:66-69)
+        self._video_writer = video_writer if video_writer is not None else (None if self.is_path else ArrayWriter())
+        if self.is_path:
             self.vd_name = Path(vd_path).stem
-            self.video_out_path = os.path.abspath(os.path.join(os.path.dirname(vd_path), f"{self.vd_name}_no_sub.mp4"))
+            ext = os.path.splitext(str(vd_path))[1].lower()
+            self.is_picture = ext in IMAGE_EXTS
+            out_ext = ext if ext in (".y4m", ".npy") else ".mp4"
+            self.video_out_path = os.path.abspath(os.path.join(os.path.dirname(vd_path), f"{self.vd_name}_no_sub{out_ext}"))
+            if self.is_picture:                                          # main.py:73-77
+                self.video_out_path = os.path.abspath(os.path.join(os.path.dirname(vd_path), "no_sub", f"{self.vd_name}{ext}"))
         else:
             self.vd_name, self.video_out_path = "clip", None
+        self.passed_through_single_frames = 0
         self.model_path = model_path or os.environ.get(
             "STTN_AUTO_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-auto", "infer_model.pth"))
         self.progress_total = 0
         self.isFinished = False
+
+    @property
+    def video_writer(self):
+        if self._video_writer is None:
+            sink = open_writer(self.video_out_path, self.fps, (self.frame_width, self.frame_height), frames=self.frame_count)
+            self._video_writer = AsyncWriter(sink)
+        return self._video_writer
+
+    @video_writer.setter
+    def video_writer(self, w):
+        self._video_writer = w
 
     # hooks the plugin calls on its host object (main.py:109-151)
     def update_progress(self, tbar, increment):
@@ -79,6 +102,10 @@ class SubtitleRemover:
                 return end_no
         return -1
 
+    def _distributed_rank(self):
+        d = self._distributed()
+        return d.get_rank() if d is not None else 0
+
     @staticmethod
     def _distributed():
         import torch.distributed as dist
@@ -102,8 +129,8 @@ class SubtitleRemover:
         """backend/main.py:159-245.  Intervals of frames with the same mask, cut at scene changes, are read whole and
         handed to the plugin in batch_generator batches of propainterMaxLoadNum.  The scene-change frame numbers come
         from tools/scene_detect.py (reference: scenedetect's ContentDetector, subtitle_detect.py:158-170) unless given; the
-        detector and the single-frame fallback (reference: LaMa, whose network is a missing blob) are injected; without a
-        fallback single frames pass through."""
+        detector is injected; isolated single frames go to LaMa as in the reference (main.py:217-224,231-237) when its weights
+        are configured (`lama_inpaint`), otherwise they pass through and are counted in `passed_through_single_frames`."""
         if propainter_inpaint is None:
             from .inpaint.propainter_inpaint import PropainterInpaint
 
@@ -112,6 +139,9 @@ class SubtitleRemover:
         dist = self._distributed()
         if dist is not None and dist.get_rank() != 0:
             return self._run_items(tbar, (), propainter_inpaint)
+        if single_frame_inpaint is None:
+            lama = self.lama_inpaint
+            single_frame_inpaint = lama.inpaint if lama is not None else None
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
         sub_list = detector.find_subtitle_frame_no(sub_remover=self)
         if len(sub_list) == 0:
@@ -150,6 +180,10 @@ class SubtitleRemover:
                 mask = create_mask(self.mask_size, sub_list[start_frame_no])
                 for batch in ([temp_frames] if len(temp_frames) == 1 else batch_generator(temp_frames, config.propainterMaxLoadNum.value)):
                     if len(batch) == 1:
+                        if single_frame_inpaint is None:
+                            self.passed_through_single_frames += 1
+                            if self.passed_through_single_frames == 1:
+                                self.append_output("warning: no LaMa weights configured (LAMA_MODEL_PATH): isolated subtitle frames pass through")
                         yield ("pass", single_frame_inpaint(batch[0], mask) if single_frame_inpaint is not None else batch[0])
                     else:
                         yield ("work", batch, mask)
@@ -213,6 +247,68 @@ class SubtitleRemover:
         finally:
             reader.release()
 
+    @property
+    def lama_inpaint(self):
+        """main.py:462-466 (cached_property): LamaInpaint over $LAMA_MODEL_PATH or backend/models/big-lama/big-lama.pt; an injected
+        object (attribute `_lama_inpaint`) wins; None when no weights can be found."""
+        if getattr(self, "_lama_inpaint", None) is None:
+            path = os.environ.get("LAMA_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "big-lama", "big-lama.pt"))
+            if not os.path.exists(path):
+                return None
+            from .inpaint.lama_inpaint import LamaInpaint
+
+            self._lama_inpaint = LamaInpaint(self.device, path)
+        return self._lama_inpaint
+
+    @lama_inpaint.setter
+    def lama_inpaint(self, plugin):
+        self._lama_inpaint = plugin
+
+    def picture_mode(self):
+        """main.py:353-371: a single image -- detect, mask, LamaInpaint.inpaint on the whole frame, write."""
+        src = open_video(self.video_path)
+        ok, frame = src.read()
+        src.release()
+        if not ok:
+            raise Exception(f"cannot read {self.video_path}")
+        detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=self._default_detector())
+        sub_list = detector.detect_subtitle(frame)
+        if len(sub_list):
+            lama = self.lama_inpaint
+            if lama is None:
+                raise Exception("inpaint mode: lama needs its weights (LAMA_MODEL_PATH)")
+            frame = lama.inpaint(frame, create_mask(frame.shape[0:2], sub_list))
+        self.video_writer.write(frame)
+
+    def merge_audio_to_video(self):
+        """main.py:418-460: copy the input's audio track into the written file; needs ffmpeg, skipped (with a note) without."""
+        import shutil
+        import subprocess
+        import tempfile
+
+        ff = ffmpeg_path()
+        out = self.video_out_path
+        if ff is None or not self.is_path or os.path.splitext(out)[1].lower() in (".y4m", ".npy"):
+            return False
+        silent = out + ".video_only" + os.path.splitext(out)[1]
+        os.replace(out, silent)
+        with tempfile.NamedTemporaryFile(suffix=".aac", delete=False) as tmp:
+            audio = tmp.name
+        try:
+            subprocess.check_output([ff, "-y", "-i", str(self.video_path), "-acodec", "copy", "-vn", "-loglevel", "error", audio],
+                                    stdin=subprocess.DEVNULL, timeout=600)
+            subprocess.check_output([ff, "-y", "-i", silent, "-i", audio, "-vcodec", "copy", "-acodec", "copy", "-loglevel", "error", out],
+                                    stdin=subprocess.DEVNULL, timeout=600)
+            os.remove(silent)
+            return True
+        except Exception as e:
+            self.append_output(f"audio not merged ({e}); keeping the silent video")
+            shutil.move(silent, out)
+            return False
+        finally:
+            if os.path.exists(audio):
+                os.remove(audio)
+
     def _default_detector(self):
         """the injected detector if any, else the MI355X TextDetection configured through the environment (tools/ocr_det.py)"""
         det = getattr(self, "text_detector", None)
@@ -227,18 +323,29 @@ class SubtitleRemover:
         if len(self.sub_areas) == 0:
             self.sub_areas.append((0, self.frame_height, 0, self.frame_width))
         mode = config.inpaintMode.value
-        if mode == InpaintMode.STTN_AUTO:
+        if self.is_picture:
+            self.picture_mode()
+        elif mode == InpaintMode.STTN_AUTO:
             self.sttn_auto_mode(None)
         elif mode == InpaintMode.STTN_DET:
             from .inpaint.sttn_det_inpaint import STTNDetInpaint
 
             det_path = os.environ.get("STTN_DET_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-det", "sttn.pth"))
             self.video_inpaint(None, STTNDetInpaint(self.device, det_path), text_detector=self._default_detector())
+        elif mode == InpaintMode.LAMA:
+            lama = self.lama_inpaint
+            if lama is None:
+                raise Exception("inpaint mode: lama needs its weights (LAMA_MODEL_PATH or backend/models/big-lama/big-lama.pt)")
+            self.video_inpaint(None, lama, text_detector=self._default_detector())
         elif mode == InpaintMode.PROPAINTER:
             self.propainter_mode(None, propainter_inpaint=getattr(self, "propainter_inpaint", None),
                                  text_detector=self._default_detector(), scene_div_points=getattr(self, "scene_div_points", None))
         else:
             raise Exception(f"inpaint mode: {mode} not implemented")     # main.py:386
+        if self._video_writer is not None:
+            self._video_writer.release()                                 # main.py:389
+            if self.is_path and self._distributed_rank() == 0:
+                self.merge_audio_to_video()
         self.isFinished = True
         self.progress_total = 100
         self.append_output(f"Finished in {round(time.time() - start_time)} s")
@@ -250,8 +357,9 @@ def main(argv=None):
     sr = SubtitleRemover(args.input)
     sr.sub_areas = [tuple(c) for c in args.subtitle_area_coords]
     if args.output is not None:
-        sr.video_out_path = args.output
+        sr.video_out_path = os.path.abspath(args.output)
     sr.run()
+    sr.append_output(f"written: {sr.video_out_path}")
 
 
 if __name__ == "__main__":

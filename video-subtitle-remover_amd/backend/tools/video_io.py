@@ -1,13 +1,28 @@
-"""Frame sources / sinks for the plugins.
+"""Frame sources / sinks for the plugins (reference backend/tools/video_io.py: FramePrefetcher :12-51, FFmpegVideoWriter :54-103).
 
-Codec work (cv2.VideoCapture, the ffmpeg libx264 pipe of backend/tools/video_io.py:50-103) is out
-of scope for the accelerated path; the plugins only need ``read() -> (ok,
-frame)`` and ``write(frame)``.  In-memory sources/sinks let the harness and tests feed synthetic
-frames without a codec; a cv2-backed source is used when OpenCV is installed.
+Codec work stays out of scope: nothing here decodes or encodes a compressed stream itself.  What is
+provided is what the hot path needs to be a drop-in -- `read() -> (ok, frame)` / `write(frame)` objects over containers of RAW
+frames, an ffmpeg pipe when a binary exists (the reference's own transport, same command line), threads on both sides so that
+reading and writing overlap the GPU work, and a loud failure when nothing can serve a path:
+
+  source                      sink
+  ArrayVideo (in memory)      ArrayWriter / CountingWriter
+  *.npy   uint8 [N,H,W,3] BGR NpyWriter         (memory-mapped, lossless: the parity container)
+  *.y4m   YUV4MPEG2           Y4mWriter         (C444 / C420 / mono, BT.601; what `ffmpeg -i x.mp4 x.y4m` writes)
+  anything else               FFmpegVideoWriter (needs an `ffmpeg` on PATH or $VSR_FFMPEG; else cv2 if importable; else an error)
 """
+import os
+import queue
+import shutil
+import subprocess
+import threading
+
 import numpy as np
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# in-memory
+# ------------------------------------------------------------------------------------------------------------------------
 class ArrayVideo:
     """In-memory clip: uint8 [N,H,W,3] BGR.  Stands in for a video path."""
 
@@ -61,15 +76,358 @@ class CountingWriter:
         pass
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# raw containers
+# ------------------------------------------------------------------------------------------------------------------------
+class NpyVideo:
+    """*.npy holding uint8 [N,H,W,3] BGR frames, memory-mapped."""
+
+    def __init__(self, path, fps=None):
+        self.frames = np.load(path, mmap_mode="r")
+        if self.frames.ndim != 4 or self.frames.shape[3] != 3 or self.frames.dtype != np.uint8:
+            raise RuntimeError(f"{path}: expected a uint8 array [N,H,W,3], found {self.frames.dtype} {self.frames.shape}")
+        side = os.path.splitext(path)[0] + ".fps"
+        self.fps = float(fps) if fps else (float(open(side).read()) if os.path.exists(side) else 30.0)
+        self._pos = 0
+
+    def info(self):
+        n, h, w, _ = self.frames.shape
+        return {"W_ori": int(w), "H_ori": int(h), "fps": self.fps, "len": int(n)}
+
+    def read(self):
+        if self._pos >= self.frames.shape[0]:
+            return False, None
+        f = np.array(self.frames[self._pos])
+        self._pos += 1
+        return True, f
+
+    def release(self):
+        self.frames = None
+
+
+class NpyWriter:
+    """Appends frames to a memory-mapped *.npy (header rewritten on release with the final count)."""
+
+    def __init__(self, path, fps, size, capacity=None):
+        self.path, self.fps = path, float(fps)
+        self.w, self.h = int(size[0]), int(size[1])
+        self.capacity = int(capacity) if capacity else 0
+        self.n = 0
+        self._mm = None
+        self._done = False
+        self._tmp = path + ".part"
+        self._raw = open(self._tmp, "wb") if not self.capacity else None
+        if self.capacity:
+            self._mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(self.capacity, self.h, self.w, 3))
+
+    def write(self, frame):
+        if frame.dtype != np.uint8:
+            frame = np.clip(frame, 0, 255).astype(np.uint8)
+        if frame.shape != (self.h, self.w, 3):
+            raise ValueError(f"frame {frame.shape} does not match the writer's {(self.h, self.w, 3)}")
+        if self._mm is not None and self.n < self.capacity:
+            self._mm[self.n] = frame
+        else:
+            if self._raw is None:
+                self._raw = open(self._tmp, "wb")
+            self._raw.write(np.ascontiguousarray(frame).tobytes())
+        self.n += 1
+
+    def release(self):
+        if self._done:
+            return
+        self._done = True
+        if self._mm is not None and self._raw is None and self.n == self.capacity:
+            self._mm.flush()
+            self._mm = None
+        else:                                       # unknown or wrong frame count: assemble the final file
+            head = np.array(self._mm[: min(self.n, self.capacity)]) if self._mm is not None else None
+            self._mm = None
+            if self._raw is not None:
+                self._raw.close()
+            out = np.lib.format.open_memmap(self.path + ".new", mode="w+", dtype=np.uint8, shape=(self.n, self.h, self.w, 3))
+            k = 0
+            if head is not None:
+                out[: head.shape[0]] = head
+                k = head.shape[0]
+            if os.path.exists(self._tmp) and self.n > k:
+                out[k:] = np.fromfile(self._tmp, dtype=np.uint8).reshape(self.n - k, self.h, self.w, 3)
+            out.flush()
+            del out
+            os.replace(self.path + ".new", self.path)
+        if os.path.exists(self._tmp):
+            os.remove(self._tmp)
+        with open(os.path.splitext(self.path)[0] + ".fps", "w") as f:
+            f.write(repr(self.fps))
+
+
+# BT.601 studio-swing integer matrices (the ones libswscale and OpenCV use for 8-bit YCbCr <-> RGB), 16.16 fixed point
+def _yuv_to_bgr(y, u, v, full_range):
+    y = y.astype(np.int32)
+    u = u.astype(np.int32) - 128
+    v = v.astype(np.int32) - 128
+    if full_range:
+        c = y << 16
+        r = (c + 91881 * v + 32768) >> 16
+        g = (c - 22554 * u - 46802 * v + 32768) >> 16
+        b = (c + 116130 * u + 32768) >> 16
+    else:
+        c = 76309 * (y - 16)
+        r = (c + 104597 * v + 32768) >> 16
+        g = (c - 25675 * u - 53279 * v + 32768) >> 16
+        b = (c + 132201 * u + 32768) >> 16
+    return np.clip(np.stack([b, g, r], axis=-1), 0, 255).astype(np.uint8)
+
+
+def _bgr_to_yuv(frame, full_range):
+    b, g, r = (frame[..., k].astype(np.int32) for k in range(3))
+    if full_range:
+        y = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16
+        u = ((-11059 * r - 21709 * g + 32768 * b + 32768) >> 16) + 128
+        v = ((32768 * r - 27439 * g - 5329 * b + 32768) >> 16) + 128
+    else:
+        y = ((16829 * r + 33039 * g + 6416 * b + 32768) >> 16) + 16
+        u = ((-9714 * r - 19070 * g + 28784 * b + 32768) >> 16) + 128
+        v = ((28784 * r - 24103 * g - 4681 * b + 32768) >> 16) + 128
+    return (np.clip(p, 0, 255).astype(np.uint8) for p in (y, u, v))
+
+
+class Y4mVideo:
+    """YUV4MPEG2 reader: 8-bit C420* / C422 / C444 / Cmono, progressive; frames come out as BGR (BT.601)."""
+
+    def __init__(self, path):
+        self.path = path
+        self._f = open(path, "rb")
+        head = self._f.readline()
+        if not head.startswith(b"YUV4MPEG2"):
+            raise RuntimeError(f"{path}: not a YUV4MPEG2 stream")
+        self.w = self.h = 0
+        self.fps, self.chroma = 30.0, "420jpeg"
+        for tok in head.split()[1:]:
+            t = tok.decode("ascii", "replace")
+            if t[0] == "W":
+                self.w = int(t[1:])
+            elif t[0] == "H":
+                self.h = int(t[1:])
+            elif t[0] == "F":
+                n, d = t[1:].split(":")
+                self.fps = float(n) / float(d or 1)
+            elif t[0] == "C":
+                self.chroma = t[1:]
+            elif t[0] == "I" and t[1:] not in ("p", "?"):
+                raise RuntimeError(f"{path}: interlaced y4m ({t}) is not supported")
+        if self.chroma.startswith("420"):
+            self.cw, self.ch = (self.w + 1) // 2, (self.h + 1) // 2
+        elif self.chroma.startswith("422"):
+            self.cw, self.ch = (self.w + 1) // 2, self.h
+        elif self.chroma.startswith("444"):
+            self.cw, self.ch = self.w, self.h
+        elif self.chroma == "mono":
+            self.cw = self.ch = 0
+        else:
+            raise RuntimeError(f"{path}: chroma format C{self.chroma} is not supported (8-bit 420 / 422 / 444 / mono)")
+        if any(s in self.chroma for s in ("p10", "p12", "p14", "p16")):
+            raise RuntimeError(f"{path}: only 8-bit y4m is supported")
+        self.full_range = b"XCOLORRANGE=FULL" in head
+        self._data0 = self._f.tell()
+        self._fsize = self.w * self.h + 2 * self.cw * self.ch
+        self._count = None
+
+    def info(self):
+        if self._count is None:                       # constant-size records: "FRAME\n" + planes (frame parameters are rare; counted exactly)
+            total = os.path.getsize(self.path) - self._data0
+            rec = 6 + self._fsize
+            if total % rec == 0:
+                self._count = total // rec
+            else:
+                pos = self._f.tell()
+                self._f.seek(self._data0)
+                n = 0
+                while True:
+                    line = self._f.readline()
+                    if not line.startswith(b"FRAME"):
+                        break
+                    self._f.seek(self._fsize, 1)
+                    n += 1
+                self._f.seek(pos)
+                self._count = n
+        return {"W_ori": self.w, "H_ori": self.h, "fps": self.fps, "len": int(self._count)}
+
+    def read(self):
+        line = self._f.readline()
+        if not line.startswith(b"FRAME"):
+            return False, None
+        buf = self._f.read(self._fsize)
+        if len(buf) < self._fsize:
+            return False, None
+        a = np.frombuffer(buf, dtype=np.uint8)
+        y = a[: self.w * self.h].reshape(self.h, self.w)
+        if self.cw == 0:
+            return True, np.repeat(_yuv_to_bgr(y, np.full_like(y, 128), np.full_like(y, 128), self.full_range)[..., :1], 3, axis=2)
+        n = self.cw * self.ch
+        u = a[self.w * self.h: self.w * self.h + n].reshape(self.ch, self.cw)
+        v = a[self.w * self.h + n:].reshape(self.ch, self.cw)
+        if (self.ch, self.cw) != (self.h, self.w):    # nearest chroma up-sampling
+            ry, rx = (1 if self.ch == self.h else 2), (1 if self.cw == self.w else 2)
+            u = np.repeat(np.repeat(u, ry, axis=0), rx, axis=1)[: self.h, : self.w]
+            v = np.repeat(np.repeat(v, ry, axis=0), rx, axis=1)[: self.h, : self.w]
+        return True, _yuv_to_bgr(y, u, v, self.full_range)
+
+    def release(self):
+        self._f.close()
+
+
+class Y4mWriter:
+    """YUV4MPEG2 writer, 8-bit, BT.601 studio range; chroma "444" (default: no sub-sampling loss) or "420"."""
+
+    def __init__(self, path, fps, size, chroma="444"):
+        self.w, self.h = int(size[0]), int(size[1])
+        self.chroma = chroma
+        num, den = (int(round(fps * 1001)), 1001) if abs(fps - round(fps)) > 1e-3 else (int(round(fps)), 1)
+        self._f = open(path, "wb", buffering=1 << 22)
+        tag = "444" if chroma == "444" else "420mpeg2"
+        self._f.write(f"YUV4MPEG2 W{self.w} H{self.h} F{num}:{den} Ip A1:1 C{tag} XCOLORRANGE=LIMITED\n".encode())
+
+    def write(self, frame):
+        if frame.dtype != np.uint8:
+            frame = np.clip(frame, 0, 255).astype(np.uint8)
+        y, u, v = _bgr_to_yuv(frame, False)
+        if self.chroma != "444":
+            h2, w2 = (self.h + 1) // 2 * 2, (self.w + 1) // 2 * 2
+            def sub(p):
+                p = np.pad(p, ((0, h2 - self.h), (0, w2 - self.w)), mode="edge").astype(np.uint16)
+                return ((p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+            u, v = sub(u), sub(v)
+        self._f.write(b"FRAME\n")
+        self._f.write(y.tobytes())
+        self._f.write(u.tobytes())
+        self._f.write(v.tobytes())
+
+    def release(self):
+        self._f.close()
+
+
+IMAGE_EXTS = (".png", ".jpg", ".jpeg", ".bmp", ".webp", ".tif", ".tiff")      # tools/common_tools.py:8-9
+
+
+class ImageVideo:
+    """A still image as a one-frame source (main.py:353-356 read_image); PIL decodes, frames are BGR like cv2's."""
+
+    def __init__(self, path):
+        from PIL import Image
+
+        self.frame = np.ascontiguousarray(np.array(Image.open(path).convert("RGB"))[:, :, ::-1])
+        self._done = False
+
+    def info(self):
+        return {"W_ori": int(self.frame.shape[1]), "H_ori": int(self.frame.shape[0]), "fps": 1.0, "len": 1}
+
+    def read(self):
+        if self._done:
+            return False, None
+        self._done = True
+        return True, self.frame.copy()
+
+    def release(self):
+        pass
+
+
+class ImageWriter:
+    def __init__(self, path):
+        self.path = path
+
+    def write(self, frame):
+        from PIL import Image
+
+        Image.fromarray(np.ascontiguousarray(frame[:, :, ::-1])).save(self.path)
+
+    def release(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# ffmpeg pipe / cv2 (only when the tool exists)
+# ------------------------------------------------------------------------------------------------------------------------
+def ffmpeg_path():
+    """$VSR_FFMPEG, else an `ffmpeg` on PATH (the reference ships its own binary, tools/ffmpeg_cli.py:24-35: a missing blob)."""
+    p = os.environ.get("VSR_FFMPEG") or shutil.which("ffmpeg")
+    return p if p and os.path.exists(p) else None
+
+
+class FFmpegVideo:
+    """`ffmpeg -i path -f rawvideo -pix_fmt bgr24 -` as a frame source; stream facts from `ffprobe` next to the binary."""
+
+    def __init__(self, path):
+        ff = ffmpeg_path()
+        if ff is None:
+            raise RuntimeError("no ffmpeg binary")
+        probe = os.path.join(os.path.dirname(ff), "ffprobe")
+        probe = probe if os.path.exists(probe) else (shutil.which("ffprobe") or "ffprobe")
+        out = subprocess.check_output([probe, "-v", "error", "-select_streams", "v:0", "-count_packets", "-show_entries",
+                                       "stream=width,height,r_frame_rate,nb_read_packets", "-of", "csv=p=0", path], text=True).strip()
+        w, h, rate, n = out.split(",")[:4]
+        num, den = rate.split("/")
+        self.w, self.h, self.fps, self.n = int(w), int(h), float(num) / float(den or 1), int(n)
+        self._p = subprocess.Popen([ff, "-loglevel", "error", "-i", path, "-f", "rawvideo", "-pix_fmt", "bgr24", "-"],
+                                   stdout=subprocess.PIPE, stdin=subprocess.DEVNULL, bufsize=1 << 24)
+
+    def info(self):
+        return {"W_ori": self.w, "H_ori": self.h, "fps": self.fps, "len": self.n}
+
+    def read(self):
+        need = self.w * self.h * 3
+        buf = self._p.stdout.read(need)
+        if len(buf) < need:
+            return False, None
+        return True, np.frombuffer(buf, dtype=np.uint8).reshape(self.h, self.w, 3).copy()
+
+    def release(self):
+        try:
+            self._p.stdout.close()
+            self._p.terminate()
+            self._p.wait(timeout=5)
+        except Exception:
+            pass
+
+
+class FFmpegVideoWriter:
+    """Raw bgr24 frames into `ffmpeg ... -c:v libx264 -crf 18 -preset fast` -- the reference's writer (video_io.py:54-103)."""
+
+    def __init__(self, output_path, fps, size):
+        ff = ffmpeg_path()
+        if ff is None:
+            raise RuntimeError("no ffmpeg binary")
+        w, h = size
+        cmd = [ff, "-y", "-f", "rawvideo", "-vcodec", "rawvideo", "-s", f"{w}x{h}", "-pix_fmt", "bgr24", "-r", str(fps), "-i", "-",
+               "-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", "18", "-preset", "fast", "-loglevel", "error", output_path]
+        self._process = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def write(self, frame):
+        if frame.dtype != np.uint8:
+            frame = np.clip(frame, 0, 255).astype(np.uint8)
+        try:
+            self._process.stdin.write(frame.tobytes())
+        except BrokenPipeError:
+            pass
+
+    def release(self):
+        try:
+            self._process.stdin.close()
+        except BrokenPipeError:
+            pass
+        try:
+            self._process.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            self._process.terminate()
+            self._process.wait(timeout=5)
+
+
 class Cv2Video:
     """cv2.VideoCapture-backed source (sttn_auto_inpaint.py:168-180); needs opencv-python."""
 
     def __init__(self, path):
-        try:
-            import cv2
-        except ImportError as e:
-            raise RuntimeError("reading a video file needs opencv-python (cv2); pass an ArrayVideo to feed "
-                               "decoded frames directly") from e
+        import cv2
+
         self._cv2 = cv2
         self.cap = cv2.VideoCapture(path)
 
@@ -87,8 +445,135 @@ class Cv2Video:
         self.cap.release()
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# threads: reading and writing overlap the GPU work
+# ------------------------------------------------------------------------------------------------------------------------
+class FramePrefetcher:
+    """Background thread that keeps up to `buffer_size` decoded frames ready; same contract as the reference's
+    FramePrefetcher (video_io.py:12-51: read / get-like info / stop / release)."""
+
+    def __init__(self, video_cap, buffer_size=10):
+        self.cap = video_cap
+        self._buffer = queue.Queue(maxsize=buffer_size)
+        self._stopped = False
+        self._thread = threading.Thread(target=self._read_loop, daemon=True)
+        self._thread.start()
+
+    def _read_loop(self):
+        while not self._stopped:
+            try:
+                ret, frame = self.cap.read()
+            except Exception:
+                ret, frame = False, None
+            while not self._stopped:
+                try:
+                    self._buffer.put((ret, frame), timeout=0.2)
+                    break
+                except queue.Full:
+                    continue
+            if not ret:
+                break
+
+    def read(self):
+        return self._buffer.get()
+
+    def info(self):
+        return self.cap.info()
+
+    def stop(self):
+        self._stopped = True
+        try:
+            while not self._buffer.empty():
+                self._buffer.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5)
+
+    def release(self):
+        self.stop()
+        self.cap.release()
+
+
+class AsyncWriter:
+    """Writer thread in front of a sink: `write` returns at once (a copy is queued, at most `buffer_size` frames deep), so colour
+    conversion / pipe writes / disk IO run beside the GPU; `release` drains, closes the sink and re-raises a sink error."""
+
+    def __init__(self, sink, buffer_size=32):
+        self.sink = sink
+        self._q = queue.Queue(maxsize=buffer_size)
+        self._err = None
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        while True:
+            f = self._q.get()
+            if f is None:
+                return
+            if self._err is None:
+                try:
+                    self.sink.write(f)
+                except Exception as e:      # keep draining so the producer never blocks on a dead sink
+                    self._err = e
+
+    def write(self, frame):
+        if self._err is not None:
+            raise self._err
+        self._q.put(np.array(frame, copy=True))
+
+    def release(self):
+        if self._t is None:                 # already released (the plugin and run() both release, as in the reference)
+            return
+        self._q.put(None)
+        self._t.join()
+        self._t = None
+        self.sink.release()
+        if self._err is not None:
+            raise self._err
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 def open_video(video):
     """A fresh reader positioned at frame 0 (the reference re-opens the file for every pass over the video)."""
     if isinstance(video, ArrayVideo):
         return ArrayVideo(video.frames, video.fps)
-    return video if hasattr(video, "read") and hasattr(video, "info") else Cv2Video(video)
+    if hasattr(video, "read") and hasattr(video, "info"):
+        return video
+    path = os.fspath(video)
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        return NpyVideo(path)
+    if ext == ".y4m":
+        return Y4mVideo(path)
+    if ext in IMAGE_EXTS:
+        return ImageVideo(path)
+    if ffmpeg_path() is not None:
+        return FFmpegVideo(path)
+    try:
+        return Cv2Video(path)
+    except ImportError as e:
+        raise RuntimeError(f"cannot read {path}: no ffmpeg binary (PATH / $VSR_FFMPEG) and no opencv-python; raw containers (*.y4m, "
+                           f"*.npy) and in-memory ArrayVideo clips need neither") from e
+
+
+def open_writer(path, fps, size, frames=None):
+    """Sink for `path` (size = (W, H)); raises when nothing on this machine can write that container -- never a silent
+    in-memory fallback for a file the caller asked for."""
+    path = os.fspath(path)
+    ext = os.path.splitext(path)[1].lower()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if ext == ".npy":
+        return NpyWriter(path, fps, size, capacity=frames)
+    if ext == ".y4m":
+        return Y4mWriter(path, fps, size)
+    if ext in IMAGE_EXTS:
+        return ImageWriter(path)
+    if ffmpeg_path() is not None:
+        return FFmpegVideoWriter(path, fps, size)
+    try:
+        import cv2
+
+        return cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"mp4v"), fps, size)
+    except ImportError as e:
+        raise RuntimeError(f"cannot write {path}: no ffmpeg binary (PATH / $VSR_FFMPEG) and no opencv-python on this machine; "
+                           f"choose a raw container (-o out.y4m or -o out.npy)") from e

@@ -23,6 +23,8 @@
 #include "rfc_plan.h"
 #include "pp_kernels.h"
 #include "pp_plan.h"
+#include "lama_kernels.h"
+#include "lama_plan.h"
 
 using namespace vsr;
 
@@ -53,9 +55,11 @@ struct FlowPlanDev {
     std::vector<int64_t> toff;
     void* dDescs = nullptr;
     unsigned int* dQueues = nullptr;
+    float* dConsts = nullptr;      // PlanIR::consts (BUF_PLAN_CONST)
     std::vector<FlowOpDev> ops;
     ~FlowPlanDev()
     {
+        if (dConsts) (void)hipFree(dConsts);
         if (dTables) (void)hipFree(dTables);
         if (dDescs) (void)hipFree(dDescs);
         if (dQueues) (void)hipFree(dQueues);
@@ -129,7 +133,11 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
     HIPCHK(hipMalloc((void**)&pd->dTables, (size_t)(tot > 0 ? tot : 4) * sizeof(int32_t)));
     HIPCHK(hipMemcpy(pd->dTables, flat.data(), (size_t)tot * sizeof(int32_t), hipMemcpyHostToDevice));
     auto T = [&](int id) -> const int32_t* { return id < 0 ? nullptr : pd->dTables + pd->toff[id]; };
-    auto F = [&](int buf, int64_t off) -> float* { return buf < 0 ? nullptr : ws.f(buf, off); };
+    if (!P.consts.empty()) {
+        HIPCHK(hipMalloc((void**)&pd->dConsts, P.consts.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(pd->dConsts, P.consts.data(), P.consts.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    auto F = [&](int buf, int64_t off) -> float* { return buf == BUF_PLAN_CONST ? pd->dConsts + off : (buf < 0 ? nullptr : ws.f(buf, off)); };
     size_t descBytes = 0;
     for (const Op& op : P.ops)
         descBytes += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64 + (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
@@ -312,6 +320,20 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
             case EW_PP_TANH_OUT:
                 rc = vsr_pp_launch_tanh_out(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], B(op.ibuf[1], 0), stream);
                 break;
+            case EW_LAMA_IM2COL7:
+                rc = vsr_lama_launch_im2col7((const uint8_t*)ws.bufs[op.ibuf[0]], (const uint8_t*)ws.bufs[op.ibuf[1]], ip[0], ip[1], ip[2], ip[3], ip[4],
+                                             B(op.ibuf[2], 0), stream);
+                break;
+            case EW_LAMA_HALO:
+                rc = vsr_lama_launch_halo(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], stream);
+                break;
+            case EW_LAMA_ADD_HALO:
+                rc = vsr_lama_launch_add_halo(B(op.ibuf[0], 0), B(op.ibuf[1], 0), B(op.ibuf[2], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], stream);
+                break;
+            case EW_LAMA_OUT:
+                rc = vsr_lama_launch_out(B(op.ibuf[0], 0), (const uint8_t*)ws.bufs[op.ibuf[1]], (const uint8_t*)ws.bufs[op.ibuf[2]], ip[0], ip[1], ip[2],
+                                         ip[3], ip[4], (uint8_t*)ws.bufs[op.ibuf[3]], stream);
+                break;
             default:
                 return rfail(VSR_ERR_STATE, "unknown elementwise op");
             }
@@ -464,7 +486,169 @@ struct vsr_pp {
     vsr_pp() { ws.init(PB_COUNT, PB_WEIGHTS, {PB_IN_MASK_U8, PB_IN_MASK_UPD_U8, PB_OUT_MASK_U8}); }
 };
 
+// ---------------------------------------------------------------------------------------
+// LaMa
+// ---------------------------------------------------------------------------------------
+struct vsr_lama {
+    LamaModel model;
+    int device = -1;
+    bool finalized = false;
+    Workspace ws;
+    std::tuple<int, int, int> geom{0, 0, 0};
+    std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> plans;
+    vsr_lama() { ws.init(LB_COUNT, LB_WEIGHTS, {LB_IN_U8, LB_MASK_U8, LB_OUT_U8}); }
+};
+
+static int lama_plan_dev(vsr_lama* h, int B, int H, int W, FlowPlanDev** out)
+{
+    const auto key = std::make_tuple(B, H, W);
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) { *out = it->second.get(); return 0; }
+    std::unique_ptr<PlanIR> plan;
+    try {
+        plan.reset(new LamaPlan(h->model, B, H, W));
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("lama plan: ") + e.what());
+    }
+    if (h->ws.needs_growth(*plan)) h->plans.clear();
+    std::unique_ptr<FlowPlanDev> pd;
+    RCCHK(materialize(h->ws, std::move(plan), &pd));
+    *out = pd.get();
+    h->plans[key] = std::move(pd);
+    return 0;
+}
+
 extern "C" {
+
+int vsr_lama_create(vsr_lama_t** out)
+{
+    if (!out) return rfail(VSR_ERR_ARG, "null out pointer");
+    *out = new vsr_lama;
+    return 0;
+}
+
+int vsr_lama_set_param(vsr_lama_t* h, const char* key, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h || !key || !data || !shape || ndim < 0 || ndim > 8) return rfail(VSR_ERR_ARG, "bad argument");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.set_param(key, data, shape, ndim, err)) return rfail(VSR_ERR_ARG, err);
+    return 0;
+}
+
+int vsr_lama_finalize(vsr_lama_t* h, int device)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    if (h->finalized) return rfail(VSR_ERR_STATE, "model already finalized");
+    std::string err;
+    if (!h->model.pack(err)) return rfail(VSR_ERR_ARG, err);
+    if (device >= 0) RCCHK(upload_weights(h->ws, h->model.packed, device));
+    h->device = device;
+    h->finalized = true;
+    return 0;
+}
+
+void vsr_lama_destroy(vsr_lama_t* h)
+{
+    if (!h) return;
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        h->plans.clear();
+        h->ws.release();
+    }
+    delete h;
+}
+
+int vsr_lama_blocks(const vsr_lama_t* h) { return (h && h->model.packed_ready()) ? h->model.nBlocks : -1; }
+
+int64_t vsr_lama_packed_weights(const vsr_lama_t* h, float* out, int64_t capacity)
+{
+    if (!h || !h->model.packed_ready()) { rfail(VSR_ERR_STATE, "model not finalized"); return -1; }
+    const int64_t n = (int64_t)h->model.packed.size();
+    if (out && capacity >= n) memcpy(out, h->model.packed.data(), (size_t)n * sizeof(float));
+    return n;
+}
+
+// LamaInpaint._inpaint_batch's network call + post-processing for B images whose rows are contiguous (full-width strips of
+// frames resident in HBM): img[b] = img_dev + b * img_frame_stride (H*W*3 bytes each), mask[b] = mask_dev + b * mask_frame_stride
+// (0: one mask for all), out likewise; out may alias img.
+int vsr_lama_inpaint(vsr_lama_t* h, const uint8_t* img_dev, int64_t img_frame_stride, const uint8_t* mask_dev, int64_t mask_frame_stride,
+                     int B, int H, int W, uint8_t* out_dev, int64_t out_frame_stride, void* stream_)
+{
+    if (!h || !img_dev || !mask_dev || !out_dev || B < 1) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->finalized || h->device < 0)
+        return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device (no GPU / finalize(device<0)); there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    FlowPlanDev* pd = nullptr;
+    RCCHK(lama_plan_dev(h, B, H, W, &pd));
+    if (h->geom != std::make_tuple(B, H, W)) {
+        RCCHK(clear_workspace(h->ws, stream));
+        h->geom = std::make_tuple(B, H, W);
+    }
+    const size_t ibytes = (size_t)H * W * 3, mbytes = (size_t)H * W;
+    HIPCHK(hipMemcpy2DAsync(h->ws.bufs[LB_IN_U8], ibytes, img_dev, (size_t)img_frame_stride, ibytes, (size_t)B, hipMemcpyDeviceToDevice, stream));
+    if (mask_frame_stride == 0) {
+        for (int b = 0; b < B; ++b)
+            HIPCHK(hipMemcpyAsync((uint8_t*)h->ws.bufs[LB_MASK_U8] + (size_t)b * mbytes, mask_dev, mbytes, hipMemcpyDeviceToDevice, stream));
+    } else {
+        HIPCHK(hipMemcpy2DAsync(h->ws.bufs[LB_MASK_U8], mbytes, mask_dev, (size_t)mask_frame_stride, mbytes, (size_t)B, hipMemcpyDeviceToDevice, stream));
+    }
+    RCCHK(range_guard_arm(h->ws, stream));
+    RCCHK(run_plan(h->ws, pd, 0, stream));
+    bool fired = false;
+    RCCHK(range_guard_fired(h->ws, stream, &fired));
+    if (fired) {
+        h->ws.precision = 0;
+        const int rc = vsr_lama_inpaint(h, img_dev, img_frame_stride, mask_dev, mask_frame_stride, B, H, W, out_dev, out_frame_stride, stream_);
+        h->ws.precision = 1;
+        return rc;
+    }
+    HIPCHK(hipMemcpy2DAsync(out_dev, (size_t)out_frame_stride, h->ws.bufs[LB_OUT_U8], ibytes, ibytes, (size_t)B, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int vsr_lama_set_precision(vsr_lama_t* h, int mode) { return h ? set_precision(h->ws, mode) : rfail(VSR_ERR_ARG, "null handle"); }
+int64_t vsr_lama_fallbacks(const vsr_lama_t* h) { return h ? h->ws.fallbacks : -1; }
+
+int vsr_lama_read_buffer(vsr_lama_t* h, int buf, int64_t offset, int64_t count, float* out_host)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    return read_buffer(h->ws, h->device, buf, offset, count, out_host);
+}
+
+double vsr_lama_flops(vsr_lama_t* h, int B, int H, int W)
+{
+    if (!h || !h->model.packed_ready()) return -1.0;
+    try {
+        return LamaPlan(h->model, B, H, W).flops;
+    } catch (const std::exception&) {
+        return -1.0;
+    }
+}
+
+int vsr_lama_plan_create(const vsr_lama_t* h, int B, int H, int W, vsr_plan_t** out)
+{
+    if (!h || !out) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return rfail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new LamaPlan(h->model, B, H, W));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("lama plan: ") + e.what());
+    }
+    return 0;
+}
+
+int64_t vsr_plan_consts(const vsr_plan_t* p, float* out, int64_t capacity)
+{
+    if (!p) return -1;
+    const int64_t n = (int64_t)p->plan->consts.size();
+    if (out && capacity >= n && n) memcpy(out, p->plan->consts.data(), (size_t)n * sizeof(float));
+    return n;
+}
 
 int vsr_raft_create(vsr_raft_t** out)
 {

@@ -121,9 +121,14 @@ struct Act {                              // NHWC activation with a physical zer
     int64_t elems() const { return (int64_t)n * frameElems(); }
 };
 
+// GemmItem::bufA / bufB may name this pseudo buffer: PlanIR::consts, fp32 constants that belong to the plan (not to the
+// checkpoint), uploaded with the offset tables -- the DFT matrices of the LaMa plan
+constexpr int BUF_PLAN_CONST = -2;
+
 // What the engines materialise and what tests replay: symbolic buffers, offset tables, op list.
 struct PlanIR {
     std::vector<int64_t> bufElems;        // one entry per buffer id (u8 buffers in bytes, others floats)
+    std::vector<float> consts;            // BUF_PLAN_CONST
     std::vector<std::vector<int32_t>> tables;
     std::vector<Op> ops;
     std::vector<int32_t> compCount;       // STTN: decodes per frame (1 => comp stays u8)

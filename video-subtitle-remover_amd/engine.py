@@ -407,3 +407,91 @@ class PpEngine:
                                              C.c_void_p(flows_b.data_ptr()), C.c_void_p(masks.data_ptr()), t, H, W,
                                              C.c_void_p(out.data_ptr()), C.c_void_p(om.data_ptr()), _stream_ptr()))
         return out, om
+
+
+class LamaEngine:
+    """big-LaMa generator resident on one GPU (reference: the TorchScript module of backend/inpaint/lama_inpaint.py:13 and the
+    array work around its call, :45-60).  state_dict: the generator's entries (`model.N...`, optional `generator.` prefix)."""
+
+    def __init__(self, state_dict, device=0):
+        self._h = C.c_void_p()
+        check(lib.vsr_lama_create(C.byref(self._h)))
+        try:
+            for key, val in state_dict.items():
+                if key.endswith("num_batches_tracked"):
+                    continue
+                arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                shape = (C.c_int64 * arr.ndim)(*arr.shape)
+                check(lib.vsr_lama_set_param(self._h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim))
+            if device is not None and device >= 0:
+                require_gpu()
+            self.device_index = -1 if device is None else int(device)
+            check(lib.vsr_lama_finalize(self._h, self.device_index))
+        except Exception:
+            lib.vsr_lama_destroy(self._h)
+            self._h = None
+            raise
+        self.device = torch.device("cuda", self.device_index) if self.device_index >= 0 else torch.device("cpu")
+        self.n_blocks = int(lib.vsr_lama_blocks(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vsr_lama_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_precision(self, mode):
+        if mode not in ("f32", "split"):
+            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
+        check(lib.vsr_lama_set_precision(self._h, 1 if mode == "split" else 0))
+
+    def fallbacks(self):
+        return int(lib.vsr_lama_fallbacks(self._h))
+
+    def packed_weights(self):
+        n = lib.vsr_lama_packed_weights(self._h, None, 0)
+        out = np.empty(n, dtype=np.float32)
+        lib.vsr_lama_packed_weights(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def flops(self, B, H, W):
+        return lib.vsr_lama_flops(self._h, B, H, W)
+
+    def read_buffer(self, buf, count, offset=0):
+        out = np.empty(count, dtype=np.float32)
+        check(lib.vsr_lama_read_buffer(self._h, buf, offset, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def inpaint(self, images, mask, out=None):
+        """images uint8 [B,H,W,3] on the GPU (rows contiguous; a row-slice of a frame batch is fine), mask uint8 [H,W] (one for
+        all) or [B,H,W] (non-zero = hole) -> uint8 [B,H,W,3]; out=None allocates, out=images works in place."""
+        assert images.dtype == torch.uint8 and images.is_cuda and images.dim() == 4 and images.shape[3] == 3
+        B, H, W, _ = images.shape
+        assert images.stride(3) == 1 and images.stride(2) == 3 and images.stride(1) == 3 * W, "image rows must be contiguous"
+        assert mask.dtype == torch.uint8 and mask.is_cuda
+        if mask.dim() == 2:
+            m, mstride = mask.contiguous(), 0
+            assert tuple(m.shape) == (H, W)
+        else:
+            m = mask
+            assert tuple(m.shape) == (B, H, W) and m.stride(2) == 1 and m.stride(1) == W
+            mstride = m.stride(0) if B > 1 else H * W
+        if out is None:
+            out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=images.device)
+        assert out.stride(3) == 1 and out.stride(2) == 3 and out.stride(1) == 3 * W
+        istr = images.stride(0) if B > 1 else H * W * 3
+        ostr = out.stride(0) if B > 1 else H * W * 3
+        with torch.cuda.device(images.device):
+            check(lib.vsr_lama_inpaint(self._h, C.c_void_p(images.data_ptr()), istr, C.c_void_p(m.data_ptr()), mstride, B, H, W,
+                                       C.c_void_p(out.data_ptr()), ostr, _stream_ptr()))
+        return out

@@ -363,3 +363,87 @@ def make_propainter_state_dict(seed=0):
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# big-LaMa generator (advimman/lama FFCResNetGenerator, ffc_resnet_075: ngf 64, 3 downsamplings, 18 FFC residual blocks at
+# 512 channels with 75 % global channels, no LFU, sigmoid output).  The reference only ships it as the TorchScript blob
+# big-lama.pt (a missing blob); key names follow the published module tree, `generator.` prefix optional.
+# ------------------------------------------------------------------------------------------------
+LAMA_NGF, LAMA_CL, LAMA_CG = 64, 128, 384          # bottleneck: 512 = 128 local + 384 global channels
+
+
+def lama_state_dict_spec(n_blocks=18):
+    spec = []
+
+    def bn(name, c):
+        spec.extend([(name + ".weight", (c,)), (name + ".bias", (c,)), (name + ".running_mean", (c,)), (name + ".running_var", (c,))])
+
+    def conv(name, co, ci, k, bias=False):
+        spec.append((name + ".weight", (co, ci, k, k)))
+        if bias:
+            spec.append((name + ".bias", (co,)))
+
+    conv("model.1.ffc.convl2l", 64, 4, 7)
+    bn("model.1.bn_l", 64)
+    conv("model.2.ffc.convl2l", 128, 64, 3)
+    bn("model.2.bn_l", 128)
+    conv("model.3.ffc.convl2l", 256, 128, 3)
+    bn("model.3.bn_l", 256)
+    conv("model.4.ffc.convl2l", LAMA_CL, 256, 3)
+    conv("model.4.ffc.convl2g", LAMA_CG, 256, 3)
+    bn("model.4.bn_l", LAMA_CL)
+    bn("model.4.bn_g", LAMA_CG)
+    for i in range(n_blocks):
+        for cv in ("conv1", "conv2"):
+            p = f"model.{5 + i}.{cv}"
+            conv(p + ".ffc.convl2l", LAMA_CL, LAMA_CL, 3)
+            conv(p + ".ffc.convl2g", LAMA_CG, LAMA_CL, 3)
+            conv(p + ".ffc.convg2l", LAMA_CL, LAMA_CG, 3)
+            conv(p + ".ffc.convg2g.conv1.0", LAMA_CG // 2, LAMA_CG, 1)
+            bn(p + ".ffc.convg2g.conv1.1", LAMA_CG // 2)
+            conv(p + ".ffc.convg2g.fu.conv_layer", LAMA_CG, LAMA_CG, 1)
+            bn(p + ".ffc.convg2g.fu.bn", LAMA_CG)
+            conv(p + ".ffc.convg2g.conv2", LAMA_CG, LAMA_CG // 2, 1)
+            bn(p + ".bn_l", LAMA_CL)
+            bn(p + ".bn_g", LAMA_CG)
+    base = 5 + n_blocks + 1                          # ConcatTupleLayer sits at 5 + n_blocks
+    for j, (ci, co) in enumerate(((512, 256), (256, 128), (128, 64))):
+        spec.append((f"model.{base + 3 * j}.weight", (ci, co, 3, 3)))          # ConvTranspose2d: [in, out, kh, kw]
+        spec.append((f"model.{base + 3 * j}.bias", (co,)))
+        bn(f"model.{base + 3 * j + 1}", co)
+    conv(f"model.{base + 10}", 3, 64, 7, bias=True)
+    return spec
+
+
+def make_lama_state_dict(seed=0, n_blocks=18):
+    """Stand-in for big-lama.pt's generator weights: variance-preserving convs, non-trivial eval-mode BatchNorm statistics; the
+    second FFC of every residual block is damped so that 18 blocks keep the activations O(1)."""
+    rng = np.random.default_rng(seed + 777)
+    sd = {}
+    for key, shape in lama_state_dict_spec(n_blocks):
+        leaf = key.rsplit(".", 1)[1]
+        is_bn = len(shape) == 1 and leaf != "bias" or (leaf == "bias" and (key[:-5] + ".running_mean") in dict(lama_state_dict_spec(n_blocks)))
+        if leaf == "running_mean":
+            sd[key] = rng.normal(0, 0.1, shape).astype(np.float32)
+        elif leaf == "running_var":
+            sd[key] = rng.uniform(0.6, 1.4, shape).astype(np.float32)
+        elif is_bn and leaf == "weight":
+            damp = 0.22 if ".conv2.bn_" in key else 1.0
+            sd[key] = (rng.uniform(0.8, 1.2, shape) * damp).astype(np.float32)
+        elif is_bn and leaf == "bias":
+            sd[key] = rng.normal(0, 0.05, shape).astype(np.float32)
+        elif leaf == "weight":
+            tr = len(shape) == 4 and key.count(".") == 2 and shape[0] > shape[1] and shape[2] == 3       # ConvTranspose2d
+            fan_in = int(shape[0] * shape[2] * shape[3] / 4) if tr else int(np.prod(shape[1:]))
+            gain = 1.0 if "fu.conv_layer" in key or "convg2g.conv2" in key else 1.3
+            if tr:
+                gain = 0.9
+            if len(shape) == 4 and shape[0] == 3:
+                gain = 2.2 if n_blocks >= 10 else 14.0       # logits of the sigmoid stay O(1)
+            if "convl2l" in key or "convg2l" in key or "convl2g" in key:
+                gain = 0.95                                  # two branches are summed before the BatchNorm
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(max(fan_in, 1)))
+        else:
+            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
+    return sd
