@@ -306,6 +306,17 @@ int vsr_pp_window_flags(const uint8_t* masks_host, int lt, int H, int W, uint8_t
 int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev,
                    const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t, int lt, int H, int W,
                    const uint8_t* window_flags, int nflags, float* out_dev, void* stream);
+/* The plugin's own array work (PropainterInpaint.inpaint, propainter_inpaint.py:190-361) on frames that stay in HBM as the uint8
+ * BGR crops [n][h][w][3]; mask: the dilated mask uint8 [h][w] (non-zero = hole), the same for every frame (:195-197).
+ *   prepare : masked_frames fp32 [n][3][h][w] = (to_tensors(RGB) * 2 - 1) * (1 - mask)                                  (:193-213,298)
+ *   compose : updated_frames = frames * (1 - mask) + prop * mask                                                        (:314)
+ *   blend   : one generator window (:345-357): pred fp32 [lt][3][h][w] (tanh output) of the frames frame_idx[0..lt), u8
+ *             truncation, hole select, pairwise 0.5 / 0.5 average with truncation after every average unless first[k];
+ *             comp uint8 [n][h][w][3] is kept in BGR order.  frame_idx / first: int32 device arrays. */
+int vsr_pp_prepare_frames(const uint8_t* bgr_dev, const uint8_t* mask_dev, int n, int h, int w, float* masked_dev, void* stream);
+int vsr_pp_compose_frames(const uint8_t* bgr_dev, const uint8_t* mask_dev, const float* prop_dev, int n, int h, int w, float* out_dev, void* stream);
+int vsr_pp_blend_window(const float* pred_dev, const uint8_t* bgr_dev, const uint8_t* mask_dev, const int32_t* frame_idx_dev,
+                        const int32_t* first_dev, int lt, int h, int w, uint8_t* comp_dev, void* stream);
 int vsr_pp_set_precision(vsr_pp_t* h, int mode);          /* see vsr_raft_set_precision; applies to vsr_pp_forward */
 int64_t vsr_pp_fallbacks(const vsr_pp_t* h);
 int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook */

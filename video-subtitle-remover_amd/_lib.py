@@ -151,6 +151,9 @@ SIGNATURES = {
     "vsr_pp_window_flags": (_I, [_P, _I, _I, _I, _P, _I]),
     "vsr_pp_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_pp_read_buffer": (_I, [_P, _I, _L, _L, _P]),
+    "vsr_pp_prepare_frames": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "vsr_pp_compose_frames": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "vsr_pp_blend_window": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "vsr_pp_set_precision": (_I, [_P, _I]),
     "vsr_pp_fallbacks": (_L, [_P]),
     "vsr_pp_flops": (_D, [_P, _I, _I, _I, _I, _P, _I]),

@@ -7,10 +7,11 @@ Mirrors backend/inpaint/propainter_inpaint.py:
   read_mask :32-77 (numpy-mask branch), get_ref_index :122-136
 All network arithmetic happens in libvsr_hip.so (RAFT, flow completion, image propagation, generator: vsr_raft_* /
 vsr_rfc_* / vsr_pp_*), in exact fp32 -- `use_fp16` is accepted for signature compatibility and ignored.  This file is the
-host loop: mask dilation, sub-video / neighbour / reference schedules, the u8 blend of overlapping windows.  The masked /
-composed frame tensors are elementwise torch ops on the GPU (plumbing).  `model_dir` may also be a dict
+host loop: mask dilation (scipy, once per batch, as in the reference), sub-video / neighbour / reference schedules.  The frames
+stay in HBM as uint8 BGR from upload to download; normalise + mask, compose and the u8 blend of overlapping windows are kernels.  `model_dir` may also be a dict
 {"raft": sd, "rfc": sd, "propainter": sd} of already loaded state_dicts (the shipped checkpoints are missing blobs).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -18,6 +19,7 @@ import scipy.ndimage
 import torch
 
 from ..tools.inpaint_tools import get_inpaint_area_by_mask
+from ..._lib import check, lib
 from ...engine import PpEngine, RaftEngine, RfcEngine
 from .sttn_auto_inpaint import _device_index
 
@@ -89,73 +91,78 @@ class PropainterInpaint:
             e.close()
 
     def inpaint(self, frames, mask):
-        """frames: list of HxWx3 uint8 BGR crops (H, W multiples of 8), mask: HxW(x1) uint8 -> list of HxWx3 uint8 BGR"""
+        """frames: list of HxWx3 uint8 BGR crops (H, W multiples of 8), mask: HxW(x1) uint8 -> list of HxWx3 uint8 BGR.
+        The batch is uploaded once as uint8 BGR and stays in HBM: RAFT reads it directly, the normalised / masked / composed
+        tensors and the u8 blend of the overlapping generator windows are kernels (vsr_pp_prepare_frames / _compose_frames /
+        _blend_window); one download at the end."""
         n = len(frames)
         dev = self.dev
-        frames_inp = np.stack([np.asarray(f)[:, :, ::-1] for f in frames])                  # cv2.COLOR_BGR2RGB
-        h, w = frames_inp.shape[1:3]
+        bgr = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in frames]))).to(dev)      # [n,h,w,3] BGR
+        h, w = int(bgr.shape[1]), int(bgr.shape[2])
         fm, md = read_mask(mask, n, self.mask_dilation, self.mask_dilation)
-        u8 = torch.from_numpy(np.ascontiguousarray(frames_inp)).to(dev)                     # [n,h,w,3] RGB
-        frames_t = u8.permute(0, 3, 1, 2).float().div(255) * 2 - 1                          # to_tensors()(frames) * 2 - 1
-        fm_dev = torch.from_numpy(fm).to(dev)[None].repeat(n, 1, 1).contiguous()            # uint8 [n,h,w]
-        md_dev = torch.from_numpy(md).to(dev)[None].repeat(n, 1, 1).contiguous()
-        md_f = md_dev[:, None].float()
-        # ---- flows (:217-247): every consecutive pair in both directions, fp32
-        gt_f, gt_b = self.fix_raft.flows(u8.contiguous(), iters=self.raft_iter)
-        # ---- flow completion (:253-281)
-        flow_length, svl = n - 1, self.sub_video_length
-        if flow_length > svl:
-            pf, pb = [], []
-            for f in range(0, flow_length, svl):
-                s_f, e_f = max(0, f - 5), min(flow_length, f + svl + 5)
-                ps, pe = max(0, f) - s_f, e_f - min(flow_length, f + svl)
-                cf, cb = self.fix_flow_complete.complete(gt_f[s_f:e_f].contiguous(), gt_b[s_f:e_f].contiguous(), fm_dev[s_f:e_f + 1].contiguous())
-                pf.append(cf[ps:e_f - s_f - pe])
-                pb.append(cb[ps:e_f - s_f - pe])
-            pred_f, pred_b = torch.cat(pf).contiguous(), torch.cat(pb).contiguous()
-        else:
-            pred_f, pred_b = self.fix_flow_complete.complete(gt_f, gt_b, fm_dev)
-        # ---- image propagation (:283-315)
-        masked_frames = (frames_t * (1 - md_f)).contiguous()
-        sip = min(100, svl)
-        if n > sip:
-            uf, um = [], []
-            for f in range(0, n, sip):
-                s_f, e_f = max(0, f - 10), min(n, f + sip + 10)
-                ps, pe = max(0, f) - s_f, e_f - min(n, f + sip)
-                prop, upd = self.model.img_propagation(masked_frames[s_f:e_f].contiguous(), pred_f[s_f:e_f - 1].contiguous(),
-                                                       pred_b[s_f:e_f - 1].contiguous(), md_dev[s_f:e_f].contiguous())
-                sub = frames_t[s_f:e_f] * (1 - md_f[s_f:e_f]) + prop * md_f[s_f:e_f]
-                uf.append(sub[ps:e_f - s_f - pe])
-                um.append(upd[ps:e_f - s_f - pe])
-            updated_frames, updated_masks = torch.cat(uf).contiguous(), torch.cat(um).contiguous()
-        else:
-            prop, updated_masks = self.model.img_propagation(masked_frames, pred_f, pred_b, md_dev)
-            updated_frames = (frames_t * (1 - md_f) + prop * md_f).contiguous()
-        # ---- feature propagation + transformer over sliding neighbour windows (:317-358)
-        comp = [None] * n
-        stride = self.neighbor_length // 2
-        ref_num = svl // self.ref_stride if n > svl else -1
-        binary = md[:, :, None].astype(np.uint8)
-        flags_cache = {}
-        for f in range(0, n, stride):
-            nb = [i for i in range(max(0, f - stride), min(n, f + stride + 1))]
-            ref = get_ref_index(f, nb, n, self.ref_stride, ref_num)
-            ids = nb + ref
-            l_t = len(nb)
-            if l_t not in flags_cache:                                                      # the same mask on every frame
-                flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
-            pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
-                                      md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t])
-            pred = ((pred + 1) / 2).permute(0, 2, 3, 1).cpu().numpy() * 255
-            for i, idx in enumerate(nb):
-                img = np.array(pred[i]).astype(np.uint8) * binary + frames_inp[idx] * (1 - binary)
-                if comp[idx] is None:
-                    comp[idx] = img
-                else:
-                    comp[idx] = comp[idx].astype(np.float32) * 0.5 + img.astype(np.float32) * 0.5
-                comp[idx] = comp[idx].astype(np.uint8)
-        return [np.ascontiguousarray(c[:, :, ::-1]) for c in comp]                          # cv2.COLOR_RGB2BGR
+        fm1, md1 = torch.from_numpy(fm).to(dev).contiguous(), torch.from_numpy(md).to(dev).contiguous()      # uint8 [h,w]
+        fm_dev = fm1[None].repeat(n, 1, 1).contiguous()                                      # the engines take one mask per frame
+        md_dev = md1[None].repeat(n, 1, 1).contiguous()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.device(dev):
+            # ---- flows (:217-247): every consecutive pair in both directions, fp32; cv2.COLOR_BGR2RGB (:192) inside the stem kernel
+            gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
+            # ---- flow completion (:253-281)
+            flow_length, svl = n - 1, self.sub_video_length
+            if flow_length > svl:
+                pf, pb = [], []
+                for f in range(0, flow_length, svl):
+                    s_f, e_f = max(0, f - 5), min(flow_length, f + svl + 5)
+                    ps, pe = max(0, f) - s_f, e_f - min(flow_length, f + svl)
+                    cf, cb = self.fix_flow_complete.complete(gt_f[s_f:e_f].contiguous(), gt_b[s_f:e_f].contiguous(), fm_dev[s_f:e_f + 1].contiguous())
+                    pf.append(cf[ps:e_f - s_f - pe])
+                    pb.append(cb[ps:e_f - s_f - pe])
+                pred_f, pred_b = torch.cat(pf).contiguous(), torch.cat(pb).contiguous()
+            else:
+                pred_f, pred_b = self.fix_flow_complete.complete(gt_f, gt_b, fm_dev)
+            # ---- image propagation (:283-315)
+            masked_frames = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+            check(lib.vsr_pp_prepare_frames(P(bgr), P(md1), n, h, w, P(masked_frames), stream()))
+            updated_frames = torch.empty_like(masked_frames)
+            sip = min(100, svl)
+            if n > sip:
+                um = []
+                for f in range(0, n, sip):
+                    s_f, e_f = max(0, f - 10), min(n, f + sip + 10)
+                    ps, pe = max(0, f) - s_f, e_f - min(n, f + sip)
+                    prop, upd = self.model.img_propagation(masked_frames[s_f:e_f].contiguous(), pred_f[s_f:e_f - 1].contiguous(),
+                                                           pred_b[s_f:e_f - 1].contiguous(), md_dev[s_f:e_f].contiguous())
+                    sub = torch.empty_like(prop)
+                    check(lib.vsr_pp_compose_frames(P(bgr[s_f:e_f]), P(md1), P(prop), e_f - s_f, h, w, P(sub), stream()))
+                    updated_frames[s_f + ps:e_f - pe] = sub[ps:e_f - s_f - pe]
+                    um.append(upd[ps:e_f - s_f - pe])
+                updated_masks = torch.cat(um).contiguous()
+            else:
+                prop, updated_masks = self.model.img_propagation(masked_frames, pred_f, pred_b, md_dev)
+                check(lib.vsr_pp_compose_frames(P(bgr), P(md1), P(prop), n, h, w, P(updated_frames), stream()))
+            # ---- feature propagation + transformer over sliding neighbour windows (:317-358)
+            comp = torch.empty_like(bgr)
+            visited = [False] * n
+            stride = self.neighbor_length // 2
+            ref_num = svl // self.ref_stride if n > svl else -1
+            flags_cache = {}
+            for f in range(0, n, stride):
+                nb = [i for i in range(max(0, f - stride), min(n, f + stride + 1))]
+                ref = get_ref_index(f, nb, n, self.ref_stride, ref_num)
+                ids = nb + ref
+                l_t = len(nb)
+                if l_t not in flags_cache:                                                  # the same mask on every frame
+                    flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
+                pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
+                                          md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t])
+                idx = torch.tensor(nb, dtype=torch.int32).to(dev, non_blocking=True)
+                first = torch.tensor([0 if visited[i] else 1 for i in nb], dtype=torch.int32).to(dev, non_blocking=True)
+                check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), stream()))
+                for i in nb:
+                    visited[i] = True
+            out = comp.cpu().numpy()                                                        # already BGR (:360)
+        return [out[i] for i in range(n)]
 
     def __call__(self, input_frames, input_mask):
         mask = input_mask[:, :, None]

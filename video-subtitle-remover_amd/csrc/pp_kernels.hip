@@ -114,3 +114,87 @@ extern "C" int vsr_pp_launch_imgprop(const float* prevProp, const float* prevMas
 {
     LAUNCH(k_pp_imgprop, (int64_t)h * w, prevProp, prevMask, cur, mcur, fprop, fcheck, C, h, w, first, prop, mprop);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Plugin glue of PropainterInpaint.inpaint (propainter_inpaint.py:190-361) on the device: the frame batch stays in HBM as the
+// uint8 BGR crops the caller uploaded; these three kernels replace the reference's cvtColor / to_tensors / numpy blends.
+// ---------------------------------------------------------------------------------------------------------------------------
+// frames = to_tensors()(RGB frames) * 2 - 1 (:193-213: x.float().div(255) * 2 - 1); masked = frames * (1 - masks_dilated) (:298)
+__global__ __launch_bounds__(256) void k_pp_prepare(const uint8_t* __restrict__ bgr, const uint8_t* __restrict__ mask, int n, int h, int w,
+                                                    float* __restrict__ masked)
+{
+    const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i % hw, f = i / hw;
+        const float keep = 1.0f - (mask[p] ? 1.0f : 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = ((float)bgr[i * 3 + (2 - c)] / 255.0f) * 2.0f - 1.0f;
+            masked[(f * 3 + c) * hw + p] = x * keep;
+        }
+    }
+}
+
+// updated_frames = frames * (1 - masks_dilated) + prop_imgs * masks_dilated (:314)
+__global__ __launch_bounds__(256) void k_pp_compose(const uint8_t* __restrict__ bgr, const uint8_t* __restrict__ mask, const float* __restrict__ prop,
+                                                    int n, int h, int w, float* __restrict__ out)
+{
+    const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i % hw, f = i / hw;
+        const float m = mask[p] ? 1.0f : 0.0f;
+        const float keep = 1.0f - m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = ((float)bgr[i * 3 + (2 - c)] / 255.0f) * 2.0f - 1.0f;
+            const int64_t at = (f * 3 + c) * hw + p;
+            out[at] = x * keep + prop[at] * m;
+        }
+    }
+}
+
+// one window of :345-357: img = ((pred + 1) / 2 * 255).astype(u8) * binary + frame * (1 - binary);
+// comp = first visit ? img : (comp.astype(f32) * 0.5 + img.astype(f32) * 0.5).astype(u8)   (truncation after every average).
+// comp is kept in the caller's BGR order (the reference swaps back at the end, :360).
+__global__ __launch_bounds__(256) void k_pp_blend(const float* __restrict__ pred, const uint8_t* __restrict__ bgr, const uint8_t* __restrict__ mask,
+                                                  const int32_t* __restrict__ frameIdx, const int32_t* __restrict__ first, int lt, int h, int w,
+                                                  uint8_t* __restrict__ comp)
+{
+    const int64_t hw = (int64_t)h * w, total = (int64_t)lt * hw;
+    GRID_STRIDE(i, total) {
+        const int64_t p = i % hw;
+        const int k = (int)(i / hw);
+        const int idx = frameIdx[k];
+        const bool fst = first[k] != 0, hole = mask[p] != 0;
+        const int64_t at = ((int64_t)idx * hw + p) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                        // c: RGB channel of the network output
+            float v = (pred[((int64_t)k * 3 + c) * hw + p] + 1.0f) / 2.0f;
+            v = v * 255.0f;
+            const uint8_t img = hole ? (uint8_t)v : bgr[at + (2 - c)];       // astype(np.uint8): wraps mod 256 only outside [0, 256)
+            uint8_t* o = comp + at + (2 - c);
+            *o = fst ? img : (uint8_t)((float)*o * 0.5f + (float)img * 0.5f);
+        }
+    }
+}
+
+extern "C" {
+
+int vsr_pp_prepare_frames(const uint8_t* bgr_dev, const uint8_t* mask_dev, int n, int h, int w, float* masked_dev, void* stream)
+{
+    LAUNCH(k_pp_prepare, (int64_t)n * h * w, bgr_dev, mask_dev, n, h, w, masked_dev);
+}
+
+int vsr_pp_compose_frames(const uint8_t* bgr_dev, const uint8_t* mask_dev, const float* prop_dev, int n, int h, int w, float* out_dev, void* stream)
+{
+    LAUNCH(k_pp_compose, (int64_t)n * h * w, bgr_dev, mask_dev, prop_dev, n, h, w, out_dev);
+}
+
+int vsr_pp_blend_window(const float* pred_dev, const uint8_t* bgr_dev, const uint8_t* mask_dev, const int32_t* frame_idx_dev,
+                        const int32_t* first_dev, int lt, int h, int w, uint8_t* comp_dev, void* stream)
+{
+    LAUNCH(k_pp_blend, (int64_t)lt * h * w, pred_dev, bgr_dev, mask_dev, frame_idx_dev, first_dev, lt, h, w, comp_dev);
+}
+
+} // extern "C"
