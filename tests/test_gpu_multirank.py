@@ -23,7 +23,15 @@ def _run(dist_on, ab):
     from vsr_amd.backend.tools.inpaint_tools import create_mask
     from vsr_amd.backend.tools.video_io import ArrayVideo, ArrayWriter
 
+    old = config.sttnMaxLoadNum.value, config.sttnNeighborStride.value, config.sttnReferenceLength.value
     config.sttnMaxLoadNum.value, config.sttnNeighborStride.value, config.sttnReferenceLength.value = GAP, 1, 6
+    try:
+        return _run_configured(ab, synth, config, STTNAutoInpaint, create_mask, ArrayVideo, ArrayWriter)
+    finally:                                   # the config object is process-global: later tests must see the defaults again
+        config.sttnMaxLoadNum.value, config.sttnNeighborStride.value, config.sttnReferenceLength.value = old
+
+
+def _run_configured(ab, synth, config, STTNAutoInpaint, create_mask, ArrayVideo, ArrayWriter):
     clip = synth.make_clip(N, H, W, BOX, seed=9)
     mask = create_mask((H, W), [(BOX[2], BOX[3], BOX[0], BOX[1])])
 

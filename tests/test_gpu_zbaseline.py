@@ -24,6 +24,21 @@ pytestmark = [pytest.mark.gpu, pytest.mark.baseline_oracle]
 PSNR_MIN_DB = 50.0
 
 
+@pytest.fixture(autouse=True)
+def reference_defaults():
+    """the plugins read the process-global config: pin the reference's defaults (backend/config.py: stride 5, references every
+    10, 50 / 70 frames per call) whatever an earlier test left behind"""
+    from vsr_amd.backend.config import config
+
+    keys = {"sttnNeighborStride": 5, "sttnReferenceLength": 10, "sttnMaxLoadNum": 50, "propainterMaxLoadNum": 70}
+    old = {k: getattr(config, k).value for k in keys}
+    for k, v in keys.items():
+        getattr(config, k).value = v
+    yield
+    for k, v in old.items():
+        getattr(config, k).value = v
+
+
 def _report(name, got, ref, m=None):
     a, b = (got, ref) if m is None else (got[:, m], ref[:, m])
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))

@@ -103,15 +103,16 @@ class STTNAutoInpaint:
             return dist
         return None
 
-    def _call_chunk_parallel(self, dist, input_mask, input_sub_remover, tbar):
-        """One process per GPU: the chunks are dealt round-robin, rank 0 owns the frame source and sink
-        (backend/tools/chunk_parallel.py).  Chunk boundaries are the reference's (clip_gap), so every frame
-        sees exactly the temporal context it sees in the single-GPU run.  Only the rows between the first and the
-        last strip travel to the GPUs (nothing else can change, :314-315); rank 0 keeps the decoded frames and
-        patches the returned rows in before writing."""
+    def _run(self, dist, input_mask, input_sub_remover, tbar):
+        """The chunk loop (:242-328) as a pipeline: read + upload of chunk i+1, inpainting of chunk i and download + write of
+        chunk i-1 overlap (backend/tools/chunk_parallel.py; the reference is strictly serial).  With one process per GPU
+        (`dist`) the chunks are dealt round-robin and rank 0 owns the frame source and sink.  Chunk boundaries are the
+        reference's (clip_gap), so every frame sees exactly the temporal context it sees in the reference.  Only the rows
+        between the first and the last strip travel to the GPUs (nothing else can change, :314-315); the decoded frames stay
+        on the host and the returned rows are patched in before writing."""
         from ..tools import chunk_parallel as cp
 
-        rank = dist.get_rank()
+        rank = dist.get_rank() if dist is not None else 0
         engine = self.sttn_inpaint.engine
         reader = open_video(self.video_path)
         frame_info = reader.info()
@@ -119,8 +120,10 @@ class STTNAutoInpaint:
         ab_sections = input_sub_remover.ab_sections if input_sub_remover is not None else None
         writer = (input_sub_remover.video_writer if input_sub_remover is not None else ArrayWriter()) if rank == 0 else None
         self.writer = writer
+        gui = input_sub_remover is not None and getattr(input_sub_remover, "gui_mode", False)
         mask = self.sttn_inpaint.read_mask(self.mask_path) if input_mask is None else threshold_mask(input_mask)
         inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, int(W_ori * 3 / 16), mask)
+        # the reference clamps clip_gap by free VRAM / (W*H*12 B) (:228-238); 288 GB never binds
         ranges = cp.chunk_ranges(frame_info["len"], self.clip_gap)
         y_lo = min((a[0] for a in inpaint_area), default=0)
         y_hi = max((a[1] for a in inpaint_area), default=0)
@@ -128,34 +131,43 @@ class STTNAutoInpaint:
         dmask = torch.from_numpy(np.ascontiguousarray(mask[y_lo:y_hi, :, 0])).to(engine.device) if inpaint_area else None
         kept = {}
 
-        def tick():
-            if input_sub_remover is not None and tbar is not None:
-                input_sub_remover.update_progress(tbar, increment=1)
+        def tick(original, frame):
+            if input_sub_remover is not None:
+                if tbar is not None:
+                    input_sub_remover.update_progress(tbar, increment=1)
+                if original is not None:
+                    input_sub_remover.update_preview_with_comp(original, frame)
 
         def load(i, out):
             s, e = ranges[i]
             frames = []
             for j in range(s, e):
                 ok, image = reader.read()
-                if not ok:
-                    raise RuntimeError(f"Failed to read frame {j}.")
+                if not ok:                               # :259-261: a short read ends the chunk with the frames read so far
+                    print(f"Warning: Failed to read frame {j}.")
+                    out[j - s:e - s] = 0
+                    break
                 if not image.flags.owndata or not image.flags.writeable:
                     image = image.copy()                 # an in-memory source hands out views of the clip
                 out[j - s] = image[y_lo:y_hi]
                 frames.append(image)
+            if not frames:
+                print(f"Warning: No valid frames found in range {s + 1}-{e}. Skipping this segment.")
             kept[i] = frames
 
         def process(i, rows):
             s, e = ranges[i]
-            sel = [j - s for j in range(s, e) if is_frame_number_in_ab_sections(j, ab_sections)]
+            n = len(kept[i]) if i in kept else e - s     # the owner of the frame source knows how many frames were read
+            sel = [j - s for j in range(s, s + n) if is_frame_number_in_ab_sections(j, ab_sections)]
             if sel:
-                engine.auto_chunk(rows, dmask, local_areas, sel=None if len(sel) == e - s else sel)
+                engine.auto_chunk(rows[:n], dmask, local_areas, sel=None if len(sel) == n else sel)
 
         def store(i, rows):
             for j, frame in enumerate(kept.pop(i)):
+                original = frame.copy() if gui else None
                 frame[y_lo:y_hi] = rows[j]
                 writer.write(frame)
-                tick()
+                tick(original, frame)
 
         try:
             if not inpaint_area:                         # nothing to inpaint anywhere: rank 0 copies the video through
@@ -165,8 +177,9 @@ class STTNAutoInpaint:
                         if not ok:
                             break
                         writer.write(image)
-                        tick()
-                dist.barrier()
+                        tick(None, image)
+                if dist is not None:
+                    dist.barrier()
             else:
                 cp.run_chunk_parallel(ranges, (y_hi - y_lo, W_ori, 3), load, process, store, dist=dist, device=engine.device)
         finally:
@@ -175,100 +188,8 @@ class STTNAutoInpaint:
                 writer.release()
 
     def __call__(self, input_mask=None, input_sub_remover=None, tbar=None):
-        reader = None
-        writer = None
         try:
-            dist = self._distributed()
-            if dist is not None:
-                return self._call_chunk_parallel(dist, input_mask, input_sub_remover, tbar)
-            reader = open_video(self.video_path)
-            frame_info = reader.info()
-            if input_sub_remover is not None:
-                ab_sections = input_sub_remover.ab_sections
-                writer = input_sub_remover.video_writer
-            else:
-                ab_sections = None
-                writer = ArrayWriter()
-            self.writer = writer
-            W_ori, H_ori = frame_info["W_ori"], frame_info["H_ori"]
-            split_h = int(W_ori * 3 / 16)
-            mask = self.sttn_inpaint.read_mask(self.mask_path) if input_mask is None else threshold_mask(input_mask)
-            inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask)
-            # the reference clamps clip_gap by free VRAM / (W*H*12 B) (:228-238); 288 GB never binds
-            clip_gap = self.clip_gap
-            engine = self.sttn_inpaint.engine
-            dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(engine.device)
-            torch.cuda.synchronize(engine.device)
-            total = frame_info["len"]
-            rec_time = total // clip_gap if total % clip_gap == 0 else total // clip_gap + 1
-            # Three-stage pipeline over the chunks (reference: read -> inpaint -> write, strictly serial,
-            # sttn_auto_inpaint.py:242-328): pinned host buffers, H2D / compute / D2H on separate HIP streams,
-            # so that chunk i computes while chunk i+1 is read + uploaded and chunk i-1 is downloaded + written.
-            dev = engine.device
-            s_h2d, s_cmp, s_d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-            shape = (clip_gap, H_ori, W_ori, 3)
-            pin_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            pin_out = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            dbuf = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)]
-            ev_up = [torch.cuda.Event() for _ in range(2)]
-            ev_cmp = [torch.cuda.Event() for _ in range(2)]
-            ev_down = [torch.cuda.Event() for _ in range(2)]
-            pending = None                                   # (slot, n_frames, originals) waiting to be written
-
-            def flush(p):
-                slot, n, originals = p
-                ev_down[slot].synchronize()
-                out = pin_out[slot].numpy()
-                for j in range(n):
-                    writer.write(out[j])
-                    if input_sub_remover is not None:
-                        if tbar is not None:
-                            input_sub_remover.update_progress(tbar, increment=1)
-                        if originals is not None:
-                            input_sub_remover.update_preview_with_comp(originals[j], out[j])
-
-            for i in range(rec_time):
-                start_f, end_f = i * clip_gap, min((i + 1) * clip_gap, total)
-                slot = i & 1
-                ev_down[slot].synchronize()                  # pin_out[slot] / dbuf[slot] of chunk i-2 are free again
-                host = pin_in[slot].numpy()
-                n, sel = 0, []
-                for j in range(start_f, end_f):
-                    ok, image = reader.read()
-                    if not ok:
-                        print(f"Warning: Failed to read frame {j}.")
-                        break
-                    host[n] = image
-                    if is_frame_number_in_ab_sections(j, ab_sections):
-                        sel.append(n)
-                    n += 1
-                if n == 0:
-                    print(f"Warning: No valid frames found in range {start_f + 1}-{end_f}. Skipping this segment.")
-                    continue
-                gui = input_sub_remover is not None and getattr(input_sub_remover, "gui_mode", False)
-                originals = host[:n].copy() if gui else None
-                with torch.cuda.stream(s_h2d):
-                    dbuf[slot][:n].copy_(pin_in[slot][:n], non_blocking=True)
-                    ev_up[slot].record(s_h2d)
-                with torch.cuda.stream(s_cmp):
-                    s_cmp.wait_event(ev_up[slot])
-                    if inpaint_area and sel:
-                        engine.auto_chunk(dbuf[slot][:n], dmask, inpaint_area, sel=None if len(sel) == n else sel)
-                    ev_cmp[slot].record(s_cmp)
-                with torch.cuda.stream(s_d2h):
-                    s_d2h.wait_event(ev_cmp[slot])
-                    pin_out[slot][:n].copy_(dbuf[slot][:n], non_blocking=True)
-                    ev_down[slot].record(s_d2h)
-                if pending is not None:
-                    flush(pending)                           # chunk i-1 is written while chunk i computes
-                pending = (slot, n, originals)
-            if pending is not None:
-                flush(pending)
+            self._run(self._distributed(), input_mask, input_sub_remover, tbar)
             gc.collect()
         except Exception as e:          # the reference swallows every error here (:329-331)
             print(f"Error during video processing: {str(e)}")
-        finally:
-            if reader:
-                reader.release()
-            if writer:
-                writer.release()
