@@ -31,6 +31,7 @@ AUTO_CLIP = dict(n=12, H=180, W=320, box=(140, 170, 40, 280), seed=31)          
 AUTO_AB = [(2, 6), (8, 11)]                                                      # range(a, b) sections
 DET_CLIP = dict(n=5, H=180, W=320, box=(130, 160, 30, 290), seed=32)            # split_h = int(320*5/18) = 88
 LAMA_CLIP = dict(n=9, H=182, W=330, box=(140, 170, 40, 280), seed=33)           # split_h = 61 -> padded to 64, W 330 -> 336
+PP_CLIP = dict(n=7, H=288, W=704, box=(236, 268, 120, 600), seed=5)             # strip 704x132 -> x8-aligned 704x136
 
 
 def area_cases():
@@ -83,7 +84,44 @@ class _Remover:
         self.ticks += increment
 
 
+def propainter_fixture():
+    """backend/inpaint/propainter_inpaint.py executed: PropainterInpaint.__call__ / .inpaint / read_mask / get_ref_index on the
+    CPU (fp32 path, :146-147) with the reference's RAFT_bi, RecurrentFlowCompleteNet and InpaintGenerator modules, the synthetic
+    checkpoints of vsr_amd.synth written as the three .pth files it loads, torchvision.ops.deform_conv2d from oracle/deform_conv.py
+    (torchvision is absent: that operator stays unpinned), 20 RAFT iterations.  -> tests/golden/wrappers_propainter.npz"""
+    import tempfile
+
+    from oracle.deform_conv import deform_conv2d
+    from vsr_amd.synth import make_clip, make_propainter_state_dict, make_raft_state_dict, make_rfc_state_dict
+
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cv2, cfg = ref_exec.install()
+    sys.modules["torchvision"].ops.deform_conv2d = deform_conv2d
+    tools = ref_exec.load_module("backend.tools.inpaint_tools", "backend/tools/inpaint_tools.py")
+    d = tempfile.mkdtemp(prefix="vsr_pp_golden_")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in make_raft_state_dict(0).items()}, os.path.join(d, "raft-things.pth"))
+    torch.save({k: torch.from_numpy(v) for k, v in make_rfc_state_dict(0).items()}, os.path.join(d, "recurrent_flow_completion.pth"))
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in make_propainter_state_dict(0).items()}, os.path.join(d, "ProPainter.pth"))
+    pp = ref_exec.load_module("backend.inpaint.propainter_inpaint", "backend/inpaint/propainter_inpaint.py")
+    plug = pp.PropainterInpaint(torch.device("cpu"), d, sub_video_length=70)            # main.py:171
+    assert plug.use_half is False and plug.raft_iter == 20
+    c = PP_CLIP
+    clip = make_clip(c["n"], c["H"], c["W"], c["box"], seed=c["seed"])
+    b = c["box"]
+    mask = tools.create_mask((c["H"], c["W"]), [(b[2], b[3], b[0], b[1])])
+    out = np.stack(plug([f.copy() for f in clip], mask))
+    changed = (out != clip).any(axis=(0, 3))
+    ys, xs = np.nonzero(changed)
+    bbox = [int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1]
+    areas = tools.get_inpaint_area_by_mask(c["W"], c["H"], int(c["W"] * 3 / 16), mask[:, :, None], multiple=8)
+    print("propainter: areas", areas, "changed bbox", bbox, "changed fraction", float(changed.mean()))
+    np.savez_compressed(os.path.join(OUT, "wrappers_propainter.npz"), bbox=np.array(bbox), area=np.array(areas[0]),
+                        out=out[:, bbox[0]:bbox[1], bbox[2]:bbox[3]], changed=np.packbits(changed))
+
+
 def main():
+    if "--propainter" in sys.argv:
+        return propainter_fixture()
     from vsr_amd.synth import make_clip, make_state_dict
 
     torch.set_num_threads(max(1, os.cpu_count() or 1))

@@ -135,3 +135,27 @@ def test_sttn_det_call_vs_reference(built_lib, gpu_device, gold, sttn_cfg):
     y0, y1 = js["det_area"]
     assert np.array_equal(out[:, :y0], clip[:, :y0]) and np.array_equal(out[:, y1:], clip[:, y1:])
     _bar(out[:, y0:y1], z["det_call_strip"], "STTNDetInpaint.__call__")
+
+
+def test_propainter_call_vs_reference(built_lib, gpu_device):
+    """PropainterInpaint.__call__ (a13) against the reference's own wrapper + modules run on the CPU (wrappers_propainter.npz):
+    288x704 clip, strip aligned to x8, 20 RAFT iterations, u8 overlap blending."""
+    from oracle.make_golden_wrappers import PP_CLIP
+    from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+    from vsr_amd.synth import make_propainter_state_dict, make_raft_state_dict, make_rfc_state_dict
+
+    with np.load(os.path.join(GOLD, "wrappers_propainter.npz")) as z:
+        bbox, want, changed = z["bbox"], z["out"], z["changed"]
+    c = PP_CLIP
+    clip = make_clip(c["n"], c["H"], c["W"], c["box"], seed=c["seed"])
+    b = c["box"]
+    mask = create_mask((c["H"], c["W"]), [(b[2], b[3], b[0], b[1])])
+    plug = PropainterInpaint("cuda:0", {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": make_propainter_state_dict(0)},
+                             sub_video_length=70)
+    frames_in = [f.copy() for f in clip]
+    out = np.stack(plug(frames_in, mask))
+    plug.close()
+    assert all(np.array_equal(a, b2) for a, b2 in zip(frames_in, clip))
+    ch = np.unpackbits(changed)[: c["H"] * c["W"]].reshape(c["H"], c["W"]).astype(bool)
+    assert np.array_equal(out[:, ~ch], clip[:, ~ch]), "pixels the reference leaves alone stay bit-identical"
+    _bar(out[:, bbox[0]:bbox[1], bbox[2]:bbox[3]], want, "PropainterInpaint.__call__")

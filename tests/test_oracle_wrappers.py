@@ -160,3 +160,30 @@ def test_sttn_det_call_equals_the_reference(gold):
     assert js["det_inputs_mutated"] is False
     assert np.array_equal(out[:, :y0], clip[:, :y0]) and np.array_equal(out[:, y1:], clip[:, y1:])
     _near(out[:, y0:y1], z["det_call_strip"], "STTNDetInpaint.__call__")
+
+
+def test_propainter_call_equals_the_reference():
+    """PropainterInpaint.__call__ / .inpaint (propainter_inpaint.py:190-418), executed from the reference on the CPU with its own
+    RAFT_bi / RecurrentFlowCompleteNet / InpaintGenerator (20 RAFT iterations): strip aligned to x8, mask dilation, sliding
+    neighbour / reference windows, u8 overlap blending with truncation after every average.  The oracle's restated wrapper over
+    the oracle networks must reproduce it (deform_conv2d is the same restatement on both sides: that operator stays unpinned)."""
+    from oracle.make_golden_wrappers import PP_CLIP
+    from oracle.propainter import ProPainterOracle
+    from oracle.propainter_wrapper import PropainterOracle
+    from oracle.raft import RaftOracle
+    from oracle.rfc import RfcOracle
+    from vsr_amd.synth import make_propainter_state_dict, make_raft_state_dict, make_rfc_state_dict
+
+    with np.load(os.path.join(GOLD, "wrappers_propainter.npz")) as z:
+        bbox, area, want, changed = z["bbox"], z["area"], z["out"], z["changed"]
+    c = PP_CLIP
+    clip = make_clip(c["n"], c["H"], c["W"], c["box"], seed=c["seed"])
+    b = c["box"]
+    mask = oauto.create_mask((c["H"], c["W"]), [(b[2], b[3], b[0], b[1])])
+    ora = PropainterOracle(RaftOracle(make_raft_state_dict(0)), RfcOracle(make_rfc_state_dict(0)), ProPainterOracle(make_propainter_state_dict(0)),
+                           sub_video_length=70, raft_iter=20)
+    out = np.stack(ora(list(clip), mask))
+    ch = (out != clip).any(axis=(0, 3))
+    assert np.array_equal(np.packbits(ch), changed), "the same pixels are repainted"
+    assert tuple(oauto.get_inpaint_area_by_mask(c["W"], c["H"], int(c["W"] * 3 / 16), mask[:, :, None], 8)[0]) == tuple(area)
+    _near(out[:, bbox[0]:bbox[1], bbox[2]:bbox[3]], want, "PropainterInpaint.__call__", max_abs=2, max_frac=5e-3)
