@@ -127,6 +127,49 @@ def test_pdiparams_reader_round_trip(tmp_path, order, packed, lod):
         paddle_graph.read_pdiparams(bad, g)
 
 
+def test_pdiparams_reader_on_literal_bytes(tmp_path):
+    """A save_combine stream written out byte by byte from Paddle's published layout (paddle/fluid/framework/lod_tensor.cc
+    SerializeToStream + tensor_util.cc TensorToStream + framework.proto VarType.TensorDesc {data_type = 1; dims = 2}), independent
+    of the writer helper above: tensor 1 = fp32 [2,3] with one LoD level and unpacked dims, tensor 2 = fp16 [4] with packed dims."""
+    from vsr_amd.backend.tools import paddle_graph
+
+    t1 = bytes.fromhex(
+        "00000000"                      # uint32 LoDTensor version 0
+        "0100000000000000"              # uint64 lod levels = 1
+        "1000000000000000"              # uint64 byte size of level 0 = 16
+        "0000000000000000" "0300000000000000"    # size_t offsets {0, 3}
+        "00000000"                      # uint32 tensor version 0
+        "06000000"                      # int32 size of the TensorDesc message
+        "0805" "1002" "1003"            # data_type = FP32 (5); dims = 2, 3 (field 2, unpacked varints)
+    ) + np.array([[1.5, -2.0, 3.25], [0.0, 1e-3, -7.0]], "<f4").tobytes()
+    t2 = bytes.fromhex(
+        "00000000" "0000000000000000"   # version 0, no LoD
+        "00000000" "05000000"           # tensor version 0, desc of 5 bytes
+        "0804" "120104"                 # data_type = FP16 (4); dims packed: length 1, value 4
+    ) + np.array([0.5, -1.0, 2.0, 65504.0], "<f2").tobytes()
+    path = str(tmp_path / "lit.pdiparams")
+    with open(path, "wb") as f:
+        f.write(t1 + t2)
+    a, b = paddle_graph.read_pdiparams_tensors(path)
+    assert a.dtype == np.float32 and a.shape == (2, 3) and a.tolist() == [[1.5, -2.0, 3.25], [0.0, float(np.float32(1e-3)), -7.0]]
+    assert b.dtype == np.float16 and b.shape == (4,) and b.astype(np.float32).tolist() == [0.5, -1.0, 2.0, 65504.0]
+
+
+def test_det_resize_shape_and_same_padding():
+    """DetResizeForTest as PaddleX's TextDetection applies it to the PP-OCRv5 det models (limit_side_len 960, limit_type "max":
+    only shrink) and Paddle's padding_algorithm "SAME" for any stride"""
+    from vsr_amd.backend.tools.ocr_det import det_resize_shape, same_padding
+
+    assert det_resize_shape(1080, 1920) == (544, 960)            # int(1080 * 0.5) = 540 -> 544
+    assert det_resize_shape(480, 852) == (480, 864)              # below the limit: no up-scaling, multiples of 32 only
+    assert det_resize_shape(720, 1280) == (544, 960)
+    assert det_resize_shape(2160, 3840) == (544, 960)
+    assert det_resize_shape(100, 20) == (96, 32)
+    assert det_resize_shape(480, 852, limit_type="long") == (544, 960)
+    assert same_padding(17, 3, 1) == (1, 17) and same_padding(16, 3, 2) == (0, 8) and same_padding(17, 3, 2) == (1, 9)
+    assert same_padding(10, 5, 1) == (2, 10) and same_padding(10, 2, 2) == (0, 5) and same_padding(7, 3, 1, 2) == (2, 7)
+
+
 def test_from_env_without_weights_is_none(monkeypatch, tmp_path):
     from vsr_amd.backend.tools import ocr_det
     monkeypatch.delenv("VSR_DET_WEIGHTS", raising=False)

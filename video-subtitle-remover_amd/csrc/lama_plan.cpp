@@ -339,14 +339,19 @@ int64_t LamaPlan::dft(const std::string& key, int rows, int cols, int kind, int 
     return off;
 }
 
-// FourierUnit.forward on S1 [B][h][w][192]: S2 = S1 + irfftn(relu(bn(conv(rfftn(S1)))))   (SpectralTransform adds x + fu(x))
+// FourierUnit.forward on S1 [B][h][w][192]: S2 = S1 + irfftn(relu(bn(conv(rfftn(S1)))))   (SpectralTransform adds x + fu(x)).
+// Each DFT stage is ONE problem per image: the transform axis is the contraction (KN mode: B rows = positions along the axis),
+// every other (position, channel) pair is a column -- 32-channel chunk j of the N axis is (other position j / 6, channels
+// 32 (j % 6) ..), which the column tables express -- so a stage is [2 wf | 2 h | w] x [thousands of columns] in 128 x 128 tiles
+// instead of hundreds of 3-tile problems.
 void LamaPlan::fourier(const LamaFfcW& f)
 {
-    const int CS = LAMA_CS, CG = LAMA_CG;
+    const int CS = LAMA_CS, CG = LAMA_CG, CH = CS / VSR_GG_KC;      // 6 chunks of 32 channels
     const int Kw = (int)rup(w, VSR_GG_KC), Kh = (int)rup(2 * h, VSR_GG_KC), Kc = (int)rup(2 * wf, VSR_GG_KC);
+    const int cfg = VSR_TILE_128x128;
     int BM, BN;
-    tileDims(VSR_TILE_128x64, BM, BN);
-    auto rowsTable = [&](const std::string& key, int count, int padTo, auto fn) {
+    tileDims(cfg, BM, BN);
+    auto makeTable = [&](const std::string& key, int count, int padTo, auto fn) {
         std::vector<int32_t> v;
         for (int i = 0; i < count; ++i) v.push_back(fits(fn(i)));
         const int32_t first = v[0];
@@ -354,40 +359,46 @@ void LamaPlan::fourier(const LamaFfcW& f)
         return table(key, std::move(v));
     };
     const std::string g = std::to_string(h) + "x" + std::to_string(w);
-    // spatial rows of S1 / S2 (one image row), spectrum rows of one image row (kx, part), spectrum rows of one column (y, part)
-    const int tSpatK = rowsTable("LF:sk:" + g, w, Kw, [&](int x) { return (int64_t)x * CS; });
-    const int tSpatM = rowsTable("LF:sm:" + g, w, BM, [&](int x) { return (int64_t)x * CS; });
-    const int tSpecWM = rowsTable("LF:wm:" + g, 2 * wf, BM, [&](int m) { return (int64_t)(m / 2) * CG + (m % 2) * CS; });
-    const int tSpecWK = rowsTable("LF:wk:" + g, 2 * wf, Kc, [&](int m) { return (int64_t)(m / 2) * CG + (m % 2) * CS; });
-    const int tSpecHM = rowsTable("LF:hm:" + g, 2 * h, BM, [&](int m) { return (int64_t)(m / 2) * wf * CG + (m % 2) * CS; });
-    const int tSpecHK = rowsTable("LF:hk:" + g, 2 * h, Kh, [&](int m) { return (int64_t)(m / 2) * wf * CG + (m % 2) * CS; });
-    const int tColN = tColsLinear(CS / VSR_GG_KC, cdiv(CS, BN) * BN / VSR_GG_KC);
+    const int padN = BN / VSR_GG_KC;
+    // rows along W: pixel x of a spatial row / spectrum slot (kx, part) of a spectrum row
+    const int tXk = makeTable("LF:xk:" + g, w, Kw, [&](int x) { return (int64_t)x * CS; });
+    const int tXm = makeTable("LF:xm:" + g, w, BM, [&](int x) { return (int64_t)x * CS; });
+    const int tFWm = makeTable("LF:fwm:" + g, 2 * wf, BM, [&](int m) { return (int64_t)(m / 2) * CG + (m % 2) * CS; });
+    const int tFWk = makeTable("LF:fwk:" + g, 2 * wf, Kc, [&](int m) { return (int64_t)(m / 2) * CG + (m % 2) * CS; });
+    // rows along H: (y, part) of a spectrum column
+    const int tFHm = makeTable("LF:fhm:" + g, 2 * h, BM, [&](int m) { return (int64_t)(m / 2) * wf * CG + (m % 2) * CS; });
+    const int tFHk = makeTable("LF:fhk:" + g, 2 * h, Kh, [&](int m) { return (int64_t)(m / 2) * wf * CG + (m % 2) * CS; });
+    // columns: (image row y, channel chunk) of the spatial tensor / of the spectrum, (kx, channel chunk) of one spectrum part
+    const int tColSpat = makeTable("LF:cs:" + g, h * CH, padN, [&](int j) { return (int64_t)(j / CH) * w * CS + (j % CH) * VSR_GG_KC; });
+    const int tColSpecY = makeTable("LF:cy:" + g, h * CH, padN, [&](int j) { return (int64_t)(j / CH) * wf * CG + (j % CH) * VSR_GG_KC; });
+    const int tColSpecX = makeTable("LF:cx:" + g, wf * CH, padN, [&](int j) { return (int64_t)(j / CH) * CG + (j % CH) * VSR_GG_KC; });
     const int64_t fw = dft("fw:" + g, 2 * wf, w, 0, w), fh = dft("fh:" + g, 2 * h, 2 * h, 1, h), fhi = dft("fhi:" + g, 2 * h, 2 * h, 2, h),
                   fwi = dft("fwi:" + g, w, 2 * wf, 3, w);
-    auto stage = [&](const char* tag, int M, int K, int Kpad, int64_t aOff, int tRowB, int tRowC, int bufB, int bufC, int nItems,
-                     auto offB, auto offC, int bufR) {
+    const int64_t imgSpat = (int64_t)h * w * CS, imgSpec = (int64_t)h * wf * CG;
+    auto stage = [&](const char* tag, int M, int N, int K, int Kpad, int64_t aOff, int tRowB, int tColB, int tRowC, int tColC, int bufB,
+                     int64_t strideB, int bufC, int64_t strideC, int bufR) {
         Op op;
         op.kind = OP_GEMM;
         op.tag = tag;
         op.bmode = VSR_BMODE_KN;
-        op.tileCfg = VSR_TILE_128x64;
-        for (int i = 0; i < nItems; ++i) {
+        op.tileCfg = cfg;
+        for (int b = 0; b < B; ++b) {
             GemmItem it{};
-            it.M = M; it.N = CS; it.K = Kpad;
-            it.tilesM = cdiv(M, BM); it.tilesN = cdiv(CS, BN);
+            it.M = M; it.N = N; it.K = Kpad;
+            it.tilesM = cdiv(M, BM); it.tilesN = cdiv(N, BN);
             it.splitK = 1; it.chunksPerSplit = Kpad / VSR_GG_KC;
             it.alpha = 1.f; it.act = VSR_ACT_NONE;
             it.bufA = BUF_PLAN_CONST; it.offA = aOff;
             it.tRowA = tRowsLinear(M, Kpad, BM);
             it.tColA = tColsLinear(Kpad / VSR_GG_KC, Kpad / VSR_GG_KC);
-            it.bufB = bufB; it.offB = offB(i);
-            it.tRowB = tRowB; it.tColB = tColN;
-            it.bufC = bufC; it.offC = offC(i);
-            it.tRowC = tRowC; it.tColC = tColN;
+            it.bufB = bufB; it.offB = b * strideB;
+            it.tRowB = tRowB; it.tColB = tColB;
+            it.bufC = bufC; it.offC = b * strideC;
+            it.tRowC = tRowC; it.tColC = tColC;
             it.offBias = -1;
-            it.bufR = bufR; it.offR = bufR >= 0 ? offC(i) : 0; it.tRowR = bufR >= 0 ? tRowC : -1;
+            it.bufR = bufR; it.offR = bufR >= 0 ? b * strideC : 0; it.tRowR = bufR >= 0 ? tRowC : -1;
             op.gemm.push_back(it);
-            op.flops += 2.0 * M * CS * (double)K;
+            op.flops += 2.0 * M * N * (double)K;
         }
         flops += op.flops;
         ops.push_back(std::move(op));
@@ -396,14 +407,11 @@ void LamaPlan::fourier(const LamaFfcW& f)
     need(LB_FA, FA.elems());
     need(LB_FB, FB.elems());
     need(LB_S2, (int64_t)B * h * w * CS);
-    auto rowOfImage = [&](int i) { return (int64_t)i * w * CS; };              // i = b * h + y
-    auto specRow = [&](int i) { return (int64_t)i * wf * CG; };
-    auto specCol = [&](int i) { return ((int64_t)(i / wf) * h * wf + (i % wf)) * CG; };   // i = b * wf + kx
-    stage("fu.dft_w", 2 * wf, w, Kw, fw, tSpatK, tSpecWM, LB_S1, LB_FA, B * h, rowOfImage, specRow, -1);
-    stage("fu.dft_h", 2 * h, 2 * h, Kh, fh, tSpecHK, tSpecHM, LB_FA, LB_FB, B * wf, specCol, specCol, -1);
+    stage("fu.dft_w", 2 * wf, h * CS, w, Kw, fw, tXk, tColSpat, tFWm, tColSpecY, LB_S1, imgSpat, LB_FA, imgSpec, -1);
+    stage("fu.dft_h", 2 * h, wf * CS, 2 * h, Kh, fh, tFHk, tColSpecX, tFHm, tColSpecX, LB_FA, imgSpec, LB_FB, imgSpec, -1);
     conv("fu.conv", FB, 0, CG, FA, 0, 1, 1, f.fu, VSR_ACT_RELU, nullptr, 0);
-    stage("fu.idft_h", 2 * h, 2 * h, Kh, fhi, tSpecHK, tSpecHM, LB_FA, LB_FB, B * wf, specCol, specCol, -1);
-    stage("fu.idft_w", w, 2 * wf, Kc, fwi, tSpecWK, tSpatM, LB_FB, LB_S2, B * h, specRow, rowOfImage, LB_S1);
+    stage("fu.idft_h", 2 * h, wf * CS, 2 * h, Kh, fhi, tFHk, tColSpecX, tFHm, tColSpecX, LB_FA, imgSpec, LB_FB, imgSpec, -1);
+    stage("fu.idft_w", w, h * CS, 2 * wf, Kc, fwi, tFWk, tColSpecY, tXm, tColSpat, LB_FB, imgSpec, LB_S2, imgSpat, LB_S1);
 }
 
 // FFC_BN_ACT (ratio 0.75 in and out, 3x3, reflect padding): x, y are 512-channel tensors [local 128 | global 384]
