@@ -263,6 +263,54 @@ def test_gather_gemm_split_format(built_lib, gpu_device, out_split, cfg, bm, bn,
     assert np.array_equal(rest, s16), f"{what}: store footprint differs"
 
 
+@pytest.mark.parametrize("out_split", [0, 1])
+@pytest.mark.parametrize("cfg,bm,bn,M,N,K,splitK", [
+    ("TILE_128x128", 128, 128, 513, 257, 2304, 1), ("TILE_128x64", 128, 64, 300, 256, 576, 1),
+    ("TILE_128x64", 128, 64, 260, 130, 96, 1),               # 3 chunks: one full pair + a lone chunk
+    ("TILE_128x64", 128, 64, 200, 64, 352, 1),               # 11 chunks
+    ("TILE_128x128", 128, 128, 375, 375, 384, 3),            # split-K: 4 chunks per slice
+    ("TILE_128x128", 128, 128, 140, 140, 480, 2),            # split-K with odd slices: 8 + 7 chunks
+    ("TILE_256x64", 256, 64, 520, 64, 576, 1),
+    ("TILE_128x64", 128, 64, 4800, 256, 32 * 150, 1),        # 150 chunks: crosses a 128-chunk super-block
+])
+def test_gather_gemm_fp16_operands(built_lib, gpu_device, out_split, cfg, bm, bn, M, N, K, splitK):
+    """Variant 6 on NK problems = gather_gemm_f16_v6: the fp16 hi halves of split-format operands alone, two K chunks per LDS
+    stage.  With operands that are exactly representable in fp16 the result is the fp32-accumulated product itself."""
+    if out_split and splitK > 1:
+        pytest.skip("partial planes are plain fp32")
+    rng = np.random.default_rng(6000 + M + N + K + out_split)
+    full = splitK == 1
+    c = _make_gemm_case(rng, M, N, K, bm, bn, 0, splitK, full, 1 if full else 0, full)
+    c.Abuf[:] = c.Abuf.astype(np.float16).astype(np.float32)
+    c.Bbuf[:] = c.Bbuf.astype(np.float16).astype(np.float32)
+    ref = _reference(c)
+    sentinel = c.Cbuf.copy()
+    _to_split_inplace(c.Abuf, _starts(c.rowA, c.colA))
+    _to_split_inplace(c.Bbuf, _starts(c.rowB, c.colB))
+    if c.use_res:
+        _to_split_inplace(c.Rbuf, _starts(c.rowR[:M], c.colC))
+    if out_split:
+        c.act |= 0x100
+    got = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), 0, 6)[0]
+    what = f"v6 {cfg} {M}x{N}x{K} splitK={splitK} out_split={out_split}"
+    if not out_split:
+        _assert_close(got, ref, K, what, case=c)
+        return
+    m, n = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    chunk = c.rowC[m] + c.colC[n // 32]
+    hi_i, lo_i = 2 * chunk + n % 32, 2 * chunk + 32 + n % 32
+    g16 = got.view(np.uint16)
+    val = g16[hi_i].view(np.float16).astype(np.float32) + g16[lo_i].view(np.float16).astype(np.float32)
+    err = np.abs(val - ref[chunk + n % 32]).max()
+    tol = 2e-5 * np.sqrt(K) * 4 + 1e-5
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e}"
+    s16 = sentinel.view(np.uint16)
+    rest = g16.copy()
+    rest[hi_i] = s16[hi_i]
+    rest[lo_i] = s16[lo_i]
+    assert np.array_equal(rest, s16), f"{what}: store footprint differs"
+
+
 def test_to_split_bit_exact(built_lib, gpu_device):
     rng = np.random.default_rng(8)
     x = (rng.standard_normal(32 * 1000) * np.exp(rng.uniform(-8, 8, 32 * 1000))).astype(np.float32)

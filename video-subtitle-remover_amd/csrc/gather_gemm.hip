@@ -302,6 +302,7 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #include "gather_gemm_v3.h"
 #include "gather_gemm_v4.h"
 #include "gather_gemm_v5.h"
+#include "gather_gemm_v6.h"
 
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
@@ -339,10 +340,34 @@ static void launch_v5_st(const GGProblem* d_probs, int nprobs, int totalBlocks, 
                            nprobs, totalBlocks, queue, nQueues, rangeFlag);
     }
 }
+// fp16-operand mode of NK problems: v6 (two K chunks of hi halves per LDS stage).  VSR_F16_KERNEL=5 keeps v5's HI_ONLY path (A/B
+// runs), VSR_V6_STAGES = 2..4 overrides the stage count.
+template <int BM, int BN, int WM, int WN, int ST>
+static void launch_v6_st(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, int nQueues, unsigned int* rangeFlag,
+                         hipStream_t stream)
+{
+    static const int resident = resident_blocks(gather_gemm_f16_v6<BM, BN, WM, WN, ST>);
+    const int g = totalBlocks < resident ? totalBlocks : resident;
+    hipLaunchKernelGGL((gather_gemm_f16_v6<BM, BN, WM, WN, ST>), dim3(g), dim3(256), 0, stream, d_probs, nprobs, totalBlocks, queue, nQueues,
+                       rangeFlag);
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 static void launch_v5(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, int nQueues,
                       unsigned int* rangeFlag, bool hiOnly, hipStream_t stream)
 {
+    if constexpr (MODE == VSR_BMODE_NK && BN >= 64) {
+        static const bool useV6 = [] { const char* e = getenv("VSR_F16_KERNEL"); return !(e && atoi(e) == 5); }();
+        static const int st6 = [] { const char* e = getenv("VSR_V6_STAGES"); int x = e ? atoi(e) : 0; return (x < 2 || x > 4) ? 3 : x; }();
+        if (hiOnly && useV6) {
+            if (st6 == 2) { launch_v6_st<BM, BN, WM, WN, 2>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, stream); return; }
+            if constexpr ((BM + BN) * 128 * 4 <= 150 * 1024) {
+                if (st6 == 4) { launch_v6_st<BM, BN, WM, WN, 4>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, stream); return; }
+            }
+            launch_v6_st<BM, BN, WM, WN, 3>(d_probs, nprobs, totalBlocks, queue, nQueues, rangeFlag, stream);
+            return;
+        }
+    }
     // VSR_V5_STAGES = 2..4 overrides the buffer count of the 128-row NK tiles (A/B runs)
     static const int over = [] { const char* e = getenv("VSR_V5_STAGES"); int x = e ? atoi(e) : 0; return (x < 2 || x > 4) ? 0 : x; }();
     if constexpr (MODE == VSR_BMODE_NK && BM == 128) {
