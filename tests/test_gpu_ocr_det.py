@@ -91,3 +91,27 @@ def test_graph_replay_equals_eager(built_lib, gpu_device, fixture):
         assert torch.equal(eager, replay)
     assert len(r._graphs) == 2
     r.close()
+
+
+@pytest.mark.parametrize("fixture,H,W", [("ppocr_det_fast_graph.json", 160, 224), ("ppocr_det_graph.json", 544, 960)])
+def test_recorded_launch_list_replay(built_lib, gpu_device, fixture, H, W):
+    """run_taped: the second pass for an input shape records every launch, later passes replay the list -- bit-identical to the
+    op-by-op walk, on fresh inputs, also after another shape was recorded in between (544x960 is the 1080p net input at which
+    the HIP-graph replay of round 1 faulted)."""
+    g = load_graph(os.path.join(GOLD, fixture))
+    r = ocr_det.PaddleGraphRunner(g, synthetic_weights(g), device=0)
+    rng = np.random.default_rng(17)
+    xs = [torch.from_numpy(rng.standard_normal((1, 3, H, W)).astype(np.float32)).to(gpu_device) for _ in range(3)]
+    small = torch.from_numpy(rng.standard_normal((1, 3, 96, 160)).astype(np.float32)).to(gpu_device)
+    want = [r.run(x).clone() for x in xs]
+    got0 = r.run_taped(xs[0]).clone()                     # records
+    r.run_taped(small)                                    # another shape in between
+    got1 = r.run_taped(xs[1]).clone()                     # replays
+    r.run_taped(small)
+    got2 = r.run_taped(xs[2]).clone()
+    got0b = r.run_taped(xs[0]).clone()
+    torch.cuda.synchronize()
+    assert len(r._tapes[tuple(xs[0].shape)][0]) > 100
+    for a, b in zip((got0, got1, got2, got0b), (want[0], want[1], want[2], want[0])):
+        assert torch.equal(a, b)
+    r.close()

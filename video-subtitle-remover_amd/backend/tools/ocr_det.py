@@ -151,8 +151,49 @@ class PaddleGraphRunner:
         self._graphs = {}                     # input shape -> (captured graph, static input, static output)
         self._gemm = {}                       # (conv op index, input shape) -> resident plan, tables, buffers
         self.use_gemm = os.environ.get("VSR_DET_GEMM", "1") != "0"
+        self._sa = C.c_void_p(0)              # the stream argument every launch shares (set per run / replay)
+        self._tape = None                     # launches being recorded: [(C function, argument tuple)]
+        self._tapes = {}                      # input shape -> (tape, static input, output, tensors kept alive)
+
+    def _call(self, fn, *args):
+        """one launcher call; recorded when a tape is open"""
+        check(fn(*args))
+        if self._tape is not None:
+            self._tape.append((fn, args))
+
+    def run_taped(self, x):
+        """run() replayed from a recorded launch list.  The forward is 300-450 launches and, walked op by op in Python (shape
+        logic, allocations, ctypes marshalling), host-bound; every launch of a fixed input shape has fixed arguments, so the
+        second pass for a shape records (C function, arguments) with all intermediates kept alive and later passes only copy the
+        input into the recorded input buffer and issue the recorded calls.  Unlike the HIP-graph replay (run_graphed) nothing is
+        captured by the driver: the same launches, on the caller's current stream.  The returned tensor is the recorded output
+        buffer: valid until the next call for that shape."""
+        key = tuple(x.shape)
+        st = self._tapes.get(key)
+        if st is None:
+            with torch.cuda.device(self.device):
+                self.run(x)                                     # creates the resident GEMM plans of this shape
+                sx = x.clone()
+                self._tape, self._keep = [], []
+                try:
+                    out = self.run(sx)
+                    st = (self._tape, sx, out, self._keep)
+                finally:
+                    self._tape, self._keep = None, None
+            self._tapes[key] = st
+            return out
+        tape, sx, out, _ = st
+        with torch.cuda.device(self.device):
+            sx.copy_(x)
+            self._sa.value = torch.cuda.current_stream().cuda_stream
+            for fn, args in tape:
+                rc = fn(*args)
+                if rc != 0:
+                    check(rc)
+        return out
 
     def close(self):
+        self._tapes.clear()
         self._graphs.clear()                  # captured graphs reference the plans' buffers: drop them first
         for st in self._gemm.values():
             lib.vsr_gemm_plan_destroy(st["plan"])
@@ -211,8 +252,8 @@ class PaddleGraphRunner:
             st["plan"] = plan
             self._gemm[key] = st
         lay = st["lay"]
-        check(lib.vsr_det_launch_nchw_to_nhwc(_p(xin), cin, h, wd, pt, pl, lay["hp"], lay["wp"], lay["cp"], _p(st["a"]), _stream()))
-        check(lib.vsr_gemm_plan_run(st["plan"], _stream()))
+        self._call(lib.vsr_det_launch_nchw_to_nhwc, _p(xin), cin, h, wd, pt, pl, lay["hp"], lay["wp"], lay["cp"], _p(st["a"]), self._sa)
+        self._call(lib.vsr_gemm_plan_run, st["plan"], self._sa)
         affine, act = self._fuse.get(i, (None, None))
         scale = shift = None
         if affine is not None and affine[0] == "bn":
@@ -225,8 +266,8 @@ class PaddleGraphRunner:
             else:
                 scale = self._ones(lay["N"])
         out = self._new(1, lay["N"], ho, wo)
-        check(lib.vsr_det_launch_nhwc_to_nchw(_p(st["c"]), lay["N"], lay["M"], lay["ncs"], _p(scale), _p(shift), act[1] if act is not None else 0,
-                                              _p(out), _stream()))
+        self._call(lib.vsr_det_launch_nhwc_to_nchw, _p(st["c"]), lay["N"], lay["M"], lay["ncs"], _p(scale), _p(shift), act[1] if act is not None else 0,
+                                              _p(out), self._sa)
         return out, [j for j in (affine[1] if affine is not None else None, act[0] if act is not None else None) if j is not None]
 
     def _ones(self, n):
@@ -253,12 +294,15 @@ class PaddleGraphRunner:
         else:
             raise NotImplementedError(f"broadcast {tuple(a.shape)} with {tuple(b.shape)}")
         out = self._new(*a.shape)
-        check(lib.vsr_det_launch_binary(_p(a), _p(b.contiguous()), op, a.numel(), c, hw, mode, _p(out), _stream()))
+        b = b.contiguous()
+        if self._tape is not None:
+            self._keep.append(b)
+        self._call(lib.vsr_det_launch_binary, _p(a), _p(b), op, a.numel(), c, hw, mode, _p(out), self._sa)
         return out
 
     def _unary(self, x, kind, p0=0.0, p1=0.0):
         out = self._new(*x.shape)
-        check(lib.vsr_det_launch_unary(_p(x), x.numel(), kind, C.c_float(p0), C.c_float(p1), _p(out), _stream()))
+        self._call(lib.vsr_det_launch_unary, _p(x), x.numel(), kind, C.c_float(p0), C.c_float(p1), _p(out), self._sa)
         return out
 
     def run(self, x):
@@ -267,6 +311,9 @@ class PaddleGraphRunner:
         val = dict(self.params)
         val[self.graph.input_id] = x
         folded = {}
+        self._sa.value = torch.cuda.current_stream().cuda_stream
+        if self._tape is not None:
+            self._keep.append(val)                              # a recorded pass keeps every intermediate alive
         with torch.cuda.device(self.device):
             for i, (kind, ins, outs, a) in enumerate(self.graph.ops):
                 g = lambda j: val[ins[j]]
@@ -293,7 +340,7 @@ class PaddleGraphRunner:
                         val[outs[0]] = out
                         continue
                     out = self._new(n, cout, ho, wo)
-                    check(lib.vsr_det_launch_conv2d(_p(xin), _p(w), None, n, cin, h, wd, cout, kh, kw, sh, sw, pt, pl, ho, wo, dw, 0, _p(out), _stream()))
+                    self._call(lib.vsr_det_launch_conv2d, _p(xin), _p(w), None, n, cin, h, wd, cout, kh, kw, sh, sw, pt, pl, ho, wo, dw, 0, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "conv2d_transpose":
                     xin, w = g(0).contiguous(), g(1)
@@ -303,13 +350,13 @@ class PaddleGraphRunner:
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
                     cout = cin if dw else w.shape[1]
                     out = self._new(n, cout, 2 * h, 2 * wd)
-                    check(lib.vsr_det_launch_deconv2x2(_p(xin), _p(w), n, cin, h, wd, cout, dw, _p(out), _stream()))
+                    self._call(lib.vsr_det_launch_deconv2x2, _p(xin), _p(w), n, cin, h, wd, cout, dw, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "batch_norm_":
                     xin = g(0).contiguous()
                     s, t = self.bn[i]
                     out = self._new(*xin.shape)
-                    check(lib.vsr_det_launch_affine(_p(xin), _p(s), _p(t), xin.numel(), xin.shape[1], xin.shape[2] * xin.shape[3], _p(out), _stream()))
+                    self._call(lib.vsr_det_launch_affine, _p(xin), _p(s), _p(t), xin.numel(), xin.shape[1], xin.shape[2] * xin.shape[3], _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "full_int_array":
                     val[outs[0]] = [int(v) for v in a["value"]]
@@ -340,7 +387,7 @@ class PaddleGraphRunner:
                         if list(ks) != [1, 1] or a["pooling_type"] != "avg":
                             raise NotImplementedError("adaptive pool other than global average")
                         out = self._new(n, c, 1, 1)
-                        check(lib.vsr_det_launch_gap(_p(xin), n * c, h * wd, _p(out), _stream()))
+                        self._call(lib.vsr_det_launch_gap, _p(xin), n * c, h * wd, _p(out), self._sa)
                     else:
                         if a["pooling_type"] != "max":
                             raise NotImplementedError("average pool")
@@ -353,7 +400,7 @@ class PaddleGraphRunner:
                         else:
                             ho, wo = (h + 2 * pt - ks[0]) // sh + 1, (wd + 2 * pl - ks[1]) // sw + 1
                         out = self._new(n, c, ho, wo)
-                        check(lib.vsr_det_launch_maxpool(_p(xin), n * c, h, wd, ks[0], ks[1], sh, sw, pt, pl, ho, wo, _p(out), _stream()))
+                        self._call(lib.vsr_det_launch_maxpool, _p(xin), n * c, h, wd, ks[0], ks[1], sh, sw, pt, pl, ho, wo, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "nearest_interp":
                     xin = g(0).contiguous()
@@ -362,12 +409,23 @@ class PaddleGraphRunner:
                     if a["scale"][0] != a["scale"][1] or s != a["scale"][0]:
                         raise NotImplementedError("non-integer nearest_interp scale")
                     out = self._new(n, c, h * s, wd * s)
-                    check(lib.vsr_det_launch_nearest(_p(xin), n * c, h, wd, s, _p(out), _stream()))
+                    self._call(lib.vsr_det_launch_nearest, _p(xin), n * c, h, wd, s, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "combine":
                     val[outs[0]] = [val[j] for j in ins]
                 elif kind == "concat":
-                    val[outs[0]] = torch.cat(g(0), dim=int(g(1)))           # pure data movement
+                    parts, dim = g(0), int(g(1))
+                    if dim == 1 and all(t.shape[0] == 1 and t.is_contiguous() for t in parts):    # channel planes of one image: block copies
+                        out = self._new(1, sum(t.shape[1] for t in parts), *parts[0].shape[2:])
+                        at = 0
+                        for t in parts:
+                            self._call(lib.vsr_det_launch_copy, _p(t), C.c_void_p(out.data_ptr() + at * 4), t.numel() * 4, self._sa)
+                            at += t.numel()
+                        val[outs[0]] = out
+                    else:
+                        if self._tape is not None:
+                            raise NotImplementedError("recorded replay of a concat that is not a channel concat of single images")
+                        val[outs[0]] = torch.cat(parts, dim=dim)            # pure data movement
                 else:
                     raise NotImplementedError(f"detector op {kind}")
         return val[self.graph.output_id]
@@ -515,6 +573,8 @@ class TextDetection:
         # VSR_DET_GRAPH=1 replays the forward from a captured HIP graph.  OFF by default: the first capture attempt on the MI355X
         # ended in a GPU memory access fault at replay and has not been debugged yet.
         self.use_graph = os.environ.get("VSR_DET_GRAPH", "0") == "1"
+        # VSR_DET_TAPE=0 walks the program op by op on every frame (the recorded launch list is the default, see run_taped)
+        self.use_tape = os.environ.get("VSR_DET_TAPE", "1") != "0"
         self.device = self.runner.device
         self._tables = {}
 
@@ -542,7 +602,7 @@ class TextDetection:
             small = self._resize(d, H, W, rh, rw)
             x = torch.empty((1, 3, rh, rw), dtype=torch.float32, device=self.device)
             check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x), _stream()))
-            prob = self.runner.run_graphed(x) if self.use_graph else self.runner.run(x)
+            prob = self.runner.run_graphed(x) if self.use_graph else (self.runner.run_taped(x) if self.use_tape else self.runner.run(x))
         return prob[0, 0], rh, rw
 
     def predict(self, img):

@@ -345,6 +345,14 @@ int vsr_det_launch_nhwc_to_nchw(const float* in, int C, int64_t P, int Np, const
     DONE();
 }
 
+// channel concat of single images = block copies (recorded like any other launch of the forward)
+int vsr_det_launch_copy(const void* src, void* dst, int64_t nbytes, void* stream)
+{
+    if (!src || !dst || nbytes < 0) return VSR_ERR_ARG;
+    if (nbytes == 0) return 0;
+    return hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
 int vsr_det_launch_normalize(const uint8_t* img, int H, int W, float* out, void* stream)
 {
     const int64_t total = (int64_t)H * W;
