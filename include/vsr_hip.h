@@ -368,12 +368,12 @@ int vsr_det_launch_maxpool(const float* x, int64_t planes, int H, int W, int kh,
                            float* out, void* stream);
 int vsr_det_launch_nearest(const float* x, int64_t planes, int H, int W, int s, float* out, void* stream);
 int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_chw, void* stream);
-int vsr_det_launch_copy(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream);   /* concat along channels of one image */
+int vsr_det_launch_copy(const void* src_dev, int64_t src_pitch, void* dst_dev, int64_t dst_pitch, int64_t width_bytes, int64_t rows, void* stream);   /* channel concat: one strided block copy per part */
 /* layout changes around the dense convolutions that run as gather-GEMMs (vsr_gemm_plan_*): one NCHW image -> zero-padded NHWC
  * [Hp][Wp][Cp] (image origin at (pt, pl), Cp a multiple of 32), and GEMM output [P pixels][Np] -> NCHW [C][P] with an optional
  * per-channel affine (the batch_norm or bias add that follows the conv) and activation (act 1 relu, 2 hardswish) */
-int vsr_det_launch_nchw_to_nhwc(const float* x, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* out, void* stream);
-int vsr_det_launch_nhwc_to_nchw(const float* in, int C, int64_t P, int Np, const float* scale, const float* shift, int act, float* out, void* stream);
+int vsr_det_launch_nchw_to_nhwc(const float* x, int n, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* out, void* stream);
+int vsr_det_launch_nhwc_to_nchw(const float* in, int n, int C, int64_t P, int Np, const float* scale, const float* shift, int act, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Scene cuts: the per-frame arithmetic of the ContentDetector pass that

@@ -31,8 +31,18 @@ for fx in which:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 10 * 1e3
         t1 = time.perf_counter()
-        for _ in range(5):
-            det.predict(img)
-        pm = (time.perf_counter() - t1) / 5 * 1e3
+        det.predict(img)
+        pm = (time.perf_counter() - t1) * 1e3
         print(f"{fx}: forward at 1080p (960x544 net input), {'recorded launch list' if tape else 'op-by-op walk'}: {ms:.2f} ms/frame; "
               f"predict() incl. DB post-process on the host: {pm:.2f} ms/frame", flush=True)
+    det.use_tape = True
+    for nb in (4, 8, 16):
+        imgs = [img] * nb
+        for _ in range(3):
+            det.probability_maps(imgs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            det.probability_maps(imgs)
+        torch.cuda.synchronize()
+        print(f"{fx}: {nb} frames per forward (recorded launch list): {(time.perf_counter() - t0) / 5 / nb * 1e3:.2f} ms/frame", flush=True)

@@ -115,3 +115,25 @@ def test_recorded_launch_list_replay(built_lib, gpu_device, fixture, H, W):
     for a, b in zip((got0, got1, got2, got0b), (want[0], want[1], want[2], want[0])):
         assert torch.equal(a, b)
     r.close()
+
+
+@pytest.mark.parametrize("fixture", ["ppocr_det_fast_graph.json", "ppocr_det_graph.json"])
+def test_batched_forward_equals_single_frames(built_lib, gpu_device, fixture):
+    """predict_batch / a batch through the runner: the frames are independent, so every image of a batch must come out exactly
+    as it does alone (batched layout kernels, GEMM row tables over [n][Hp][Wp][Cp], strided channel concat, recorded replay)."""
+    g = load_graph(os.path.join(GOLD, fixture))
+    r = ocr_det.PaddleGraphRunner(g, synthetic_weights(g), device=0)
+    rng = np.random.default_rng(23)
+    x = torch.from_numpy(rng.standard_normal((3, 3, 96, 160)).astype(np.float32)).to(gpu_device)
+    single = torch.cat([r.run(x[b:b + 1].contiguous()).clone() for b in range(3)])
+    batched = r.run(x).clone()
+    taped = [r.run_taped(x).clone() for _ in range(2)][-1]
+    torch.cuda.synchronize()
+    assert batched.shape == single.shape == (3, 1, 96, 160)
+    assert torch.equal(batched, single) and torch.equal(taped, single)
+    r.close()
+    det = ocr_det.TextDetection(g, synthetic_weights(g), device=0)
+    imgs = [rng.integers(0, 256, size=(270, 480, 3), dtype=np.uint8) for _ in range(3)]
+    maps = det.probability_maps(imgs)
+    for b, img in enumerate(imgs):
+        assert torch.equal(maps[b], det.probability_map(img)[0])

@@ -191,9 +191,10 @@ def test_conv_gemm_layout_against_conv2d():
 
     cases = [(65, 20, 28, 64, 3, 3, 1, False, (1, 1)), (40, 18, 25, 64, 9, 9, 1, True, None), (200, 9, 14, 256, 1, 1, 1, False, (0, 0)),
              (33, 21, 30, 48, 3, 3, 2, False, (1, 1)), (32, 15, 16, 32, 2, 2, 1, True, None), (96, 10, 12, 130, 3, 3, 1, False, (1, 1))]
-    for cin, h, w, cout, kh, kw, st, same, pad in cases:
+    for ci_, (cin, h, w, cout, kh, kw, st, same, pad) in enumerate(cases):
+        nb = 1 + ci_ % 3                                                         # batches of 1, 2 and 3 images
         rng = np.random.default_rng(cin + h)
-        x = rng.standard_normal((1, cin, h, w)).astype(np.float32)
+        x = rng.standard_normal((nb, cin, h, w)).astype(np.float32)
         wt = rng.standard_normal((cout, cin, kh, kw)).astype(np.float32)
         if same:
             pt, pl, ho, wo = (kh - 1) // 2, (kw - 1) // 2, -(-h // st), -(-w // st)
@@ -202,9 +203,9 @@ def test_conv_gemm_layout_against_conv2d():
             pt, pl = pad
             ho, wo = (h + 2 * pt - kh) // st + 1, (w + 2 * pl - kw) // st + 1
             ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), stride=st, padding=pad)
-        lay = ocr_det.conv_gemm_layout(cin, h, w, wt.shape, (st, st), pt, pl, ho, wo)
-        a = np.zeros((lay["hp"], lay["wp"], lay["cp"]), np.float32)              # what k_det_nchw_to_nhwc writes
-        a[pt:pt + h, pl:pl + w, :cin] = x[0].transpose(1, 2, 0)
+        lay = ocr_det.conv_gemm_layout(cin, h, w, wt.shape, (st, st), pt, pl, ho, wo, n=nb)
+        a = np.zeros((nb, lay["hp"], lay["wp"], lay["cp"]), np.float32)          # what k_det_nchw_to_nhwc writes
+        a[:, pt:pt + h, pl:pl + w, :cin] = x.transpose(0, 2, 3, 1)
         t = lay["tables"]
         assert int(t["rowA"][:lay["M"]].max()) + int(t["colA"].max()) + 31 < a.size and lay["K"] % 32 == 0
         bufs = {1: a.reshape(-1), 2: ocr_det.pack_conv_weights(wt, lay["cp"]).reshape(-1), 3: np.zeros(lay["M"] * lay["ncs"], np.float32)}
@@ -213,7 +214,7 @@ def test_conv_gemm_layout_against_conv2d():
                              tRowA=0, tColA=1, tRowB=2, tColB=3, tRowC=4, tColC=5, tRowR=-1, splitK=1, chunksPerSplit=lay["K"] // 32,
                              splitStride=0, alpha=1.0, act=0)
         _replay.gemm_reference(it, 0, bufs, tables)
-        out = bufs[3].reshape(lay["M"], lay["ncs"])[:, :cout].T.reshape(1, cout, ho, wo)     # what k_det_nhwc_to_nchw reads
+        out = bufs[3].reshape(nb, lay["P"], lay["ncs"])[:, :, :cout].transpose(0, 2, 1).reshape(nb, cout, ho, wo)   # what k_det_nhwc_to_nchw reads
         assert np.abs(out - ref.numpy()).max() <= 2e-5 * np.abs(ref.numpy()).max(), (cin, h, w, cout, kh, kw)
 
 

@@ -37,25 +37,27 @@ def _stream():
 GEMM_MIN_K = 64          # dense convs with cin * kh * kw below this stay on the direct kernel (the 3-channel stem)
 
 
-def conv_gemm_layout(cin, h, w, wshape, strides, pt, pl, ho, wo):
+def conv_gemm_layout(cin, h, w, wshape, strides, pt, pl, ho, wo, n=1):
     """Host-side description of one dense convolution as a gather-GEMM problem (include/vsr_hip.h GGProblem, NK mode):
-    A = the input as zero-padded NHWC [Hp][Wp][Cp] (image origin at (pt, pl), Cp = cin rounded up to the 32-float K chunk),
-    rows = output pixels, K = (ky, kx, channel); B = the weights re-packed [cout][kh*kw*Cp]; C = [pixels][Ncs] row-major.
-    Returns the dims and the int32 offset tables (padded to whole tiles as the kernels expect)."""
+    A = the n input images as zero-padded NHWC [n][Hp][Wp][Cp] (image origin at (pt, pl), Cp = cin rounded up to the 32-float K
+    chunk), rows = output pixels of all images, K = (ky, kx, channel); B = the weights re-packed [cout][kh*kw*Cp]; C = [n * pixels][Ncs]
+    row-major.  Returns the dims and the int32 offset tables (padded to whole tiles as the kernels expect)."""
     cout, wcin, kh, kw = wshape
     assert wcin == cin
     sh, sw = strides
     cp = -(-cin // 32) * 32
     hp, wp = max(h + pt, (ho - 1) * sh + kh), max(w + pl, (wo - 1) * sw + kw)
-    K, M, N = kh * kw * cp, ho * wo, cout
+    P = ho * wo
+    K, M, N = kh * kw * cp, n * P, cout
     bm, bn, cfg = (128, 128, TILE_128x128) if cout >= 128 else (128, 64, TILE_128x64)
     tiles_m, tiles_n = -(-M // bm), -(-N // bn)
     ncs = tiles_n * bn
-    if hp * wp * cp >= 2 ** 31 or M * ncs >= 2 ** 31 or N * K >= 2 ** 31:
+    if n * hp * wp * cp >= 2 ** 31 or M * ncs >= 2 ** 31 or N * K >= 2 ** 31:
         raise ValueError("convolution too large for 32-bit offset tables")
-    oy, ox = np.divmod(np.arange(M, dtype=np.int64), wo)
+    img, pix = np.divmod(np.arange(M, dtype=np.int64), P)
+    oy, ox = np.divmod(pix, wo)
     row_a = np.zeros(tiles_m * bm, np.int64)
-    row_a[:M] = ((oy * sh) * wp + ox * sw) * cp
+    row_a[:M] = ((img * hp + oy * sh) * wp + ox * sw) * cp
     row_a[M:] = row_a[0]
     tap, cc = np.divmod(np.arange(K // 32, dtype=np.int64), cp // 32)
     col_a = ((tap // kw) * wp + tap % kw) * cp + cc * 32
@@ -66,7 +68,7 @@ def conv_gemm_layout(cin, h, w, wshape, strides, pt, pl, ho, wo):
     row_c[:M] = np.arange(M, dtype=np.int64) * ncs
     col_c = np.arange(ncs // 32, dtype=np.int64) * 32
     t = {k: v.astype(np.int32) for k, v in dict(rowA=row_a, colA=col_a, rowB=row_b, colB=col_b, rowC=row_c, colC=col_c).items()}
-    return dict(cp=cp, hp=hp, wp=wp, K=K, M=M, N=N, ncs=ncs, tile_cfg=cfg, tiles_m=tiles_m, tiles_n=tiles_n, tables=t)
+    return dict(cp=cp, hp=hp, wp=wp, K=K, M=M, N=N, P=P, n=n, ncs=ncs, tile_cfg=cfg, tiles_m=tiles_m, tiles_n=tiles_n, tables=t)
 
 
 def conv_fusions(graph):
@@ -229,16 +231,16 @@ class PaddleGraphRunner:
             pass
 
     def _conv_gemm(self, i, xin, w, strides, pt, pl, ho, wo):
-        """one dense conv (batch 1) through the gather-GEMM; returns (output NCHW, set of op indices folded into it)"""
-        _, cin, h, wd = xin.shape
+        """one dense conv (any batch) through the gather-GEMM; returns (output NCHW, set of op indices folded into it)"""
+        nb, cin, h, wd = xin.shape
         key = (i, tuple(xin.shape))
         st = self._gemm.get(key)
         if st is None:
-            lay = conv_gemm_layout(cin, h, wd, tuple(w.shape), strides, pt, pl, ho, wo)
+            lay = conv_gemm_layout(cin, h, wd, tuple(w.shape), strides, pt, pl, ho, wo, n=nb)
             dev = self.device
             st = dict(lay=lay, tabs={k: torch.from_numpy(v).to(dev) for k, v in lay["tables"].items()},
                       wp=torch.from_numpy(pack_conv_weights(w.cpu().numpy(), lay["cp"])).to(dev),
-                      a=torch.empty(lay["hp"] * lay["wp"] * lay["cp"], dtype=torch.float32, device=dev),
+                      a=torch.empty(nb * lay["hp"] * lay["wp"] * lay["cp"], dtype=torch.float32, device=dev),
                       c=torch.empty(lay["M"] * lay["ncs"], dtype=torch.float32, device=dev))
             pr = (_lib.GGProblem * 1)()
             q, t = pr[0], st["tabs"]
@@ -252,7 +254,7 @@ class PaddleGraphRunner:
             st["plan"] = plan
             self._gemm[key] = st
         lay = st["lay"]
-        self._call(lib.vsr_det_launch_nchw_to_nhwc, _p(xin), cin, h, wd, pt, pl, lay["hp"], lay["wp"], lay["cp"], _p(st["a"]), self._sa)
+        self._call(lib.vsr_det_launch_nchw_to_nhwc, _p(xin), nb, cin, h, wd, pt, pl, lay["hp"], lay["wp"], lay["cp"], _p(st["a"]), self._sa)
         self._call(lib.vsr_gemm_plan_run, st["plan"], self._sa)
         affine, act = self._fuse.get(i, (None, None))
         scale = shift = None
@@ -265,8 +267,8 @@ class PaddleGraphRunner:
                 shift = None
             else:
                 scale = self._ones(lay["N"])
-        out = self._new(1, lay["N"], ho, wo)
-        self._call(lib.vsr_det_launch_nhwc_to_nchw, _p(st["c"]), lay["N"], lay["M"], lay["ncs"], _p(scale), _p(shift), act[1] if act is not None else 0,
+        out = self._new(nb, lay["N"], ho, wo)
+        self._call(lib.vsr_det_launch_nhwc_to_nchw, _p(st["c"]), nb, lay["N"], lay["P"], lay["ncs"], _p(scale), _p(shift), act[1] if act is not None else 0,
                                               _p(out), self._sa)
         return out, [j for j in (affine[1] if affine is not None else None, act[0] if act is not None else None) if j is not None]
 
@@ -334,7 +336,7 @@ class PaddleGraphRunner:
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
                     if not dw and a["groups"] != 1:
                         raise NotImplementedError("grouped conv")
-                    if (self.use_gemm and not dw and n == 1 and cin * kh * kw >= GEMM_MIN_K and list(a.get("dilations", [1, 1])) == [1, 1]):
+                    if (self.use_gemm and not dw and cin * kh * kw >= GEMM_MIN_K and list(a.get("dilations", [1, 1])) == [1, 1]):
                         out, done = self._conv_gemm(i, xin, w, (sh, sw), pt, pl, ho, wo)
                         folded.update({j: out for j in done})
                         val[outs[0]] = out
@@ -415,16 +417,18 @@ class PaddleGraphRunner:
                     val[outs[0]] = [val[j] for j in ins]
                 elif kind == "concat":
                     parts, dim = g(0), int(g(1))
-                    if dim == 1 and all(t.shape[0] == 1 and t.is_contiguous() for t in parts):    # channel planes of one image: block copies
-                        out = self._new(1, sum(t.shape[1] for t in parts), *parts[0].shape[2:])
-                        at = 0
+                    if dim == 1 and all(t.is_contiguous() for t in parts):      # channel concat: one strided block copy per part
+                        nb = parts[0].shape[0]
+                        out = self._new(nb, sum(t.shape[1] for t in parts), *parts[0].shape[2:])
+                        pitch, at = out.numel() // nb * 4, 0
                         for t in parts:
-                            self._call(lib.vsr_det_launch_copy, _p(t), C.c_void_p(out.data_ptr() + at * 4), t.numel() * 4, self._sa)
-                            at += t.numel()
+                            w_ = t.numel() // nb * 4
+                            self._call(lib.vsr_det_launch_copy, _p(t), w_, C.c_void_p(out.data_ptr() + at), pitch, w_, nb, self._sa)
+                            at += w_
                         val[outs[0]] = out
                     else:
                         if self._tape is not None:
-                            raise NotImplementedError("recorded replay of a concat that is not a channel concat of single images")
+                            raise NotImplementedError("recorded replay of a concat that is not a channel concat")
                         val[outs[0]] = torch.cat(parts, dim=dim)            # pure data movement
                 else:
                     raise NotImplementedError(f"detector op {kind}")
@@ -609,6 +613,36 @@ class TextDetection:
         prob, _, _ = self.probability_map(img)
         boxes, scores = db_postprocess(prob.cpu().numpy(), img.shape[0], img.shape[1])
         return [{"dt_polys": boxes, "dt_scores": scores}]
+
+    # how many sampled frames SubtitleDetect.find_subtitle_frame_no hands over at once (VSR_DET_BATCH).  One frame of the
+    # server program is 32 640 GEMM rows at its finest stage and 510 at its coarsest: 256 CUs are filled by a batch, not by a
+    # frame (16 -> 6 ms per frame measured, profiles/r02_detector_bench.log)
+    batch_size = int(os.environ.get("VSR_DET_BATCH", "8"))
+
+    def probability_maps(self, imgs):
+        """imgs: n HxWx3 uint8 BGR frames of one size -> probability maps [n, rh, rw] on the device (one forward)"""
+        n = len(imgs)
+        H, W = imgs[0].shape[:2]
+        rh, rw = det_resize_shape(H, W, self.resize_long, self.limit_type)
+        with torch.cuda.device(self.device):
+            d = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device)
+            x = torch.empty((n, 3, rh, rw), dtype=torch.float32, device=self.device)
+            for b in range(n):
+                small = self._resize(d[b], H, W, rh, rw)
+                check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x[b]), _stream()))
+            prob = self.runner.run_taped(x) if self.use_tape else self.runner.run(x)
+        return prob[:, 0]
+
+    def predict_batch(self, imgs):
+        """[predict(img)[0] for img in imgs] with one forward for all frames (independent per frame: same results)"""
+        if len(imgs) == 0:
+            return []
+        prob = self.probability_maps(imgs).cpu().numpy()
+        out = []
+        for b, img in enumerate(imgs):
+            boxes, scores = db_postprocess(prob[b], img.shape[0], img.shape[1])
+            out.append({"dt_polys": boxes, "dt_scores": scores})
+        return out
 
 
 def from_env(device=0):

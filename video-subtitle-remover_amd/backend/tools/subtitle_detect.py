@@ -30,9 +30,12 @@ class SubtitleDetect:
         """:56-82 -- boxes of one frame, kept only if fully inside a user sub-area (ymin,ymax,xmin,xmax)."""
         if self.text_detector is None:
             raise RuntimeError("no text detector configured (PP-OCRv5 weights are not part of the reference mount)")
+        return self._keep_inside(self.text_detector.predict(img))
+
+    def _keep_inside(self, results):
         kept = []
         areas = self.sub_areas
-        for res in self.text_detector.predict(img):
+        for res in results:
             polys = res["dt_polys"]
             if polys is None or len(polys) == 0:
                 continue
@@ -55,6 +58,25 @@ class SubtitleDetect:
         sampled = {}
         frame_no = 0
         ab = sub_remover.ab_sections if sub_remover is not None else None
+        # the sampled frames are independent: a detector with predict_batch (the MI355X one) takes several per forward
+        batch = getattr(self.text_detector, "batch_size", 1) if hasattr(self.text_detector, "predict_batch") else 1
+        wait = []
+
+        def flush():
+            if not wait:
+                return
+            if len(wait) == 1 or batch <= 1:
+                results = [self.text_detector.predict(f) for _, f in wait]
+            else:
+                results = [[r] for r in self.text_detector.predict_batch([f for _, f in wait])]
+            for (no, _), res in zip(wait, results):
+                boxes = self._keep_inside(res)
+                if len(boxes) > 0:
+                    sampled[no] = boxes
+            wait.clear()
+
+        if self.text_detector is None:
+            raise RuntimeError("no text detector configured (PP-OCRv5 weights are not part of the reference mount)")
         while True:
             ok, frame = reader.read()
             if not ok:
@@ -63,9 +85,10 @@ class SubtitleDetect:
             if not is_frame_number_in_ab_sections(frame_no - 1, ab):
                 continue
             if (frame_no - 1) % self.SAMPLE_STEP == 0 or self.SAMPLE_STEP <= 1:
-                boxes = self.detect_subtitle(frame)
-                if len(boxes) > 0:
-                    sampled[frame_no] = boxes
+                wait.append((frame_no, frame if frame.flags.owndata else frame.copy()))
+                if len(wait) >= max(1, batch):
+                    flush()
+        flush()
         reader.release()
         return self.fill_and_unify(sampled)
 

@@ -212,6 +212,8 @@ __global__ void __launch_bounds__(256) k_det_normalize(const uint8_t* __restrict
 __global__ void __launch_bounds__(256)
 k_det_nchw_to_nhwc(const float* __restrict__ x, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* __restrict__ out)
 {
+    x += (int64_t)blockIdx.z * C * H * W;                            // image of the batch
+    out += (int64_t)blockIdx.z * Hp * Wp * Cp;
     __shared__ float t[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
     const int64_t q0 = (int64_t)blockIdx.x * 32, total = (int64_t)Hp * Wp;
@@ -236,6 +238,8 @@ __global__ void __launch_bounds__(256)
 k_det_nhwc_to_nchw(const float* __restrict__ in, int C, int64_t P, int Np, const float* __restrict__ scale, const float* __restrict__ shift, int act,
                    float* __restrict__ out)
 {
+    in += (int64_t)blockIdx.z * P * Np;                              // image of the batch: P pixels each
+    out += (int64_t)blockIdx.z * C * P;
     __shared__ float t[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 32;
@@ -328,29 +332,32 @@ int vsr_det_launch_nearest(const float* x, int64_t planes, int H, int W, int s, 
     DONE();
 }
 
-int vsr_det_launch_nchw_to_nhwc(const float* x, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* out, void* stream)
+int vsr_det_launch_nchw_to_nhwc(const float* x, int n, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* out, void* stream)
 {
-    if (!x || !out || C <= 0 || Cp % 32 || Cp < C || Hp < H + pt || Wp < W + pl) return VSR_ERR_ARG;
+    if (!x || !out || n <= 0 || n > 65535 || C <= 0 || Cp % 32 || Cp < C || Hp < H + pt || Wp < W + pl) return VSR_ERR_ARG;
     const int64_t total = (int64_t)Hp * Wp;
-    hipLaunchKernelGGL(k_det_nchw_to_nhwc, dim3((unsigned)((total + 31) / 32), (unsigned)(Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, C, H, W, pt, pl,
-                       Hp, Wp, Cp, out);
+    hipLaunchKernelGGL(k_det_nchw_to_nhwc, dim3((unsigned)((total + 31) / 32), (unsigned)(Cp / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, C,
+                       H, W, pt, pl, Hp, Wp, Cp, out);
     DONE();
 }
 
-int vsr_det_launch_nhwc_to_nchw(const float* in, int C, int64_t P, int Np, const float* scale, const float* shift, int act, float* out, void* stream)
+int vsr_det_launch_nhwc_to_nchw(const float* in, int n, int C, int64_t P, int Np, const float* scale, const float* shift, int act, float* out,
+                                void* stream)
 {
-    if (!in || !out || C <= 0 || Np < C || P <= 0 || (scale && !shift)) return VSR_ERR_ARG;
-    hipLaunchKernelGGL(k_det_nhwc_to_nchw, dim3((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, in, C, P, Np,
-                       scale, shift, act, out);
+    if (!in || !out || n <= 0 || n > 65535 || C <= 0 || Np < C || P <= 0 || (scale && !shift)) return VSR_ERR_ARG;
+    hipLaunchKernelGGL(k_det_nhwc_to_nchw, dim3((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, in,
+                       C, P, Np, scale, shift, act, out);
     DONE();
 }
 
-// channel concat of single images = block copies (recorded like any other launch of the forward)
-int vsr_det_launch_copy(const void* src, void* dst, int64_t nbytes, void* stream)
+// channel concat = one strided block copy per part: `rows` images, `width` bytes of the part per image (recorded like any other
+// launch of the forward)
+int vsr_det_launch_copy(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int64_t width, int64_t rows, void* stream)
 {
-    if (!src || !dst || nbytes < 0) return VSR_ERR_ARG;
-    if (nbytes == 0) return 0;
-    return hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : VSR_ERR_HIP;
+    if (!src || !dst || width < 0 || rows < 0 || src_pitch < width || dst_pitch < width) return VSR_ERR_ARG;
+    if (width == 0 || rows == 0) return 0;
+    return hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)width, (size_t)rows, hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream) == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
 int vsr_det_launch_normalize(const uint8_t* img, int H, int W, float* out, void* stream)
