@@ -368,6 +368,11 @@ int vsr_det_launch_maxpool(const float* x, int64_t planes, int H, int W, int kh,
                            float* out, void* stream);
 int vsr_det_launch_nearest(const float* x, int64_t planes, int H, int W, int s, float* out, void* stream);
 int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_chw, void* stream);
+/* DBPostProcess, device part (paddleocr DBPostProcess.boxes_from_bitmap on `prob > thresh`): 8-connected components by union-find;
+ * labels int32 [H*W] (label = raster index of the component's first pixel, -1 = background), stats int32 [5*H*W] scratch, comps
+ * int32 [cap][6] = (label, area, xmin, xmax, ymin, ymax) unordered, *count = components found (may exceed cap) */
+int vsr_det_launch_ccl(const float* prob_dev, int H, int W, float thresh, int32_t* labels_dev, int32_t* stats_dev, int32_t* comps_dev, int cap,
+                       int32_t* count_dev, void* stream);
 int vsr_det_launch_copy(const void* src_dev, int64_t src_pitch, void* dst_dev, int64_t dst_pitch, int64_t width_bytes, int64_t rows, void* stream);   /* channel concat: one strided block copy per part */
 /* layout changes around the dense convolutions that run as gather-GEMMs (vsr_gemm_plan_*): one NCHW image -> zero-padded NHWC
  * [Hp][Wp][Cp] (image origin at (pt, pl), Cp a multiple of 32), and GEMM output [P pixels][Np] -> NCHW [C][P] with an optional

@@ -137,3 +137,56 @@ def test_batched_forward_equals_single_frames(built_lib, gpu_device, fixture):
     maps = det.probability_maps(imgs)
     for b, img in enumerate(imgs):
         assert torch.equal(maps[b], det.probability_map(img)[0])
+
+
+def _blob_map(seed, H, W, nboxes):
+    """probability map with rotated text-like boxes, touching pairs, specks and diagonal (8-connected only) links"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    prob = rng.random((H, W)).astype(np.float32) * 0.25
+    for _ in range(nboxes):
+        cy, cx = rng.uniform(10, H - 10), rng.uniform(30, W - 30)
+        hw, hh, th = rng.uniform(8, 120), rng.uniform(3, 14), rng.uniform(-0.3, 0.3)
+        u, v = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th), -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        inside = (np.abs(u) <= hw) & (np.abs(v) <= hh)
+        prob[inside] = np.maximum(prob[inside], rng.uniform(0.55, 0.95))
+    for k in range(40):                                   # staircases: pixels that touch only diagonally
+        y, x = int(rng.integers(2, H - 12)), int(rng.integers(2, W - 12))
+        for j in range(8):
+            prob[y + j, x + j] = 0.9
+    return prob
+
+
+@pytest.mark.parametrize("seed,H,W,nboxes", [(1, 544, 960, 6), (2, 544, 960, 60), (3, 96, 160, 3), (4, 544, 960, 0)])
+def test_device_db_postprocess_equals_host(built_lib, gpu_device, seed, H, W, nboxes):
+    """threshold + 8-connected union-find labelling + component boxes on the GPU, polygon work on the crops: the boxes and scores
+    of DBPostProcess must equal the all-host version (scipy labelling of the downloaded map) exactly"""
+    prob = _blob_map(seed, H, W, nboxes)
+    want_b, want_s = ocr_det.db_postprocess(prob, 1080, 1920)
+    post = ocr_det.DeviceDBPostProcess(gpu_device)
+    got_b, got_s = post(torch.from_numpy(prob).to(gpu_device), 1080, 1920)
+    assert got_b.shape == want_b.shape and np.array_equal(got_b, want_b)
+    assert np.allclose(got_s, want_s, rtol=0, atol=1e-7)
+    if nboxes:
+        assert len(want_s) >= 1
+    # the labelling itself: same partition as scipy's, labels = raster index of the first pixel
+    import scipy.ndimage
+
+    ref, n = scipy.ndimage.label(prob > 0.3, structure=np.ones((3, 3), dtype=int))
+    labels = post._work[(H, W)][0].view(H, W).cpu().numpy()
+    assert ((labels >= 0) == (ref > 0)).all()
+    first = {}
+    flat_ref, flat_lab = ref.reshape(-1), labels.reshape(-1)
+    idx = np.nonzero(flat_ref)[0]
+    firsts = np.full(n + 1, -1, np.int64)
+    for i in idx[::-1]:
+        firsts[flat_ref[i]] = i
+    assert np.array_equal(flat_lab[idx], firsts[flat_ref[idx]])
+
+
+def test_device_db_postprocess_overflow_falls_back(built_lib, gpu_device):
+    """a noise map has more components than the device list holds: the host labels the downloaded map, same result"""
+    prob = np.random.default_rng(9).random((256, 384)).astype(np.float32)
+    want_b, want_s = ocr_det.db_postprocess(prob, 512, 768)
+    got_b, got_s = ocr_det.DeviceDBPostProcess(gpu_device, cap=64)(torch.from_numpy(prob).to(gpu_device), 512, 768)
+    assert np.array_equal(got_b, want_b) and np.allclose(got_s, want_s)

@@ -261,6 +261,84 @@ k_det_nhwc_to_nchw(const float* __restrict__ in, int C, int64_t P, int Np, const
     }
 }
 
+// ---- DBPostProcess, device part (inference.yml PostProcess; paddleocr DBPostProcess.boxes_from_bitmap): bitmap = prob > thresh,
+// 8-connected components (what cv2.findContours' outer contours enclose), per-component area and bounding box.  Union-find
+// labelling (one merge pass over the four forward neighbours with atomicMin on the parent links, then path flattening): the
+// label of a component is the raster index of its first pixel, which is also the order scipy.ndimage.label / findContours visit.
+__device__ __forceinline__ int ccl_find(volatile int* L, int i)
+{
+    int p = L[i];
+    while (p != i) { i = p; p = L[i]; }
+    return i;
+}
+
+__device__ __forceinline__ void ccl_unite(int* L, int a, int b)
+{
+    for (;;) {
+        a = ccl_find(L, a);
+        b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }          // a > b: hang a under b
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;                                               // somebody moved a meanwhile: unite its new parent with b
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ccl_init(const float* __restrict__ prob, float thresh, int64_t total, int* __restrict__ L, int* __restrict__ st)
+{
+    GRID_STRIDE(i, total) {
+        L[i] = prob[i] > thresh ? (int)i : -1;
+        st[i * 5 + 0] = 0;                                     // area
+        st[i * 5 + 1] = 0x7fffffff; st[i * 5 + 2] = -1;        // x min / max
+        st[i * 5 + 3] = 0x7fffffff; st[i * 5 + 4] = -1;        // y min / max
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ccl_merge(int H, int W, int* __restrict__ L)
+{
+    const int64_t total = (int64_t)H * W;
+    GRID_STRIDE(i, total) {
+        if (L[i] < 0) continue;
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        if (x + 1 < W && L[i + 1] >= 0) ccl_unite(L, (int)i, (int)i + 1);
+        if (y + 1 < H) {
+            const int64_t d = i + W;
+            if (x > 0 && L[d - 1] >= 0) ccl_unite(L, (int)i, (int)(d - 1));
+            if (L[d] >= 0) ccl_unite(L, (int)i, (int)d);
+            if (x + 1 < W && L[d + 1] >= 0) ccl_unite(L, (int)i, (int)(d + 1));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ccl_flatten_stats(int H, int W, int* __restrict__ L, int* __restrict__ st)
+{
+    const int64_t total = (int64_t)H * W;
+    GRID_STRIDE(i, total) {
+        if (L[i] < 0) continue;
+        const int r = ccl_find(L, (int)i);
+        L[i] = r;                                              // roots keep L[r] == r: concurrent finds stay correct
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        atomicAdd(&st[(int64_t)r * 5 + 0], 1);
+        atomicMin(&st[(int64_t)r * 5 + 1], x); atomicMax(&st[(int64_t)r * 5 + 2], x);
+        atomicMin(&st[(int64_t)r * 5 + 3], y); atomicMax(&st[(int64_t)r * 5 + 4], y);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ccl_compact(int64_t total, const int* __restrict__ L, const int* __restrict__ st, int* __restrict__ comps, int cap,
+                                                     int* __restrict__ count)
+{
+    GRID_STRIDE(i, total) {
+        if (L[i] != (int)i) continue;
+        const int k = atomicAdd(count, 1);
+        if (k < cap) {
+            comps[k * 6 + 0] = (int)i;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) comps[k * 6 + 1 + j] = st[i * 5 + j];
+        }
+    }
+}
+
 extern "C" {
 
 int vsr_det_launch_conv2d(const float* x, const float* w, const float* bias, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
@@ -347,6 +425,22 @@ int vsr_det_launch_nhwc_to_nchw(const float* in, int n, int C, int64_t P, int Np
     if (!in || !out || n <= 0 || n > 65535 || C <= 0 || Np < C || P <= 0 || (scale && !shift)) return VSR_ERR_ARG;
     hipLaunchKernelGGL(k_det_nhwc_to_nchw, dim3((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, in,
                        C, P, Np, scale, shift, act, out);
+    DONE();
+}
+
+// labels int32 [H*W] (component = raster index of its first pixel, -1 background), stats int32 [H*W*5] scratch, comps int32
+// [cap][6] = (label, area, xmin, xmax, ymin, ymax) in no particular order, count = number of components found (may exceed cap)
+int vsr_det_launch_ccl(const float* prob, int H, int W, float thresh, int32_t* labels, int32_t* stats, int32_t* comps, int cap, int32_t* count,
+                       void* stream)
+{
+    const int64_t total = (int64_t)H * W;
+    if (!prob || !labels || !stats || !comps || !count || total <= 0 || total >= 0x7fffffff / 5 || cap <= 0) return VSR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(int32_t), s) != hipSuccess) return VSR_ERR_HIP;
+    hipLaunchKernelGGL(k_ccl_init, dim3(grid_for(total)), dim3(256), 0, s, prob, thresh, total, labels, stats);
+    hipLaunchKernelGGL(k_ccl_merge, dim3(grid_for(total)), dim3(256), 0, s, H, W, labels);
+    hipLaunchKernelGGL(k_ccl_flatten_stats, dim3(grid_for(total)), dim3(256), 0, s, H, W, labels, stats);
+    hipLaunchKernelGGL(k_ccl_compact, dim3(grid_for(total)), dim3(256), 0, s, total, labels, stats, comps, cap, count);
     DONE();
 }
 
