@@ -69,7 +69,8 @@ def ew_reference(info, bufs):
                 d[:, halo:halo + H, halo:halo + W] = s[:, halo:halo + H, halo:halo + W]
     elif k == EW_LAMA_OUT:
         B, H, W, Hp, Wp = ip[:5]
-        lg = bufs[ib[0]][: B * Hp * Wp * 3].reshape(B, Hp, Wp, 3)[:, :H, :W]
+        blk = bufs[ib[0]][: B * (Hp // 4) * (Wp // 4) * 64].reshape(B, Hp // 4, Wp // 4, 64)[..., :48].reshape(B, Hp // 4, Wp // 4, 4, 4, 3)
+        lg = blk.transpose(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, 3)[:, :H, :W]       # logits arrive as 4x4 pixel blocks
         img = bufs[ib[1]][: B * H * W * 3].reshape(B, H, W, 3).astype(np.float32) / np.float32(255)
         m = (bufs[ib[2]][: B * H * W].reshape(B, H, W, 1) > 0).astype(np.float32)
         p = torch.sigmoid(torch.from_numpy(np.ascontiguousarray(lg))).numpy()

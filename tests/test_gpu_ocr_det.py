@@ -167,7 +167,7 @@ def test_device_db_postprocess_equals_host(built_lib, gpu_device, seed, H, W, nb
     got_b, got_s = post(torch.from_numpy(prob).to(gpu_device), 1080, 1920)
     assert got_b.shape == want_b.shape and np.array_equal(got_b, want_b)
     assert np.allclose(got_s, want_s, rtol=0, atol=1e-7)
-    if nboxes:
+    if nboxes >= 6:
         assert len(want_s) >= 1
     # the labelling itself: same partition as scipy's, labels = raster index of the first pixel
     import scipy.ndimage

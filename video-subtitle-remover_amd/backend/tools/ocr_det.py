@@ -548,8 +548,8 @@ def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidate
 class DeviceDBPostProcess:
     """DBPostProcess with the bitmap work on the GPU: threshold, 8-connected labelling (union-find) and per-component area /
     bounding box run as kernels on the probability map where the forward left it (vsr_det_launch_ccl); the host receives the
-    component list (a few dozen integers for a subtitle frame) and, per component, the crop of the label and probability maps
-    its box needs -- the polygon work (hull, minimum-area rectangle, box score, unclip) stays numpy on those crops.  Same results
+    component list (a few dozen integers for a subtitle frame) and the rows of the label and probability maps the components
+    span -- the polygon work (hull, minimum-area rectangle, box score, unclip) stays numpy on crops of those.  Same results
     as db_postprocess on the downloaded map (components are visited in raster order of their first pixel on both sides)."""
 
     def __init__(self, device, cap=4096):
@@ -578,15 +578,14 @@ class DeviceDBPostProcess:
                 return db_postprocess(prob_dev.cpu().numpy(), src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
             lst = comps[: n * 6].cpu().numpy().reshape(n, 6)
             lst = lst[np.argsort(lst[:, 0])][:max_candidates]                        # raster order of the first pixel = scipy's label order
-            lab2d = labels.view(H, W)
-            crop_area = int(((lst[:, 3] - lst[:, 2] + 3) * (lst[:, 5] - lst[:, 4] + 3)).sum())
-            if crop_area * 2 > H * W:        # crops would move more than the maps themselves
-                lab_h, prob_h = lab2d.cpu().numpy(), prob_dev.cpu().numpy()
-                get_lab = lambda ya, yb, xa, xb: lab_h[ya:yb, xa:xb]
-                get_prob = lambda ya, yb, xa, xb: (prob_h[ya:yb, xa:xb], (ya, xa))
-            else:
-                get_lab = lambda ya, yb, xa, xb: lab2d[ya:yb, xa:xb].cpu().numpy()
-                get_prob = lambda ya, yb, xa, xb: (prob_dev[ya:yb, xa:xb].cpu().numpy(), (ya, xa))
+            # one download of the rows the components span (every small device-to-host copy costs a synchronisation: per-component
+            # crops were slower than the all-host version); the host then only slices
+            ya0, yb0 = int(lst[:, 4].min()), int(lst[:, 5].max()) + 1
+            ya0, yb0 = max(0, ya0 - 2), min(H, yb0 + 2)
+            lab_h = labels.view(H, W)[ya0:yb0].cpu().numpy()
+            prob_h = prob_dev[ya0:yb0].cpu().numpy()
+            get_lab = lambda ya, yb, xa, xb: lab_h[ya - ya0:yb - ya0, xa:xb]
+            get_prob = lambda ya, yb, xa, xb: (prob_h[ya - ya0:yb - ya0, xa:xb], (ya, xa))
         boxes, scores = [], []
         for lab, _area, x0, x1, y0, y1 in lst.tolist():
             comp = get_lab(y0, y1 + 1, x0, x1 + 1) == lab

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void k_lama_out(const float* __restrict__ logi
         const int X = (int)(i % W), Y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
         const float m = mask[i] > 0 ? 1.f : 0.f;
         const float keep = 1.f - m;
-        const float* lg = logits + (((int64_t)b * Hp + Y) * Wp + X) * 3;
+        // logits of the 7x7 conv: [image][block row][block col][(dy, dx, c) of the 4 x 4 block, padded to 64]
+        const float* lg = logits + ((((int64_t)b * (Hp / 4) + (Y >> 2)) * (Wp / 4) + (X >> 2)) * 64) + (((Y & 3) * 4 + (X & 3)) * 3);
         for (int c = 0; c < 3; ++c) {
             const float p = 1.f / (1.f + expf(-lg[c]));
             const float im = (float)img[i * 3 + c] / 255.f;

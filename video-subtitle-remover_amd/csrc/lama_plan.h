@@ -28,7 +28,7 @@ enum LamaEw {
     EW_LAMA_IM2COL7 = 50,   // u8 image + mask -> pad to x8 (symmetric), /255, *(1-mask), cat mask, reflect pad 3, 7x7 im2col
     EW_LAMA_HALO = 51,      // fill the reflect halo of an NHWC activation from its interior (border pixels only)
     EW_LAMA_ADD_HALO = 52,  // dst = a + b on the interior, then dst's reflect halo (or none: zero halo kept)
-    EW_LAMA_OUT = 53        // sigmoid, mask blend with the image, clip(.*255) -> u8 truncation, crop
+    EW_LAMA_OUT = 53        // sigmoid (logits in 4x4-block layout), mask blend with the image, clip(.*255) -> u8 truncation, crop
 };
 
 enum LamaBuf {
@@ -37,6 +37,7 @@ enum LamaBuf {
 };
 
 constexpr int LAMA_CL = 128, LAMA_CG = 384, LAMA_C = 512, LAMA_CS = 192;   // local / global / total / spectral channels
+constexpr int LAMA_OUT_BLOCK = 4, LAMA_PRED_LD = 64;   // the last conv writes logits as [4x4 pixel blocks][(dy, dx, c) padded to 64]
 
 struct LamaFfcW {            // one FFC_BN_ACT of a residual block (ratio_gin = ratio_gout = 0.75)
     ConvW outL;              // [convl2l | convg2l]: 3x3, 512 -> 128, bn_l folded
@@ -57,7 +58,7 @@ public:
     ConvW down3;                          // model.4: [convl2l ; convl2g] 3x3 stride 2, 256 -> 512
     std::vector<LamaFfcW> ffc;            // 2 per residual block
     ConvW up[3][4];                       // transposed convs, one packed matrix per output phase (a, b) = (y & 1, x & 1)
-    ConvW last;                           // 7x7, 64 -> 3 (+ bias)
+    ConvW last;                           // 7x7, 64 -> 3 (+ bias) packed for 4 x 4 output blocks: [48][10 * 10 * 64]
     std::vector<float> packed;
 private:
     struct Raw { std::vector<float> v; std::vector<int64_t> shape; };
@@ -65,10 +66,6 @@ private:
     bool ready_ = false;
     const Raw* get(const std::string& key, std::string& err) const;
     bool bn_affine(const std::string& bn, int c, std::vector<float>& scale, std::vector<float>& shift, std::string& err) const;
-    // rows n of `w` ([cout][cin][k][k]) scaled by s[n]; input channels [ci0, ci0+cin) of the packed K axis of width cinTotal
-    bool pack_conv(ConvW& cw, const std::vector<std::pair<std::string, int>>& parts /* (key, ci0) */, int cout, int cinTotal, int k,
-                   const std::vector<float>& scale, const std::vector<float>& bias, const std::vector<int>* inPerm,
-                   const std::vector<int>* outPerm, std::string& err);
     bool pack_ffc(const std::string& p, LamaFfcW& f, std::string& err);
     bool pack_up(const std::string& key, const std::string& bn, int cin, int cout, ConvW out[4], std::string& err);
 };
