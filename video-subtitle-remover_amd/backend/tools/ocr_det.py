@@ -464,20 +464,18 @@ def min_area_rect(points):
     hull = _convex_hull(points)
     if len(hull) == 1:
         return np.repeat(hull, 4, axis=0), 0.0, 0.0
-    best = None
-    for i in range(len(hull)):
-        e = hull[(i + 1) % len(hull)] - hull[i]
-        nrm = np.hypot(*e)
-        if nrm == 0:
-            continue
-        u = e / nrm
-        v = np.array([-u[1], u[0]])
-        pu, pv = hull @ u, hull @ v
-        w, h = pu.max() - pu.min(), pv.max() - pv.min()
-        if best is None or w * h < best[0]:
-            c = [pu.min() * u + pv.min() * v, pu.max() * u + pv.min() * v, pu.max() * u + pv.max() * v, pu.min() * u + pv.max() * v]
-            best = (w * h, np.array(c), w, h)
-    return best[1], best[2], best[3]
+    # rotating calipers over all hull edges at once: project the hull on every edge direction u and its normal v
+    e = np.roll(hull, -1, axis=0) - hull
+    nrm = np.hypot(e[:, 0], e[:, 1])
+    e, nrm = e[nrm > 0], nrm[nrm > 0]
+    u = e / nrm[:, None]
+    v = np.stack([-u[:, 1], u[:, 0]], 1)
+    pu, pv = hull @ u.T, hull @ v.T                                   # [points, edges]
+    umin, umax, vmin, vmax = pu.min(0), pu.max(0), pv.min(0), pv.max(0)
+    w, h = umax - umin, vmax - vmin
+    i = int(np.argmin(w * h))                                         # first minimum, as a strict '<' scan finds it
+    c = [umin[i] * u[i] + vmin[i] * v[i], umax[i] * u[i] + vmin[i] * v[i], umax[i] * u[i] + vmax[i] * v[i], umin[i] * u[i] + vmax[i] * v[i]]
+    return np.array(c), float(w[i]), float(h[i])
 
 
 def _order_box(c):
@@ -505,9 +503,12 @@ def _box_score(prob, box):
 def _box_of_component(comp, y0, x0, prob_of, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size):
     """get_mini_boxes + box_score_fast + unclip + rescale for one component.  comp: bool mask of the component inside its bounding
     box whose top-left pixel is (y0, x0); prob_of(ya, yb, xa, xb) -> (probability crop, its origin).  -> (box int32 [4,2], score) or None"""
-    edge = comp & ~scipy.ndimage.binary_erosion(comp, structure=np.ones((3, 3), dtype=bool), border_value=0)
-    ys, xs = np.nonzero(edge)
-    pts = np.stack([xs + x0, ys + y0], 1)
+    # the minimum-area rectangle only depends on the convex hull, and the hull's vertices are among the leftmost / rightmost pixel
+    # of every row: a few dozen points instead of the whole contour (the pure-Python hull was the cost of the post-process)
+    rows = np.nonzero(comp.any(axis=1))[0]
+    sub = comp[rows]
+    xl, xr = sub.argmax(axis=1), comp.shape[1] - 1 - sub[:, ::-1].argmax(axis=1)
+    pts = np.concatenate([np.stack([xl + x0, rows + y0], 1), np.stack([xr + x0, rows + y0], 1)])
     corners, w, h = min_area_rect(pts)
     if min(w, h) < min_size:
         return None
