@@ -13,7 +13,7 @@
 #pragma once
 #include <type_traits>
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES GG_ABL_PARAM>
 __global__ void __launch_bounds__(256, (STAGES * (BM + BN) * 128 + 2 * BM * 4 <= 78 * 1024) ? 2 : 1)
 gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue, int nQueues,
                    unsigned int* __restrict__ rangeFlag)
@@ -45,27 +45,49 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
     for (int st = 0; st < 4; ++st) rd[st] = (((2 * st + hi) ^ ((l31 >> 1) & 7)) << 4);
 
+    // Tile queue (see gather_gemm_v5.h).  The home range's counter is bumped at the START of a tile and its answer is only looked
+    // at after the main loop (the round trip of the atomic hides behind the tile); once the home range is empty the workgroup
+    // steals, but PEEKS at a foreign counter with a plain load first -- at the tail of a launch every workgroup scans the other
+    // ranges, and hundreds of same-address atomics on exhausted counters serialise in L2 (tens of microseconds).
     int qFirst = 0;
-    auto fetchTile = [&]() -> int {
-        const int home = blockIdx.x % nQueues;
+    const int home = blockIdx.x % nQueues;
+    auto rangeOf = [&](int x, int& lo, int& hi_) {
+        lo = (int)(((long long)totalTiles * x) / nQueues);
+        hi_ = (int)(((long long)totalTiles * (x + 1)) / nQueues);
+    };
+    auto stealTile = [&]() -> int {
         for (; qFirst < nQueues; ++qFirst) {
             const int x = (home + qFirst) % nQueues;
-            const int lo = (int)(((long long)totalTiles * x) / nQueues), hi_ = (int)(((long long)totalTiles * (x + 1)) / nQueues);
-            if (lo < hi_) {
-                const int i = lo + (int)atomicAdd(queue + x, 1u);
-                if (i < hi_) return i;
-            }
+            int lo, hi_;
+            rangeOf(x, lo, hi_);
+            if (lo >= hi_) continue;
+            if (qFirst > 0 && (int)__hip_atomic_load(queue + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi_ - lo) continue;
+            const int i = lo + (int)atomicAdd(queue + x, 1u);
+            if (i < hi_) return i;
         }
         return totalTiles;
     };
-    if (tid == 0) *nextTile = fetchTile();
+    if (tid == 0) *nextTile = stealTile();
     __syncthreads();
 
+#ifdef GG_ABLATE
+    int tr_ = 0;                                     // 256: wall-clock stamps of wave 0 (100 MHz), 4 per tile
+#define V6_STAMP(drain)                                                                                        \
+    if constexpr (GG_ABL(256)) {                                                                               \
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                 \
+        if (tid == 0 && blockIdx.x < 1024 && tr_ < 256) gg_trace[blockIdx.x * 256 + tr_] = wall_clock64();     \
+        ++tr_;                                                                                                 \
+    }
+#else
+#define V6_STAMP(drain)
+#endif
     for (;;) {
         const int bid = __builtin_amdgcn_readfirstlane(*nextTile);
         __syncthreads();
         if (bid >= totalTiles) break;
-        if (tid == 0) *nextTile = fetchTile();
+        V6_STAMP(0)
+        unsigned int pend = 0;
+        if (tid == 0 && qFirst == 0) pend = atomicAdd(queue + home, 1u);
 
         int pi = 0;
         for (int lo_ = 0, hi_ = nprobs - 1; lo_ < hi_;) {
@@ -108,6 +130,7 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) boff[it] = rowB[tn * BN + s_r + 32 * it] + srcSwz;
 
+        V6_STAMP(1)
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -120,7 +143,8 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         auto dma_pair = [&](int buf, int ca0, int ca1, int cb0, int cb1) {
             float* As = smem + buf * BUF_FLOATS;
             float* Bs = As + AS_FLOATS;
-            const int ca = second ? ca1 : ca0, cb = second ? cb1 : cb0;
+            if constexpr (GG_ABL(2)) { if (buf >= 0) return; }     // ablation: no operand fetch at all
+            const int ca = GG_ABL(8) ? 0 : (second ? ca1 : ca0), cb = GG_ABL(8) ? 0 : (second ? cb1 : cb0);   // 8: one hot chunk
 #pragma unroll
             for (int it = 0; it < A_IT; ++it)
                 glds16(A + (aoff[it] + ca), (lds_vptr)(As + (wave * 8 + 32 * it) * 32));
@@ -128,21 +152,40 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             for (int it = 0; it < B_IT; ++it)
                 glds16(B + (boff[it] + cb), (lds_vptr)(Bs + (wave * 8 + 32 * it) * 32));
         };
-        auto compute_step = [&](int buf, int st) {
+        struct Frag { f16x8 a[MI], b[NI]; };
+        auto load_frag = [&](int buf, int st, Frag& f) {
             const char* As = reinterpret_cast<const char*>(smem + buf * BUF_FLOATS);
             const char* Bs = As + AS_FLOATS * 4;
-            f16x8 ah[MI], bh[NI];
+            if constexpr (GG_ABL(16)) {                             // ablation: MFMA on register operands (no fragment reads)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                ah[mi] = *reinterpret_cast<const f16x8*>(As + (wm * WTM + mi * 32 + l31) * 128 + rd[st]);
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bh[ni] = *reinterpret_cast<const f16x8*>(Bs + (wn * WTN + ni * 32 + l31) * 128 + rd[st]);
+                    for (int j = 0; j < 8; ++j) f.a[mi][j] = (_Float16)(float)(lane + st + mi + j);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f.b[ni][j] = (_Float16)(float)(lane - st - ni - j);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    f.a[mi] = *reinterpret_cast<const f16x8*>(As + (wm * WTM + mi * 32 + l31) * 128 + rd[st]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    f.b[ni] = *reinterpret_cast<const f16x8*>(Bs + (wn * WTN + ni * 32 + l31) * 128 + rd[st]);
+            }
+        };
+        auto mfma_frag = [&](const Frag& f) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+        };
+        auto compute_step = [&](int buf, int st) {
+            if constexpr (GG_ABL(4)) return;                        // ablation: no fragment reads, no MFMA
+            Frag f;
+            load_frag(buf, st, f);
+            mfma_frag(f);
         };
 
         // Operand pipeline, D = STAGES - 1 pairs deep, counted vmcnt (each wave waits only for ITS pieces of the pair it is about
@@ -158,7 +201,10 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             const int i1 = sb + 64 + lane < nchunksTotal ? sb + 64 + lane : nchunksTotal - 1;
             const int ca0v = colA[i0], ca1v = colA[i1], cb0v = colB[i0], cb1v = colB[i1];
             asm volatile("" ::"v"(ca0v), "v"(ca1v), "v"(cb0v), "v"(cb1v));
-            auto pick = [&](int v0, int v1, int i) { return i < 64 ? __builtin_amdgcn_readlane(v0, i) : __builtin_amdgcn_readlane(v1, i - 64); };
+            auto pick = [&](int v0, int v1, int i) {           // both halves read, scalar select: no branch in the loop
+                const int a = __builtin_amdgcn_readlane(v0, i & 63), b = __builtin_amdgcn_readlane(v1, i & 63);
+                return i < 64 ? a : b;
+            };
             auto issue = [&](int kc, int buf) {                 // pair (kc, kc + 1); a lone last chunk is fetched twice
                 const int i = kc - sb, j = kc + 1 < sbEnd ? i + 1 : i;
                 dma_pair(buf, pick(ca0v, ca1v, i), pick(ca0v, ca1v, j), pick(cb0v, cb1v, i), pick(cb0v, cb1v, j));
@@ -177,7 +223,7 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (D >= 2 ? 1 : 0)) : "memory");
                 else                           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!GG_ABL(1)) __builtin_amdgcn_s_barrier();
                 if (kc + 2 * D < sbEnd) issue(kc + 2 * D, nxt);
                 compute_step(cur, 0);
                 compute_step(cur, 1);
@@ -189,7 +235,18 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
             }
         }
+        if (tid == 0) {                            // the next tile: the home counter's answer, else steal
+            int nt = totalTiles;
+            if (qFirst == 0) {
+                int lo, hi_;
+                rangeOf(home, lo, hi_);
+                if (lo + (int)pend < hi_) nt = lo + (int)pend; else qFirst = 1;
+            }
+            if (nt == totalTiles) nt = stealTile();
+            *nextTile = nt;
+        }
         __syncthreads();                           // rowTab visible even when the k range is empty; LDS-DMA queue empty
+        V6_STAMP(0)
 
         // ---- epilogue (as v5): C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const float alpha = P->alpha;
@@ -200,7 +257,7 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         bool nonFinite = false;
         const bool partial = (splitK > 1);
         const gcf32 bias = partial ? (gcf32) nullptr : (gcf32)P->bias;
-        const gcf32 R = partial ? (gcf32) nullptr : (gcf32)P->R;
+        const gcf32 R = (partial || GG_ABL(64)) ? (gcf32) nullptr : (gcf32)P->R;
         const cci32 colC = (cci32)P->colC;
         const gf32 C = (gf32)(P->C + (partial ? (int64_t)split * P->splitStride : (int64_t)0));
         int ccol[NI];
@@ -256,7 +313,8 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                         else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
                         if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
                         nonFinite |= !(__builtin_fabsf(v) <= vmax);
-                        if (mok && (FULL || nok[ni])) {
+                        if constexpr (GG_ABL(32)) { if (v == 12345.678f) C[0] = v; }   // ablation: no output stores
+                        else if (mok && (FULL || nok[ni])) {
                             if (cSplit) {
                                 typedef _Float16 __attribute__((address_space(1)))* gh;
                                 const gh C16 = (gh)C;
@@ -277,6 +335,7 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         if (fullTile) { if (R != nullptr) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
         else          { if (R != nullptr) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
         if (rangeFlag != nullptr && __any(nonFinite) && lane == 0) atomicOr(rangeFlag, 1u);
+        V6_STAMP(1)
         __syncthreads();
     }
 }
