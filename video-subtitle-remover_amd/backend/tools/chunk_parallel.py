@@ -122,9 +122,12 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
     def nframes(i):
         return ranges[i][1] - ranges[i][0]
 
+    if st.gpu:
+        torch.cuda.set_device(dev)             # RCCL point-to-point needs the current device to be this rank's
+    if dist is not None:
+        dist.barrier()                         # the grouped p2p below must not be the first call on the communicator:
+                                               # ranks without a chunk in round 0 post nothing in X[0]
     if maxn == 0:
-        if dist is not None:
-            dist.barrier()
         return
     owners = range(world) if rank == 0 else [rank]
     dbuf = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8, device=dev) for q in range(RING) for k in owners}
