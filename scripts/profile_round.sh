@@ -12,4 +12,11 @@ B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-split-half --e2e
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r -- $B1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r -- $B1 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o r -- $B1 > $OUT/pmc_sq.log 2>&1
-rm -f $OUT/trace/r_kernel_trace.csv.bak; ls $OUT $OUT/trace; du -sh $OUT
+# the fp16-operand mode (BASELINE.json config 5's arithmetic): kernel-trace stats + counters of its own kernels
+F1="$B1 --precision f16"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f16_trace -o r -- $B --steps 3 --warmup 1 --precision f16 > $OUT/f16_trace.log 2>&1
+grep '"metric"' $OUT/f16_trace.log > $OUT/f16_bench_under_rocprof.json
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f16_pmc_fetch -o r -- $F1 > $OUT/f16_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/f16_pmc_write -o r -- $F1 > $OUT/f16_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/f16_pmc_sq -o r -- $F1 > $OUT/f16_pmc_sq.log 2>&1
+rm -f $OUT/f16_trace/r_kernel_trace.csv $OUT/trace/r_kernel_trace.csv.bak; ls $OUT $OUT/trace; du -sh $OUT

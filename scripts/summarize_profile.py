@@ -43,6 +43,29 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
     for (k, c), (n, tot) in sorted(agg.items()):
         w.writerow([k, c, n, tot / n, tot])
 
+# ---- the fp16-operand mode's own passes (f16_trace, f16_pmc_*)
+p16 = os.path.join(src, "f16_trace", "r_kernel_stats.csv")
+if os.path.exists(p16):
+    shutil.copy(p16, os.path.join(dst, f"{tag}_f16_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "f16_bench_under_rocprof.json")):
+    shutil.copy(os.path.join(src, "f16_bench_under_rocprof.json"), os.path.join(dst, f"{tag}_f16_bench_under_rocprof.json"))
+agg16 = defaultdict(lambda: [0, 0.0])
+for d in sorted(os.listdir(src)):
+    p = os.path.join(src, d, "r_counter_collection.csv")
+    if not d.startswith("f16_pmc") or not os.path.exists(p):
+        continue
+    with open(p, newline="") as f:
+        for row in csv.DictReader(f):
+            k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+            agg16[k][0] += 1
+            agg16[k][1] += float(row["Counter_Value"])
+if agg16:
+    with open(os.path.join(dst, f"{tag}_f16_pmc_summary.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "Counter_Name", "dispatches", "mean", "total"])
+        for (k, c), (n, tot) in sorted(agg16.items()):
+            w.writerow([k, c, n, tot / n, tot])
+
 # ---- dominant kernel: largest total duration in the kernel-trace stats
 dom = None
 if os.path.exists(stats):
