@@ -373,6 +373,15 @@ int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_ch
  * int32 [cap][6] = (label, area, xmin, xmax, ymin, ymax) unordered, *count = components found (may exceed cap) */
 int vsr_det_launch_ccl(const float* prob_dev, int H, int W, float thresh, int32_t* labels_dev, int32_t* stats_dev, int32_t* comps_dev, int cap,
                        int32_t* count_dev, void* stream);
+/* The whole DBPostProcess of one probability map on the device (reference: backend/tools/subtitle_detect.py:41-82 calls paddleocr's
+ * TextDetection, whose post-process is DBPostProcess with inference.yml:46-53's thresh / box_thresh / unclip_ratio): the labelling
+ * above, then per component get_mini_boxes (hull of the per-row extreme pixels, minimum-area rectangle), box_score_fast, unclip,
+ * rescale to the source image.  ext int32 [cap][H][2] scratch; out int32 [1 + 16*cap]: out[0] = components found, then per slot
+ * (flag, x0,y0, x1,y1, x2,y2, x3,y3, score bits, ...): flag 1 = box (top-left, top-right, bottom-right, bottom-left), 0 = rejected,
+ * -1 = component taller than 256 rows (not processed); out[0] > cap: nothing else is valid. */
+int vsr_det_launch_db_boxes(const float* prob_dev, int H, int W, float thresh, int src_h, int src_w, float box_thresh, float unclip_ratio,
+                            int min_size, int32_t* labels_dev, int32_t* stats_dev, int32_t* comps_dev, int32_t* count_dev, int32_t* ext_dev,
+                            int32_t* out_dev, int cap, void* stream);
 int vsr_det_launch_copy(const void* src_dev, int64_t src_pitch, void* dst_dev, int64_t dst_pitch, int64_t width_bytes, int64_t rows, void* stream);   /* channel concat: one strided block copy per part */
 /* layout changes around the dense convolutions that run as gather-GEMMs (vsr_gemm_plan_*): one NCHW image -> zero-padded NHWC
  * [Hp][Wp][Cp] (image origin at (pt, pl), Cp a multiple of 32), and GEMM output [P pixels][Np] -> NCHW [C][P] with an optional

@@ -159,14 +159,19 @@ def _blob_map(seed, H, W, nboxes):
 
 @pytest.mark.parametrize("seed,H,W,nboxes", [(1, 544, 960, 6), (2, 544, 960, 60), (3, 96, 160, 3), (4, 544, 960, 0)])
 def test_device_db_postprocess_equals_host(built_lib, gpu_device, seed, H, W, nboxes):
-    """threshold + 8-connected union-find labelling + component boxes on the GPU, polygon work on the crops: the boxes and scores
-    of DBPostProcess must equal the all-host version (scipy labelling of the downloaded map) exactly"""
+    """threshold + 8-connected union-find labelling + hull / minimum-area rectangle / score / unclip per component, all on the GPU:
+    the boxes and scores of DBPostProcess must equal the all-host version (scipy labelling of the downloaded map, numpy geometry).
+    Both sides compute in fp64 but not in the same operation order (BLAS projections on the host), so a corner may land on the
+    other side of a rounding boundary: at most one source pixel, scores to 1e-5 (fp32 mean on the host, fp64 on the device)."""
     prob = _blob_map(seed, H, W, nboxes)
     want_b, want_s = ocr_det.db_postprocess(prob, 1080, 1920)
     post = ocr_det.DeviceDBPostProcess(gpu_device)
     got_b, got_s = post(torch.from_numpy(prob).to(gpu_device), 1080, 1920)
-    assert got_b.shape == want_b.shape and np.array_equal(got_b, want_b)
-    assert np.allclose(got_s, want_s, rtol=0, atol=1e-7)
+    assert got_b.shape == want_b.shape
+    if len(want_s):
+        assert np.abs(got_b.astype(np.int64) - want_b).max() <= 1, np.abs(got_b.astype(np.int64) - want_b).max()
+        assert (got_b != want_b).mean() <= 0.02
+    assert np.allclose(got_s, want_s, rtol=0, atol=1e-5)
     if nboxes >= 6:
         assert len(want_s) >= 1
     # the labelling itself: same partition as scipy's, labels = raster index of the first pixel
@@ -185,8 +190,19 @@ def test_device_db_postprocess_equals_host(built_lib, gpu_device, seed, H, W, nb
 
 
 def test_device_db_postprocess_overflow_falls_back(built_lib, gpu_device):
-    """a noise map has more components than the device list holds: the host labels the downloaded map, same result"""
-    prob = np.random.default_rng(9).random((256, 384)).astype(np.float32)
+    """more components than the device record list holds: the labelling stays on the device, the polygon work runs in numpy on the
+    downloaded rows (exactly the host result); a map with more than 4096 components is labelled on the host"""
+    rng = np.random.default_rng(9)
+    prob = np.full((256, 384), 0.05, np.float32)
+    for y in range(4, 250, 12):                                  # 21 x 31 = 651 isolated 6x7 blobs
+        for x in range(4, 376, 12):
+            prob[y:y + 6, x:x + 7] = rng.uniform(0.5, 0.95)
     want_b, want_s = ocr_det.db_postprocess(prob, 512, 768)
+    assert len(want_s) > 300
     got_b, got_s = ocr_det.DeviceDBPostProcess(gpu_device, cap=64)(torch.from_numpy(prob).to(gpu_device), 512, 768)
     assert np.array_equal(got_b, want_b) and np.allclose(got_s, want_s)
+    noise = rng.random((256, 384)).astype(np.float32)            # one giant component and a few specks: whatever path, same boxes
+    want_b, want_s = ocr_det.db_postprocess(noise, 512, 768)
+    got_b, got_s = ocr_det.DeviceDBPostProcess(gpu_device, cap=64)(torch.from_numpy(noise).to(gpu_device), 512, 768)
+    assert got_b.shape == want_b.shape and (len(want_s) == 0 or np.abs(got_b.astype(np.int64) - want_b).max() <= 1)
+    assert np.allclose(got_s, want_s, atol=1e-5)

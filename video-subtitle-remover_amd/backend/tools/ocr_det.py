@@ -547,49 +547,71 @@ def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidate
 
 
 class DeviceDBPostProcess:
-    """DBPostProcess with the bitmap work on the GPU: threshold, 8-connected labelling (union-find) and per-component area /
-    bounding box run as kernels on the probability map where the forward left it (vsr_det_launch_ccl); the host receives the
-    component list (a few dozen integers for a subtitle frame) and the rows of the label and probability maps the components
-    span -- the polygon work (hull, minimum-area rectangle, box score, unclip) stays numpy on crops of those.  Same results
-    as db_postprocess on the downloaded map (components are visited in raster order of their first pixel on both sides)."""
+    """DBPostProcess on the GPU, on the probability map where the forward left it (vsr_det_launch_db_boxes): threshold, 8-connected
+    labelling (union-find), per-component bounding box, then per component the hull of its per-row extreme pixels, the minimum-area
+    rectangle, the box score, unclip and the rescale to the source image -- one wave per component.  The host receives one
+    buffer: the component count and a 16-int record per component, i.e. one synchronisation per frame.  Same boxes as
+    db_postprocess on the downloaded map (components are reported in raster order of their first pixel on both sides; the
+    geometry runs in fp64 on both).  More than `cap` components (a noise map, not a subtitle frame) or a component taller than
+    256 rows: the labelling result is downloaded and the numpy statement of the polygon work runs on it (`_host_polygons`)."""
 
-    def __init__(self, device, cap=4096):
+    REC = 16
+
+    def __init__(self, device, cap=256):
         self.device, self.cap = device, cap
         self._work = {}
 
     def _buffers(self, H, W):
         key = (H, W)
         if key not in self._work:
-            dev = self.device
-            self._work[key] = (torch.empty(H * W, dtype=torch.int32, device=dev), torch.empty(H * W * 5, dtype=torch.int32, device=dev),
-                               torch.empty(self.cap * 6, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+            dev, i32 = self.device, torch.int32
+            self._work[key] = (torch.empty(H * W, dtype=i32, device=dev), torch.empty(H * W * 5, dtype=i32, device=dev),
+                               torch.empty(self.cap * 6, dtype=i32, device=dev), torch.zeros(1, dtype=i32, device=dev),
+                               torch.empty(self.cap * H * 2, dtype=i32, device=dev), torch.zeros(1 + self.cap * self.REC, dtype=i32, device=dev))
         return self._work[key]
 
     def __call__(self, prob_dev, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
         assert prob_dev.is_cuda and prob_dev.dtype == torch.float32 and prob_dev.dim() == 2
         prob_dev = prob_dev.contiguous()
         H, W = prob_dev.shape
-        labels, stats, comps, count = self._buffers(H, W)
+        labels, stats, comps, count, ext, out = self._buffers(H, W)
         with torch.cuda.device(self.device):
-            check(lib.vsr_det_launch_ccl(_p(prob_dev), H, W, C.c_float(thresh), _p(labels), _p(stats), _p(comps), self.cap, _p(count), _stream()))
-            n = int(count.item())
-            if n == 0:
-                return np.zeros((0, 4, 2), np.int32), []
-            if n > self.cap:                 # more components than the list holds (a noise map): the host labels the downloaded map
-                return db_postprocess(prob_dev.cpu().numpy(), src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
+            check(lib.vsr_det_launch_db_boxes(_p(prob_dev), H, W, C.c_float(thresh), src_h, src_w, C.c_float(box_thresh), C.c_float(unclip_ratio),
+                                              min_size, _p(labels), _p(stats), _p(comps), _p(count), _p(ext), _p(out), self.cap, _stream()))
+            host = torch.cat([out, comps]).cpu().numpy()                             # the one synchronisation of the post-process
+        n = int(host[0])
+        if n == 0:
+            return np.zeros((0, 4, 2), np.int32), []
+        rec = host[1:1 + self.cap * self.REC].reshape(self.cap, self.REC)[:min(n, self.cap)]
+        if n > self.cap or (rec[:, 0] < 0).any():
+            return self._host_polygons(prob_dev, labels, count, n, src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
+        first = host[1 + self.cap * self.REC:].reshape(self.cap, 6)[:n, 0]
+        order = np.argsort(first)[:max_candidates]                                   # raster order of the first pixel = findContours' order
+        rec = rec[order]
+        rec = rec[rec[:, 0] == 1]
+        boxes = rec[:, 1:9].reshape(-1, 4, 2).astype(np.int32)
+        scores = [float(v) for v in np.ascontiguousarray(rec[:, 9]).view(np.float32)]
+        return boxes, scores
+
+    def _host_polygons(self, prob_dev, labels, count, n, src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size):
+        """the labelling stays on the device, the polygon work of every component runs in numpy on the downloaded rows"""
+        H, W = prob_dev.shape
+        cap = 4096
+        if n > cap:                          # a noise map: the host labels the downloaded map itself
+            return db_postprocess(prob_dev.cpu().numpy(), src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
+        with torch.cuda.device(self.device):
+            stats = torch.empty(H * W * 5, dtype=torch.int32, device=self.device)
+            comps = torch.empty(cap * 6, dtype=torch.int32, device=self.device)
+            check(lib.vsr_det_launch_ccl(_p(prob_dev), H, W, C.c_float(thresh), _p(labels), _p(stats), _p(comps), cap, _p(count), _stream()))
             lst = comps[: n * 6].cpu().numpy().reshape(n, 6)
-            lst = lst[np.argsort(lst[:, 0])][:max_candidates]                        # raster order of the first pixel = scipy's label order
-            # one download of the rows the components span (every small device-to-host copy costs a synchronisation: per-component
-            # crops were slower than the all-host version); the host then only slices
-            ya0, yb0 = int(lst[:, 4].min()), int(lst[:, 5].max()) + 1
-            ya0, yb0 = max(0, ya0 - 2), min(H, yb0 + 2)
+            lst = lst[np.argsort(lst[:, 0])][:max_candidates]
+            ya0, yb0 = max(0, int(lst[:, 4].min()) - 2), min(H, int(lst[:, 5].max()) + 3)
             lab_h = labels.view(H, W)[ya0:yb0].cpu().numpy()
             prob_h = prob_dev[ya0:yb0].cpu().numpy()
-            get_lab = lambda ya, yb, xa, xb: lab_h[ya - ya0:yb - ya0, xa:xb]
-            get_prob = lambda ya, yb, xa, xb: (prob_h[ya - ya0:yb - ya0, xa:xb], (ya, xa))
+        get_prob = lambda ya, yb, xa, xb: (prob_h[ya - ya0:yb - ya0, xa:xb], (ya, xa))
         boxes, scores = [], []
         for lab, _area, x0, x1, y0, y1 in lst.tolist():
-            comp = get_lab(y0, y1 + 1, x0, x1 + 1) == lab
+            comp = lab_h[y0 - ya0:y1 + 1 - ya0, x0:x1 + 1] == lab
             r = _box_of_component(comp, y0, x0, get_prob, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size)
             if r is not None:
                 boxes.append(r[0])

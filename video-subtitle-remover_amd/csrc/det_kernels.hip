@@ -339,6 +339,196 @@ __global__ void __launch_bounds__(256) k_ccl_compact(int64_t total, const int* _
     }
 }
 
+// ---- DBPostProcess, polygon part on the device (paddleocr DBPostProcess: get_mini_boxes, box_score_fast, unclip; the numpy
+// statement of the same steps is ocr_det._box_of_component).  A minimum-area rectangle only depends on the convex hull, and the
+// hull's vertices are among the leftmost / rightmost pixel of every row of the component: k_db_ext collects those per
+// (component, row) with atomics, k_db_boxes (one wave per component) sorts the <= 2 * rows points by rank, builds the hull with
+// Andrew's monotone chain (integer cross products), runs the calipers with one lane per hull edge, scores the rectangle by the
+// mean probability of the pixels inside it (lanes over its bounding box) and offsets / rescales it.  All geometry in fp64.
+#define DB_MAXROWS 256
+#define DB_MAXPTS (2 * DB_MAXROWS)
+#define DB_REC 16                                                  // ints per output record: flag, 8 corner coordinates, score bits
+
+__global__ void __launch_bounds__(256) k_db_slots(const int* __restrict__ comps, const int* __restrict__ count, int cap, int* __restrict__ st)
+{
+    const int n = *count < cap ? *count : cap;
+    GRID_STRIDE(k, (int64_t)n) st[(int64_t)comps[k * 6] * 5 + 0] = (int)k;      // root pixel -> slot (the area now lives in comps)
+}
+
+__global__ void __launch_bounds__(256) k_db_ext_init(const int* __restrict__ count, int cap, int H, int* __restrict__ ext)
+{
+    const int n = *count < cap ? *count : cap;
+    GRID_STRIDE(i, (int64_t)n * H) { ext[2 * i] = 0x7fffffff; ext[2 * i + 1] = -1; }
+}
+
+__global__ void __launch_bounds__(256) k_db_ext(int H, int W, const int* __restrict__ L, const int* __restrict__ st, const int* __restrict__ count, int cap,
+                                                int* __restrict__ ext)
+{
+    if (*count > cap) return;                                      // the host labels a map with that many components itself
+    const int64_t total = (int64_t)H * W;
+    GRID_STRIDE(i, total) {
+        const int r = L[i];
+        if (r < 0) continue;
+        const int k = st[(int64_t)r * 5 + 0];
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        atomicMin(&ext[((int64_t)k * H + y) * 2], x);
+        atomicMax(&ext[((int64_t)k * H + y) * 2 + 1], x);
+    }
+}
+
+__device__ __forceinline__ void db_order_box(const double (*c)[2], double (*o)[2])
+{   // get_mini_boxes: stable sort by x, the left pair and the right pair by y -> top-left, top-right, bottom-right, bottom-left
+    int idx[4] = {0, 1, 2, 3};
+    for (int i = 1; i < 4; ++i)
+        for (int j = i; j > 0 && c[idx[j]][0] < c[idx[j - 1]][0]; --j) { const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+    int a = idx[0], b = idx[1], d = idx[2], e = idx[3];
+    if (c[b][1] < c[a][1]) { const int t = a; a = b; b = t; }
+    if (c[e][1] < c[d][1]) { const int t = d; d = e; e = t; }
+    const int r[4] = {a, d, e, b};
+    for (int i = 0; i < 4; ++i) { o[i][0] = c[r[i]][0]; o[i][1] = c[r[i]][1]; }
+}
+
+__global__ void __launch_bounds__(64) k_db_boxes(const float* __restrict__ prob, int H, int W, const int* __restrict__ comps, const int* __restrict__ count, int cap,
+                                                 const int* __restrict__ ext, int src_h, int src_w, float box_thresh, float unclip_ratio, int min_size,
+                                                 int* __restrict__ out)
+{
+    __shared__ int px[DB_MAXPTS], py[DB_MAXPTS], sx[DB_MAXPTS], sy[DB_MAXPTS], hxI[2 * DB_MAXPTS + 2], hyI[2 * DB_MAXPTS + 2];   // the two chains share hxI / hyI
+    __shared__ int npts, nh;
+    __shared__ double box[4][2], wh[2];
+    __shared__ int state;                                         // 1 = still a candidate
+    const int lane = threadIdx.x, k = blockIdx.x;
+    if (k == 0 && lane == 0) out[0] = *count;
+    if (*count > cap || k >= *count) return;
+    int* o = out + 1 + (int64_t)k * DB_REC;
+    const int y0 = comps[k * 6 + 4], y1 = comps[k * 6 + 5];
+    if (y1 - y0 + 1 > DB_MAXROWS) { if (lane == 0) o[0] = -1; return; }      // a tall component: the host does this map
+    if (lane == 0) {
+        int m = 0;
+        for (int y = y0; y <= y1; ++y) {
+            const int xl = ext[((int64_t)k * H + y) * 2], xr = ext[((int64_t)k * H + y) * 2 + 1];
+            if (xr < 0) continue;
+            px[m] = xl; py[m] = y; ++m;
+            if (xr != xl) { px[m] = xr; py[m] = y; ++m; }
+        }
+        npts = m;
+        state = 1;
+    }
+    __syncthreads();
+    for (int i = lane; i < npts; i += 64) {                        // rank sort by (x, y); the points are distinct
+        int r = 0;
+        for (int j = 0; j < npts; ++j) r += (px[j] < px[i] || (px[j] == px[i] && py[j] < py[i])) ? 1 : 0;
+        sx[r] = px[i]; sy[r] = py[i];
+    }
+    __syncthreads();
+    if (lane == 0) {                                               // monotone chain: lower[:-1] + upper[:-1]
+        if (npts <= 2) {
+            nh = npts;
+            for (int i = 0; i < npts; ++i) { hxI[i] = sx[i]; hyI[i] = sy[i]; }
+        } else {
+            auto cross = [](long long ox, long long oy, long long ax, long long ay, long long bx, long long by) {
+                return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
+            };
+            int n = 0;
+            for (int i = 0; i < npts; ++i) {
+                while (n >= 2 && cross(hxI[n - 2], hyI[n - 2], hxI[n - 1], hyI[n - 1], sx[i], sy[i]) <= 0) --n;
+                hxI[n] = sx[i]; hyI[n] = sy[i]; ++n;
+            }
+            const int lo = n - 1;                                  // drop lower's last point, upper starts there
+            n = lo;
+            const int base = n;
+            for (int i = npts - 1; i >= 0; --i) {
+                while (n - base >= 2 && cross(hxI[n - 2], hyI[n - 2], hxI[n - 1], hyI[n - 1], sx[i], sy[i]) <= 0) --n;
+                hxI[n] = sx[i]; hyI[n] = sy[i]; ++n;
+            }
+            nh = n - 1;                                            // drop upper's last point (= lower's first)
+        }
+    }
+    __syncthreads();
+    const int h_ = nh;
+    if (h_ <= 2) { if (lane == 0) o[0] = 0; return; }              // a point or a segment: one side is 0 < min_size
+    // calipers: lane i projects the hull on the direction of edge i and on its normal
+    double bestA = 1e300; int bestI = 0x7fffffff;
+    for (int i = lane; i < h_; i += 64) {
+        const int j1 = i + 1 == h_ ? 0 : i + 1;
+        const double ex = (double)(hxI[j1] - hxI[i]), ey = (double)(hyI[j1] - hyI[i]);
+        const double nrm = hypot(ex, ey);
+        const double u0 = ex / nrm, u1 = ey / nrm, v0 = -u1, v1 = u0;
+        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+        for (int j = 0; j < h_; ++j) {
+            const double pu = (double)hxI[j] * u0 + (double)hyI[j] * u1, pv = (double)hxI[j] * v0 + (double)hyI[j] * v1;
+            umin = fmin(umin, pu); umax = fmax(umax, pu); vmin = fmin(vmin, pv); vmax = fmax(vmax, pv);
+        }
+        const double a = (umax - umin) * (vmax - vmin);
+        if (a < bestA) { bestA = a; bestI = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {                       // first minimum over the edges
+        const double a2 = __shfl_xor(bestA, off);
+        const int i2 = __shfl_xor(bestI, off);
+        if (a2 < bestA || (a2 == bestA && i2 < bestI)) { bestA = a2; bestI = i2; }
+    }
+    if (lane == 0) {
+        const int i = bestI, j1 = i + 1 == h_ ? 0 : i + 1;
+        const double ex = (double)(hxI[j1] - hxI[i]), ey = (double)(hyI[j1] - hyI[i]);
+        const double nrm = hypot(ex, ey);
+        const double u0 = ex / nrm, u1 = ey / nrm, v0 = -u1, v1 = u0;
+        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+        for (int j = 0; j < h_; ++j) {
+            const double pu = (double)hxI[j] * u0 + (double)hyI[j] * u1, pv = (double)hxI[j] * v0 + (double)hyI[j] * v1;
+            umin = fmin(umin, pu); umax = fmax(umax, pu); vmin = fmin(vmin, pv); vmax = fmax(vmax, pv);
+        }
+        const double w = umax - umin, h = vmax - vmin;
+        wh[0] = w; wh[1] = h;
+        if (fmin(w, h) < (double)min_size) state = 0;
+        const double c[4][2] = {{umin * u0 + vmin * v0, umin * u1 + vmin * v1}, {umax * u0 + vmin * v0, umax * u1 + vmin * v1},
+                                {umax * u0 + vmax * v0, umax * u1 + vmax * v1}, {umin * u0 + vmax * v0, umin * u1 + vmax * v1}};
+        db_order_box(c, box);
+    }
+    __syncthreads();
+    if (!state) { if (lane == 0) o[0] = 0; return; }
+    // box_score_fast: mean probability over the pixels inside the rectangle
+    double bx[4], by[4];
+    for (int i = 0; i < 4; ++i) { bx[i] = box[i][0]; by[i] = box[i][1]; }
+    const double mnx = fmin(fmin(bx[0], bx[1]), fmin(bx[2], bx[3])), mxx = fmax(fmax(bx[0], bx[1]), fmax(bx[2], bx[3]));
+    const double mny = fmin(fmin(by[0], by[1]), fmin(by[2], by[3])), mxy = fmax(fmax(by[0], by[1]), fmax(by[2], by[3]));
+    const int xa = (int)fmin(fmax(floor(mnx), 0.0), (double)(W - 1)), xb = (int)fmin(fmax(ceil(mxx), 0.0), (double)(W - 1));
+    const int ya = (int)fmin(fmax(floor(mny), 0.0), (double)(H - 1)), yb = (int)fmin(fmax(ceil(mxy), 0.0), (double)(H - 1));
+    const int bw = xb - xa + 1, npx = bw * (yb - ya + 1);
+    double sum = 0.0; int cnt = 0;
+    for (int t = lane; t < npx; t += 64) {
+        const int y = ya + t / bw, x = xa + t % bw;
+        bool in = true;
+        for (int i = 0; i < 4; ++i) {
+            const int q = (i + 1) & 3;
+            in = in && ((bx[q] - bx[i]) * ((double)y - by[i]) - (by[q] - by[i]) * ((double)x - bx[i]) >= -1e-6);
+        }
+        if (in) { sum += (double)prob[(int64_t)y * W + x]; ++cnt; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
+    if (lane != 0) return;
+    const float score = cnt ? (float)(sum / cnt) : 0.f;
+    if ((double)score < (double)box_thresh) { o[0] = 0; return; }
+    // unclip: offset the rectangle by area * ratio / perimeter, then rescale to the source image
+    const double w = wh[0], h = wh[1];
+    const double d = (w * h) * (double)unclip_ratio / (2 * (w + h));
+    const double cx = (bx[0] + bx[1] + bx[2] + bx[3]) / 4, cy = (by[0] + by[1] + by[2] + by[3]) / 4;
+    const double e1x = bx[1] - bx[0], e1y = by[1] - by[0], e3x = bx[3] - bx[0], e3y = by[3] - by[0];
+    const double l1 = hypot(e1x, e1y), l3 = hypot(e3x, e3y);
+    const double ux = e1x / fmax(l1, 1e-9), uy = e1y / fmax(l1, 1e-9), vx = e3x / fmax(l3, 1e-9), vy = e3y / fmax(l3, 1e-9);
+    const double hw = l1 / 2 + d, hh = l3 / 2 + d;
+    if (fmin(2 * hw, 2 * hh) < (double)(min_size + 2)) { o[0] = 0; return; }
+    double big[4][2] = {{cx - hw * ux - hh * vx, cy - hw * uy - hh * vy}, {cx + hw * ux - hh * vx, cy + hw * uy - hh * vy},
+                        {cx + hw * ux + hh * vx, cy + hw * uy + hh * vy}, {cx - hw * ux + hh * vx, cy - hw * uy + hh * vy}};
+    for (int i = 0; i < 4; ++i) {
+        big[i][0] = fmin(fmax(rint(big[i][0] / (double)W * (double)src_w), 0.0), (double)src_w);
+        big[i][1] = fmin(fmax(rint(big[i][1] / (double)H * (double)src_h), 0.0), (double)src_h);
+    }
+    double ob[4][2];
+    db_order_box(big, ob);
+    for (int i = 0; i < 4; ++i) { o[1 + 2 * i] = (int)ob[i][0]; o[2 + 2 * i] = (int)ob[i][1]; }
+    o[9] = __float_as_int(score);
+    o[0] = 1;
+}
+
 extern "C" {
 
 int vsr_det_launch_conv2d(const float* x, const float* w, const float* bias, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
@@ -441,6 +631,26 @@ int vsr_det_launch_ccl(const float* prob, int H, int W, float thresh, int32_t* l
     hipLaunchKernelGGL(k_ccl_merge, dim3(grid_for(total)), dim3(256), 0, s, H, W, labels);
     hipLaunchKernelGGL(k_ccl_flatten_stats, dim3(grid_for(total)), dim3(256), 0, s, H, W, labels, stats);
     hipLaunchKernelGGL(k_ccl_compact, dim3(grid_for(total)), dim3(256), 0, s, total, labels, stats, comps, cap, count);
+    DONE();
+}
+
+// The whole DBPostProcess of one probability map on the device: vsr_det_launch_ccl's labelling, then the polygon work per
+// component.  ext int32 [cap][H][2] scratch; out int32 [1 + cap * 16]: out[0] = number of components found, then per component
+// slot k (same order as comps) a record (flag, x0, y0, x1, y1, x2, y2, x3, y3, score bits): flag 1 = box (source-image pixels,
+// ordered top-left, top-right, bottom-right, bottom-left), 0 = rejected (size / score), -1 = taller than 256 rows (not
+// processed).  More than cap components: only out[0] is valid.
+int vsr_det_launch_db_boxes(const float* prob, int H, int W, float thresh, int src_h, int src_w, float box_thresh, float unclip_ratio, int min_size,
+                            int32_t* labels, int32_t* stats, int32_t* comps, int32_t* count, int32_t* ext, int32_t* out, int cap, void* stream)
+{
+    if (!ext || !out || cap <= 0 || cap > 65535) return VSR_ERR_ARG;
+    const int rc = vsr_det_launch_ccl(prob, H, W, thresh, labels, stats, comps, cap, count, stream);
+    if (rc != 0) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)H * W;
+    hipLaunchKernelGGL(k_db_slots, dim3(grid_for(cap)), dim3(256), 0, s, comps, count, cap, stats);
+    hipLaunchKernelGGL(k_db_ext_init, dim3(grid_for((int64_t)cap * H)), dim3(256), 0, s, count, cap, H, ext);
+    hipLaunchKernelGGL(k_db_ext, dim3(grid_for(total)), dim3(256), 0, s, H, W, labels, stats, count, cap, ext);
+    hipLaunchKernelGGL(k_db_boxes, dim3(cap), dim3(64), 0, s, prob, H, W, comps, count, cap, ext, src_h, src_w, box_thresh, unclip_ratio, min_size, out);
     DONE();
 }
 

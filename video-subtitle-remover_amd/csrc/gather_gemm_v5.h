@@ -67,9 +67,9 @@ gather_gemm_f32_v5(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             const int x = (home + qFirst) % nQueues;
             const int lo = (int)(((long long)totalTiles * x) / nQueues), hi = (int)(((long long)totalTiles * (x + 1)) / nQueues);
             if (lo < hi) {
-                // stealing: peek with a plain load first -- at the tail of a launch every workgroup scans the other ranges, and
-                // hundreds of same-address atomics on exhausted counters serialise in L2 (tens of microseconds per launch)
-                if (qFirst > 0 && (int)__hip_atomic_load(queue + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi - lo) continue;
+                // (a plain-load peek in front of the atomic was tried here: it removes the same-address atomics on exhausted
+                // counters at the tail of a launch, but adds a round trip to every steal -- the fp32 bench lost 2 %,
+                // profiles/r02_peek_ab.log; only the short-tile fp16 kernel v6 keeps it)
                 const int i = lo + (int)atomicAdd(queue + x, 1u);
                 if (i < hi) return i;
             }
