@@ -402,6 +402,21 @@ int vsr_launch_bgr2hsv_u8(const uint8_t* bgr_dev, uint8_t* hsv_dev, int64_t npix
 int vsr_launch_absdiff_sums_u8x3(const uint8_t* hsv_dev, int npairs, int64_t pix_per_frame, uint64_t* sums_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Frame transport: colour conversion of raw planar video.  The reference gets BGR frames from
+ * cv2.VideoCapture.read() (backend/inpaint/sttn_auto_inpaint.py:254-262, backend/main.py:171-176) and hands bgr24 frames to an
+ * ffmpeg pipe that converts to yuv420p (backend/tools/video_io.py:54-81) -- libswscale on the CPU on both sides.  The *.y4m
+ * reader / writer of backend/tools/video_io.py keep the planes as stored and convert on the GPU: 8-bit BT.601, 16.16 fixed point,
+ * bit-exact against the numpy statement of the same matrices.  Integer, HBM-bound.
+ * ------------------------------------------------------------------------------------- */
+/* planes_dev: nframes records `frame_bytes` apart, each [Y: H*W][U: chroma_h*chroma_w][V: same] (chroma_w = W or (W+1)/2, chroma_h = H
+ * or (H+1)/2, nearest replication; chroma_w = 0: luma only, grey output) -> bgr_dev uint8 [nframes][H][W][3] */
+int vsr_io_yuv_to_bgr(const uint8_t* planes_dev, int64_t frame_bytes, int H, int W, int chroma_w, int chroma_h, int full_range,
+                      uint8_t* bgr_dev, int nframes, void* stream);
+/* bgr_dev uint8 [nframes][H][W][3] -> records [Y][U][V]; subsample_420: chroma = rounded mean of each 2x2 block (edges repeated) */
+int vsr_io_bgr_to_yuv(const uint8_t* bgr_dev, int H, int W, int subsample_420, int full_range, uint8_t* planes_dev,
+                      int64_t frame_bytes, int nframes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Plan introspection (host only, no GPU needed): the op list the engine runs for inpaint(L),
  * with symbolic buffers and the offset tables -- replayed on the CPU by tests/.
  * ------------------------------------------------------------------------------------- */

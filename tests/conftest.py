@@ -48,8 +48,14 @@ def built_lib():
 
 @pytest.fixture(scope="session")
 def gpu_device(built_lib):
+    import time
+
     import torch
 
-    if not torch.cuda.is_available() or built_lib.lib.vsr_device_count() <= 0:
-        pytest.fail("this test is marked gpu but no HIP device is visible")
-    return torch.device("cuda", 0)
+    # a fresh box has been seen to report no device to the first process that asks (profiles/r02_cli_e2e.log: pytest found none,
+    # the command after it did): ask again for a while before giving up -- there is still no CPU path to fall back to
+    for attempt in range(30):
+        if torch.cuda.is_available() and built_lib.lib.vsr_device_count() > 0:
+            return torch.device("cuda", 0)
+        time.sleep(1.0)
+    pytest.fail("this test is marked gpu but no HIP device is visible")

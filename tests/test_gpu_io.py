@@ -1,0 +1,145 @@
+"""The GPU colour conversion of the *.y4m transport (csrc/io_kernels.hip through backend/tools/video_io.py) against the numpy
+statement of the same BT.601 integer matrices (video_io._yuv_to_bgr / _bgr_to_yuv): bit-exact, every chroma layout the reader
+accepts, odd sizes (edge replication of the 4:2:0 sub-sampler), both ranges."""
+import numpy as np
+import pytest
+
+from vsr_amd.backend.tools import video_io
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_raw_y4m(path, planes, H, W, tag, full):
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{W} H{H} F25:1 Ip A1:1 C{tag}{' XCOLORRANGE=FULL' if full else ''}\n".encode())
+        for rec in planes:
+            f.write(b"FRAME\n")
+            f.write(rec.tobytes())
+
+
+def _read_all(path):
+    r = video_io.Y4mVideo(path)
+    out = []
+    while True:
+        ok, fr = r.read()
+        if not ok:
+            break
+        out.append(fr)
+    r.release()
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("tag,H,W,full", [("420jpeg", 1080, 1920, False), ("420mpeg2", 37, 53, False), ("420paldv", 64, 130, True),
+                                          ("422", 36, 51, True), ("444", 35, 50, False), ("mono", 33, 47, False)])
+def test_y4m_reader_on_the_device_equals_numpy(built_lib, gpu_device, tmp_path, monkeypatch, tag, H, W, full):
+    rng = np.random.default_rng(H * W)
+    cw, ch = {"420": ((W + 1) // 2, (H + 1) // 2), "422": ((W + 1) // 2, H), "444": (W, H), "mon": (0, 0)}[tag[:3]]
+    planes = [rng.integers(0, 256, size=H * W + 2 * cw * ch, dtype=np.uint8) for _ in range(3)]
+    planes[1][: H * W] = np.repeat(np.arange(256, dtype=np.uint8), (H * W + 255) // 256)[: H * W]     # every luma level with random chroma
+    p = str(tmp_path / "v.y4m")
+    _write_raw_y4m(p, planes, H, W, tag, full)
+    monkeypatch.setenv("VSR_IO_COLOR", "host")
+    want = _read_all(p)
+    monkeypatch.setenv("VSR_IO_COLOR", "device")
+    r = video_io.Y4mVideo(p)
+    assert r._dc is not None, "the GPU path was not taken"
+    r.release()
+    got = _read_all(p)
+    assert got.shape == want.shape == (3, H, W, 3) and got.dtype == np.uint8
+    assert np.array_equal(got, want)
+    assert got[0].flags.owndata or got[0].base is not None          # a frame of its own (the plugins patch rows into it)
+    got[0][:] = 0
+    assert not np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("chroma,H,W", [("444", 1080, 1920), ("420", 1080, 1920), ("420", 37, 53), ("444", 35, 51), ("420", 2, 2)])
+def test_y4m_writer_on_the_device_equals_numpy(built_lib, gpu_device, tmp_path, monkeypatch, chroma, H, W):
+    rng = np.random.default_rng(H + W)
+    frames = rng.integers(0, 256, size=(3, H, W, 3), dtype=np.uint8)
+    frames[0, :, :, :] = np.arange(H * W * 3, dtype=np.int64).reshape(H, W, 3) % 256
+    files = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("VSR_IO_COLOR", mode)
+        p = str(tmp_path / f"{mode}.y4m")
+        w = video_io.Y4mWriter(p, 25.0, (W, H), chroma=chroma)
+        assert (w._dc is not None) == (mode == "device")
+        for fr in frames:
+            w.write(fr)
+        w.write(frames[1].astype(np.float32) + 0.4)                  # non-u8 frames are clipped and truncated first, as the reference's writer does
+        w.release()
+        files[mode] = open(p, "rb").read()
+    assert files["host"] == files["device"]
+
+
+def test_all_bgr_triples_and_all_yuv_triples(built_lib, gpu_device, tmp_path, monkeypatch):
+    """every (Y, U, V) and every (B, G, R) byte triple through both kernels, both ranges on the way in"""
+    g = np.arange(256, dtype=np.uint8)
+    yy, uu, vv = np.meshgrid(g, g, g, indexing="ij")
+    H, W = 4096, 4096
+    rec = np.concatenate([yy.reshape(-1), uu.reshape(-1), vv.reshape(-1)])
+    for full in (False, True):
+        p = str(tmp_path / f"all{int(full)}.y4m")
+        _write_raw_y4m(p, [rec], H, W, "444", full)
+        monkeypatch.setenv("VSR_IO_COLOR", "device")
+        got = _read_all(p)[0]
+        want = video_io._yuv_to_bgr(yy.reshape(H, W), uu.reshape(H, W), vv.reshape(H, W), full)
+        assert np.array_equal(got, want)
+    frame = np.stack([yy.reshape(H, W), uu.reshape(H, W), vv.reshape(H, W)], axis=-1)        # read as (B, G, R)
+    dc = video_io._DeviceColor(H, W, 3 * H * W, batch=1)
+    dc.bgr_buffer()[0] = frame
+    got = dc.from_bgr(1, False, False)[0].copy()
+    y, u, v = video_io._bgr_to_yuv(frame, False)
+    assert np.array_equal(got, np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]))
+
+
+@pytest.mark.parametrize("ab", [False, True])
+def test_resident_chunk_loop_writes_the_same_file(built_lib, gpu_device, tmp_path, monkeypatch, ab):
+    """*.y4m in -> SubtitleRemover.run() (sttn-auto) -> *.y4m out: with the decoded frames resident in HBM (planes up, GPU colour
+    conversion, planes down) the written file is byte for byte the one the host-frame loop writes (numpy colour conversion on
+    both sides of it), ragged last chunk and A/B sections included."""
+    from vsr_amd import synth
+    from vsr_amd.backend.config import config
+    from vsr_amd.backend.main import SubtitleRemover
+    from vsr_amd.backend.tools.constant import InpaintMode
+
+    H, W, N, GAP = 480, 852, 20, 6
+    box = (400, 450, 100, 760)
+    clip = synth.make_clip(N, H, W, box, seed=11)
+    src = str(tmp_path / "in.y4m")
+    monkeypatch.setenv("VSR_IO_COLOR", "host")
+    w = video_io.Y4mWriter(src, 25.0, (W, H), chroma="420")
+    for f in clip:
+        w.write(f)
+    w.release()
+    keys = {"sttnMaxLoadNum": GAP, "sttnNeighborStride": 1, "sttnReferenceLength": 6}
+    old = {k: getattr(config, k).value for k in keys}
+    old_mode = config.inpaintMode.value
+    outs = {}
+    try:
+        for k, v in keys.items():
+            getattr(config, k).value = v
+        config.inpaintMode.value = InpaintMode.STTN_AUTO
+        for mode, color, resident in (("host", "host", "0"), ("device-frames", "device", "0"), ("resident", "device", "1")):
+            monkeypatch.setenv("VSR_IO_COLOR", color)
+            monkeypatch.setenv("VSR_IO_RESIDENT", resident)
+            sr = SubtitleRemover(src, model_path={"netG": synth.make_state_dict(0, "auto")})
+            sr.sub_areas = [box]
+            if ab:
+                sr.ab_sections = [range(2, 9), range(13, 19)]
+            sr.video_out_path = str(tmp_path / f"out_{mode}.y4m")
+            ticks = []
+            sr.update_progress = lambda tbar, increment: ticks.append(increment)
+            sr.sttn_auto_mode(tbar=object())
+            sr.video_writer.release()
+            outs[mode] = open(sr.video_out_path, "rb").read()
+            assert sum(ticks) == N
+    finally:
+        for k, v in old.items():
+            getattr(config, k).value = v
+        config.inpaintMode.value = old_mode
+    assert outs["host"] == outs["device-frames"] == outs["resident"]
+    monkeypatch.setenv("VSR_IO_COLOR", "host")
+    got, want = _read_all(str(tmp_path / "out_resident.y4m")), _read_all(src)
+    assert got.shape == want.shape
+    ymin, ymax, xmin, xmax = box
+    assert (got[:, ymin:ymax, xmin:xmax] != want[:, ymin:ymax, xmin:xmax]).mean() > (0.15 if ab else 0.4)

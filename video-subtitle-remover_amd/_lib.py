@@ -142,6 +142,8 @@ SIGNATURES = {
     "vsr_gemm_plan_create": (_I, [C.POINTER(GGProblem), _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_gemm_plan_run": (_I, [_P, _P]),
     "vsr_gemm_plan_destroy": (None, [_P]),
+    "vsr_io_yuv_to_bgr": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "vsr_io_bgr_to_yuv": (_I, [_P, _I, _I, _I, _I, _P, _L, _I, _P]),
     "vsr_launch_bgr2hsv_u8": (_I, [_P, _P, _L, _P]),
     "vsr_launch_absdiff_sums_u8x3": (_I, [_P, _I, _L, _P, _P]),
     "vsr_pp_create": (_I, [_I, C.POINTER(_P)]),
@@ -192,6 +194,12 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build the HIP extension first (__graft_entry__.build() or "
         f"`make -C {os.path.join(_HERE, 'csrc')}`); this package has no CPU fallback")
+
+# torch first: the library shares the process's HIP runtime with PyTorch (its streams and device pointers cross this ABI), and
+# that has to be the runtime PyTorch ships and loads.  Loaded the other way round (/opt/rocm's libamdhip64 first, through this
+# library's NEEDED entry) PyTorch reports no device at all -- seen on the GPU box when a test module imported this package
+# before anything had imported torch (profiles/r02_cli_e2e.log).
+import torch  # noqa: E402,F401
 
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():

@@ -82,6 +82,16 @@ class STTNInpaint:
         return [comp[i].astype(np.uint8) if counts[i] == 1 else comp[i] for i in range(len(frames))]
 
 
+class _ResidentFrames:
+    """the decoded frames of a chunk that stay in HBM while its strip rows are away (len() = frames actually read)"""
+
+    def __init__(self, full, n):
+        self.full, self.n = full, n
+
+    def __len__(self):
+        return self.n
+
+
 class STTNAutoInpaint:
     def __init__(self, device, model_path, video_path, mask_path=None, clip_gap=None):
         self.sttn_inpaint = STTNInpaint(device, model_path)
@@ -169,6 +179,9 @@ class STTNAutoInpaint:
                 writer.write(frame)
                 tick(original, frame)
 
+        resident = self._resident_io(rank, reader, writer, gui, inpaint_area)
+        if resident is not None:
+            load, store = self._resident_load_store(resident, engine, reader, writer, ranges, kept, (H_ori, W_ori), (y_lo, y_hi), tick)
         try:
             if not inpaint_area:                         # nothing to inpaint anywhere: rank 0 copies the video through
                 if rank == 0:
@@ -181,11 +194,87 @@ class STTNAutoInpaint:
                 if dist is not None:
                     dist.barrier()
             else:
-                cp.run_chunk_parallel(ranges, (y_hi - y_lo, W_ori, 3), load, process, store, dist=dist, device=engine.device)
+                # `io` only changes what rank 0 hands to load / store (pinned host rows or device rows); the exchange is the same
+                cp.run_chunk_parallel(ranges, (y_hi - y_lo, W_ori, 3), load, process, store, dist=dist, device=engine.device,
+                                      io="device" if resident is not None else "host")
         finally:
             reader.release()
             if writer:
                 writer.release()
+
+    @staticmethod
+    def _resident_io(rank, reader, writer, gui, inpaint_area):
+        """(reader format, writer format) when the frames of this run can stay in HBM from the stored planes to the stored planes:
+        a raw planar source and sink whose colour conversion runs on the GPU (*.y4m, tools/video_io.py), no preview consumer.
+        VSR_IO_RESIDENT=0 keeps the host-frame loop."""
+        if rank != 0 or gui or not inpaint_area or os.environ.get("VSR_IO_RESIDENT", "1") == "0":
+            return None
+        rf = getattr(reader, "planes_format", None)
+        wf = getattr(writer, "planes_format", None)
+        rf, wf = (rf() if rf is not None else None), (wf() if wf is not None else None)
+        return (rf, wf) if rf is not None and wf is not None else None
+
+    @staticmethod
+    def _resident_load_store(fmt, engine, reader, writer, ranges, kept, size, rows, tick):
+        """load / store of the chunk loop with the decoded frames resident in HBM (io="device" of tools/chunk_parallel.py): a chunk's
+        stored planes go to pinned memory and up as they are (half the bytes of the BGR frames), vsr_io_yuv_to_bgr converts, the strip
+        rows are copied out for the owner of the chunk; on the way back the rows are patched in, vsr_io_bgr_to_yuv converts and the
+        planes come down into pinned memory for the writer thread.  The host touches no pixel: the reference's loop
+        (sttn_auto_inpaint.py:254-262 read, :314-328 write) is cv2 / libswscale work on the CPU, 47 + 26 ms per 1080p frame in numpy."""
+        import ctypes as C
+
+        from ..._lib import check, lib
+
+        (rf, wf), (H, W), (y_lo, y_hi) = fmt, size, rows
+        dev = engine.device
+        maxn = max((e - s for s, e in ranges), default=0)
+        u8 = torch.uint8
+        pin_in = [torch.empty((maxn, rf["frame_bytes"]), dtype=u8).pin_memory() for _ in range(2)]
+        pin_out = [torch.empty((maxn, wf["frame_bytes"]), dtype=u8).pin_memory() for _ in range(2)]
+        ev_in, ev_out = [None, None], [None, None]
+        d_in = torch.empty((maxn, rf["frame_bytes"]), dtype=u8, device=dev)
+        d_out = torch.empty((maxn, wf["frame_bytes"]), dtype=u8, device=dev)
+        free, turn = [], {"in": 0, "out": 0}
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        cur = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+        def load(i, out):                                # rank 0, called on the io stream of the chunk loop
+            s, e = ranges[i]
+            b = turn["in"] = turn["in"] ^ 1
+            if ev_in[b] is not None:
+                ev_in[b].synchronize()                   # the upload that last used this pinned buffer is done
+            k = reader.read_planes_into(pin_in[b].numpy()[: e - s])
+            if k < e - s:
+                print(f"Warning: Failed to read frame {s + k}.")                 # :259-261: the chunk ends with the frames read so far
+            full = free.pop() if free else torch.empty((maxn, H, W, 3), dtype=u8, device=dev)
+            if k:
+                d_in[:k].copy_(pin_in[b][:k], non_blocking=True)
+                ev_in[b] = torch.cuda.Event()
+                ev_in[b].record(torch.cuda.current_stream(dev))
+                check(lib.vsr_io_yuv_to_bgr(ptr(d_in), rf["frame_bytes"], H, W, rf["cw"], rf["ch"], int(rf["full_range"]), ptr(full), k, cur()))
+                out[:k].copy_(full[:k, y_lo:y_hi])
+            else:
+                print(f"Warning: No valid frames found in range {s + 1}-{e}. Skipping this segment.")
+            out[k:].zero_()
+            kept[i] = _ResidentFrames(full, k)
+
+        def store(i, rows_dev):                          # rank 0, io stream, chunk order
+            kf = kept.pop(i)
+            k = len(kf)
+            if k:
+                kf.full[:k, y_lo:y_hi].copy_(rows_dev[:k])
+                b = turn["out"] = turn["out"] ^ 1
+                check(lib.vsr_io_bgr_to_yuv(ptr(kf.full), H, W, int(wf["subsample_420"]), int(wf["full_range"]), ptr(d_out), wf["frame_bytes"], k, cur()))
+                pin_out[b][:k].copy_(d_out[:k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                ev.synchronize()
+                writer.write_planes(pin_out[b].numpy()[:k])      # the writer thread takes its own copy
+                for _ in range(k):
+                    tick(None, None)
+            free.append(kf.full)
+
+        return load, store
 
     def __call__(self, input_mask=None, input_sub_remover=None, tbar=None):
         try:

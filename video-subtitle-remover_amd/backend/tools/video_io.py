@@ -8,7 +8,8 @@ reading and writing overlap the GPU work, and a loud failure when nothing can se
   source                      sink
   ArrayVideo (in memory)      ArrayWriter / CountingWriter
   *.npy   uint8 [N,H,W,3] BGR NpyWriter         (memory-mapped, lossless: the parity container)
-  *.y4m   YUV4MPEG2           Y4mWriter         (C444 / C420 / mono, BT.601; what `ffmpeg -i x.mp4 x.y4m` writes)
+  *.y4m   YUV4MPEG2           Y4mWriter         (C444 / C420 / mono, BT.601; what `ffmpeg -i x.mp4 x.y4m` writes; the colour
+                                                conversion runs on the GPU, csrc/io_kernels.hip)
   anything else               FFmpegVideoWriter (needs an `ffmpeg` on PATH or $VSR_FFMPEG; else cv2 if importable; else an error)
 """
 import os
@@ -192,6 +193,80 @@ def _bgr_to_yuv(frame, full_range):
     return (np.clip(p, 0, 255).astype(np.uint8) for p in (y, u, v))
 
 
+def _device_color_enabled():
+    """the GPU does the colour conversion whenever there is one (VSR_IO_COLOR=host keeps the numpy statement, which is also what a
+    machine without a GPU -- where nothing but IO can run anyway -- uses)"""
+    if os.environ.get("VSR_IO_COLOR", "device") == "host":
+        return False
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except ImportError:
+        return False
+
+
+class _DeviceColor:
+    """Planar YCbCr <-> packed BGR on the GPU (csrc/io_kernels.hip: vsr_io_yuv_to_bgr / vsr_io_bgr_to_yuv, the integer matrices
+    of _yuv_to_bgr / _bgr_to_yuv bit for bit).  numpy needs 47 ms to turn one 1080p 4:2:0 frame into BGR and 26 ms for the way
+    back -- the whole 50-frame STTN chunk takes 310 ms on the GPU -- so the raw planes go up as they are on disk (half the bytes
+    of the BGR frame), the kernel converts, and the frames come back.  Frames move in batches of up to `batch` (one upload, one
+    launch, one download, one synchronisation per batch: beside a busy compute stream every single operation waits for a slot).
+    One instance per reader / writer (own stream and pinned staging: the reader works in the caller's or the prefetch thread, the
+    writer in AsyncWriter's)."""
+
+    def __init__(self, H, W, frame_bytes, batch=8):
+        import ctypes as C
+
+        import torch
+
+        from ..._lib import check, lib
+
+        self.torch, self.C, self.check, self.lib = torch, C, check, lib
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.H, self.W, self.frame_bytes, self.batch = H, W, frame_bytes, max(1, int(batch))
+        self.stream = torch.cuda.Stream(self.dev)
+        B, u8 = self.batch, torch.uint8
+        with torch.cuda.stream(self.stream):
+            self.d_planes = torch.empty((B, frame_bytes), dtype=u8, device=self.dev)
+            self.d_bgr = torch.empty((B, H, W, 3), dtype=u8, device=self.dev)
+        self.pin_planes = torch.empty((B, frame_bytes), dtype=u8).pin_memory()
+        self.pin_bgr = torch.empty((B, H, W, 3), dtype=u8).pin_memory()
+
+    def _p(self, t):
+        return self.C.c_void_p(t.data_ptr())
+
+    def planes_buffer(self):
+        """pinned host records [batch][frame_bytes]: where the reader puts stored frames / where from_bgr leaves converted ones"""
+        return self.pin_planes.numpy()
+
+    def bgr_buffer(self):
+        """pinned host frames [batch][H][W][3]: where the writer collects frames / where to_bgr leaves converted ones"""
+        return self.pin_bgr.numpy()
+
+    def to_bgr(self, n, cw, ch, full_range):
+        """the first n records of planes_buffer() -> the first n frames of bgr_buffer()"""
+        t = self.torch
+        with t.cuda.stream(self.stream):
+            self.d_planes[:n].copy_(self.pin_planes[:n], non_blocking=True)
+            self.check(self.lib.vsr_io_yuv_to_bgr(self._p(self.d_planes), self.frame_bytes, self.H, self.W, cw, ch, int(bool(full_range)),
+                                                  self._p(self.d_bgr), n, self.C.c_void_p(self.stream.cuda_stream)))
+            self.pin_bgr[:n].copy_(self.d_bgr[:n], non_blocking=True)
+        self.stream.synchronize()
+        return self.pin_bgr.numpy()[:n]
+
+    def from_bgr(self, n, subsample_420, full_range):
+        """the first n frames of bgr_buffer() -> the first n records of planes_buffer()"""
+        t = self.torch
+        with t.cuda.stream(self.stream):
+            self.d_bgr[:n].copy_(self.pin_bgr[:n], non_blocking=True)
+            self.check(self.lib.vsr_io_bgr_to_yuv(self._p(self.d_bgr), self.H, self.W, int(bool(subsample_420)), int(bool(full_range)),
+                                                  self._p(self.d_planes), self.frame_bytes, n, self.C.c_void_p(self.stream.cuda_stream)))
+            self.pin_planes[:n].copy_(self.d_planes[:n], non_blocking=True)
+        self.stream.synchronize()
+        return self.pin_planes.numpy()[:n]
+
+
 class Y4mVideo:
     """YUV4MPEG2 reader: 8-bit C420* / C422 / C444 / Cmono, progressive; frames come out as BGR (BT.601)."""
 
@@ -232,6 +307,15 @@ class Y4mVideo:
         self._data0 = self._f.tell()
         self._fsize = self.w * self.h + 2 * self.cw * self.ch
         self._count = None
+        self._dc_args = (self.h, self.w, self._fsize) if _device_color_enabled() else None     # the converter is built on first use
+        self._dc_obj = None
+        self._ready = []                              # frames converted ahead (device path): popped from the end
+
+    @property
+    def _dc(self):
+        if self._dc_obj is None and self._dc_args is not None:
+            self._dc_obj = _DeviceColor(*self._dc_args)
+        return self._dc_obj
 
     def info(self):
         if self._count is None:                       # constant-size records: "FRAME\n" + planes (frame parameters are rare; counted exactly)
@@ -254,6 +338,14 @@ class Y4mVideo:
         return {"W_ori": self.w, "H_ori": self.h, "fps": self.fps, "len": int(self._count)}
 
     def read(self):
+        if self._dc is not None:                      # planes as stored -> pinned memory -> GPU -> BGR frames, a batch at a time
+            if not self._ready:
+                n = self.read_planes_into(self._dc.planes_buffer())
+                if n == 0:
+                    return False, None
+                bgr = self._dc.to_bgr(n, self.cw, self.ch, self.full_range)
+                self._ready = [bgr[k].copy() for k in range(n - 1, -1, -1)]       # frames of their own: the plugins patch rows into them
+            return True, self._ready.pop()
         line = self._f.readline()
         if not line.startswith(b"FRAME"):
             return False, None
@@ -273,6 +365,25 @@ class Y4mVideo:
             v = np.repeat(np.repeat(v, ry, axis=0), rx, axis=1)[: self.h, : self.w]
         return True, _yuv_to_bgr(y, u, v, self.full_range)
 
+    # raw access for the device-resident chunk loop (STTNAutoInpaint._run): the planes travel as stored, the GPU converts
+    def planes_format(self):
+        """None without a GPU; else the layout of one stored frame: [Y: H*W][U: ch*cw][V: ch*cw], `frame_bytes` in all"""
+        if self._dc_args is None:
+            return None
+        if self._ready:
+            raise RuntimeError("read() and read_planes_into() cannot be mixed on one reader")
+        return {"frame_bytes": self._fsize, "cw": self.cw, "ch": self.ch, "full_range": self.full_range}
+
+    def read_planes_into(self, out):
+        """fill out[k] (uint8 [n][frame_bytes], e.g. pinned memory) with the next frames as stored; returns how many were read"""
+        k = 0
+        while k < out.shape[0]:
+            line = self._f.readline()
+            if not line.startswith(b"FRAME") or self._f.readinto(out[k]) < self._fsize:
+                break
+            k += 1
+        return k
+
     def release(self):
         self._f.close()
 
@@ -287,10 +398,31 @@ class Y4mWriter:
         self._f = open(path, "wb", buffering=1 << 22)
         tag = "444" if chroma == "444" else "420mpeg2"
         self._f.write(f"YUV4MPEG2 W{self.w} H{self.h} F{num}:{den} Ip A1:1 C{tag} XCOLORRANGE=LIMITED\n".encode())
+        cw, ch = (self.w, self.h) if chroma == "444" else ((self.w + 1) // 2, (self.h + 1) // 2)
+        self._dc_args = (self.h, self.w, self.w * self.h + 2 * cw * ch) if _device_color_enabled() else None
+        self._dc_obj = None
+        self._pending = 0
+
+    @property
+    def _dc(self):
+        if self._dc_obj is None and self._dc_args is not None:
+            self._dc_obj = _DeviceColor(*self._dc_args)
+        return self._dc_obj
+
+    def _flush(self):
+        if self._pending:
+            n, self._pending = self._pending, 0
+            self.write_planes(self._dc.from_bgr(n, self.chroma != "444", False))
 
     def write(self, frame):
         if frame.dtype != np.uint8:
             frame = np.clip(frame, 0, 255).astype(np.uint8)
+        if self._dc is not None:                      # collected in pinned memory, converted a batch at a time
+            self._dc.bgr_buffer()[self._pending] = frame
+            self._pending += 1
+            if self._pending == self._dc.batch:
+                self._flush()
+            return
         y, u, v = _bgr_to_yuv(frame, False)
         if self.chroma != "444":
             h2, w2 = (self.h + 1) // 2 * 2, (self.w + 1) // 2 * 2
@@ -303,7 +435,23 @@ class Y4mWriter:
         self._f.write(u.tobytes())
         self._f.write(v.tobytes())
 
+    def planes_format(self):
+        """None without a GPU; else what write_planes expects per frame (BT.601 studio range)"""
+        if self._dc_args is None:
+            return None
+        return {"frame_bytes": self._dc_args[2], "subsample_420": self.chroma != "444", "full_range": False}
+
+    def write_planes(self, recs):
+        """frames already converted on the device: uint8 [n][frame_bytes]"""
+        if self._pending:
+            self._flush()
+        for rec in recs:
+            self._f.write(b"FRAME\n")
+            self._f.write(rec)
+
     def release(self):
+        if self._dc_obj is not None:
+            self._flush()
         self._f.close()
 
 
@@ -512,7 +660,10 @@ class AsyncWriter:
                 return
             if self._err is None:
                 try:
-                    self.sink.write(f)
+                    if isinstance(f, tuple):
+                        self.sink.write_planes(f[1])
+                    else:
+                        self.sink.write(f)
                 except Exception as e:      # keep draining so the producer never blocks on a dead sink
                     self._err = e
 
@@ -520,6 +671,16 @@ class AsyncWriter:
         if self._err is not None:
             raise self._err
         self._q.put(np.array(frame, copy=True))
+
+    def planes_format(self):
+        fmt = getattr(self.sink, "planes_format", None)
+        return fmt() if fmt is not None else None
+
+    def write_planes(self, recs):
+        """a batch of frames converted on the device (see Y4mWriter.write_planes); keeps its place in the frame order"""
+        if self._err is not None:
+            raise self._err
+        self._q.put(("planes", np.array(recs, copy=True)))
 
     def release(self):
         if self._t is None:                 # already released (the plugin and run() both release, as in the reference)
