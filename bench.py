@@ -264,6 +264,9 @@ def main():
                     a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}:v{var}")
                     if b:
                         per_kernel[f"{sym}<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)
+            a, b, c = eng.timing_get(f"kernel:gg:{cfg}:1:v1x")          # P.V of the fused attention (gather_gemm_pvx.h)
+            if b:
+                per_kernel[f"gather_gemm_f32_aexp<{bm}, {bn}, {wm}, {wn}>"] = (a, b, c)
         dom = max(per_kernel, key=lambda k: per_kernel[k][0])
         ms, n, fl = per_kernel[dom]
         breakdown = {}

@@ -127,7 +127,16 @@ int vsr_sttn_timing_reset(vsr_sttn_t* h);
 enum { VSR_BMODE_NK = 0, VSR_BMODE_KN = 1 };
 enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2, VSR_ACT_LRELU01 = 3,
        VSR_ACT_OUT_SPLIT = 0x100, /* variants 5, 6: OR-ed into act, C is written in split format */
-       VSR_ACT_POST_RELU = 0x200  /* OR-ed into act: C = relu(act(..) + R)  (residual blocks, raft/extractor.py:48-58) */ };
+       VSR_ACT_POST_RELU = 0x200, /* OR-ed into act: C = relu(act(..) + R)  (residual blocks, raft/extractor.py:48-58) */
+       /* the two halves of softmax(QK^T / sqrt(D)) . V (auto_sttn.py:141-145) without a probability matrix in memory:
+        * ROW_MAX on the score GEMM (NK, variant 3, splitK 1, no residual): besides C, the maximum of every output row is kept in
+        * ((uint32_t*)R)[m] -- monotone unsigned encoding of the float, atomic max over the N tiles, zeroed by the caller;
+        * A_EXP on the P.V GEMM (KN, variant 1 | VSR_VARIANT_A_EXP): the A operand is exp(A[m][k] - rowmax[m]) with rowmax =
+        * ((const uint32_t*)bias)[m] in that encoding, and the row sums l[m] = sum_k exp(..) are taken while the tiles are staged:
+        * splitK 1 writes C = (expA . B) / l; splitK > 1 writes the partial planes unnormalised and the partial sums to
+        * ((float*)R)[split * tilesM * BM + m], for vsr_launch_reduce_scatter's caller to divide by their total. */
+       VSR_ACT_ROW_MAX = 0x400, VSR_ACT_A_EXP = 0x800 };
+#define VSR_VARIANT_A_EXP 0x100 /* OR-ed into the kernel variant 1 of a KN launch whose problems may carry VSR_ACT_A_EXP */
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3 };
 
 /* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]

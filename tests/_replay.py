@@ -63,7 +63,7 @@ def _cols(table, n):
     return full[:n]
 
 
-def gemm_reference(it, bmode, bufs, tables):
+def gemm_reference(it, bmode, bufs, tables, tile_m=128):
     """Execute one gather-GEMM descriptor exactly as include/vsr_hip.h defines it."""
     M, N, K = it.M, it.N, it.K
     A = bufs[it.bufA]
@@ -82,6 +82,18 @@ def gemm_reference(it, bmode, bufs, tables):
     rowC = tables[it.tRowC][:M]
     colC = _cols(tables[it.tColC], N)
     Cbuf = bufs[it.bufC]
+    if it.act & 0x800:                     # VSR_ACT_A_EXP: A holds scores; the product is softmax(A) . B, normalised here or by the reduce op
+        Am = torch.exp(Am - Am.max(dim=1, keepdim=True).values)
+        if it.splitK > 1:
+            ldl = it.tilesM * tile_m
+            for s in range(it.splitK):
+                k0 = s * it.chunksPerSplit * 32
+                k1 = min(K, k0 + it.chunksPerSplit * 32)
+                Cbuf[it.offC + s * it.splitStride + rowC[:, None] + colC[None, :]] = (Am[:, k0:k1] @ Bm[k0:k1, :]).numpy()
+                bufs[it.bufR][it.offR + s * ldl: it.offR + s * ldl + M] = Am[:, k0:k1].sum(dim=1).numpy()
+        else:
+            Cbuf[it.offC + rowC[:, None] + colC[None, :]] = ((Am @ Bm) / Am.sum(dim=1, keepdim=True)).numpy()
+        return
     if it.splitK > 1:
         for s in range(it.splitK):
             k0 = s * it.chunksPerSplit * 32
@@ -98,7 +110,9 @@ def gemm_reference(it, bmode, bufs, tables):
         acc = torch.relu(acc)
     elif it.act & 0xff == 3:
         acc = torch.nn.functional.leaky_relu(acc, 0.1)
-    if it.bufR >= 0:
+    if it.act & 0x400:                     # VSR_ACT_ROW_MAX: bufR receives the row maxima (ordered-uint images; the replay's A_EXP takes its own)
+        pass
+    elif it.bufR >= 0:
         rowR = tables[it.tRowR][:M]
         acc = acc + torch.from_numpy(bufs[it.bufR][it.offR + rowR[:, None] + colC[None, :]])
         if it.act & 0x200:                 # VSR_ACT_POST_RELU
@@ -175,6 +189,13 @@ def reduce_scatter_reference(info, bufs, tables):
         o = info.off_src + s * info.split_stride
         plane = part[o: o + M * N].reshape(M, N)
         acc = plane.copy() if acc is None else acc + plane
+    if info.ibuf[0] >= 0:                  # planes of a VSR_ACT_A_EXP product: divide by the total of the splits' row sums
+        lbuf, ldl = bufs[info.ibuf[0]], info.ipar[0]
+        l = None
+        for s in range(info.nsplit):
+            part_l = lbuf[info.ioff[0] + s * ldl: info.ioff[0] + s * ldl + M]
+            l = part_l.copy() if l is None else l + part_l
+        acc = acc / l[:, None]
     rowC = tables[info.t_rowC][:M]
     colC = _cols(tables[info.t_colC], N)
     bufs[info.buf_dst][info.off_dst + rowC[:, None] + colC[None, :]] = acc
@@ -204,7 +225,7 @@ def replay(view, packed_weights, frames_u8, masks_u8=None):
         for info, items in view.ops:
             if info.kind == OP_GEMM:
                 for it in items:
-                    gemm_reference(it, info.bmode, bufs, view.tables)
+                    gemm_reference(it, info.bmode, bufs, view.tables, tile_m={0: 128, 1: 256, 2: 256, 3: 128}[info.tile_cfg])
             elif info.kind == OP_SOFTMAX:
                 for it in items:
                     softmax_reference(it, bufs)

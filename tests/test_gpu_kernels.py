@@ -516,3 +516,107 @@ def test_upscale_blend_bit_exact(built_lib, gpu_device, W, sh):
         c = comp[i] if isf[i] else comp[i].astype(np.uint8)
         o.blend_strip(ref, c, mask[:, :, None], (ymin, ymin + sh, 0, W), W, sh)
         assert np.array_equal(got[i], ref), f"frame {i} (float path={bool(isf[i])})"
+
+
+# ---- fused attention: row maxima out of the score GEMM, exp + row sums inside the P.V GEMM -------------------------------
+def _ordered_to_float(u):
+    """inverse of the kernels' monotone unsigned image of a float (csrc/gather_gemm.hip f32_ordered)"""
+    u = u.astype(np.uint32)
+    pos = (u & np.uint32(0x80000000)) != 0
+    bits = np.where(pos, u & np.uint32(0x7FFFFFFF), ~u)
+    return bits.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(320, 320, 960, "128x64"), (130, 75, 64, "128x64"), (300, 200, 96, "128x128"), (4800, 4800, 64, "128x64")])
+def test_score_gemm_leaves_row_maxima(built_lib, gpu_device, M, N, K, tile):
+    """VSR_ACT_ROW_MAX on the persistent NK kernel: C as without the flag, and max_n C[m][n] of every row in the side array
+    (atomic max over the N tiles of an ordered-uint image; rows beyond M untouched)"""
+    rng = np.random.default_rng(M + N + K)
+    bm, bn = (128, 64) if tile == "128x64" else (128, 128)
+    cfg = built_lib.TILE_128x64 if tile == "128x64" else built_lib.TILE_128x128
+    c = _make_gemm_case(rng, M, N, K, bm, bn, 0, 1, False, 0, False, alpha=0.125)
+    ref = _reference(c)
+    mp = c.tilesM * bm
+    rowmax = torch.zeros(mp + 8, dtype=torch.int32, device=gpu_device)
+    c.act = 0x400
+    keep = []
+    probs = (built_lib.GGProblem * 1)()
+    d = {k: _dev(getattr(c, k), gpu_device) for k in ("Abuf", "Bbuf", "Cbuf")}
+    t = {k: _dev(getattr(c, k).astype(np.int32), gpu_device) for k in ("rowA", "colA", "rowB", "colB", "rowC", "colC")}
+    p = probs[0]
+    p.A, p.B, p.C, p.bias, p.R = d["Abuf"].data_ptr(), d["Bbuf"].data_ptr(), d["Cbuf"].data_ptr(), None, rowmax.data_ptr()
+    p.rowA, p.colA, p.rowB, p.colB, p.rowC, p.colC = (t[k].data_ptr() for k in ("rowA", "colA", "rowB", "colB", "rowC", "colC"))
+    p.rowR = None
+    p.M, p.N, p.K, p.tilesM, p.tilesN = c.M, c.N, c.K, c.tilesM, c.tilesN
+    p.splitK, p.chunksPerSplit, p.act, p.alpha, p.splitStride = 1, c.chunksPerSplit, c.act, c.alpha, c.splitStride
+    built_lib.check(built_lib.lib.vsr_run_gather_gemm_variant(probs, 1, cfg, 0, 3, None))
+    torch.cuda.synchronize()
+    got = d["Cbuf"].cpu().numpy()
+    _assert_close(got, ref, K, f"scores {M}x{N}x{K}", c)
+    m, n = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    Cmat = got[c.rowC[m] + c.colC[n // 32] + n % 32]
+    rm = rowmax.cpu().numpy()
+    assert np.array_equal(_ordered_to_float(rm[:M]), Cmat.max(axis=1)), "row maxima are not the maxima of the stored scores"
+    assert not rm[M:].any(), "rows beyond M were touched"
+
+
+@pytest.mark.parametrize("M,K,N,splitK,tile", [(320, 320, 960, 1, "128x64"), (4800, 4800, 64, 3, "128x64"), (200, 96, 130, 1, "128x64"),
+                                               (640, 640, 320, 2, "128x128")])
+def test_pv_gemm_exponentiates_its_scores(built_lib, gpu_device, M, K, N, splitK, tile):
+    """VSR_ACT_A_EXP on the KN kernel (variant 1 | VSR_VARIANT_A_EXP): C = softmax_rows(A) . B without a probability matrix --
+    normalised in the epilogue (splitK 1) or left as partial planes + partial row sums (splitK > 1); a problem without the flag
+    in the same launch runs as the plain KN kernel"""
+    rng = np.random.default_rng(M + N + K + splitK)
+    bm, bn = (128, 64) if tile == "128x64" else (128, 128)
+    cfg = built_lib.TILE_128x64 if tile == "128x64" else built_lib.TILE_128x128
+    c = _make_gemm_case(rng, M, N, K, bm, bn, 1, splitK, False, 0, False)
+    c.Abuf *= 3.0                                                 # scores with a spread: exp() spans ~e^25
+    plain = _make_gemm_case(rng, 150, 70, 64, bm, bn, 1, 1, False, 0, False)
+    mp = c.tilesM * bm
+    m_idx, k_idx = np.meshgrid(np.arange(M), np.arange(K), indexing="ij")
+    S = c.Abuf[c.rowA[m_idx] + c.colA[k_idx // 32] + k_idx % 32]
+    rowmax_f = np.zeros(mp, np.float32)
+    rowmax_f[:M] = S.max(axis=1)
+    b = rowmax_f.view(np.uint32)
+    enc = np.where((b & np.uint32(0x80000000)) != 0, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
+    enc[M:] = 0
+    rowmax = torch.from_numpy(enc.view(np.int32)).to(gpu_device)
+    lsum = torch.full((splitK * mp + 8,), -3.0, dtype=torch.float32, device=gpu_device)
+    probs = (built_lib.GGProblem * 2)()
+    keep, outs = [], []
+    for i, cc in enumerate((c, plain)):
+        d = {k: _dev(getattr(cc, k), gpu_device) for k in ("Abuf", "Bbuf", "Cbuf")}
+        t = {k: _dev(getattr(cc, k).astype(np.int32), gpu_device) for k in ("rowA", "colA", "rowB", "colB", "rowC", "colC")}
+        keep.append((d, t))
+        p = probs[i]
+        p.A, p.B, p.C = d["Abuf"].data_ptr(), d["Bbuf"].data_ptr(), d["Cbuf"].data_ptr()
+        p.bias, p.R = (rowmax.data_ptr(), lsum.data_ptr() if splitK > 1 else None) if i == 0 else (None, None)
+        p.rowA, p.colA, p.rowB, p.colB, p.rowC, p.colC = (t[k].data_ptr() for k in ("rowA", "colA", "rowB", "colB", "rowC", "colC"))
+        p.rowR = None
+        p.M, p.N, p.K, p.tilesM, p.tilesN = cc.M, cc.N, cc.K, cc.tilesM, cc.tilesN
+        p.splitK, p.chunksPerSplit, p.alpha, p.splitStride = cc.splitK, cc.chunksPerSplit, 1.0, cc.splitStride
+        p.act = 0x800 if i == 0 else 0
+        outs.append(d["Cbuf"])
+    built_lib.check(built_lib.lib.vsr_run_gather_gemm_variant(probs, 2, cfg, 1, 1 | 0x100, None))
+    torch.cuda.synchronize()
+    _assert_close(outs[1].cpu().numpy(), _reference(plain), plain.K, "plain problem beside a fused one", plain)
+    got = outs[0].cpu().numpy()
+    k2, n2 = np.meshgrid(np.arange(K), np.arange(N), indexing="ij")
+    Bm = torch.from_numpy(c.Bbuf[c.rowB[k2] + c.colB[n2 // 32] + n2 % 32]).double()
+    E = torch.exp(torch.from_numpy(S).double() - torch.from_numpy(rowmax_f[:M]).double()[:, None])
+    want = (E @ Bm) / E.sum(dim=1, keepdim=True)
+    m2, n3 = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    cells = c.rowC[m2] + c.colC[n3 // 32] + n3 % 32
+    if splitK == 1:
+        out = torch.from_numpy(got[cells]).double()
+    else:
+        ls = lsum.cpu().numpy()
+        parts = sum(torch.from_numpy(got[cells + s * c.splitStride]).double() for s in range(splitK))
+        ltot = sum(torch.from_numpy(ls[s * mp: s * mp + M]).double() for s in range(splitK))
+        assert np.allclose(ltot.numpy(), E.sum(dim=1).numpy(), rtol=2e-6), "partial row sums"
+        assert (ls[splitK * mp:] == -3.0).all()
+        out = parts / ltot[:, None]
+    err = (out - want).abs().max().item()
+    assert err <= 2e-6 * max(1.0, want.abs().max().item()) * np.sqrt(K) / 4 + 2e-6, err
+    keepmask = ~_written_mask(c)
+    assert np.array_equal(got[keepmask], c.Cbuf[keepmask]), "store footprint differs"

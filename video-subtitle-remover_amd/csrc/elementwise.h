@@ -12,6 +12,6 @@ extern "C" int vsr_launch_norm_im2col_fmt(const uint8_t* img, int ih, int iw, in
                                           const uint8_t* mask, int outSplit, void* stream);
 extern "C" int vsr_launch_reduce_scatter_fmt(const float* part, int nsplit, int64_t splitStride, int M, int N,
                                              const int32_t* rowC, const int32_t* colC, float* out, int outSplit,
-                                             void* stream);
+                                             const float* lsum, int ldL, void* stream);   // lsum [nsplit][ldL]: divide row m by their sum (fused attention), or NULL
 extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
                                          int nframes, int split, void* stream);

@@ -395,7 +395,8 @@ k_upscale_blend(const float* __restrict__ comp /*[n][mh][mw][3] RGB*/, int mw, i
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_reduce_scatter(const float* __restrict__ part, int nsplit, int64_t splitStride, int M, int N,
-                 const int32_t* __restrict__ rowC, const int32_t* __restrict__ colC, float* __restrict__ out, int outSplit)
+                 const int32_t* __restrict__ rowC, const int32_t* __restrict__ colC, float* __restrict__ out, int outSplit,
+                 const float* __restrict__ lsum, int ldL)
 {
     const int N4 = N / 4;
     const int64_t total = (int64_t)M * N4;
@@ -408,6 +409,13 @@ k_reduce_scatter(const float* __restrict__ part, int nsplit, int64_t splitStride
             const f32x4 v = *reinterpret_cast<const f32x4*>(part + s * splitStride + (int64_t)m * N + n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        }
+        if (lsum != nullptr) {       // planes of a fused attention (VSR_ACT_A_EXP): unnormalised, the splits' row sums beside them
+            float l = lsum[m];
+            for (int s = 1; s < nsplit; ++s) l += lsum[(int64_t)s * ldL + m];
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] *= inv;
         }
         store4_fmt(out, (int64_t)rowC[m] + colC[n >> 5] + (n & 31), acc, outSplit);
     }
@@ -477,15 +485,16 @@ extern "C" int vsr_launch_softmax_dev(const SMProblem* d_probs, int nprobs, int 
 extern "C" int vsr_launch_reduce_scatter(const float* part, int nsplit, int64_t splitStride, int M, int N,
                                          const int32_t* rowC, const int32_t* colC, float* out, void* stream)
 {
-    return vsr_launch_reduce_scatter_fmt(part, nsplit, splitStride, M, N, rowC, colC, out, 0, stream);
+    return vsr_launch_reduce_scatter_fmt(part, nsplit, splitStride, M, N, rowC, colC, out, 0, nullptr, 0, stream);
 }
 extern "C" int vsr_launch_reduce_scatter_fmt(const float* part, int nsplit, int64_t splitStride, int M, int N,
-                                             const int32_t* rowC, const int32_t* colC, float* out, int outSplit, void* stream)
+                                             const int32_t* rowC, const int32_t* colC, float* out, int outSplit,
+                                             const float* lsum, int ldL, void* stream)
 {
     const int64_t total = (int64_t)M * (N / 4);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_reduce_scatter, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, part, nsplit,
-                       splitStride, M, N, rowC, colC, out, outSplit);
+                       splitStride, M, N, rowC, colC, out, outSplit, lsum, ldL);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 

@@ -31,6 +31,17 @@ typedef const f32x4 __attribute__((address_space(1)))* gcf32x4;
 // wave-uniform, read-only table entries (chunk offsets): constant address space -> s_load
 typedef const int32_t __attribute__((address_space(4)))* cci32;
 
+// monotone unsigned image of a float (0 sorts below every number): row maxima of the attention scores are kept with atomicMax
+__device__ __forceinline__ unsigned int f32_ordered(float f)
+{
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(unsigned int e)
+{
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
 // Ablation hooks (scripts/gg_ablate.hip defines GG_ABLATE and adds an ABL template argument that
 // switches single mechanisms off to price them); compiled out of the product.
 #ifdef GG_ABLATE
@@ -300,6 +311,9 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 }
 
 #include "gather_gemm_v3.h"
+#ifndef GG_ABLATE
+#include "gather_gemm_pvx.h"
+#endif
 #include "gather_gemm_v4.h"
 #include "gather_gemm_v5.h"
 #include "gather_gemm_v6.h"
@@ -415,10 +429,17 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
                                           int bmode, unsigned int* queue, int variant, int nQueues,
                                           unsigned int* rangeFlag, void* stream_)
 {
-    if (variant <= 1) queue = nullptr;
     hipStream_t stream = (hipStream_t)stream_;
     if (totalBlocks <= 0) return 0;
     dim3 block(256);
+    if (variant & VSR_VARIANT_A_EXP) {   // P.V of a fused attention: the KN kernel that exponentiates its A operand (gather_gemm_pvx.h)
+        if ((variant & 0xff) != 1 || bmode != VSR_BMODE_KN) return -1;
+        if (tileCfg == VSR_TILE_128x64) hipLaunchKernelGGL((gather_gemm_f32_aexp<128, 64, 2, 2>), dim3(totalBlocks), block, 0, stream, d_probs, nprobs);
+        else if (tileCfg == VSR_TILE_128x128) hipLaunchKernelGGL((gather_gemm_f32_aexp<128, 128, 2, 2>), dim3(totalBlocks), block, 0, stream, d_probs, nprobs);
+        else return -1;
+        return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+    }
+    if (variant <= 1) queue = nullptr;
     if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_NK);
     else if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_KN) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_KN);
     else if (tileCfg == VSR_TILE_256x32 && bmode == VSR_BMODE_NK) GG_LAUNCH(256, 32, 4, 1, VSR_BMODE_NK);

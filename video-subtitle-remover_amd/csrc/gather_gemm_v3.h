@@ -149,7 +149,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             // global table read per row
             const gci32 rowCt = (gci32)P->rowC;
             const gci32 rowRt = (gci32)P->rowR;
-            const bool hasR = (P->R != nullptr) && (splitK == 1);
+            const bool hasR = (P->R != nullptr) && (splitK == 1) && !(P->act & VSR_ACT_ROW_MAX);
 #pragma unroll
             for (int i = tid; i < 2 * BM; i += 256)
                 rowTab[i] = i < BM ? rowCt[tm * BM + i] : (hasR ? rowRt[tm * BM + i - BM] : 0);
@@ -274,8 +274,9 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const int act = P->act & 0xff;
         const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;   // relu(act(..) + R): residual blocks of RAFT
         const bool partial = (splitK > 1);
+        const bool rowMax = (P->act & VSR_ACT_ROW_MAX) != 0;       // R is the row-maximum array of the scores, not a residual
         const gcf32 bias = partial ? (gcf32) nullptr : (gcf32)P->bias;
-        const gcf32 R = partial ? (gcf32) nullptr : (gcf32)P->R;
+        const gcf32 R = (partial || rowMax) ? (gcf32) nullptr : (gcf32)P->R;
         const cci32 colC = (cci32)P->colC;
         const gf32 C = (gf32)(P->C + (partial ? (int64_t)split * P->splitStride : (int64_t)0));
         int ccol[NI];
@@ -334,6 +335,31 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         using F_ = std::false_type;
         if (fullTile) { if (R != nullptr) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
         else          { if (R != nullptr) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
+        if (rowMax) {
+            // VSR_ACT_ROW_MAX (the QK^T of a fused attention): the largest score of every row of this tile joins the row's running
+            // maximum -- 32 lanes hold a row's columns, the waves side by side meet in LDS (the operand buffers are idle: the main
+            // loop ended on a barrier), then one atomic per row in a coalesced burst.  The P.V kernel subtracts it (VSR_ACT_A_EXP).
+            float* scr = smem;                                      // [BM][WN]
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        if (nok[ni]) mx = fmaxf(mx, acc[mi][ni][r] * alpha + bv[ni]);
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                    if (l31 == 0) scr[(wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * WN + wn] = mx;
+                }
+            __syncthreads();
+            if (tid < BM && tm * BM + tid < M) {
+                float mx = scr[tid * WN];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) mx = fmaxf(mx, scr[tid * WN + w]);
+                atomicMax(reinterpret_cast<unsigned int*>(const_cast<float*>(P->R)) + tm * BM + tid, f32_ordered(mx));
+            }
+        }
         __syncthreads();
         GG_STAMP()   // epilogue done
     }

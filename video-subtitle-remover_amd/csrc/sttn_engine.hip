@@ -63,6 +63,9 @@ struct OpDev {
     const int32_t* tRowC = nullptr;
     const int32_t* tColC = nullptr;
     int split = 0;               // precision mode 2: this elementwise op reads / writes split-format tensors
+    bool aexp = false;           // GEMM: the launch carries VSR_ACT_A_EXP problems (P.V of a fused attention)
+    const float* lsum = nullptr; // reduce_scatter of a fused attention: partial row sums [nsplit][ldL]
+    int ldL = 0;
     double flops = 0;
     std::string tag;
 };
@@ -198,7 +201,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
                 GGProblem& q = hp[j];
                 q.A = F(g.bufA, g.offA); q.B = F(g.bufB, g.offB); q.C = F(g.bufC, g.offC);
                 if (fmt && g.bufB == BUF_WEIGHTS) q.B = h->weightsSplit + g.offB;
-                q.bias = g.offBias >= 0 ? F(BUF_WEIGHTS, g.offBias) : nullptr;
+                q.bias = g.offBias >= 0 ? F(g.bufBias, g.offBias) : nullptr;      // bufBias 0 = BUF_WEIGHTS; BUF_ROWMAX for VSR_ACT_A_EXP
                 q.R = g.bufR >= 0 ? F(g.bufR, g.offR) : nullptr;
                 q.rowA = T(g.tRowA); q.colA = T(g.tColA); q.rowB = T(g.tRowB); q.colB = T(g.tColB);
                 q.rowC = T(g.tRowC); q.colC = T(g.tColC); q.rowR = T(g.tRowR);
@@ -212,6 +215,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
             od.nitems = (int)op.gemm.size();
             od.total = tileStart;
             od.nQueues = 8;
+            od.aexp = op.ipar[0] != 0;
             for (const GemmItem& g : op.gemm)
                 if (g.tilesN > 4) od.nQueues = 1;
             cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
@@ -236,6 +240,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
             od.M = op.M; od.N = op.N; od.nsplit = op.nsplit; od.splitStride = op.splitStride;
             od.tRowC = T(op.tRowC); od.tColC = T(op.tColC);
             od.split = fmt ? 1 : 0;
+            if (op.ibuf[0] >= 0) { od.lsum = F(op.ibuf[0], op.ioff[0]); od.ldL = op.ipar[0]; }
         } else {
             od.split = (fmt && op.kind != OP_DECODE_OUT) ? 1 : 0;
             od.src = op.bufSrc >= 0 ? h->bufs[op.bufSrc] : nullptr;
@@ -286,6 +291,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
     const int prec = pd->plan->precision;
     const bool persistent = prec ? true : use_persistent();
     if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
+    if (pd->plan->bufElems[BUF_ROWMAX] > 0)     // fused attention: every instance's row maxima start below every float
+        HIPCHK(hipMemsetAsync(h->bufs[BUF_ROWMAX], 0, (size_t)pd->plan->bufElems[BUF_ROWMAX] * sizeof(unsigned int), stream));
     size_t opIndex = 0;
     for (const OpDev& od : pd->ops) {
         unsigned int* queue = persistent ? pd->dQueues + 8 * opIndex : nullptr;
@@ -294,7 +301,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         if (h->timing) {
             tr.tag = od.tag; tr.flops = od.flops;
             tr.kernel = od.kind == OP_GEMM ? ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode) + ":v" +
-                                              std::to_string(gg_variant(od.bmode, prec)))
+                                              std::to_string(gg_variant(od.bmode, prec)) + (od.aexp ? "x" : ""))
                                            : ("kernel:op:" + std::to_string(od.kind));
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
@@ -303,7 +310,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         int rc = 0;
         switch (od.kind) {
         case OP_GEMM:
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue, gg_variant(od.bmode, prec), od.nQueues,
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue,
+                                            gg_variant(od.bmode, prec) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
                                             prec ? h->dRangeFlag : nullptr, stream);
             break;
         case OP_SOFTMAX:
@@ -321,7 +329,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             break;
         case OP_REDUCE_SCATTER:
             rc = vsr_launch_reduce_scatter_fmt((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,
-                                               (float*)od.dst, od.split, stream);
+                                               (float*)od.dst, od.split, od.lsum, od.ldL, stream);
             break;
         default:
             return fail(VSR_ERR_STATE, "unknown op kind");
@@ -730,7 +738,7 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
 
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
 {
-    if (variant < 1 || variant > 6) return fail(VSR_ERR_ARG, "kernel variant must be 1..6");
+    if (variant != (1 | VSR_VARIANT_A_EXP) && (variant < 1 || variant > 6)) return fail(VSR_ERR_ARG, "kernel variant must be 1..6 (or 1 | VSR_VARIANT_A_EXP)");
     return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, variant, stream_);
 }
 

@@ -26,6 +26,8 @@ const Tuning& Tuning::get(int precision)
             x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
             x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
+            // the fused path needs the kernels it was written into: v3 for the scores, v1 (+ A_EXP) for P.V -- the defaults
+            x.fuseSoftmax = envInt("VSR_FUSE_SOFTMAX", 1) && envInt("VSR_GG_VARIANT", 3) == 3 && envInt("VSR_PV_VARIANT", 1) == 1;
             return x;
         }(),
         [] {
@@ -35,6 +37,7 @@ const Tuning& Tuning::get(int precision)
             x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
             x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
+            x.fuseSoftmax = 0;      // split-format tensors: the probabilities are a GEMM operand in that format, k_softmax_rows writes it
             return x;
         }()};
     return t[precision ? 1 : 0];
@@ -461,7 +464,8 @@ void Plan::addAttention(int T, const BlockW&)
     tileDims(qk.tileCfg, qBM, qBN);
     tileDims(pv.tileCfg, pBM, pBN);
     std::vector<Op> reduces;
-    int64_t sOff = 0, pOff = 0, partOff = 0;
+    bool pvFused = false;
+    int64_t sOff = 0, pOff = 0, partOff = 0, lOff = 0;
     for (int s = g.nscales - 1; s >= 0; --s) { // finest scale (most tokens, most work) first
         const int pw = g.patchW[s], ph = g.patchH[s];
         const int Pn = (g.featW / pw) * (g.featH / ph);
@@ -490,15 +494,31 @@ void Plan::addAttention(int T, const BlockW&)
         a.tRowC = tRowsLinear(Ntok, ldS, qBM);
         a.tColC = tColsLinear(a.tilesN * qBN / VSR_GG_KC, a.tilesN * qBN / VSR_GG_KC);
         a.bufR = -1; a.tRowR = -1; a.offBias = -1;
+        // Fused softmax (exact-fp32 mode): a scale whose scores are not split along K and whose token count is whole chunks keeps
+        // no probability matrix -- the score GEMM scales by 1/sqrt(D) itself and leaves the row maxima (VSR_ACT_ROW_MAX), the P.V
+        // GEMM reads the scores, exponentiates them while staging and normalises by the row sums (VSR_ACT_A_EXP).  At the
+        // 4800-token scale that is 92 MB written and read once instead of twice, and no k_softmax_rows pass over them.
+        const bool fused = tu.fuseSoftmax && precision == 0 && splitK == 1 && Ntok % VSR_GG_KC == 0;
+        const float scale = (float)(1.0 / sqrt((double)D)); // scores / math.sqrt(query.size(-1))
+        int64_t rmaxOff = -1;
+        if (fused) {
+            rmaxOff = rowmaxElems_;
+            rowmaxElems_ += rup((int64_t)a.tilesM * qBM > (int64_t)cdiv(Ntok, pBM) * pBM ? (int64_t)a.tilesM * qBM : (int64_t)cdiv(Ntok, pBM) * pBM, 32);
+            a.alpha = scale;
+            a.act |= VSR_ACT_ROW_MAX;
+            a.bufR = BUF_ROWMAX; a.offR = rmaxOff;
+        }
         qk.gemm.push_back(a);
         qk.flops += 2.0 * Ntok * (double)Ntok * D;
 
-        SoftmaxItem m{};
-        m.bufS = BUF_S; m.offS = sOff; m.splitStride = plane; m.nsplit = splitK;
-        m.bufP = BUF_P; m.offP = pOff;
-        m.M = Ntok; m.N = Ntok; m.ldS = ldS; m.ldP = ldS;
-        m.scale = (float)(1.0 / sqrt((double)D)); // scores / math.sqrt(query.size(-1))
-        sm.softmax.push_back(m);
+        if (!fused) {
+            SoftmaxItem m{};
+            m.bufS = BUF_S; m.offS = sOff; m.splitStride = plane; m.nsplit = splitK;
+            m.bufP = BUF_P; m.offP = pOff;
+            m.M = Ntok; m.N = Ntok; m.ldS = ldS; m.ldP = ldS;
+            m.scale = scale;
+            sm.softmax.push_back(m);
+        }
 
         const int kchunks = ldS / VSR_GG_KC;
         int pvSplit = 1, pvCps = kchunks;
@@ -512,7 +532,7 @@ void Plan::addAttention(int T, const BlockW&)
         b.tilesM = cdiv(Ntok, pBM); b.tilesN = cdiv(D, pBN);
         b.splitK = pvSplit; b.chunksPerSplit = pvCps;
         b.alpha = 1.f; b.act = VSR_ACT_NONE;
-        b.bufA = BUF_P; b.offA = pOff;
+        b.bufA = fused ? BUF_S : BUF_P; b.offA = fused ? sOff : pOff;
         b.tRowA = tRowsLinear(Ntok, ldS, pBM);
         b.tColA = tColsLinear(kchunks, kchunks);
         b.bufB = BUF_QKV; b.offB = 0;
@@ -532,23 +552,33 @@ void Plan::addAttention(int T, const BlockW&)
             r.kind = OP_REDUCE_SCATTER; r.tag = "attn.pv.reduce";
             r.bufSrc = BUF_PVPART; r.offSrc = partOff; r.splitStride = b.splitStride; r.nsplit = pvSplit;
             r.bufDst = BUF_ATT; r.offDst = 0; r.M = Ntok; r.N = D; r.tRowC = tRowAtt; r.tColC = tColAtt;
+            if (fused) { r.ibuf[0] = BUF_LSUM; r.ioff[0] = lOff; r.ipar[0] = b.tilesM * pBM; }
             reduces.push_back(std::move(r));
             partOff += rup(b.splitStride * pvSplit, 32);
         }
         b.bufR = -1; b.tRowR = -1; b.offBias = -1;
+        if (fused) {
+            b.act |= VSR_ACT_A_EXP;
+            b.bufBias = BUF_ROWMAX; b.offBias = rmaxOff;
+            if (pvSplit > 1) { b.bufR = BUF_LSUM; b.offR = lOff; lOff += rup((int64_t)pvSplit * b.tilesM * pBM, 32); }
+            pvFused = true;
+        }
         pv.gemm.push_back(b);
         pv.flops += 2.0 * Ntok * (double)Ntok * D;
 
         sOff += rup(plane * splitK, 32);
-        pOff += rup(plane, 32);
+        if (!fused) pOff += rup(plane, 32);
     }
+    if (pvFused) pv.ipar[0] = 1;       // the launch may carry VSR_ACT_A_EXP problems: kernel variant 1 | VSR_VARIANT_A_EXP
     need(BUF_S, sOff);
     need(BUF_P, pOff);
+    need(BUF_ROWMAX, rowmaxElems_);
+    need(BUF_LSUM, lOff);
     need(BUF_PVPART, partOff);
     need(BUF_ATT, att.elems());
     flops += qk.flops + pv.flops;
     ops.push_back(std::move(qk));
-    ops.push_back(std::move(sm));
+    if (!sm.softmax.empty()) ops.push_back(std::move(sm));
     ops.push_back(std::move(pv));
     for (Op& r : reduces) ops.push_back(std::move(r));
 }

@@ -34,6 +34,8 @@ struct Tuning {
     int pvSplitChunks;   // VSR_PV_SPLIT_CHUNKS: split the P.V contraction into slices of ~this many 32-token
                          //   chunks when it has at least twice as many (0 = never split)
     int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
+    int fuseSoftmax;     // VSR_FUSE_SOFTMAX: 1 = exact-fp32 mode keeps no probability matrix for the scales whose scores are not
+                         //   split along K: row max in the QK^T epilogue, exp + row sum while P.V stages its A tiles (0 = k_softmax_rows)
     // precision 0: exact fp32 MFMA kernels; 1: split-half f16 MFMA kernels (larger tiles pay there)
     static const Tuning& get(int precision = 0);
 };
@@ -67,7 +69,10 @@ private:
 // ---- plan IR ----
 enum BufId {
     BUF_WEIGHTS = 0, BUF_IN_U8, BUF_IM2COL, BUF_E1, BUF_E2, BUF_E3, BUF_FEATS, BUF_X0, BUF_X1, BUF_QKV,
-    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_MASK_U8, BUF_COUNT
+    BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_MASK_U8,
+    BUF_ROWMAX,   // fused attention: row maxima of the scores (uint32 images of floats, one array per attention instance of the plan; zeroed per run)
+    BUF_LSUM,     // fused attention: partial row sums of the exponentials [split][rows] of a split P.V
+    BUF_COUNT
 };
 
 enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5,
@@ -82,6 +87,7 @@ struct GemmItem {
     int64_t splitStride;
     float alpha;
     int act;
+    int bufBias;                         // buffer `offBias` indexes: 0 = BUF_WEIGHTS (the zero-initialised default); VSR_ACT_A_EXP: the row maxima
 };
 struct SoftmaxItem {
     int bufS, bufP;
@@ -100,6 +106,7 @@ struct Op {
     int premask = 0;
     int bufMask = -1;                    // sttn-det: model-res resized mask [L][mh][mw] u8 (BUF_MASK_U8)
     // REDUCE_SCATTER: out[bufDst+offDst][rowC[m]+colC[n/32]+n%32] = sum_s part[bufSrc+offSrc][s*splitStride + m*N + n]
+    //   (ibuf[0] >= 0: divided by sum_s lsum[ibuf[0] + ioff[0]][s*ipar[0] + m], the row sums a VSR_ACT_A_EXP product left)
     int M = 0, N = 0, nsplit = 0, tRowC = -1, tColC = -1;
     int64_t offSrc = 0, offDst = 0, splitStride = 0;
     double flops = 0;                    // algorithmic flops of this op (2*M*N*K, unpadded)
@@ -161,6 +168,7 @@ public:
 private:
     const Model& m_;
     const Tuning& tu_;
+    int64_t rowmaxElems_ = 0;            // BUF_ROWMAX handed out so far: every fused attention instance of the plan has its own array
     int pickTile(int N) const;
     int tRowsTokens(int T, int s, int choff, int count, int padTo);
     int tColsPatch(int s, int padTo);
