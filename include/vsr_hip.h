@@ -131,8 +131,9 @@ enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2, VSR_ACT_LRELU01 
        /* the two halves of softmax(QK^T / sqrt(D)) . V (auto_sttn.py:141-145) without a probability matrix in memory:
         * ROW_MAX on the score GEMM (NK, variant 3, splitK 1, no residual): besides C, the maximum of every output row is kept in
         * ((uint32_t*)R)[m] -- monotone unsigned encoding of the float, atomic max over the N tiles, zeroed by the caller;
-        * A_EXP on the P.V GEMM (KN, variant 1 | VSR_VARIANT_A_EXP): the A operand is exp(A[m][k] - rowmax[m]) with rowmax =
-        * ((const uint32_t*)bias)[m] in that encoding, and the row sums l[m] = sum_k exp(..) are taken while the tiles are staged:
+        * A_EXP on the P.V GEMM (KN, variant 1 | VSR_VARIANT_A_EXP): the A operand is 2^(A[m][k] - rowmax[m]) (the caller folds
+        * log2(e) into the scores' scale) with rowmax = ((const uint32_t*)bias)[m] in that encoding, and the row sums l[m] =
+        * sum_k 2^(..) are taken while the tiles are staged:
         * splitK 1 writes C = (expA . B) / l; splitK > 1 writes the partial planes unnormalised and the partial sums to
         * ((float*)R)[split * tilesM * BM + m], for vsr_launch_reduce_scatter's caller to divide by their total. */
        VSR_ACT_ROW_MAX = 0x400, VSR_ACT_A_EXP = 0x800 };

@@ -83,7 +83,7 @@ def gemm_reference(it, bmode, bufs, tables, tile_m=128):
     colC = _cols(tables[it.tColC], N)
     Cbuf = bufs[it.bufC]
     if it.act & 0x800:                     # VSR_ACT_A_EXP: A holds scores; the product is softmax(A) . B, normalised here or by the reduce op
-        Am = torch.exp(Am - Am.max(dim=1, keepdim=True).values)
+        Am = torch.exp2(Am - Am.max(dim=1, keepdim=True).values)    # the scores carry log2(e) / sqrt(D)
         if it.splitK > 1:
             ldl = it.tilesM * tile_m
             for s in range(it.splitK):

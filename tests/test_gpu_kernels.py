@@ -563,14 +563,14 @@ def test_score_gemm_leaves_row_maxima(built_lib, gpu_device, M, N, K, tile):
 @pytest.mark.parametrize("M,K,N,splitK,tile", [(320, 320, 960, 1, "128x64"), (4800, 4800, 64, 3, "128x64"), (200, 96, 130, 1, "128x64"),
                                                (640, 640, 320, 2, "128x128")])
 def test_pv_gemm_exponentiates_its_scores(built_lib, gpu_device, M, K, N, splitK, tile):
-    """VSR_ACT_A_EXP on the KN kernel (variant 1 | VSR_VARIANT_A_EXP): C = softmax_rows(A) . B without a probability matrix --
+    """VSR_ACT_A_EXP on the KN kernel (variant 1 | VSR_VARIANT_A_EXP): C = (2^(A - rowmax) . B) / row sums without a probability matrix --
     normalised in the epilogue (splitK 1) or left as partial planes + partial row sums (splitK > 1); a problem without the flag
     in the same launch runs as the plain KN kernel"""
     rng = np.random.default_rng(M + N + K + splitK)
     bm, bn = (128, 64) if tile == "128x64" else (128, 128)
     cfg = built_lib.TILE_128x64 if tile == "128x64" else built_lib.TILE_128x128
     c = _make_gemm_case(rng, M, N, K, bm, bn, 1, splitK, False, 0, False)
-    c.Abuf *= 3.0                                                 # scores with a spread: exp() spans ~e^25
+    c.Abuf *= 3.0                                                 # scores with a spread: 2^x spans ~2^25
     plain = _make_gemm_case(rng, 150, 70, 64, bm, bn, 1, 1, False, 0, False)
     mp = c.tilesM * bm
     m_idx, k_idx = np.meshgrid(np.arange(M), np.arange(K), indexing="ij")
@@ -603,7 +603,7 @@ def test_pv_gemm_exponentiates_its_scores(built_lib, gpu_device, M, K, N, splitK
     got = outs[0].cpu().numpy()
     k2, n2 = np.meshgrid(np.arange(K), np.arange(N), indexing="ij")
     Bm = torch.from_numpy(c.Bbuf[c.rowB[k2] + c.colB[n2 // 32] + n2 % 32]).double()
-    E = torch.exp(torch.from_numpy(S).double() - torch.from_numpy(rowmax_f[:M]).double()[:, None])
+    E = torch.exp2(torch.from_numpy(S).double() - torch.from_numpy(rowmax_f[:M]).double()[:, None])
     want = (E @ Bm) / E.sum(dim=1, keepdim=True)
     m2, n3 = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
     cells = c.rowC[m2] + c.colC[n3 // 32] + n3 % 32

@@ -2,7 +2,7 @@
 // second half of a fused attention, softmax(S) . V (reference backend/inpaint/sttn/auto_sttn.py:141-145) with no probability
 // matrix in memory.  A problem that carries VSR_ACT_A_EXP hands over the SCORES as its A operand and the row maxima the score
 // GEMM left behind (VSR_ACT_ROW_MAX, gather_gemm_v3.h); while a 128x32 score tile sits in registers between its global load and
-// its LDS store every value becomes exp(s - max_row) -- sixteen v_exp_f32 per lane and chunk, issued in the shadow of the other
+// its LDS store every value becomes 2^(s - max_row) (the scores carry the factor log2(e) / sqrt(D)) -- sixteen v_exp_f32 per lane and chunk, issued in the shadow of the other
 // workgroups' MFMAs -- and joins its row's running sum.  The thread -> row assignment of the staging is the same for every chunk,
 // so the sums live in four registers per lane and meet once, after the loop.  splitK 1: the epilogue divides by the row sum;
 // splitK > 1 (the 4800-token scale is cut in three): partial planes stay unnormalised and the N-tile 0 of every split writes its
@@ -109,16 +109,19 @@ gather_gemm_f32_aexp(const GGProblem* __restrict__ probs, int nprobs)
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) rb[it] = *(gcf32x4)(B + (boff[it] + bcolKN));
     };
+    // the row sums are only read where they are used: by every tile of an unsplit product (its epilogue divides), by the N-tile 0 of
+    // a split one (it writes them for the reduce pass)
+    const bool needSum = aexp && (splitK == 1 || tn == 0);
     auto store_tile = [&]() {
-        if (aexp) {
+        if (aexp) {            // scores arrive scaled by log2(e) / sqrt(D) (the score GEMM's alpha): one subtract and one v_exp_f32 each
 #pragma unroll
             for (int it = 0; it < A_IT; ++it)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = __expf(ra[it][j] - mrow[it]);
-                    ra[it][j] = e;
-                    lsum[it] += e;
-                }
+                for (int j = 0; j < 4; ++j) ra[it][j] = __builtin_amdgcn_exp2f(ra[it][j] - mrow[it]);
+            if (needSum) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) lsum[it] += (ra[it][0] + ra[it][1]) + (ra[it][2] + ra[it][3]);
+            }
         }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)

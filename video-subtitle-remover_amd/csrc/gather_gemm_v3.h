@@ -340,6 +340,12 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             // maximum -- 32 lanes hold a row's columns, the waves side by side meet in LDS (the operand buffers are idle: the main
             // loop ended on a barrier), then one atomic per row in a coalesced burst.  The P.V kernel subtracts it (VSR_ACT_A_EXP).
             float* scr = smem;                                      // [BM][WN]
+            // A lane holds one column of 16 * MI rows; a row's 32 columns sit in the 32 lanes of its half wave.  Halving butterfly:
+            // at every step a lane keeps one half of its rows and hands the other half to its partner, so after log2(32) steps
+            // lane l31 holds the maximum of row-slot l31 -- 31 exchanges per lane instead of 5 for each of the 32 rows.
+            static_assert(MI * 16 == 32 || MI * 16 == 16, "row slots per lane");
+            constexpr int NV = MI * 16;
+            float v[NV];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -348,10 +354,27 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         if (nok[ni]) mx = fmaxf(mx, acc[mi][ni][r] * alpha + bv[ni]);
-#pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-                    if (l31 == 0) scr[(wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * WN + wn] = mx;
+                    v[mi * 16 + r] = mx;
                 }
+            if constexpr (NV == 16) {                               // 16 row slots: the first exchange is a plain maximum
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], __shfl_xor(v[i], 16, 64));
+            }
+#pragma unroll
+            for (int half = (NV == 32 ? 16 : 8), bit = (NV == 32 ? 16 : 8); half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (l31 & bit) != 0;                   // this lane keeps slots [half, 2 half), its partner [0, half)
+#pragma unroll
+                for (int i = 0; i < half; ++i) {
+                    const float lo = v[i], hi_ = v[i + half];
+                    const float got = __shfl_xor(up ? lo : hi_, bit, 64);
+                    v[i] = fmaxf(up ? hi_ : lo, got);
+                }
+            }
+            {   // slot -> row of the wave's sub-tile: slot = mi * 16 + r, row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
+                const int slot = (NV == 32) ? l31 : (l31 & 15);
+                const int r = slot & 15, mi = slot >> 4;
+                if (NV == 32 || l31 < 16) scr[(wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * WN + wn] = v[0];
+            }
             __syncthreads();
             if (tid < BM && tm * BM + tid < M) {
                 float mx = scr[tid * WN];

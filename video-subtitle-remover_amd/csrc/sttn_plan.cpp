@@ -495,8 +495,8 @@ void Plan::addAttention(int T, const BlockW&)
         a.tColC = tColsLinear(a.tilesN * qBN / VSR_GG_KC, a.tilesN * qBN / VSR_GG_KC);
         a.bufR = -1; a.tRowR = -1; a.offBias = -1;
         // Fused softmax (exact-fp32 mode): a scale whose scores are not split along K and whose token count is whole chunks keeps
-        // no probability matrix -- the score GEMM scales by 1/sqrt(D) itself and leaves the row maxima (VSR_ACT_ROW_MAX), the P.V
-        // GEMM reads the scores, exponentiates them while staging and normalises by the row sums (VSR_ACT_A_EXP).  At the
+        // no probability matrix -- the score GEMM scales by log2(e)/sqrt(D) itself and leaves the row maxima (VSR_ACT_ROW_MAX), the
+        // P.V GEMM reads the scores, takes 2^(s - max) while staging and normalises by the row sums (VSR_ACT_A_EXP).  At the
         // 4800-token scale that is 92 MB written and read once instead of twice, and no k_softmax_rows pass over them.
         const bool fused = tu.fuseSoftmax && precision == 0 && splitK == 1 && Ntok % VSR_GG_KC == 0;
         const float scale = (float)(1.0 / sqrt((double)D)); // scores / math.sqrt(query.size(-1))
@@ -504,7 +504,7 @@ void Plan::addAttention(int T, const BlockW&)
         if (fused) {
             rmaxOff = rowmaxElems_;
             rowmaxElems_ += rup((int64_t)a.tilesM * qBM > (int64_t)cdiv(Ntok, pBM) * pBM ? (int64_t)a.tilesM * qBM : (int64_t)cdiv(Ntok, pBM) * pBM, 32);
-            a.alpha = scale;
+            a.alpha = (float)((double)scale * 1.4426950408889634);   // log2(e): the P.V kernel exponentiates with v_exp_f32 (2^x)
             a.act |= VSR_ACT_ROW_MAX;
             a.bufR = BUF_ROWMAX; a.offR = rmaxOff;
         }
