@@ -160,7 +160,12 @@ def norm_im2col_reference(info, bufs):
 
 def decode_out_reference(info, bufs, tables):
     n, pix, ldy = info.n, info.pix, info.ldy
-    y = bufs[info.buf_src][: n * pix * ldy].reshape(n, pix, ldy)[:, :, :3]
+    if getattr(info, "W", 0) > 0:           # rows are 2x4 pixel blocks of a W-wide image, columns (dy, dx, channel): the blocked output conv
+        mw, mh = info.W, pix // info.W
+        blk = bufs[info.buf_src][: n * (pix // 8) * ldy].reshape(n, mh // 2, mw // 4, ldy)[..., :24].reshape(n, mh // 2, mw // 4, 2, 4, 3)
+        y = blk.transpose(0, 1, 3, 2, 4, 5).reshape(n, pix, 3)
+    else:
+        y = bufs[info.buf_src][: n * pix * ldy].reshape(n, pix, ldy)[:, :, :3]
     v = torch.tanh(torch.from_numpy(np.ascontiguousarray(y)))
     v = ((v + 1) / 2).numpy() * 255
     img = v.astype(np.uint8).astype(np.float32)

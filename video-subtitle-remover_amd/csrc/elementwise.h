@@ -13,5 +13,9 @@ extern "C" int vsr_launch_norm_im2col_fmt(const uint8_t* img, int ih, int iw, in
 extern "C" int vsr_launch_reduce_scatter_fmt(const float* part, int nsplit, int64_t splitStride, int M, int N,
                                              const int32_t* rowC, const int32_t* colC, float* out, int outSplit,
                                              const float* lsum, int ldL, void* stream);   // lsum [nsplit][ldL]: divide row m by their sum (fused attention), or NULL
+// y rows are 2x4 pixel blocks of a blkW-wide image with columns (dy, dx, channel) -- the blocked 64 -> 3 conv (sttn_plan.cpp); 0 = vsr_launch_decode_out
+extern "C" int vsr_launch_decode_out_blk(const float* y, int ldy, int pix, int nframes, const int32_t* frameIdx,
+                                         const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
+                                         int blkW, void* stream);
 extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
                                          int nframes, int split, void* stream);

@@ -310,7 +310,8 @@ k_decode_out(const float* __restrict__ y /*[n*pix][ldy] first 3 cols = RGB pre-t
              int nframes, const int32_t* __restrict__ frameIdx, const int32_t* __restrict__ first,
              float* __restrict__ comp /*[L][pix][3]*/,
              const uint8_t* __restrict__ inBGR /*[L][pix][3] model-res input frames, sttn-det only*/,
-             const uint8_t* __restrict__ mask /*[L][pix] resized 0..255 mask, sttn-det only (null = sttn-auto)*/)
+             const uint8_t* __restrict__ mask /*[L][pix] resized 0..255 mask, sttn-det only (null = sttn-auto)*/,
+             int blkW /*0: y row = pixel; image width: y row = 2x4 pixel block, columns (dy, dx, channel) -- the blocked output conv*/)
 {
     const int64_t total = (int64_t)nframes * pix;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -319,6 +320,10 @@ k_decode_out(const float* __restrict__ y /*[n*pix][ldy] first 3 cols = RGB pre-t
         const int idx = frameIdx[f];
         const bool fst = first[f] != 0;
         const float* s = y + i * ldy;
+        if (blkW > 0) {
+            const int yy = p / blkW, xx = p - yy * blkW;
+            s = y + ((int64_t)f * (pix >> 3) + (int64_t)(yy >> 1) * (blkW >> 2) + (xx >> 2)) * ldy + (((yy & 1) << 2) + (xx & 3)) * 3;
+        }
         float* c = comp + ((int64_t)idx * pix + p) * 3;
         // sttn-det: img = pred*binary_mask + frame*(1-binary_mask), binary_mask = resized mask > 0.5 on 0..255
         // data, i.e. any non-zero value (sttn_det_inpaint.py:132,168); frame is the RGB model-res input
@@ -517,10 +522,17 @@ extern "C" int vsr_launch_decode_out(const float* y, int ldy, int pix, int nfram
                                      const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
                                      void* stream)
 {
+    return vsr_launch_decode_out_blk(y, ldy, pix, nframes, frameIdx, first, comp, inBGR, mask, 0, stream);
+}
+extern "C" int vsr_launch_decode_out_blk(const float* y, int ldy, int pix, int nframes, const int32_t* frameIdx,
+                                         const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
+                                         int blkW, void* stream)
+{
     const int64_t total = (int64_t)nframes * pix;
     if (total <= 0) return 0;
+    if (blkW < 0 || (blkW > 0 && (blkW % 4 || pix % blkW || (pix / blkW) % 2 || ldy < 24))) return VSR_ERR_ARG;
     hipLaunchKernelGGL(k_decode_out, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, pix, nframes,
-                       frameIdx, first, comp, inBGR, mask);
+                       frameIdx, first, comp, inBGR, mask, blkW);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 

@@ -324,8 +324,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             rc = vsr_launch_upsample2x_fmt((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, od.split, stream);
             break;
         case OP_DECODE_OUT:
-            rc = vsr_launch_decode_out((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
-                                       od.maskU8 ? od.inU8 : nullptr, od.maskU8, stream);
+            rc = vsr_launch_decode_out_blk((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
+                                           od.maskU8 ? od.inU8 : nullptr, od.maskU8, od.W, stream);
             break;
         case OP_REDUCE_SCATTER:
             rc = vsr_launch_reduce_scatter_fmt((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,

@@ -28,6 +28,7 @@ const Tuning& Tuning::get(int precision)
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
             // the fused path needs the kernels it was written into: v3 for the scores, v1 (+ A_EXP) for P.V -- the defaults
             x.fuseSoftmax = envInt("VSR_FUSE_SOFTMAX", 1) && envInt("VSR_GG_VARIANT", 3) == 3 && envInt("VSR_PV_VARIANT", 1) == 1;
+            x.outConvBlocked = envInt("VSR_OUT_CONV_BLOCKED", 1);
             return x;
         }(),
         [] {
@@ -38,6 +39,7 @@ const Tuning& Tuning::get(int precision)
             x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
             x.fuseSoftmax = 0;      // split-format tensors: the probabilities are a GEMM operand in that format, k_softmax_rows writes it
+            x.outConvBlocked = envInt("VSR_OUT_CONV_BLOCKED", 1);
             return x;
         }()};
     return t[precision ? 1 : 0];
@@ -145,6 +147,44 @@ bool Model::pack_conv(const std::string& key, ConvW& cw, int /*cinPad*/, std::st
     return true;
 }
 
+// A 3x3 conv with very few output channels as a GEMM over bh x bw output blocks: one GEMM row per block, N = bh*bw*cout
+// columns (dy, dx, c), K = the (bh+2) x (bw+2) window the block's pixels share x cin; the taps outside a pixel's own 3x3 are zero
+// rows of the packed matrix.  For the 64 -> 3 output conv of the decoder (auto_sttn.py:93) with 2x4 blocks: 24 of 32 MFMA
+// columns carry outputs instead of 3, for 2.7x the multiply-adds per pixel -- a third of the matrix-core time (the LaMa plan
+// does the same with its 7x7 output conv, lama_plan.cpp).  K order mirrors Plan::buildWindow's window table.
+bool Model::pack_conv_blocked(const std::string& key, ConvW& cw, int bh, int bw, std::string& err)
+{
+    auto wi = raw_.find(key + ".weight"), bi = raw_.find(key + ".bias");
+    if (wi == raw_.end() || bi == raw_.end()) { err = "missing key in state_dict: " + key; return false; }
+    const Raw& w = wi->second;
+    const int cout = (int)w.shape[0], cin = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
+    if (kh != 3 || kw != 3 || cin % VSR_GG_KC) { err = "blocked conv: 3x3 over whole channel chunks only: " + key; return false; }
+    const int wh = bh + 2, ww = bw + 2, taps = wh * ww;
+    const int K = taps * cin, N = bh * bw * cout;
+    cw.cout = N;
+    cw.K = K;
+    cw.w = (int64_t)packed.size();
+    packed.resize(packed.size() + (size_t)rup((int64_t)N * K, 32), 0.f);
+    float* dst = packed.data() + cw.w;
+    const bool chanMajor = Tuning::get().convChannelMajor != 0;
+    for (int dy = 0; dy < bh; ++dy)
+        for (int dx = 0; dx < bw; ++dx)
+            for (int c = 0; c < cout; ++c) {
+                const int n = (dy * bw + dx) * cout + c;
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int tap = (dy + ky) * ww + (dx + kx);     // window position of this pixel's tap
+                            const int k = chanMajor ? ((ci / VSR_GG_KC) * taps + tap) * VSR_GG_KC + (ci % VSR_GG_KC) : tap * cin + ci;
+                            dst[(int64_t)n * K + k] = w.v[(((int64_t)c * cin + ci) * 3 + ky) * 3 + kx];
+                        }
+            }
+    cw.b = (int64_t)packed.size();
+    packed.resize(packed.size() + (size_t)rup(N, 32), 0.f);
+    for (int n = 0; n < N; ++n) packed[cw.b + n] = bi->second.v[n % cout];
+    return true;
+}
+
 bool Model::pack(std::string& err)
 {
     packed.clear();
@@ -171,6 +211,7 @@ bool Model::pack(std::string& err)
         if (!check(decKeys[i], decShape[i][0], decShape[i][1], 3)) return false;
         if (!pack_conv(decKeys[i], dec[i], 0, err)) return false;
     }
+    if (!pack_conv_blocked(decKeys[3], dec4blk, kOutBlkH, kOutBlkW, err)) return false;
     const int C = g.channels;
     for (int b = 0; b < g.blocks; ++b) {
         const std::string p = "transformer." + std::to_string(b) + ".";
@@ -659,6 +700,52 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         ops.push_back(std::move(op));
     }
     addConv("dec.3", up2, idN, d3, nn, 3, 1, 1, m_.dec[2], VSR_ACT_LRELU02, nullptr, nullptr);
+    if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) {
+        // 64 -> 3 conv over 2x4 output blocks (Model::pack_conv_blocked): row = block, columns (dy, dx, c) in a [blocks][32] buffer
+        const ConvW& w = m_.dec4blk;
+        const int bh = Model::kOutBlkH, bw = Model::kOutBlkW, wh = bh + 2, ww = bw + 2;
+        Op op;
+        op.kind = OP_GEMM; op.tag = "dec.4"; op.tileCfg = VSR_TILE_256x32; op.bmode = VSR_BMODE_NK;
+        const int BM = 256, BN = 32;
+        GemmItem it{};
+        it.M = nn * (mh / bh) * (mw / bw); it.N = w.cout; it.K = w.K;
+        it.tilesM = cdiv(it.M, BM); it.tilesN = 1;
+        it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
+        it.bufA = d3.buf; it.offA = 0;
+        {   // rows: the block's top-left pixel; columns: the (bh+2) x (bw+2) window around the block, K order as packed
+            std::vector<int32_t> rows;
+            for (int f = 0; f < nn; ++f)
+                for (int by = 0; by < mh / bh; ++by)
+                    for (int bx = 0; bx < mw / bw; ++bx) rows.push_back((int32_t)d3.pix(f, by * bh, bx * bw));
+            while ((int)rows.size() % BM) rows.push_back(rows[0]);
+            it.tRowA = table("RBLK:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw), std::move(rows));
+            std::vector<int32_t> cols;
+            auto off = [&](int wy, int wx, int c) { return (int32_t)(((int64_t)(wy - 1) * d3.Wp() + (wx - 1)) * d3.C + c); };
+            if (tu_.convChannelMajor) {
+                for (int c = 0; c < d3.C; c += VSR_GG_KC)
+                    for (int wy = 0; wy < wh; ++wy)
+                        for (int wx = 0; wx < ww; ++wx) cols.push_back(off(wy, wx, c));
+            } else {
+                for (int wy = 0; wy < wh; ++wy)
+                    for (int wx = 0; wx < ww; ++wx)
+                        for (int c = 0; c < d3.C; c += VSR_GG_KC) cols.push_back(off(wy, wx, c));
+            }
+            it.tColA = table("CBLK:" + std::to_string(d3.Wp()) + ":" + std::to_string(d3.C) + ":" + std::to_string(tu_.convChannelMajor), std::move(cols));
+        }
+        it.bufB = BUF_WEIGHTS; it.offB = w.w;
+        it.tRowB = tRowsLinear(it.N, it.K, BN);
+        it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
+        it.bufC = BUF_D4; it.offC = 0;
+        it.tRowC = tRowsLinear(it.M, 32, BM);
+        it.tColC = tColsLinear(1, 1);
+        it.offBias = w.b;
+        it.bufR = -1; it.tRowR = -1;
+        op.flops = 2.0 * (double)nn * mh * mw * 3.0 * (9.0 * d3.C);     // the algorithmic work of the 3x3 conv, not the padded window's
+        flops += op.flops;
+        op.gemm.push_back(it);
+        need(BUF_D4, (int64_t)it.tilesM * BM * 32);
+        ops.push_back(std::move(op));
+    } else
     {   // 64 -> 3 conv into a plain [M][32] buffer (columns 0..2 valid)
         const ConvW& w = m_.dec[3];
         Op op;
@@ -689,6 +776,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         Op op;
         op.kind = OP_DECODE_OUT; op.tag = "dec.out";
         op.bufSrc = BUF_D4; op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
+        if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) op.W = mw;   // src rows are 2x4 blocks of a mw-wide image
         op.bufMask = g.variant == 1 ? BUF_MASK_U8 : -1;   // sttn-det: model-resolution blend with the input frames
         std::vector<int32_t> fi, fs;
         for (int i = 0; i < nn; ++i) {

@@ -34,6 +34,7 @@ struct Tuning {
     int pvSplitChunks;   // VSR_PV_SPLIT_CHUNKS: split the P.V contraction into slices of ~this many 32-token
                          //   chunks when it has at least twice as many (0 = never split)
     int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
+    int outConvBlocked;  // VSR_OUT_CONV_BLOCKED: 1 = the 64 -> 3 output conv runs over 2x4 output blocks (Model::pack_conv_blocked)
     int fuseSoftmax;     // VSR_FUSE_SOFTMAX: 1 = exact-fp32 mode keeps no probability matrix for the scales whose scores are not
                          //   split along K: row max in the QK^T epilogue, exp + row sum while P.V stages its A tiles (0 = k_softmax_rows)
     // precision 0: exact fp32 MFMA kernels; 1: split-half f16 MFMA kernels (larger tiles pay there)
@@ -56,6 +57,8 @@ public:
     bool packed_ready() const { return ready_; }
     Geometry g;
     ConvW enc[4], dec[4];
+    ConvW dec4blk;          // the 64 -> 3 conv as a GEMM over 2x4 output blocks (pack_conv_blocked): cout = 24 = (dy, dx, c), K = 4x6x64
+    static constexpr int kOutBlkH = 2, kOutBlkW = 4;
     std::vector<BlockW> blk;
     std::vector<float> packed;
     static std::vector<std::string> expected_keys(int variant);
@@ -64,6 +67,7 @@ private:
     std::map<std::string, Raw> raw_;
     bool ready_ = false;
     bool pack_conv(const std::string& key, ConvW& cw, int cinPad, std::string& err);
+    bool pack_conv_blocked(const std::string& key, ConvW& cw, int bh, int bw, std::string& err);
 };
 
 // ---- plan IR ----
