@@ -71,7 +71,7 @@ def cpu_baseline(sd, clip, mask01, areas):
     probe = STTNInpaintOracle(sd, "auto")
     pf = list(np.random.default_rng(0).integers(0, 256, size=(3, 120, 640, 3), dtype=np.uint8))
     best, threads, tried = None, 1, {}
-    for cand in sorted({c for c in (16, 32, 64, ncpu) if c <= ncpu} or {ncpu}):
+    for cand in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}):      # all 256 hardware threads took 75 s for the probe alone (profiles/r02_bench.log)
         torch.set_num_threads(cand)
         probe.inpaint(pf[:1])
         t0 = time.perf_counter()

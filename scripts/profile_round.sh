@@ -1,7 +1,8 @@
 # Round profile: GPU tests, the default bench line, rocprofv3 kernel-trace stats of the same command, PMC passes.
 # usage: bash scripts/profile_round.sh <tag>     (results under gpurun_out/<tag>/)
 TAG=${1:-prof}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-(timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40) > $OUT/pytest_gpu.log 2>&1
+# PYTEST_ARGS narrows the GPU test run (the whole suite takes 16 minutes of box time, most of it waiting for the BASELINE-size CPU oracles)
+(timeout 1500 python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q --tb=short 2>&1 | tail -40) > $OUT/pytest_gpu.log 2>&1
 tail -2 $OUT/pytest_gpu.log
 (timeout 400 python -c "import __graft_entry__ as g; g.smoke()") > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 python bench.py > $OUT/bench.log 2>&1; grep '"metric"' $OUT/bench.log | cut -c1-400

@@ -23,6 +23,7 @@ const Tuning& Tuning::get(int precision)
             Tuning x;
             x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
             x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
+            x.qkvTile = envInt("VSR_QKV_TILE", x.convTile);
             x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
             x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
@@ -35,6 +36,7 @@ const Tuning& Tuning::get(int precision)
             Tuning x;
             x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
             x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
+            x.qkvTile = envInt("VSR_QKV_TILE", x.convTile);
             x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
             x.pvSplitChunks = envInt("VSR_PV_SPLIT_CHUNKS", 50);
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
@@ -643,7 +645,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         const BlockW& bw = m_.blk[b];
         {   // fused Q/K/V 1x1 (auto_sttn.py:172-174) -> plain [T*fh*fw][3C]
             Op op;
-            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = tu_.convTile; op.bmode = VSR_BMODE_NK;
+            op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = tu_.qkvTile; op.bmode = VSR_BMODE_NK;
             int BM, BN;
             tileDims(op.tileCfg, BM, BN);
             GemmItem it{};

@@ -30,6 +30,7 @@ struct Geometry {
 struct Tuning {
     int convTile;        // VSR_CONV_TILE: tile config of the N >= 128 convs / QKV GEMM (VSR_TILE_*)
     int qkTile;          // VSR_QK_TILE
+    int qkvTile;         // VSR_QKV_TILE: the fused Q/K/V 1x1 GEMM (K = 256: eight chunks per tile)
     int pvTile;          // VSR_PV_TILE
     int pvSplitChunks;   // VSR_PV_SPLIT_CHUNKS: split the P.V contraction into slices of ~this many 32-token
                          //   chunks when it has at least twice as many (0 = never split)
