@@ -115,7 +115,9 @@ int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h);
 /* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded) */
 double vsr_sttn_flops(vsr_sttn_t* h, int L);
 
-/* per-op-tag GPU timing of the next calls (hipEvents on the launch stream) */
+/* GPU timing of the next calls with hipEvents on the launch stream, per op tag and per kernel symbol: enable = 1 brackets every op
+ * (about 2.5 % of a chunk's wall time: 1 300 launches), 2 only the launches of the 128x64 NK gather-GEMM -- the dominant kernel
+ * symbol, what bench.py's roofline object needs inside its timed region --, 0 = off */
 int vsr_sttn_timing(vsr_sttn_t* h, int enable);
 int vsr_sttn_timing_get(vsr_sttn_t* h, const char* tag_prefix, double* total_ms, int32_t* launches, double* flops);
 int vsr_sttn_timing_reset(vsr_sttn_t* h);

@@ -8,8 +8,8 @@ for l in open(sys.argv[1]):
     if l.startswith('{"metric"'):
         d=json.loads(l); ok=True
         print(sys.argv[2],'fps',d['value'],'ms/step',d['ms_per_step'])
-        for k,v in d['op_breakdown_timed_region'].items(): print('   ',k,v)
-        for k,v in d['kernel_breakdown_timed_region'].items(): print('   ',k,v)
+        for k,v in d['op_breakdown'].items(): print('   ',k,v)
+        for k,v in d['kernel_breakdown'].items(): print('   ',k,v)
 if not ok: print(sys.argv[2],'FAILED'); print(open(sys.argv[1]).read()[-1500:])
 PY
 }

@@ -12,7 +12,7 @@ ok=False
 for l in open(sys.argv[1]):
     if l.startswith('{"metric"'):
         d=json.loads(l); ok=True
-        print(sys.argv[2],'fps',d['value'],'ms/step',d['ms_per_step'], {k:(v['ms'],v['tflops']) for k,v in d['op_breakdown_timed_region'].items()})
+        print(sys.argv[2],'fps',d['value'],'ms/step',d['ms_per_step'], {k:(v['ms'],v['tflops']) for k,v in d['op_breakdown'].items()})
 if not ok: print(sys.argv[2],'FAILED'); print(open(sys.argv[1]).read()[-1500:])
 PY
 }

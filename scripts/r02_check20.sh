@@ -10,7 +10,7 @@ ok=False
 for l in open(sys.argv[1]):
     if l.startswith('{"metric"'):
         d=json.loads(l); ok=True
-        print(sys.argv[2],'fps',d['value'],'ms/step',d['ms_per_step'], {k:(v['ms'],v['tflops']) for k,v in d['op_breakdown_timed_region'].items() if k in ('dec','ffn')}, {k:(v['ms'],v['tflops']) for k,v in d['kernel_breakdown_timed_region'].items() if '256, 32' in k})
+        print(sys.argv[2],'fps',d['value'],'ms/step',d['ms_per_step'], {k:(v['ms'],v['tflops']) for k,v in d['op_breakdown'].items() if k in ('dec','ffn')}, {k:(v['ms'],v['tflops']) for k,v in d['kernel_breakdown'].items() if '256, 32' in k})
 if not ok: print(sys.argv[2],'FAILED'); print(open(sys.argv[1]).read()[-1500:])
 PY
 }

@@ -11,5 +11,5 @@ for f in ("gpurun_out/r02d/bench_f16_4k.log","gpurun_out/r02d/bench_e2e.log"):
     l=[x for x in open(f) if x.startswith('{')]
     if not l: print(f, "no line"); continue
     d=json.loads(l[-1]); print(f, d["value"], d["ms_per_step"], d.get("pcie_inclusive"))
-    for k,v in d["op_breakdown_timed_region"].items(): print("   ",k,v)
+    for k,v in d["op_breakdown"].items(): print("   ",k,v)
 PY

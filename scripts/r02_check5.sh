@@ -15,5 +15,5 @@ for f in sorted(glob.glob("gpurun_out/r02e/bench_f16_*.log")):
     l=[x for x in open(f) if x.startswith('{')]
     if not l: print(f, "no line", open(f).read()[-300:]); continue
     d=json.loads(l[-1]); print(f, d["value"], d["ms_per_step"])
-    print("   ", {k:(v['ms'],v['tflops']) for k,v in d["op_breakdown_timed_region"].items()})
+    print("   ", {k:(v['ms'],v['tflops']) for k,v in d["op_breakdown"].items()})
 PY

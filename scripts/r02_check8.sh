@@ -9,5 +9,5 @@ python - <<'PY'
 import json
 l=[x for x in open("gpurun_out/r02h/bench.log") if x.startswith('{')]
 d=json.loads(l[-1]); print(d["value"], d["ms_per_step"], {k:d[k]["value"] for k in ("split_half_mode","split_format_mode","fp16_mode")})
-print({k:(v['ms'],v['launches']) for k,v in d["op_breakdown_timed_region"].items()})
+print({k:(v['ms'],v['launches']) for k,v in d["op_breakdown"].items()})
 PY

@@ -118,7 +118,7 @@ struct vsr_sttn {
     float* weightsSplit = nullptr;     // mode 2: the packed weights in split format (biases are read from BUF_WEIGHTS)
     unsigned int* dRangeFlag = nullptr;
     int64_t fallbacks = 0;             // chunks recomputed in fp32 because the range guard fired
-    bool timing = false;
+    int timing = 0;              // 0 off; 1 every op; 2 only the launches of the 128x64 NK gather-GEMM (the dominant kernel symbol)
     std::vector<TimingRec> pending;
     std::map<std::string, std::pair<double, std::pair<int, double>>> timed; // tag -> (ms, (launches, flops))
     explicit vsr_sttn(int variant) : model(variant)
@@ -298,7 +298,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         unsigned int* queue = persistent ? pd->dQueues + 8 * opIndex : nullptr;
         ++opIndex;
         TimingRec tr;
-        if (h->timing) {
+        const bool timed = h->timing == 1 || (h->timing == 2 && od.kind == OP_GEMM && od.tileCfg == VSR_TILE_128x64 && od.bmode == VSR_BMODE_NK);
+        if (timed) {
             tr.tag = od.tag; tr.flops = od.flops;
             tr.kernel = od.kind == OP_GEMM ? ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode) + ":v" +
                                               std::to_string(gg_variant(od.bmode, prec)) + (od.aexp ? "x" : ""))
@@ -335,7 +336,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             return fail(VSR_ERR_STATE, "unknown op kind");
         }
         if (rc != 0) return fail(VSR_ERR_HIP, "kernel launch failed: " + od.tag + ": " + hipGetErrorString(hipGetLastError()));
-        if (h->timing) {
+        if (timed) {
             HIPCHK(hipEventRecord(tr.b, stream));
             h->pending.push_back(tr);
         }
@@ -696,7 +697,7 @@ double vsr_sttn_flops(vsr_sttn_t* h, int L)
 int vsr_sttn_timing(vsr_sttn_t* h, int enable)
 {
     if (!h) return fail(VSR_ERR_ARG, "null handle");
-    h->timing = enable != 0;
+    h->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return 0;
 }
 

@@ -146,7 +146,8 @@ class SttnEngine:
 
     # ---- measurement ----------------------------------------------------------------------
     def timing(self, enable=True):
-        check(lib.vsr_sttn_timing(self._h, 1 if enable else 0))
+        """True / 1: HIP events around every op; 2: only around the launches of the dominant gather-GEMM symbol; False / 0: off"""
+        check(lib.vsr_sttn_timing(self._h, int(enable)))
 
     def timing_reset(self):
         check(lib.vsr_sttn_timing_reset(self._h))
