@@ -139,10 +139,13 @@ def launch(names=None):
     if not names:
         return
     ncpu = os.cpu_count() or 8
-    threads = max(4, min(32, ncpu // max(1, len(names))))      # oneDNN on 30x160 / 60x108 maps stops scaling around 32 threads
+    base = max(4, min(32, ncpu // max(1, len(names))))         # oneDNN on 30x160 / 60x108 maps stops scaling around 32 threads
     tmp = tempfile.mkdtemp(prefix="vsr_baseline_")
     for n in names:
         out = os.path.join(tmp, n + ".npy")
+        # the propainter job is the long pole of the whole GPU suite (RAFT: 38 pair-directions x 20 iterations on 1920x360 maps,
+        # which do scale): it gets a third of the box
+        threads = max(base, min(96, ncpu // 3)) if JOBS[n]["kind"] == "pp" else base
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), VSR_ORACLE_THREADS=str(threads),
                    HIP_VISIBLE_DEVICES="", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         log = open(os.path.join(tmp, n + ".log"), "w")

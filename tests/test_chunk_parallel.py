@@ -14,7 +14,7 @@ def _clip(total):
     return (np.arange(total * 4 * 6 * 3) % 251).astype(np.uint8).reshape(total, 4, 6, 3)
 
 
-def _worker(rank, world, port, total, gap, q):
+def _worker(rank, world, port, total, gap, q, io="host"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -32,7 +32,13 @@ def _worker(rank, world, port, total, gap, q):
         assert rank == 0
         s, e = ranges[i]
         loaded.append(i)
-        out[:e - s] = clip[s:e]
+        if io == "device":                 # the resident loop of STTNAutoInpaint hands over / receives device tensors (here: CPU tensors)
+            import torch
+
+            assert isinstance(out, torch.Tensor)
+            out[:e - s] = torch.from_numpy(clip[s:e])
+        else:
+            out[:e - s] = clip[s:e]
 
     def process(i, frames):                # stand-in for engine.auto_chunk (in place): mark which rank / chunk touched it
         processed.append(i)
@@ -44,7 +50,7 @@ def _worker(rank, world, port, total, gap, q):
         assert rank == 0 and i == len(written), "results are written in chunk order"
         written[i] = np.array(arr, copy=True)
 
-    cp.run_chunk_parallel(ranges, (4, 6, 3), load, process, store, dist=dist)
+    cp.run_chunk_parallel(ranges, (4, 6, 3), load, process, store, dist=dist, io=io)
     if rank == 0:
         assert loaded == list(range(len(ranges))), "the source is read once, in order"
         q.put(("written", written))
@@ -52,14 +58,15 @@ def _worker(rank, world, port, total, gap, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total,gap", [(2, 23, 5), (2, 20, 5), (2, 3, 5), (3, 41, 4), (2, 0, 5)])
-def test_chunk_parallel_over_gloo_ranks(world, total, gap):
+@pytest.mark.parametrize("world,total,gap,io", [(2, 23, 5, "host"), (2, 20, 5, "host"), (2, 3, 5, "host"), (3, 41, 4, "host"), (2, 0, 5, "host"),
+                                                (2, 23, 5, "device"), (3, 10, 4, "device")])
+def test_chunk_parallel_over_gloo_ranks(world, total, gap, io):
     from vsr_amd.backend.tools import chunk_parallel as cp
 
-    port = 29500 + (os.getpid() % 2000) + total + 7 * world
+    port = 29500 + (os.getpid() % 2000) + total + 7 * world + (500 if io == "device" else 0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, gap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, gap, q, io)) for r in range(world)]
     for p in procs:
         p.start()
     msgs = [q.get(timeout=120) for _ in range(world + 1)]

@@ -146,3 +146,45 @@ def test_lama_mode_without_weights_is_an_error(tmp_path, monkeypatch):
             sr.run()
     finally:
         config.inpaintMode.value = old
+
+
+def test_y4m_planes_access_round_trip(tmp_path):
+    """the raw access the HBM-resident chunk loop uses (planes as stored, no conversion): records read with read_planes_into and
+    written back with write_planes reproduce the file; without a GPU both ends report that no device conversion is available"""
+    from vsr_amd.backend.tools import video_io
+
+    H, W, N = 18, 26, 7
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=(N, H, W, 3), dtype=np.uint8)
+    src, dst = str(tmp_path / "a.y4m"), str(tmp_path / "b.y4m")
+    w = video_io.Y4mWriter(src, 25.0, (W, H), chroma="420")
+    for f in frames:
+        w.write(f)
+    w.release()
+    r = video_io.Y4mVideo(src)
+    fsize = W * H + 2 * ((W + 1) // 2) * ((H + 1) // 2)
+    buf = np.zeros((5, fsize), np.uint8)
+    w2 = video_io.Y4mWriter(dst, 25.0, (W, H), chroma="420")
+    got = 0
+    while True:
+        k = r.read_planes_into(buf)
+        if k == 0:
+            break
+        w2.write_planes(buf[:k])
+        got += k
+    r.release()
+    w2.release()
+    assert got == N
+    assert open(src, "rb").read() == open(dst, "rb").read()
+    import torch
+
+    if not torch.cuda.is_available():
+        assert video_io.Y4mVideo(src).planes_format() is None and video_io.Y4mWriter(str(tmp_path / "c.y4m"), 25.0, (W, H)).planes_format() is None
+    aw = video_io.AsyncWriter(video_io.Y4mWriter(str(tmp_path / "d.y4m"), 25.0, (W, H), chroma="420"))
+    r = video_io.Y4mVideo(src)
+    k = r.read_planes_into(buf)
+    aw.write_planes(buf[:k])                      # batches keep their place between frames in the writer thread's queue
+    aw.write(frames[5])
+    aw.release()
+    out = video_io.Y4mVideo(str(tmp_path / "d.y4m"))
+    assert out.info()["len"] == 6
