@@ -143,3 +143,26 @@ def test_resident_chunk_loop_writes_the_same_file(built_lib, gpu_device, tmp_pat
     assert got.shape == want.shape
     ymin, ymax, xmin, xmax = box
     assert (got[:, ymin:ymax, xmin:xmax] != want[:, ymin:ymax, xmin:xmax]).mean() > (0.15 if ab else 0.4)
+
+
+def test_bt601_colour_bars_on_the_device(built_lib, gpu_device, tmp_path, monkeypatch):
+    """known answers: the published BT.601 colour-bar code values out of vsr_io_bgr_to_yuv, the primaries back out of vsr_io_yuv_to_bgr"""
+    from tests.test_video_io import BT601_BARS
+
+    monkeypatch.setenv("VSR_IO_COLOR", "device")
+    bars = list(BT601_BARS.items())
+    H, W = 2, 4 * len(bars)
+    frame = np.zeros((H, W, 3), np.uint8)
+    for i, ((r, g, b), _) in enumerate(bars):
+        frame[:, 4 * i: 4 * i + 4] = (b, g, r)
+    p = str(tmp_path / "bars.y4m")
+    w = video_io.Y4mWriter(p, 25.0, (W, H), chroma="444")
+    assert w._dc is not None
+    w.write(frame)
+    w.release()
+    raw = open(p, "rb").read()
+    rec = np.frombuffer(raw[raw.index(b"FRAME\n") + 6:], np.uint8).reshape(3, H, W)
+    for i, (_, (y, cb, cr)) in enumerate(bars):
+        assert (int(rec[0, 0, 4 * i]), int(rec[1, 0, 4 * i]), int(rec[2, 0, 4 * i])) == (y, cb, cr)
+    back = _read_all(p)[0]
+    assert np.abs(back.astype(int) - frame.astype(int)).max() <= 1

@@ -188,3 +188,21 @@ def test_y4m_planes_access_round_trip(tmp_path):
     aw.release()
     out = video_io.Y4mVideo(str(tmp_path / "d.y4m"))
     assert out.info()["len"] == 6
+
+
+# the 100 % colour bars of ITU-R BT.601 in 8-bit studio range, as every table of the standard's worked values lists them
+BT601_BARS = {  # (R, G, B) -> (Y, Cb, Cr)
+    (255, 255, 255): (235, 128, 128), (255, 255, 0): (210, 16, 146), (0, 255, 255): (170, 166, 16), (0, 255, 0): (145, 54, 34),
+    (255, 0, 255): (106, 202, 222), (255, 0, 0): (81, 90, 240), (0, 0, 255): (41, 240, 110), (0, 0, 0): (16, 128, 128)}
+
+
+def test_bt601_colour_bars_known_answers():
+    """the integer matrices of the y4m transport reproduce the published BT.601 colour-bar code values (the numpy statement the
+    GPU kernels are held to, tests/test_gpu_io.py), and the way back lands within one level of the primaries"""
+    from vsr_amd.backend.tools import video_io
+
+    for (r, g, b), want in BT601_BARS.items():
+        y, u, v = (int(p[0, 0]) for p in video_io._bgr_to_yuv(np.array([[[b, g, r]]], np.uint8), False))
+        assert (y, u, v) == want, ((r, g, b), (y, u, v), want)
+        back = video_io._yuv_to_bgr(np.array([[y]], np.uint8), np.array([[u]], np.uint8), np.array([[v]], np.uint8), False)[0, 0]
+        assert np.abs(back.astype(int) - np.array([b, g, r])).max() <= 1
