@@ -32,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL / device-memory IPC on this pool needs dmabuf handles (set before HIP starts)
+
 import numpy as np
 import torch
 
