@@ -137,7 +137,10 @@ def main():
         if dry:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=device)
+            import datetime
+
+            # a stuck exchange ends the run with an error after five minutes instead of holding the node
+            dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
 
     import vsr_amd  # noqa: F401
     from vsr_amd.backend.tools.inpaint_tools import create_mask, get_inpaint_area_by_mask, threshold_mask
