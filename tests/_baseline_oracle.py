@@ -143,9 +143,9 @@ def launch(names=None):
     tmp = tempfile.mkdtemp(prefix="vsr_baseline_")
     for n in names:
         out = os.path.join(tmp, n + ".npy")
-        # the propainter job is the long pole of the whole GPU suite (RAFT: 38 pair-directions x 20 iterations on 1920x360 maps,
-        # which do scale): it gets a third of the box
-        threads = max(base, min(96, ncpu // 3)) if JOBS[n]["kind"] == "pp" else base
+        # every job keeps the thread count the suite was measured with: on this host oneDNN gets SLOWER beyond ~32 threads on maps of
+        # this size (bench.py's probe: 16 threads 0.46 s, 64 threads 1.19 s, 256 threads 75 s for the same three frames)
+        threads = base
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), VSR_ORACLE_THREADS=str(threads),
                    HIP_VISIBLE_DEVICES="", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         log = open(os.path.join(tmp, n + ".log"), "w")
