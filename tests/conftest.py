@@ -9,6 +9,19 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # The CPU oracle runs inside this process in most GPU tests.  On the GPU box (256 hardware threads) torch's default thread
+    # count makes it pathologically slow on the 30x160 / 45x240 maps of this path -- bench.py's probe of the same oracle: 16 threads
+    # 0.46 s, 64 threads 1.19 s, 256 threads 75 s for three frames -- so big hosts are capped (VSR_TEST_THREADS overrides).
+    try:
+        import torch
+
+        want = int(os.environ.get("VSR_TEST_THREADS", "0"))
+        if want > 0:
+            torch.set_num_threads(want)
+        elif (os.cpu_count() or 1) > 32:
+            torch.set_num_threads(16)
+    except ImportError:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "baseline_oracle: compares against a BASELINE-size CPU oracle run (tests/_baseline_oracle.py)")
 
