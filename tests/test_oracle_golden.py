@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import sttn_auto
@@ -162,3 +163,29 @@ def test_propainter_generator_matches_reference():
     out = o.forward(torch.cat([upd_frames, masked[lt:]]), ff, fb, masks, torch.cat([upd, masks[lt:]]), lt)
     err = np.abs(out.numpy() - g["out"]).max()
     assert err <= 2e-3, f"generator output: max abs err {err:.3e} (tanh range)"
+
+
+@pytest.mark.parametrize("sh,sw,dh,dw", [(360, 1920, 120, 640), (120, 640, 360, 1920), (240, 1280, 120, 640), (120, 640, 240, 1280),
+                                         (159, 853, 120, 640), (120, 640, 159, 853), (720, 3840, 120, 640), (7, 5, 3, 11)])
+def test_cv2_resize_restatement_agrees_with_an_independent_bilinear(sh, sw, dh, dw):
+    """opencv is absent, so cv2.resize stays "parity unpinned" -- but its sampling rule (half-pixel centres, source index clamped at
+    the borders, no antialiasing) is also torch.nn.functional.interpolate(bilinear, align_corners=False), written by other people:
+    the float path of the restatement must agree with it to rounding, the uint8 fixed-point path (11-bit coefficients, 22-bit
+    product shift) within one level of its rounded values.  Catches any error in the coordinate mapping or the border rule."""
+    import numpy as np
+    import torch
+
+    from oracle import cv2_restate as cv2r
+
+    rng = np.random.default_rng(sh * 7 + dw)
+    img = rng.integers(0, 256, size=(sh, sw, 3), dtype=np.uint8)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None].double(), size=(dh, dw),
+                                          mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+    got_f = cv2r.resize_linear(img.astype(np.float32), (dw, dh))
+    assert got_f.shape == (dh, dw, 3) and got_f.dtype == np.float32
+    # OpenCV takes the source coordinate in fp32: at x ~ 1900 its fraction is good to ~6e-5, times a pixel step of up to 255
+    assert np.abs(got_f - ref).max() <= 0.04
+    got_u = cv2r.resize_linear(img, (dw, dh))
+    assert got_u.dtype == np.uint8
+    d = np.abs(got_u.astype(np.float64) - ref)
+    assert d.max() <= 1.0 + 0.04 and (d > 0.75).mean() < 0.02

@@ -199,3 +199,30 @@ def test_propainter_mode_asks_for_scene_cuts_when_none_are_given(monkeypatch):
     sr2.sub_areas = [(0, 120, 0, 780)]
     sr2.propainter_mode(None, propainter_inpaint=lambda b, m: seen.append(len(b)) or [f.copy() for f in b], text_detector=Det(), scene_div_points=[])
     assert asked == [3] and seen == [35]                       # given (even empty) scene points are used as they are
+
+
+def test_bgr2hsv_restatement_agrees_with_colorsys():
+    """opencv is absent, so cvtColor(BGR2HSV) on uint8 stays "parity unpinned" -- but its integer algorithm approximates the
+    textbook conversion that Python's own colorsys implements (written by other people): H in half degrees, S and V scaled to 255.
+    On a grid over the BGR cube the restatement stays within one level of the rounded textbook values (hue compared on the
+    circle; grey pixels have no hue).  Catches a wrong sector, channel order or scale -- not the last bit of OpenCV's rounding."""
+    import colorsys
+
+    import numpy as np
+
+    from oracle.scene_cuts import bgr2hsv_u8
+
+    g = np.array(sorted(set(list(range(0, 256, 15)) + [1, 2, 127, 128, 254, 255])), dtype=np.uint8)
+    b, gg, r = np.meshgrid(g, g, g, indexing="ij")
+    img = np.stack([b.reshape(-1), gg.reshape(-1), r.reshape(-1)], axis=-1)[None]
+    got = bgr2hsv_u8(img)[0].astype(int)
+    worst_h = worst_s = 0
+    for (bb, g_, rr), (h, s, v) in zip(img[0].tolist(), got.tolist()):
+        hh, ss, vv = colorsys.rgb_to_hsv(rr / 255.0, g_ / 255.0, bb / 255.0)
+        assert v == max(bb, g_, rr) == round(vv * 255)
+        worst_s = max(worst_s, abs(s - ss * 255))
+        if max(bb, g_, rr) - min(bb, g_, rr) > 0:
+            dh = abs(h - hh * 180.0)
+            worst_h = max(worst_h, min(dh, 180.0 - dh))
+        assert 0 <= h < 180
+    assert worst_s <= 1.0 and worst_h <= 1.0, (worst_s, worst_h)
