@@ -189,3 +189,38 @@ def test_cv2_resize_restatement_agrees_with_an_independent_bilinear(sh, sw, dh, 
     assert got_u.dtype == np.uint8
     d = np.abs(got_u.astype(np.float64) - ref)
     assert d.max() <= 1.0 + 0.04 and (d > 0.75).mean() < 0.02
+
+
+def test_deform_conv_restatement_against_grid_sample():
+    """torchvision is absent, so deform_conv2d stays unpinned against its own binary -- but its definition (Dai et al.; the layout
+    torchvision documents: offsets [B, 2*G*K, H, W] ordered (group, tap, (dy, dx)), modulation mask [B, G*K, H, W]) can be composed
+    from torch's own bilinear sampler, written by other people: per offset group and tap, the group's channels sampled at
+    (y + ky - 1 + dy, x + kx - 1 + dx) with zeros outside (grid_sample, align_corners=True on pixel coordinates), times the mask,
+    contracted with that tap's weights.  Fractional offsets, different per group and tap, spatially varying."""
+    from oracle.deform_conv import deform_conv2d
+
+    rng = np.random.default_rng(11)
+    B, C, H, W, G, Co = 2, 32, 10, 13, 4, 6
+    K = 9
+    x = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((Co, C, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(Co).astype(np.float32))
+    off = torch.from_numpy((rng.standard_normal((B, 2 * G * K, H, W)) * 1.7).astype(np.float32))
+    mask = torch.from_numpy(rng.random((B, G * K, H, W)).astype(np.float32))
+    got = deform_conv2d(x, off, w, b, 1, 1, 1, mask)
+
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    want = b.double()[None, :, None, None].expand(B, Co, H, W).clone()
+    cg = C // G
+    for g in range(G):
+        xg = x[:, g * cg:(g + 1) * cg].double()
+        for t in range(K):
+            ky, kx = t // 3, t % 3
+            dy = off[:, g * 2 * K + 2 * t].double()
+            dx = off[:, g * 2 * K + 2 * t + 1].double()
+            py, px = ys[None] + ky - 1 + dy, xs[None] + kx - 1 + dx
+            grid = torch.stack([px / (W - 1) * 2 - 1, py / (H - 1) * 2 - 1], dim=-1)          # align_corners=True: -1 .. 1 = pixel 0 .. size-1
+            samp = torch.nn.functional.grid_sample(xg, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+            samp = samp * mask[:, g * K + t].double()[:, None]
+            want += torch.einsum("bchw,oc->bohw", samp, w[:, g * cg:(g + 1) * cg, ky, kx].double())
+    assert torch.allclose(got.double(), want, atol=2e-4, rtol=1e-4), (got.double() - want).abs().max()
