@@ -240,3 +240,28 @@ def test_conv_fusion_analysis(fixture, nconv, min_affine):
         if act is not None:
             assert g.ops[act[0]][0] == {1: "relu", 2: "hardswish"}[act[1]] and g.ops[act[0]][1][0] == g.ops[j][2][0] and readers[g.ops[j][2][0]] == 1
     assert n_aff >= min_affine
+
+
+def test_min_area_rect_is_minimal_and_encloses():
+    """definition check, independent of any library: for random integer point clouds the rectangle encloses every point, and no
+    orientation on a 0.02-degree grid gives a smaller bounding box (the minimum lies on a hull edge, so the grid can only lose)"""
+    rng = np.random.default_rng(2)
+    ang = np.deg2rad(np.arange(0.0, 90.0, 0.02))
+    ca, sa = np.cos(ang), np.sin(ang)
+    for trial in range(25):
+        n = int(rng.integers(3, 60))
+        th = rng.uniform(0, np.pi)
+        base = rng.normal(size=(n, 2)) * [rng.uniform(5, 80), rng.uniform(2, 15)]
+        pts = np.round(base @ np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]).T + [200, 100]).astype(int)
+        corners, w, h = ocr_det.min_area_rect(pts)
+        u = (corners[1] - corners[0]) / max(np.hypot(*(corners[1] - corners[0])), 1e-12)
+        v = (corners[3] - corners[0]) / max(np.hypot(*(corners[3] - corners[0])), 1e-12)
+        if w > 0 and h > 0:
+            assert abs(u @ v) < 1e-9
+            rel = pts - corners[0]
+            assert (rel @ u >= -1e-6).all() and (rel @ u <= w + 1e-6).all() and (rel @ v >= -1e-6).all() and (rel @ v <= h + 1e-6).all()
+        pu = pts[:, :1] * ca[None] + pts[:, 1:] * sa[None]
+        pv = -pts[:, :1] * sa[None] + pts[:, 1:] * ca[None]
+        brute = ((pu.max(0) - pu.min(0)) * (pv.max(0) - pv.min(0))).min()
+        assert w * h <= brute + 1e-6, (trial, w * h, brute)
+        assert w * h >= brute * (1 - 2e-3) - 1e-6, (trial, w * h, brute)
