@@ -45,12 +45,21 @@ __device__ unsigned long long gg_trace[1024 * 256];
             gg_trace[blockIdx.x * 256 + tr_] = __builtin_readcyclecounter();           \
         ++tr_;                                                                         \
     }
+// 32: per-workgroup cycle sums of wave 0's chunk phases (operand DMA issue | fragment reads + MFMAs | vmcnt(0) wait | barrier wait)
+#define GG_PH(k)                                                                       \
+    if constexpr (GG_ABL(32)) {                                                        \
+        const unsigned long long now_ = __builtin_readcyclecounter();                  \
+        ph_[k] += now_ - tl_;                                                          \
+        tl_ = now_;                                                                    \
+    }
 #else
 #define GG_STAMP()
+#define GG_PH(k)
 #endif
 
+// (second launch bound = waves per SIMD: three workgroups of the 128x64 tile share a CU, which needs <= 168 registers)
 template <int BM, int BN, int WM, int WN, int BMODE GG_ABL_PARAM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (BM + BN) * 32 * 4 * 2 <= 50 * 1024 ? 3 : 2)
 gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue, int nQueues)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -106,6 +115,8 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
     __syncthreads();
 #ifdef GG_ABLATE
     int tr_ = 0;
+    unsigned long long ph_[5] = {0, 0, 0, 0, 0}, tl_ = 0;
+    const unsigned long long kc0_ = __builtin_readcyclecounter(), kr0_ = __builtin_amdgcn_s_memrealtime();   // shader clock vs 100 MHz
 #endif
 
     for (;;) {
@@ -114,6 +125,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         if (bid >= totalTiles) break;
         if (tid == 0) *nextTile = fetchTile();
         GG_STAMP()   // tile start
+        if constexpr (!GG_ABL(1024)) __builtin_amdgcn_s_setprio(3);
 
         // last problem whose first tile id is <= bid (tileStart is non-decreasing; binary search: a grouped launch
         // can carry thousands of problems, e.g. ProPainter's per-window / per-frame attention)
@@ -189,11 +201,49 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) dst[it] = rowB[kc * VSR_GG_KC + k_r + RPP * it];
         };
-        // LDS-DMA of chunk kc into buffer buf (destination = wave-uniform base + lane*16)
-        auto dma_tile = [&](int kc, int buf) {
+        // LDS-DMA of chunk kc into buffer buf (destination = wave-uniform base + lane*16).  Round 3: when every row offset of
+        // this wave is in [0, 2^30) floats (always, except for tensors beyond 4 GB) a piece is addressed as
+        // (scalar base = operand + chunk offset) + (unsigned 32-bit byte offset of the lane's row, constant over the tile):
+        // the saddr form of global_load_lds, no vector ALU work per piece.  (Per piece the 64-bit vector address cost a
+        // v_add, a v_ashrrev and a v_lshl_add_u64, each of which waits behind the co-resident waves' MFMAs.)
+        bool narrow = true;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) narrow = narrow && ((unsigned)aoff[it] < (1u << 30));
+        if constexpr (BMODE == VSR_BMODE_NK) {
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) narrow = narrow && ((unsigned)boff[it] < (1u << 30));
+        } else {
+            narrow = false;                     // KN: the B row offsets change with every chunk; keep the vector form
+        }
+        narrow = __all(narrow) != 0;
+        unsigned aoffB[A_IT], boffB[B_IT];          // byte offsets of the lane's rows
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) aoffB[it] = (unsigned)aoff[it] << 2;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) boffB[it] = (unsigned)boff[it] << 2;
+        auto dma_tile = [&](int kc, auto bufTag) {
+            constexpr int buf = decltype(bufTag)::value;
             float* As = smem + buf * BUF_FLOATS;
             float* Bs = As + AS_FLOATS;
             const int ca = __builtin_amdgcn_readlane(vcolA, kc - colBase);
+            if (narrow) {
+                const char __attribute__((address_space(1)))* baseA = (const char __attribute__((address_space(1)))*)A + (long long)ca * 4;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    asm volatile("" : "+v"(aoffB[it]));       // keeps the zero-extension next to the load, where hipcc folds it into the saddr form
+                    glds16((gcf32)(baseA + aoffB[it]), (lds_vptr)(As + (wave * 8 + 32 * it) * 32));
+                }
+                if constexpr (BMODE == VSR_BMODE_NK) {
+                    const int cb = __builtin_amdgcn_readlane(vcolB, kc - colBase);
+                    const char __attribute__((address_space(1)))* baseB = (const char __attribute__((address_space(1)))*)B + (long long)cb * 4;
+#pragma unroll
+                    for (int it = 0; it < B_IT; ++it) {
+                        asm volatile("" : "+v"(boffB[it]));
+                        glds16((gcf32)(baseB + boffB[it]), (lds_vptr)(Bs + (wave * 8 + 32 * it) * 32));
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int it = 0; it < A_IT; ++it)
                 glds16(A + (aoff[it] + ca), (lds_vptr)(As + (wave * 8 + 32 * it) * 32));
@@ -208,10 +258,14 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     glds16(B + (boff[it] + bcolKN), (lds_vptr)(Bs + (wave * (64 / TPR) + RPP * it) * BN));
             }
         };
-        auto compute_group = [&](int buf, int g) {
+        // Fragment reads of group g (four k-steps); the MFMAs take the WEIGHT fragment as their first operand and the
+        // ACTIVATION fragment as their second, i.e. they accumulate the transposed tile: lane l31 of an accumulator owns output
+        // ROW l31 and its 16 registers are columns (r&3) + 8*(r>>2) + 4*hi -- four runs of four consecutive columns, so the
+        // epilogue moves 16 bytes per lane and instruction (round 3; before, a lane owned a column and stored 16 single floats).
+        auto read_group = [&](auto bufTag, int g, f32x4 (&af)[MI], f32x4 (&bf)[NI]) {
+            constexpr int buf = decltype(bufTag)::value;             // compile-time buffer: the reads fold it into their offset field
             const float* As = smem + buf * BUF_FLOATS;
             const float* Bs = As + AS_FLOATS;
-            f32x4 af[MI], bf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 af[mi] = *reinterpret_cast<const f32x4*>(&As[(wm * WTM + mi * 32 + l31) * 32 + rdOff[g]]);
@@ -226,13 +280,35 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     for (int j = 0; j < 4; ++j)
                         bf[ni][j] = Bs[(8 * g + 4 * hi + j) * BN + wn * WTN + ni * 32 + l31];
             }
+        };
+        auto mfma_group = [&](const f32x4 (&af)[MI], const f32x4 (&bf)[NI]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni][j], af[mi][j], acc[mi][ni], 0, 0, 0);
+        };
+        // one chunk: the reads of group g+1 are in flight while the MFMAs of group g issue (two fragment sets), so a wave
+        // stalls on LDS latency once per chunk instead of four times -- with three waves per SIMD the matrix pipe idles
+        // whenever all three wait at once (timeline in profiles/r03_v3_probe.log: 6975 cycles per chunk against 6144 pipe-bound)
+        auto compute_chunk = [&](auto buf) {
+            f32x4 af0[MI], bf0[NI], af1[MI], bf1[NI];
+            // (sched_barrier: hipcc otherwise sinks every read group back in front of its own MFMAs)
+            read_group(buf, 0, af0, bf0);
+            read_group(buf, 1, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(buf, 2, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(buf, 3, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(af0, bf0);
+            mfma_group(af1, bf1);
         };
 
         if (kcBeg < kcEnd) {
@@ -240,12 +316,20 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 load_rowB_KN(kcBeg, boff);
                 if (kcBeg + 1 < kcEnd) load_rowB_KN(kcBeg + 1, boffNext);
             }
-            dma_tile(kcBeg, 0);
+            using B0_ = std::integral_constant<int, 0>;
+            using B1_ = std::integral_constant<int, 1>;
+            dma_tile(kcBeg, B0_{});
             __syncthreads();                       // drains the DMA (vmcnt(0)) and publishes buffer 0
+            if constexpr (!GG_ABL(1024) || !GG_ABL(512)) __builtin_amdgcn_s_setprio(0);
             GG_STAMP()   // prologue done
-            int cur = 0;
-            for (int kc = kcBeg; kc < kcEnd; ++kc) {
-                if (kc + 1 < kcEnd) {
+            const int kcEndU = __builtin_amdgcn_readfirstlane(kcEnd);      // scalar loop control
+            // one chunk out of buffer `cur` while the DMA of the next one fills the other buffer
+            auto chunk = [&](int kc, auto cur, auto nxt) {
+#ifdef GG_ABLATE
+                if constexpr (GG_ABL(32)) { tl_ = __builtin_readcyclecounter(); ph_[4] += 1; }
+#endif
+                if constexpr (!GG_ABL(256)) __builtin_amdgcn_s_setprio(3);    // the few non-MFMA instructions of a chunk go first: they issue in the shadow of the other waves' MFMAs
+                if (kc + 1 < kcEndU) {
                     if (kc + 1 - colBase >= 64) {  // next 64 table entries become current
                         colBase += 64;
                         vcolA = vcolAn; vcolB = vcolBn;
@@ -254,22 +338,34 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     if constexpr (BMODE == VSR_BMODE_KN) {
 #pragma unroll
                         for (int it = 0; it < B_IT; ++it) boff[it] = boffNext[it];
-                        if (kc + 2 < kcEnd) load_rowB_KN(kc + 2, boffNext);
+                        if (kc + 2 < kcEndU) load_rowB_KN(kc + 2, boffNext);
                     }
-                    dma_tile(kc + 1, cur ^ 1);     // buffer last read in iteration kc-1, fenced by its barrier
+                    if constexpr (!GG_ABL(2)) dma_tile(kc + 1, nxt);         // buffer last read in iteration kc-1, fenced by its barrier
                 }
-                compute_group(cur, 0);
-                compute_group(cur, 1);
-                compute_group(cur, 2);
-                compute_group(cur, 3);
-                __syncthreads();                   // vmcnt(0) + barrier: chunk kc+1 landed, chunk kc retired
+                if constexpr (!GG_ABL(256)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+                GG_PH(0)
+                compute_chunk(cur);
+                GG_PH(1)
+#ifdef GG_ABLATE
+                if constexpr (GG_ABL(32)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+                GG_PH(2)
+                if constexpr (!GG_ABL(1)) __syncthreads();                   // vmcnt(0) + barrier: chunk kc+1 landed, chunk kc retired
+                GG_PH(3)
                 GG_STAMP()   // chunk done
-                cur ^= 1;
+            };
+            int kc = __builtin_amdgcn_readfirstlane(kcBeg);
+            for (; kc + 1 < kcEndU; kc += 2) {
+                chunk(kc, B0_{}, B1_{});
+                chunk(kc + 1, B1_{}, B0_{});
             }
+            if (kc < kcEndU) chunk(kc, B0_{}, B1_{});
         }
 
-        // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-        // Row offsets come from LDS, the residual reads of 16 rows are issued back to back.
+        if constexpr (!GG_ABL(512)) __builtin_amdgcn_s_setprio(3);     // epilogue, queue and tables of the next tile at priority: +2 % (profiles/r03_v3_probe.log)
+        // ---- epilogue.  Transposed accumulators (see read_group): lane l31 owns output row l31 of its 32x32 block, register
+        // r is column (r&3) + 8*(r>>2) + 4*hi.  One row offset per lane, and interior tiles whose output (and residual) rows are
+        // 16-byte aligned move float4s: 4 stores per accumulator instead of 16 (the store tail is issue-bound, not bandwidth-bound).
         const float alpha = P->alpha;
         const int act = P->act & 0xff;
         const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;   // relu(act(..) + R): residual blocks of RAFT
@@ -279,101 +375,150 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const gcf32 R = (partial || rowMax) ? (gcf32) nullptr : (gcf32)P->R;
         const cci32 colC = (cci32)P->colC;
         const gf32 C = (gf32)(P->C + (partial ? (int64_t)split * P->splitStride : (int64_t)0));
-        int ccol[NI];
-        float bv[NI];
-        bool nok[NI];
+        int ccol[NI];            // offset of column (32-block start + 4*hi) of this lane
+        int ncol[NI];            // its global column index
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n0 = tn * BN + wn * WTN + ni * 32;
-            ccol[ni] = colC[n0 / VSR_GG_KC] + l31;
-            nok[ni] = (n0 + l31) < N;
-            bv[ni] = (bias != nullptr && nok[ni]) ? bias[n0 + l31] : 0.f;
+            ccol[ni] = colC[n0 / VSR_GG_KC] + 4 * hi;
+            ncol[ni] = n0 + 4 * hi;
         }
-        // interior tiles (the vast majority) take a branch-free path: per-element predicates put every
-        // store into its own basic block, and hipcc then drains vmcnt(0) in front of each one -- 32-64
-        // serialised store round trips (~45k cycles per tile, measured) instead of a pipelined burst
         const bool fullTile = (tm * BM + BM <= M) && (tn * BN + BN <= N);
-        auto epilogue = [&](auto fullTag, auto resTag) {
-            constexpr bool FULL = decltype(fullTag)::value, HASR = decltype(resTag)::value;
+        auto activate = [&](float v) {
+            if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+            else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
+            return v;
+        };
+        // float4 epilogue of an interior tile.  ACTK: the activation as a compile-time constant (0 none, 1 LeakyReLU 0.2, 2 ReLU,
+        // 3 LeakyReLU 0.1), -1 = decided per element at run time (POST_RELU and anything else).  Every bias and residual load of
+        // the wave is issued before the first value is touched: one exposed memory latency per tile (the first version loaded the
+        // bias inside the store loop and paid eight serialised round trips, 50 k cycles per tile in profiles/r03_v3_probe.log).
+        auto epilogue_vec = [&](auto resTag, auto actTag) {
+            constexpr bool HASR = decltype(resTag)::value;
+            constexpr int ACTK = decltype(actTag)::value;
+            typedef const f32x4 __attribute__((address_space(1)))* gv4;
+            f32x4 bq[NI][4];
+            f32x4 rv[HASR ? MI : 1][NI][4];
+            int rc[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (bias != nullptr) bq[ni][q] = *reinterpret_cast<gv4>(bias + (ncol[ni] + 8 * q));
+                    else bq[ni][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                int rc[16], rr[16];
-                float rv[16][NI];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    rc[r] = rowTab[row];
-                    if constexpr (HASR) rr[r] = rowTab[BM + row];
-                }
+                const int row = wm * WTM + mi * 32 + l31;
+                rc[mi] = rowTab[row];
                 if constexpr (HASR) {
+                    const int rr = rowTab[BM + row];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rv[mi][ni][q] = *reinterpret_cast<gv4>(R + (rr + ccol[ni] + 8 * q));
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[mi][ni][4 * q + e] * alpha + bq[ni][q][e];
+                            if constexpr (ACTK == 1) v = fmaxf(v, 0.2f * v);          // == v > 0 ? v : 0.2 v
+                            else if constexpr (ACTK == 2) v = fmaxf(v, 0.f);
+                            else if constexpr (ACTK == 3) v = fmaxf(v, 0.1f * v);
+                            else if constexpr (ACTK < 0) v = activate(v);
+                            if constexpr (HASR) {
+                                v += rv[mi][ni][q][e];
+                                if constexpr (ACTK < 0) { if (postRelu) v = fmaxf(v, 0.f); }
+                            }
+                            o[e] = v;
+                        }
+                        *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(C + (rc[mi] + ccol[ni] + 8 * q)) = o;
+                    }
+        };
+        // border tiles and unaligned outputs: one float at a time, predicated
+        auto epilogue_scalar = [&](auto resTag) {
+            constexpr bool HASR = decltype(resTag)::value;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * WTM + mi * 32 + l31;
+                const int rc = rowTab[row];
+                const int rr = HASR ? rowTab[BM + row] : 0;
+                const bool mok = (tm * BM + row) < M;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool mok = FULL || (tm * BM + row) < M;
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            rv[r][ni] = (mok && (FULL || nok[ni])) ? R[rr[r] + ccol[ni]] : 0.f;
+                        const int cofs = (r & 3) + 8 * (r >> 2);
+                        const bool ok = mok && (ncol[ni] + cofs) < N;
+                        float v = acc[mi][ni][r] * alpha + ((bias != nullptr && ok) ? bias[ncol[ni] + cofs] : 0.f);
+                        v = activate(v);
+                        if constexpr (HASR) { if (ok) v += R[rr + ccol[ni] + cofs]; if (postRelu) v = fmaxf(v, 0.f); }
+                        if (ok) C[rc + ccol[ni] + cofs] = v;
                     }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool mok = FULL || (tm * BM + row) < M;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        float v = acc[mi][ni][r] * alpha + bv[ni];
-                        if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-                        else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
-                        if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
-                        if (mok && (FULL || nok[ni])) C[rc[r] + ccol[ni]] = v;
-                    }
-                }
             }
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-        if (fullTile) { if (R != nullptr) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
-        else          { if (R != nullptr) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
+        // float4 path: an interior tile whose row / column offsets keep 16-byte alignment for every lane of this wave
+        bool vec = fullTile && ((reinterpret_cast<uintptr_t>(P->C) | (uintptr_t)(partial ? P->splitStride * 4 : 0)) & 15) == 0 &&
+                   (bias == nullptr || (reinterpret_cast<uintptr_t>(P->bias) & 15) == 0) && (R == nullptr || (reinterpret_cast<uintptr_t>(P->R) & 15) == 0);
+        {
+            int low = 0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) low |= ccol[ni];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                low |= rowTab[wm * WTM + mi * 32 + l31];
+                if (R != nullptr) low |= rowTab[BM + wm * WTM + mi * 32 + l31];
+            }
+            vec = vec && __all((low & 3) == 0);
+        }
+        if constexpr (GG_ABL(128)) {           // ablation: no epilogue (one store keeps the accumulators alive)
+            if (acc[0][0][0] == 12345.678f) C[0] = acc[MI - 1][NI - 1][15];
+        } else
+        if (vec) {
+            using IC = std::integral_constant<int, -1>;
+            const int ak = postRelu ? -1 : act;
+            if (R != nullptr) {
+                if (ak == VSR_ACT_NONE) epilogue_vec(T_{}, std::integral_constant<int, 0>{});
+                else if (ak == VSR_ACT_LRELU02) epilogue_vec(T_{}, std::integral_constant<int, 1>{});
+                else epilogue_vec(T_{}, IC{});
+            } else {
+                if (ak == VSR_ACT_NONE) epilogue_vec(F_{}, std::integral_constant<int, 0>{});
+                else if (ak == VSR_ACT_LRELU02) epilogue_vec(F_{}, std::integral_constant<int, 1>{});
+                else if (ak == VSR_ACT_RELU) epilogue_vec(F_{}, std::integral_constant<int, 2>{});
+                else epilogue_vec(F_{}, IC{});
+            }
+        } else {
+            if (R != nullptr) epilogue_scalar(T_{}); else epilogue_scalar(F_{});
+        }
         if (rowMax) {
             // VSR_ACT_ROW_MAX (the QK^T of a fused attention): the largest score of every row of this tile joins the row's running
-            // maximum -- 32 lanes hold a row's columns, the waves side by side meet in LDS (the operand buffers are idle: the main
-            // loop ended on a barrier), then one atomic per row in a coalesced burst.  The P.V kernel subtracts it (VSR_ACT_A_EXP).
+            // maximum.  A lane holds 16 * NI columns of one row per mi, its partner lane ^ 32 the other half of the row's 32-block;
+            // the waves side by side meet in LDS (the operand buffers are idle: the main loop ended on a barrier), then one atomic
+            // per row in a coalesced burst.  The P.V kernel subtracts it (VSR_ACT_A_EXP).
             float* scr = smem;                                      // [BM][WN]
-            // A lane holds one column of 16 * MI rows; a row's 32 columns sit in the 32 lanes of its half wave.  Halving butterfly:
-            // at every step a lane keeps one half of its rows and hands the other half to its partner, so after log2(32) steps
-            // lane l31 holds the maximum of row-slot l31 -- 31 exchanges per lane instead of 5 for each of the 32 rows.
-            static_assert(MI * 16 == 32 || MI * 16 == 16, "row slots per lane");
-            constexpr int NV = MI * 16;
-            float v[NV];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                float mx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float mx = -INFINITY;
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        if (nok[ni]) mx = fmaxf(mx, acc[mi][ni][r] * alpha + bv[ni]);
-                    v[mi * 16 + r] = mx;
-                }
-            if constexpr (NV == 16) {                               // 16 row slots: the first exchange is a plain maximum
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], __shfl_xor(v[i], 16, 64));
-            }
-#pragma unroll
-            for (int half = (NV == 32 ? 16 : 8), bit = (NV == 32 ? 16 : 8); half >= 1; half >>= 1, bit >>= 1) {
-                const bool up = (l31 & bit) != 0;                   // this lane keeps slots [half, 2 half), its partner [0, half)
-#pragma unroll
-                for (int i = 0; i < half; ++i) {
-                    const float lo = v[i], hi_ = v[i + half];
-                    const float got = __shfl_xor(up ? lo : hi_, bit, 64);
-                    v[i] = fmaxf(up ? hi_ : lo, got);
-                }
-            }
-            {   // slot -> row of the wave's sub-tile: slot = mi * 16 + r, row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
-                const int slot = (NV == 32) ? l31 : (l31 & 15);
-                const int r = slot & 15, mi = slot >> 4;
-                if (NV == 32 || l31 < 16) scr[(wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * WN + wn] = v[0];
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = ncol[ni] + (r & 3) + 8 * (r >> 2);
+                        const float bvv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+                        if (n < N) mx = fmaxf(mx, acc[mi][ni][r] * alpha + bvv);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (hi == 0) scr[(wm * WTM + mi * 32 + l31) * WN + wn] = mx;
             }
             __syncthreads();
             if (tid < BM && tm * BM + tid < M) {
@@ -386,4 +531,14 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         __syncthreads();
         GG_STAMP()   // epilogue done
     }
+#ifdef GG_ABLATE
+    if constexpr (GG_ABL(32)) {
+        if (tid == 0 && blockIdx.x < 4096)
+            for (int k = 0; k < 5; ++k) gg_dbg[blockIdx.x * 8 + k] = ph_[k];
+        if (tid == 0 && blockIdx.x < 4096) {
+            gg_dbg[blockIdx.x * 8 + 5] = __builtin_readcyclecounter() - kc0_;
+            gg_dbg[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime() - kr0_;
+        }
+    }
+#endif
 }
