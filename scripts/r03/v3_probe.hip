@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <vector>
 #include <algorithm>
+#include <string.h>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -69,8 +70,42 @@ static Prob make(int T, int CS, int KS, bool hot, bool residual)
     return pr;
 }
 
+// plain dense problem: A [M][K] row-major, B [N][K], C [M][N]
+template <int BM, int BN>
+static Prob make_dense(int M, int N, int K)
+{
+    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
+    std::vector<int32_t> rowA(tilesM * BM), colA(K / 32), rowB(tilesN * BN), colB(K / 32), rowC(tilesM * BM), colC(tilesN * BN / 32);
+    for (int m = 0; m < tilesM * BM; ++m) { rowA[m] = (m < M ? m : 0) * K; rowC[m] = (m < M ? m : 0) * N; }
+    for (int k = 0; k < K / 32; ++k) { colA[k] = 32 * k; colB[k] = 32 * k; }
+    for (int n = 0; n < tilesN * BN; ++n) rowB[n] = (n < N ? n : 0) * K;
+    for (int n = 0; n < tilesN * BN / 32; ++n) colC[n] = 32 * n;
+    float *A, *B, *Cc, *bias;
+    Prob pr;
+    CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&Cc, (size_t)M * N * 4)); CK(hipMalloc(&B, (size_t)N * K * 4)); CK(hipMalloc(&bias, N * 4));
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned s = 999;
+    for (auto& v : hA) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 32768.f - 1.f; }
+    for (auto& v : hB) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 32768.f - 1.f) * 0.05f; }
+    CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(Cc, 0, (size_t)M * N * 4)); CK(hipMemset(bias, 0, N * 4));
+    int32_t *dRowA, *dColA, *dRowB, *dColB, *dRowC, *dColC;
+    UP(dRowA, rowA); UP(dColA, colA); UP(dRowB, rowB); UP(dColB, colB); UP(dRowC, rowC); UP(dColC, colC);
+    pr.owned.push_back(A); pr.owned.push_back(B); pr.owned.push_back(Cc); pr.owned.push_back(bias);
+    GGProblem p{};
+    p.A = A; p.B = B; p.C = Cc; p.bias = bias; p.R = nullptr;
+    p.rowA = dRowA; p.colA = dColA; p.rowB = dRowB; p.colB = dColB; p.rowC = dRowC; p.colC = dColC; p.rowR = dRowC;
+    p.M = M; p.N = N; p.K = K; p.tilesM = tilesM; p.tilesN = tilesN; p.splitK = 1; p.chunksPerSplit = K / 32; p.tileStart = 0;
+    p.act = 0; p.alpha = 1.f; p.splitStride = 0;
+    CK(hipMalloc(&pr.d, sizeof(p))); CK(hipMemcpy(pr.d, &p, sizeof(p), hipMemcpyHostToDevice));
+    pr.blocks = tilesM * tilesN;
+    pr.gflop = 2.0 * M * N * (double)K / 1e9;
+    return pr;
+}
+
 template <int BM, int BN, int WM, int WN, int ABL>
-static float time_v3(const Prob& pr, int residentPerCU, int iters = 12)
+static float time_v3(const Prob& pr, int residentPerCU, int iters = 12, int nq = 8)
 {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -85,7 +120,7 @@ static float time_v3(const Prob& pr, int residentPerCU, int iters = 12)
         hipMemset(q, 0, 64 * 8 * sizeof(unsigned int));
         hipEventRecord(a, 0);
         for (int i = 0; i < iters; ++i)
-            hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, ABL>), dim3(grid), dim3(256), 0, 0, pr.d, 1, pr.blocks, q + 8 * i, 8);
+            hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, ABL>), dim3(grid), dim3(256), 0, 0, pr.d, 1, pr.blocks, q + 8 * i, nq);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;
@@ -97,7 +132,7 @@ static float time_v3(const Prob& pr, int residentPerCU, int iters = 12)
 }
 
 template <int BM, int BN, int WM, int WN>
-static void trace(const Prob& pr, int K)
+static void trace(const Prob& pr, int K, int nq = 8)
 {
     std::vector<unsigned long long> z(1024 * 256, 0), h(1024 * 256);
     hipMemcpyToSymbol(HIP_SYMBOL(gg_trace), z.data(), z.size() * 8);
@@ -105,7 +140,7 @@ static void trace(const Prob& pr, int K)
     int occ = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 64>, 256, 0);
     const int grid = 256 * occ;
-    hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 64>), dim3(grid), dim3(256), 0, 0, pr.d, 1, pr.blocks, q, 8);
+    hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 64>), dim3(grid), dim3(256), 0, 0, pr.d, 1, pr.blocks, q, nq);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gg_trace), h.size() * 8);
     hipFree(q);
@@ -117,7 +152,8 @@ static void trace(const Prob& pr, int K)
         std::vector<double> chunkAvg;
         for (int w = x; w < grid && w < 1024; w += 8) {
             const unsigned long long* s = &h[w * 256];
-            for (int tile = 0; tile < 2; ++tile) {
+            for (int tile = 0; tile < (per <= 40 ? 3 : 2); ++tile) {
+                if (per <= 40 && tile == 0) continue;      // short tiles: skip the first (plain-sequence) tile
                 const unsigned long long* p = s + tile * per;
                 if ((tile + 1) * per > 256 || !p[0] || !p[per - 1]) break;
                 double sum = 0;
@@ -165,8 +201,62 @@ static void phases(const Prob& pr, int residentPerCU)
            occ, t[0] / n, t[1] / n, t[2] / n, t[3] / n, all / n, occ * 2048);
 }
 
-int main()
+// the same launch over and over: any difference between two results of identical inputs is a race
+template <int BM, int BN, int WM, int WN>
+static void stress(const Prob& pr, size_t cElems, float* Cdev, int launches, int nq)
 {
+    std::vector<float> ref(cElems), got(cElems);
+    unsigned int* q; hipMalloc(&q, 64 * 8 * 4);
+    int occ = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>, 256, 0);
+    const int grid = pr.blocks < 256 * occ ? pr.blocks : 256 * occ;
+    int bad = 0;
+    for (int it = 0; it < launches; ++it) {
+        if (it % 25 == 0) { hipMemset(q, 0, 64 * 8 * 4); hipMemset(Cdev, 0xff, cElems * 4); }
+        hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, VSR_BMODE_NK, 0>), dim3(grid), dim3(256), 0, 0, pr.d, 1, pr.blocks, q + 8 * (it % 25), nq);
+        if (it % 25 == 0) {
+            CK(hipMemcpy(it == 0 ? ref.data() : got.data(), Cdev, cElems * 4, hipMemcpyDeviceToHost));
+            if (it > 0 && memcmp(ref.data(), got.data(), cElems * 4) != 0) {
+                size_t nd = 0, first = 0;
+                for (size_t i = 0; i < cElems; ++i) if (memcmp(&ref[i], &got[i], 4)) { if (!nd) first = i; ++nd; }
+                printf("    launch %d: %zu values differ from launch 0 (first at %zu: %g vs %g)\n", it, nd, first, ref[first], got[first]);
+                ++bad;
+            }
+        }
+    }
+    CK(hipDeviceSynchronize());
+    hipFree(q);
+    printf("  stress: %d launches, %d of %d compared results differ\n", launches, bad, (launches + 24) / 25 - 1);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "stress")) {
+        constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
+        {
+            Prob pr = make<BM, BN>(15, 256, 2304, false, true);
+            GGProblem hp; CK(hipMemcpy(&hp, pr.d, sizeof(hp), hipMemcpyDeviceToHost));
+            printf("== stress, conv T=15\n"); fflush(stdout);
+            stress<BM, BN, WM, WN>(pr, (size_t)15 * 34 * 164 * 256, hp.C, 1500, 8);
+            pr.free_all();
+        }
+        {
+            Prob pr = make_dense<BM, BN>(72000, 768, 256);
+            GGProblem hp; CK(hipMemcpy(&hp, pr.d, sizeof(hp), hipMemcpyDeviceToHost));
+            printf("== stress, QKV shape\n"); fflush(stdout);
+            stress<BM, BN, WM, WN>(pr, (size_t)72000 * 768, hp.C, 1500, 1);
+            pr.free_all();
+        }
+        {
+            Prob pr = make_dense<BM, BN>(4800, 4800, 960);
+            GGProblem hp; CK(hipMemcpy(&hp, pr.d, sizeof(hp), hipMemcpyDeviceToHost));
+            printf("== stress, QK^T shape\n"); fflush(stdout);
+            stress<BM, BN, WM, WN>(pr, (size_t)4800 * 4800, hp.C, 1500, 1);
+            pr.free_all();
+        }
+        return 0;
+    }
     constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
     const int T = 15, K = 2304;
 #define RUN(label, pr, abl, occ) { const float ms = time_v3<BM, BN, WM, WN, abl>(pr, occ); printf("  %-58s %8.1f us  %6.1f TF\n", label, ms * 1e3, pr.gflop / ms); fflush(stdout); }
@@ -183,9 +273,7 @@ int main()
             Prob pr = make<BM, BN>(T, 256, 2304, false, true);
             RUN("(again) shipped kernel", pr, 0, 0);
             RUN("shipped strides, 2 workgroups / CU", pr, 0, 2);
-            RUN("  no s_setprio 3 around the operand DMA issue", pr, 256, 0);
-            RUN("  no s_setprio 3 in the epilogue", pr, 512, 0);
-            RUN("  no s_setprio at all", pr, 1792, 0);
+            RUN("  no tile pipelining (plain claim / tables / first chunk sequence per tile)", pr, 2048, 0);
             RUN("(again) shipped kernel", pr, 0, 0);
             RUN("  no epilogue", pr, 128, 0);
             RUN("  no operand DMA in the loop", pr, 2, 0);
@@ -200,6 +288,21 @@ int main()
             RUN("  hot rows, no epilogue", hot, 128, 0);
             hot.free_all();
         }
+    }
+    for (int which = 0; which < 2; ++which) {
+        // the short-K GEMMs of the step: QKV (K = 256: 8 chunks per tile) and the 4800-token QK^T (K = 960: 30 chunks)
+        const int M_ = which == 0 ? 72000 : 4800, N_ = which == 0 ? 768 : 4800, K_ = which == 0 ? 256 : 960;
+        Prob pr = make_dense<BM, BN>(M_, N_, K_);
+        printf("== dense %d x %d x %d (%s), %d tiles of %d chunks, %.1f GFLOP\n", M_, N_, K_, which == 0 ? "QKV" : "QK^T 4800 tokens", pr.blocks, K_ / 32, pr.gflop);
+        for (int rep = 0; rep < 2; ++rep) {
+            { const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 24, 1); printf("  shipped kernel, one global queue                     %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+            { const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 24, 8); printf("  shipped kernel, per-XCD queues                       %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+            { const float ms = time_v3<BM, BN, WM, WN, 2048>(pr, 0, 24, 1); printf("  no tile pipelining, one global queue                 %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+            { const float ms = time_v3<BM, BN, WM, WN, 128>(pr, 0, 24, 1); printf("  no epilogue, one global queue                        %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+            { const float ms = time_v3<BM, BN, WM, WN, 2>(pr, 0, 24, 1); printf("  no operand DMA in the loop, one global queue         %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+        }
+        trace<BM, BN, WM, WN>(pr, K_, 1);
+        pr.free_all();
     }
     {
         Prob pr = make<BM, BN>(T, 256, 2304, false, true);
