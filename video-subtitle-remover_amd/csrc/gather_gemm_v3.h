@@ -94,16 +94,23 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
     constexpr int AS_FLOATS = BM * 32;
     constexpr int BS_FLOATS = BN * 32;          // NK: [BN][32] swizzled ; KN: [32][BN] linear
     constexpr int BUF_FLOATS = AS_FLOATS + BS_FLOATS;
-    constexpr int RT_IT = (2 * BM + 255) / 256; // row-table entries per thread
+    // A tile's CONTROL BLOCK in LDS (two slots, so that the next tile's can be written under the current tile): everything the
+    // epilogue needs, fetched with the tile's tables (i.e. a tile ahead) instead of by a chain of dependent scalar / global loads
+    // after the last MFMA:  [rowC offsets BM][rowR offsets BM][bias slice BN][colC chunk offsets BN/32][16 control words]
+    constexpr int CB_BIAS = 2 * BM, CB_COLC = 2 * BM + BN, CB_CTL = CB_COLC + BN / 32;
+    constexpr int CB_WORDS = (CB_CTL + 16 + 3) / 4 * 4;
+    constexpr int RT_IT = (CB_WORDS + 255) / 256; // control-block words per thread
+    // control words: 0 M, 1 N, 2 alpha, 3 act, 4 splitK, 5/6 C (split plane), 7/8 R as given, 9 has bias
+    enum { CW_M = 0, CW_N, CW_ALPHA, CW_ACT, CW_SPLITK, CW_CLO, CW_CHI, CW_RLO, CW_RHI, CW_HASBIAS };
     // tiles follow each other without a round trip (see the header) for NK problems; the KN form keeps the plain sequence
     constexpr bool PIPE = (BMODE == VSR_BMODE_NK) && !GG_ABL(2048);
     static_assert(WM * WN == 4, "4 waves");
 
-    // [2 operand buffers][2 row tables: rowC | rowR offsets of a tile's BM rows][row maxima scratch BM x WN][next tile id]
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS + 4 * BM + BM * WN + 4];
+    // [2 operand buffers][2 control blocks][row maxima scratch BM x WN][next tile id]
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS + 2 * CB_WORDS + BM * WN + 4];
     int* rowTabs = reinterpret_cast<int*>(smem + 2 * BUF_FLOATS);
-    float* scr = smem + 2 * BUF_FLOATS + 4 * BM;
-    volatile int* nextTile = reinterpret_cast<volatile int*>(smem + 2 * BUF_FLOATS + 4 * BM + BM * WN);
+    float* scr = smem + 2 * BUF_FLOATS + 2 * CB_WORDS;
+    volatile int* nextTile = reinterpret_cast<volatile int*>(smem + 2 * BUF_FLOATS + 2 * CB_WORDS + BM * WN);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -236,17 +243,31 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         }
         fetchCols(q, q.kcBeg, tb.vcolA, tb.vcolB);
         fetchCols(q, q.kcBeg + 64, tb.vcolAn, tb.vcolBn);
-        // output / residual row offsets of the tile (read back from LDS in the epilogue, so that it starts without a
-        // dependent global table read per row)
-        const gci32 rowCt = (gci32)q.P->rowC;
-        const gci32 rowRt = (gci32)q.P->rowR;
-        const bool hasR = (q.P->R != nullptr) && (q.P->splitK == 1) && !(q.P->act & VSR_ACT_ROW_MAX);
+        // this thread's words of the control block
+        const gci32 rowCt = (gci32)gg_uniform_ptr(q.P->rowC);
+        const gci32 rowRt = (gci32)gg_uniform_ptr(q.P->rowR);
+        const int pact = q.P->act, psplitK = q.P->splitK, pN = q.P->N;
+        const bool partial = psplitK > 1;
+        const bool hasR = (q.P->R != nullptr) && !partial && !(pact & VSR_ACT_ROW_MAX);
+        const gcf32 biasp = partial ? (gcf32) nullptr : (gcf32)gg_uniform_ptr(q.P->bias);
+        const cci32 colCp = (cci32)gg_uniform_ptr(q.P->colC);
+        const unsigned long long cptr = reinterpret_cast<unsigned long long>(q.P->C + (partial ? (int64_t)q.split * q.P->splitStride : (int64_t)0));
+        const unsigned long long rptr = reinterpret_cast<unsigned long long>(q.P->R);
 #pragma unroll
         for (int k = 0; k < RT_IT; ++k) {
             const int i = tid + 256 * k;
-            tb.rt[k] = 0;
-            if (i < BM) tb.rt[k] = rowCt[q.tm * BM + i];
-            else if (i < 2 * BM && hasR) tb.rt[k] = rowRt[q.tm * BM + i - BM];
+            int v = 0;
+            if (i < BM) v = rowCt[q.tm * BM + i];
+            else if (i < 2 * BM) { if (hasR) v = rowRt[q.tm * BM + i - BM]; }
+            else if (i < CB_COLC) { const int n = q.tn * BN + i - CB_BIAS; if (biasp != nullptr && n < pN) v = __float_as_int(biasp[n]); }
+            else if (i < CB_CTL) v = colCp[(q.tn * BN) / VSR_GG_KC + i - CB_COLC];
+            else {
+                const int w = i - CB_CTL;
+                v = w == CW_M ? q.P->M : w == CW_N ? pN : w == CW_ALPHA ? __float_as_int(q.P->alpha) : w == CW_ACT ? pact : w == CW_SPLITK ? psplitK
+                  : w == CW_CLO ? (int)(unsigned)cptr : w == CW_CHI ? (int)(unsigned)(cptr >> 32) : w == CW_RLO ? (int)(unsigned)rptr
+                  : w == CW_RHI ? (int)(unsigned)(rptr >> 32) : w == CW_HASBIAS ? (biasp != nullptr ? 1 : 0) : 0;
+            }
+            tb.rt[k] = v;
         }
     };
     auto make_rows = [&](const Tab& tb, Rows& rw) __attribute__((always_inline)) {
@@ -275,7 +296,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
         for (int k = 0; k < RT_IT; ++k) {
             const int i = tid + 256 * k;
-            if (i < 2 * BM) rowTabs[slot_ * 2 * BM + i] = tb.rt[k];
+            if (i < CB_WORDS) rowTabs[slot_ * CB_WORDS + i] = tb.rt[k];
         }
     };
     // LDS-DMA of one chunk of tile q into buffer buf (destination = wave-uniform base + lane*16).  A piece is addressed as (scalar
@@ -359,7 +380,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const gcf32 A = (gcf32)gg_uniform_ptr(P->A);
         const gcf32 B = (gcf32)gg_uniform_ptr(P->B);
         const gci32 rowB = (gci32)P->rowB;
-        int* rowTab = rowTabs + slot * 2 * BM;
+        int* rowTab = rowTabs + slot * CB_WORDS;
 
         int boff[B_IT], boffNext[B_IT];             // KN: row offsets of this / the next chunk's B rows
 #pragma unroll
@@ -557,24 +578,31 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         // ---- epilogue.  Transposed accumulators (see read_group): lane l31 owns output row l31 of its 32x32 block, register
         // r is column (r&3) + 8*(r>>2) + 4*hi.  One row offset per lane, and interior tiles whose output (and residual) rows are
         // 16-byte aligned move float4s: 4 stores per accumulator instead of 16 (the store tail is issue-bound, not bandwidth-bound).
-        const int M = P->M, N = P->N;
-        const int splitK = P->splitK;
-        const float alpha = P->alpha;
-        const int act = P->act & 0xff;
-        const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;   // relu(act(..) + R): residual blocks of RAFT
+        // (nothing below reads the problem descriptor: the control block was fetched a tile ahead)
+        const float* biasL = reinterpret_cast<const float*>(rowTab + CB_BIAS);
+        const int* ctl = rowTab + CB_CTL;
+        const int M = __builtin_amdgcn_readfirstlane(ctl[CW_M]), N = __builtin_amdgcn_readfirstlane(ctl[CW_N]);
+        const int splitK = __builtin_amdgcn_readfirstlane(ctl[CW_SPLITK]);
+        const float alpha = __int_as_float(__builtin_amdgcn_readfirstlane(ctl[CW_ALPHA]));
+        const int pact = __builtin_amdgcn_readfirstlane(ctl[CW_ACT]);
+        const int act = pact & 0xff;
+        const bool postRelu = (pact & VSR_ACT_POST_RELU) != 0;     // relu(act(..) + R): residual blocks of RAFT
         const bool partial = (splitK > 1);
-        const bool rowMax = (P->act & VSR_ACT_ROW_MAX) != 0;       // R is the row-maximum array of the scores, not a residual
-        const gcf32 bias = partial ? (gcf32) nullptr : (gcf32)P->bias;
-        const gcf32 R = (partial || rowMax) ? (gcf32) nullptr : (gcf32)P->R;
-        const cci32 colC = (cci32)P->colC;
-        const gf32 C = (gf32)(P->C + (partial ? (int64_t)split * P->splitStride : (int64_t)0));
+        const bool rowMax = (pact & VSR_ACT_ROW_MAX) != 0;         // R is the row-maximum array of the scores, not a residual
+        const bool hasBias = __builtin_amdgcn_readfirstlane(ctl[CW_HASBIAS]) != 0;
+        const unsigned long long cptr = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ctl[CW_CHI]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(ctl[CW_CLO]);
+        const unsigned long long rptr = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ctl[CW_RHI]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(ctl[CW_RLO]);
+        const gcf32 Rgiven = (gcf32) reinterpret_cast<const float*>(rptr);
+        const gcf32 R = (partial || rowMax) ? (gcf32) nullptr : Rgiven;
+        const gf32 C = (gf32) reinterpret_cast<float*>(cptr);
         int ccol[NI];            // offset of column (32-block start + 4*hi) of this lane
         int ncol[NI];            // its global column index
+        int lcol[NI];            // its column inside the tile
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int n0 = tn * BN + wn * WTN + ni * 32;
-            ccol[ni] = colC[n0 / VSR_GG_KC] + 4 * hi;
-            ncol[ni] = n0 + 4 * hi;
+            lcol[ni] = wn * WTN + ni * 32 + 4 * hi;
+            ccol[ni] = rowTab[CB_COLC + (wn * WTN + ni * 32) / VSR_GG_KC] + 4 * hi;
+            ncol[ni] = tn * BN + lcol[ni];
         }
         const bool fullTile = (tm * BM + BM <= M) && (tn * BN + BN <= N);
         auto activate = [&](float v) __attribute__((always_inline)) {
@@ -596,8 +624,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (bias != nullptr) bq[ni][q] = *reinterpret_cast<gv4>(bias + (ncol[ni] + 8 * q));
-                    else bq[ni][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bq[ni][q] = *reinterpret_cast<const f32x4*>(biasL + (lcol[ni] + 8 * q));       // zeros where there is no bias
                 }
             // (the residual of one 32-row block at a time: holding both blocks' took the kernel over the 168 registers that three
             // workgroups per CU allow)
@@ -649,7 +676,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     for (int r = 0; r < 16; ++r) {
                         const int cofs = (r & 3) + 8 * (r >> 2);
                         const bool ok = mok && (ncol[ni] + cofs) < N;
-                        float v = acc[mi][ni][r] * alpha + ((bias != nullptr && ok) ? bias[ncol[ni] + cofs] : 0.f);
+                        float v = acc[mi][ni][r] * alpha + biasL[lcol[ni] + cofs];
                         v = activate(v);
                         if constexpr (HASR) { if (ok) v += R[rr + ccol[ni] + cofs]; if (postRelu) v = fmaxf(v, 0.f); }
                         if (ok) C[rc + ccol[ni] + cofs] = v;
@@ -657,8 +684,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             }
         };
         // float4 path: an interior tile whose row / column offsets keep 16-byte alignment for every lane of this wave
-        bool vec = fullTile && ((reinterpret_cast<uintptr_t>(P->C) | (uintptr_t)(partial ? P->splitStride * 4 : 0)) & 15) == 0 &&
-                   (bias == nullptr || (reinterpret_cast<uintptr_t>(P->bias) & 15) == 0) && (R == nullptr || (reinterpret_cast<uintptr_t>(P->R) & 15) == 0);
+        bool vec = fullTile && (cptr & 15) == 0 && (R == nullptr || (rptr & 15) == 0);
         {
             int low = 0;
 #pragma unroll
@@ -701,9 +727,8 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int n = ncol[ni] + (r & 3) + 8 * (r >> 2);
-                        const float bvv = (bias != nullptr && n < N) ? bias[n] : 0.f;
-                        if (n < N) mx = fmaxf(mx, acc[mi][ni][r] * alpha + bvv);
+                        const int cofs = (r & 3) + 8 * (r >> 2);
+                        if (ncol[ni] + cofs < N) mx = fmaxf(mx, acc[mi][ni][r] * alpha + biasL[lcol[ni] + cofs]);
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 if (hi == 0) scr[(wm * WTM + mi * 32 + l31) * WN + wn] = mx;
@@ -713,7 +738,7 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 float mx = scr[tid * WN];
 #pragma unroll
                 for (int w = 1; w < WN; ++w) mx = fmaxf(mx, scr[tid * WN + w]);
-                atomicMax(reinterpret_cast<unsigned int*>(const_cast<float*>(P->R)) + tm * BM + tid, f32_ordered(mx));
+                atomicMax(reinterpret_cast<unsigned int*>(reinterpret_cast<float*>(rptr)) + tm * BM + tid, f32_ordered(mx));
             }
         }
         GG_STAMP()   // epilogue done
