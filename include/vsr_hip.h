@@ -386,11 +386,13 @@ int vsr_det_launch_normalize(const uint8_t* img_bgr, int H, int W, float* out_ch
 int vsr_det_launch_ccl(const float* prob_dev, int H, int W, float thresh, int32_t* labels_dev, int32_t* stats_dev, int32_t* comps_dev, int cap,
                        int32_t* count_dev, void* stream);
 /* The whole DBPostProcess of one probability map on the device (reference: backend/tools/subtitle_detect.py:41-82 calls paddleocr's
- * TextDetection, whose post-process is DBPostProcess with inference.yml:46-53's thresh / box_thresh / unclip_ratio): the labelling
- * above, then per component get_mini_boxes (hull of the per-row extreme pixels, minimum-area rectangle), box_score_fast, unclip,
- * rescale to the source image.  ext int32 [cap][H][2] scratch; out int32 [1 + 16*cap]: out[0] = components found, then per slot
+ * TextDetection, whose post-process is PaddleX's DBPostProcess with inference.yml:49-53's thresh / box_thresh / unclip_ratio): the
+ * labelling above, the hole count (Euler number), then per component get_mini_boxes (hull of the per-row extreme pixels,
+ * minimum-area rectangle), box_score_fast (cv2.fillPoly's raster of the integer-truncated rectangle), unclip (ClipperLib's rounded
+ * offset), the second get_mini_boxes, rescale to the source image.  count int32 [4]; ext int32 [cap][H][2] scratch; out int32
+ * [4 + 16*cap]: out[0] = components found, out[1] = holes (their borders are contours too: such a map is the host's), then per slot
  * (flag, x0,y0, x1,y1, x2,y2, x3,y3, score bits, ...): flag 1 = box (top-left, top-right, bottom-right, bottom-left), 0 = rejected,
- * -1 = component taller than 256 rows (not processed); out[0] > cap: nothing else is valid. */
+ * -1 = not processed (component taller than 256 rows / offset polygon beyond the point buffer); out[0] > cap: nothing else is valid. */
 int vsr_det_launch_db_boxes(const float* prob_dev, int H, int W, float thresh, int src_h, int src_w, float box_thresh, float unclip_ratio,
                             int min_size, int32_t* labels_dev, int32_t* stats_dev, int32_t* comps_dev, int32_t* count_dev, int32_t* ext_dev,
                             int32_t* out_dev, int cap, void* stream);

@@ -16,7 +16,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("fixture,H,W", [("ppocr_det_fast_graph.json", 96, 160), ("ppocr_det_fast_graph.json", 544, 960),
-                                         ("ppocr_det_graph.json", 96, 160), ("ppocr_det_graph.json", 224, 352)])
+                                         ("ppocr_det_graph.json", 96, 160), ("ppocr_det_graph.json", 224, 352), ("ppocr_det_graph.json", 544, 960)])
 def test_program_matches_interpreter(built_lib, gpu_device, fixture, H, W):
     g = load_graph(os.path.join(GOLD, fixture))
     w = synthetic_weights(g)
@@ -28,9 +28,12 @@ def test_program_matches_interpreter(built_lib, gpu_device, fixture, H, W):
     err = (got.cpu().double() - ref64).abs().max().item()
     cpu32 = (ref32 - ref64).abs().max().item()
     print(f"{fixture} {H}x{W}: max abs err of the probability map vs the fp64 interpreter {err:.2e} (fp32 CPU interpreter: {cpu32:.2e})")
-    # sigmoid output in [0, 1].  The 22 M-parameter server program is ~150 layers deep and saturates with synthetic weights, so
-    # fp32 rounding alone moves it by 1e-3..1e-2: the bar is the fp32 CPU interpreter's own distance from fp64
-    assert got.shape == ref64.shape and err <= 3 * cpu32 + 1e-4
+    # sigmoid output in [0, 1], both programs at the 1080p net input (544 x 960) too.  Round 3: the synthetic weights are calibrated
+    # (oracle/ppocr_det.synthetic_weights: unit-variance activations through all ~150 layers of the server program), so the map is
+    # no longer saturated and an ABSOLUTE bar holds: 1e-4 against the fp64 interpreter (measured 1e-6 .. 1e-5; a wrong layer moves
+    # the map by 1e-2 or more)
+    spread = ((ref64 > 0.05) & (ref64 < 0.95)).double().mean().item()
+    assert got.shape == ref64.shape and err <= 1e-4 and spread > 0.5, (err, spread)
 
 
 def test_predict_preprocessing_and_plumbing(built_lib, gpu_device):
@@ -70,7 +73,7 @@ def test_gemm_convs_agree_with_direct_convs(built_lib, gpu_device, fixture, H, W
     ea, eb = (a.cpu().double() - ref64).abs().max().item(), (b.cpu().double() - ref64).abs().max().item()
     print(f"{fixture}: {n_plans} convs on the gather-GEMM; err vs fp64 {ea:.2e} (GEMM) / {eb:.2e} (direct) / {cpu32:.2e} (fp32 CPU)")
     assert n_plans > 10 and len(r._gemm) == n_plans and torch.equal(a, a2)
-    assert ea <= 5 * cpu32 + 1e-4 and eb <= 5 * cpu32 + 1e-4          # measured: 3.1x / 2.3x on the saturating server program
+    assert ea <= 1e-4 and eb <= 1e-4                                   # absolute, on calibrated weights (round 3)
     r.close()
 
 
@@ -139,48 +142,48 @@ def test_batched_forward_equals_single_frames(built_lib, gpu_device, fixture):
         assert torch.equal(maps[b], det.probability_map(img)[0])
 
 
-def _blob_map(seed, H, W, nboxes):
-    """probability map with rotated text-like boxes, touching pairs, specks and diagonal (8-connected only) links"""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
-    prob = rng.random((H, W)).astype(np.float32) * 0.25
-    for _ in range(nboxes):
-        cy, cx = rng.uniform(10, H - 10), rng.uniform(30, W - 30)
-        hw, hh, th = rng.uniform(8, 120), rng.uniform(3, 14), rng.uniform(-0.3, 0.3)
-        u, v = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th), -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
-        inside = (np.abs(u) <= hw) & (np.abs(v) <= hh)
-        prob[inside] = np.maximum(prob[inside], rng.uniform(0.55, 0.95))
-    for k in range(40):                                   # staircases: pixels that touch only diagonally
-        y, x = int(rng.integers(2, H - 12)), int(rng.integers(2, W - 12))
-        for j in range(8):
-            prob[y + j, x + j] = 0.9
-    return prob
+from oracle import db_postprocess as dbo
+from test_db_postprocess import blob_map
 
 
-@pytest.mark.parametrize("seed,H,W,nboxes", [(1, 544, 960, 6), (2, 544, 960, 60), (3, 96, 160, 3), (4, 544, 960, 0)])
-def test_device_db_postprocess_equals_host(built_lib, gpu_device, seed, H, W, nboxes):
-    """threshold + 8-connected union-find labelling + hull / minimum-area rectangle / score / unclip per component, all on the GPU:
-    the boxes and scores of DBPostProcess must equal the all-host version (scipy labelling of the downloaded map, numpy geometry).
-    Both sides compute in fp64 but not in the same operation order (BLAS projections on the host), so a corner may land on the
-    other side of a rounding boundary: at most one source pixel, scores to 1e-5 (fp32 mean on the host, fp64 on the device)."""
-    prob = _blob_map(seed, H, W, nboxes)
-    want_b, want_s = ocr_det.db_postprocess(prob, 1080, 1920)
+@pytest.mark.parametrize("seed,H,W,nboxes,holes,specks,tilt", [(1, 544, 960, 6, 0, 0, 0.3), (2, 544, 960, 60, 0, 12, 0.3), (3, 96, 160, 3, 0, 4, 0.3),
+                                                               (4, 544, 960, 0, 0, 0, 0.3), (5, 544, 960, 10, 0, 30, 1.2), (6, 544, 960, 8, 0, 0, 0.0),
+                                                               (7, 272, 480, 8, 0, 40, 0.6), (8, 544, 960, 12, 6, 5, 0.3), (9, 544, 960, 9, 0, 6, 0.2),
+                                                               (10, 544, 960, 7, 0, 3, 0.8), (11, 544, 960, 5, 0, 0, 0.05), (12, 1088, 1920, 8, 0, 4, 0.3)])
+def test_device_db_postprocess_equals_the_oracle(built_lib, gpu_device, seed, H, W, nboxes, holes, specks, tilt):
+    """DBPostProcess on the GPU (threshold, union-find labelling, hull / minimum-area rectangle / fillPoly-rule score / Clipper-rule
+    offset / second rectangle per component) against oracle/db_postprocess.py, the restatement of PaddleX's DBPostProcess over
+    restated cv2 / pyclipper primitives: rotated, touching, tiny (specks: below min_size) and axis-aligned boxes.
+    Bar: the same boxes in the same order, corners EQUAL (both sides compute the geometry in fp64 without contraction, through the
+    same float32 / integer truncation points; a corner may still differ by one source pixel where libm's sin / cos / acos / atan2 of the two
+    machines disagree in the last bit at a rounding boundary -- allowed on at most 1 % of the coordinates), scores to 1e-6.
+    A map with holes (seed 8) takes the host path, which must give the oracle's boxes exactly."""
+    prob = blob_map(seed, H, W, nboxes, holes, specks, max_tilt=tilt)
+    want_b, want_s = dbo.db_postprocess(prob, 1080, 1920)
     post = ocr_det.DeviceDBPostProcess(gpu_device)
     got_b, got_s = post(torch.from_numpy(prob).to(gpu_device), 1080, 1920)
-    assert got_b.shape == want_b.shape
+    assert got_b.shape == want_b.shape, (got_b.shape, want_b.shape)
     if len(want_s):
-        assert np.abs(got_b.astype(np.int64) - want_b).max() <= 1, np.abs(got_b.astype(np.int64) - want_b).max()
-        assert (got_b != want_b).mean() <= 0.02
-    assert np.allclose(got_s, want_s, rtol=0, atol=1e-5)
-    if nboxes >= 6:
-        assert len(want_s) >= 1
-    # the labelling itself: same partition as scipy's, labels = raster index of the first pixel
+        diff = np.abs(got_b.astype(np.int64) - want_b.astype(np.int64))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 0.01, (diff.max(), (diff != 0).mean())
+    assert np.allclose(got_s, want_s, rtol=0, atol=1e-6)
+    # which path ran: the device keeps hole-free maps whose components are at most 256 rows tall
     import scipy.ndimage
 
     ref, n = scipy.ndimage.label(prob > 0.3, structure=np.ones((3, 3), dtype=int))
+    n_holes = scipy.ndimage.label(np.pad(~(prob > 0.3), 1, constant_values=True))[1] - 1
+    tall = any(sl[0].stop - sl[0].start > 256 for sl in scipy.ndimage.find_objects(ref))
+    to_host = n_holes > 0 or tall or n > post.cap
+    assert post.host_fallbacks == (1 if to_host else 0), (n_holes, tall, n)
+    assert (holes > 0) <= (n_holes > 0)
+    print(f"seed {seed}: {n} components, {n_holes} holes, {len(want_s)} boxes, {'host' if to_host else 'device'} path")
+    if nboxes >= 6 and tilt <= 0.3:
+        assert len(want_s) >= 3
+    if to_host:
+        assert np.array_equal(got_b, want_b)
+    # the labelling itself: same partition as scipy's, labels = raster index of the first pixel
     labels = post._work[(H, W)][0].view(H, W).cpu().numpy()
     assert ((labels >= 0) == (ref > 0)).all()
-    first = {}
     flat_ref, flat_lab = ref.reshape(-1), labels.reshape(-1)
     idx = np.nonzero(flat_ref)[0]
     firsts = np.full(n + 1, -1, np.int64)
@@ -189,20 +192,40 @@ def test_device_db_postprocess_equals_host(built_lib, gpu_device, seed, H, W, nb
     assert np.array_equal(flat_lab[idx], firsts[flat_ref[idx]])
 
 
+def test_device_hole_count(built_lib, gpu_device):
+    """the Euler-number hole count that routes a map to the host: enclosed background regions (4-connected), not notches"""
+    prob = np.full((64, 96), 0.1, np.float32)
+    prob[10:30, 10:50] = 0.9
+    prob[15:18, 20:24] = 0.1                                     # one hole
+    prob[22, 30] = 0.1                                           # another
+    prob[10:14, 40:44] = 0.1                                     # a notch open to the outside: not a hole
+    prob[40:50, 20:60] = 0.8
+    prob[44, 20:25] = 0.1                                        # a slit from the edge: not a hole
+    prob[5, 5] = 0.9
+    prob[6, 6] = 0.9                                             # diagonal pair: one component
+    post = ocr_det.DeviceDBPostProcess(gpu_device)
+    post(torch.from_numpy(prob).to(gpu_device), 64, 96)
+    host = post._work[(64, 96)][5].cpu().numpy()
+    assert host[0] == 3 and host[1] == 2
+    assert post.host_fallbacks == 1
+
+
 def test_device_db_postprocess_overflow_falls_back(built_lib, gpu_device):
-    """more components than the device record list holds: the labelling stays on the device, the polygon work runs in numpy on the
-    downloaded rows (exactly the host result); a map with more than 4096 components is labelled on the host"""
+    """more components than the device record list holds, or a component taller than 256 rows: the host statement runs on the
+    downloaded map (exactly the oracle's result)"""
     rng = np.random.default_rng(9)
     prob = np.full((256, 384), 0.05, np.float32)
     for y in range(4, 250, 12):                                  # 21 x 31 = 651 isolated 6x7 blobs
         for x in range(4, 376, 12):
             prob[y:y + 6, x:x + 7] = rng.uniform(0.5, 0.95)
-    want_b, want_s = ocr_det.db_postprocess(prob, 512, 768)
+    want_b, want_s = dbo.db_postprocess(prob, 512, 768)
     assert len(want_s) > 300
-    got_b, got_s = ocr_det.DeviceDBPostProcess(gpu_device, cap=64)(torch.from_numpy(prob).to(gpu_device), 512, 768)
-    assert np.array_equal(got_b, want_b) and np.allclose(got_s, want_s)
-    noise = rng.random((256, 384)).astype(np.float32)            # one giant component and a few specks: whatever path, same boxes
-    want_b, want_s = ocr_det.db_postprocess(noise, 512, 768)
-    got_b, got_s = ocr_det.DeviceDBPostProcess(gpu_device, cap=64)(torch.from_numpy(noise).to(gpu_device), 512, 768)
-    assert got_b.shape == want_b.shape and (len(want_s) == 0 or np.abs(got_b.astype(np.int64) - want_b).max() <= 1)
-    assert np.allclose(got_s, want_s, atol=1e-5)
+    post = ocr_det.DeviceDBPostProcess(gpu_device, cap=64)
+    got_b, got_s = post(torch.from_numpy(prob).to(gpu_device), 512, 768)
+    assert post.host_fallbacks == 1 and np.array_equal(got_b, want_b) and np.allclose(got_s, want_s, atol=1e-6)
+    tall = np.full((544, 200), 0.05, np.float32)
+    tall[20:400, 50:90] = 0.9                                    # 380 rows
+    want_b, want_s = dbo.db_postprocess(tall, 1088, 400)
+    post = ocr_det.DeviceDBPostProcess(gpu_device)
+    got_b, got_s = post(torch.from_numpy(tall).to(gpu_device), 1088, 400)
+    assert post.host_fallbacks == 1 and np.array_equal(got_b, want_b) and len(want_s) == 1

@@ -437,7 +437,15 @@ class PaddleGraphRunner:
 
 
 # ------------------------------------------------------------------------------------------------
-# DBPostProcess (inference.yml PostProcess; paddleocr's DBPostProcess: boxes_from_bitmap, get_mini_boxes, box_score_fast, unclip)
+# DBPostProcess (inference.yml PostProcess: thresh 0.3, box_thresh 0.6, max_candidates 1000, unclip_ratio 1.5) as PaddleX runs it
+# behind TextDetection.predict (box_type "quad", score_mode "fast"): borders of the thresholded map (cv2.findContours, RETR_LIST:
+# outer borders AND hole borders, last found first) -> minimum-area rectangle of every border -> mean probability over the
+# rectangle rasterised the way cv2.fillPoly does it (integer-truncated corners, outline drawn, scan lines between) ->
+# pyclipper's rounded polygon offset of the integer-truncated rectangle by area * ratio / perimeter -> minimum-area rectangle of
+# the offset polygon -> rescale, round half to even, clip.  Round 3: the first version scored by pixel-centre containment, grew
+# the rectangle analytically and ignored hole borders; against the restated reference (oracle/db_postprocess.py, tests/
+# test_db_postprocess.py) its scores were off by up to 0.1 -- boxes near box_thresh came and went -- and corners by up to three
+# source pixels.  This is the host statement; DeviceDBPostProcess below runs the same steps on the GPU.
 # ------------------------------------------------------------------------------------------------
 def _convex_hull(pts):
     pts = sorted(set(map(tuple, pts)))
@@ -464,13 +472,15 @@ def min_area_rect(points):
     hull = _convex_hull(points)
     if len(hull) == 1:
         return np.repeat(hull, 4, axis=0), 0.0, 0.0
+    if len(hull) == 2:
+        return np.array([hull[0], hull[0], hull[1], hull[1]]), float(np.hypot(*(hull[1] - hull[0]))), 0.0
     # rotating calipers over all hull edges at once: project the hull on every edge direction u and its normal v
     e = np.roll(hull, -1, axis=0) - hull
     nrm = np.hypot(e[:, 0], e[:, 1])
-    e, nrm = e[nrm > 0], nrm[nrm > 0]
     u = e / nrm[:, None]
     v = np.stack([-u[:, 1], u[:, 0]], 1)
-    pu, pv = hull @ u.T, hull @ v.T                                   # [points, edges]
+    pu = hull[:, 0:1] * u[None, :, 0] + hull[:, 1:2] * u[None, :, 1]   # [points, edges]
+    pv = hull[:, 0:1] * v[None, :, 0] + hull[:, 1:2] * v[None, :, 1]
     umin, umax, vmin, vmax = pu.min(0), pu.max(0), pv.min(0), pv.max(0)
     w, h = umax - umin, vmax - vmin
     i = int(np.argmin(w * h))                                         # first minimum, as a strict '<' scan finds it
@@ -479,95 +489,239 @@ def min_area_rect(points):
 
 
 def _order_box(c):
-    """get_mini_boxes: corners ordered top-left, top-right, bottom-right, bottom-left"""
-    p = sorted(c.tolist(), key=lambda q: q[0])
-    (a, b), (d, e) = sorted(p[:2], key=lambda q: q[1]), sorted(p[2:], key=lambda q: q[1])
-    return np.array([a, d, e, b], dtype=np.float64)
+    """get_mini_boxes: the corners as float32 (cv2.boxPoints), sorted by x; of the left pair the upper one first, of the right pair
+    the upper one second -> top-left, top-right, bottom-right, bottom-left (ties exactly as the reference's comparisons break them)"""
+    p = sorted(np.asarray(c, np.float32).tolist(), key=lambda q: q[0])
+    a, d = (0, 1) if p[1][1] > p[0][1] else (1, 0)
+    b, e = (2, 3) if p[3][1] > p[2][1] else (3, 2)
+    return np.array([p[a], p[b], p[e], p[d]], dtype=np.float32)
 
 
-def _box_score(prob, box):
-    """box_score_fast: mean probability over the pixels inside the box polygon"""
-    h, w = prob.shape
-    x0, x1 = int(np.clip(np.floor(box[:, 0].min()), 0, w - 1)), int(np.clip(np.ceil(box[:, 0].max()), 0, w - 1))
-    y0, y1 = int(np.clip(np.floor(box[:, 1].min()), 0, h - 1)), int(np.clip(np.ceil(box[:, 1].max()), 0, h - 1))
-    ys, xs = np.mgrid[y0:y1 + 1, x0:x1 + 1]
-    inside = np.ones(ys.shape, dtype=bool)
-    for i in range(4):
-        p, q = box[i], box[(i + 1) % 4]
-        inside &= (q[0] - p[0]) * (ys - p[1]) - (q[1] - p[1]) * (xs - p[0]) >= -1e-6
-    if not inside.any():
-        return 0.0
-    return float(prob[y0:y1 + 1, x0:x1 + 1][inside].mean())
+_RING = np.array([(0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1)])      # (dy, dx), counter-clockwise from east
 
 
-def _box_of_component(comp, y0, x0, prob_of, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size):
-    """get_mini_boxes + box_score_fast + unclip + rescale for one component.  comp: bool mask of the component inside its bounding
-    box whose top-left pixel is (y0, x0); prob_of(ya, yb, xa, xb) -> (probability crop, its origin).  -> (box int32 [4,2], score) or None"""
-    # the minimum-area rectangle only depends on the convex hull, and the hull's vertices are among the leftmost / rightmost pixel
-    # of every row: a few dozen points instead of the whole contour (the pure-Python hull was the cost of the post-process)
-    rows = np.nonzero(comp.any(axis=1))[0]
-    sub = comp[rows]
-    xl, xr = sub.argmax(axis=1), comp.shape[1] - 1 - sub[:, ::-1].argmax(axis=1)
-    pts = np.concatenate([np.stack([xl + x0, rows + y0], 1), np.stack([xr + x0, rows + y0], 1)])
-    corners, w, h = min_area_rect(pts)
+def trace_borders(bitmap):
+    """cv2.findContours(bitmap, RETR_LIST, ...): every border of the 8-connected foreground by border following (Suzuki & Abe),
+    outer and hole borders alike, in cv2's order (the border found last by the raster scan comes first) -> list of int [n,2] (x, y).
+    Straight runs keep their interior points (CHAIN_APPROX_SIMPLE would drop them; the rectangle fit only sees the hull)."""
+    H, W = bitmap.shape
+    g = np.zeros((H + 2, W + 2), np.int32)
+    g[1:-1, 1:-1] = bitmap
+    flat = g.reshape(-1)
+    Wp = W + 2
+    step = (_RING[:, 0] * Wp + _RING[:, 1]).tolist()
+    starts = np.flatnonzero((flat != 0) & ((np.roll(flat, 1) == 0) | (np.roll(flat, -1) == 0))).tolist()
+    mark, out = 1, []
+    for p0 in starts:
+        v = flat[p0]
+        if v == 1 and flat[p0 - 1] == 0:
+            d = 4
+        elif v >= 1 and flat[p0 + 1] == 0:
+            d = 0
+        else:
+            continue
+        mark += 1
+        k = 0
+        while k < 8 and flat[p0 + step[(d - k) % 8]] == 0:              # clockwise from the background neighbour
+            k += 1
+        if k == 8:
+            flat[p0] = -mark
+            out.append(np.array([[p0 % Wp - 1, p0 // Wp - 1]], np.int32))
+            continue
+        p1 = p0 + step[(d - k) % 8]
+        prev, cur, pts = p1, p0, []
+        while True:
+            d0 = step.index(prev - cur)
+            east_bg = False
+            for k in range(1, 9):                                       # counter-clockwise, after the pixel we came from
+                dd = (d0 + k) % 8
+                nxt = cur + step[dd]
+                if flat[nxt] != 0:
+                    break
+                east_bg = east_bg or dd == 0
+            if east_bg:
+                flat[cur] = -mark
+            elif flat[cur] == 1:
+                flat[cur] = mark
+            pts.append((cur % Wp - 1, cur // Wp - 1))
+            if nxt == p0 and cur == p1:
+                break
+            prev, cur = cur, nxt
+        out.append(np.array(pts, np.int32))
+    return out[::-1]
+
+
+def _line_mask(xx, yy, x0, y0, x1, y1):
+    """pixels of the 8-connected line cv2 draws from (x0, y0) to (x1, y1) (LineIterator, left to right), as a closed form of its
+    error recurrence: along the major axis the minor coordinate has advanced max(0, (2 * minor * k + major - 1) // (2 * major)) after k steps"""
+    if x1 < x0:
+        x0, y0, x1, y1 = x1, y1, x0, y0
+    dx, dy = x1 - x0, abs(y1 - y0)
+    sy = 1 if y1 >= y0 else -1
+    if dy > dx:
+        k = (yy - y0) * sy
+        return (k >= 0) & (k <= dy) & (xx == x0 + np.maximum(0, (2 * dx * k + dy - 1) // (2 * dy)))
+    k = xx - x0
+    adv = np.maximum(0, (2 * dy * k + dx - 1) // (2 * dx)) if dx else 0
+    return (k >= 0) & (k <= dx) & (yy == y0 + sy * adv)
+
+
+def fill_poly_mask(quad, h, w):
+    """cv2.fillPoly(zeros((h, w)), [quad], 1) for a convex quadrilateral with integer vertices: the outline as 8-connected lines plus,
+    for every scan line y in [top, bottom) of the two edges that span it, the pixels floor(x_left) .. floor(x_right) with the edge
+    positions in 16.16 fixed point advancing by the truncated per-row slope"""
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = np.zeros((h, w), bool)
+    rows = np.arange(h)
+    lo = np.full(h, np.iinfo(np.int64).max, np.int64)
+    hi = np.full(h, np.iinfo(np.int64).min, np.int64)
+    for a in range(4):
+        x0, y0, x1, y1 = int(quad[a - 1][0]), int(quad[a - 1][1]), int(quad[a][0]), int(quad[a][1])
+        m |= _line_mask(xx, yy, x0, y0, x1, y1)
+        if y0 == y1:
+            continue
+        num, den = (x1 - x0) << 16, y1 - y0
+        slope = (abs(num) // abs(den)) * (1 if (num >= 0) == (den > 0) else -1)          # C integer division: toward zero
+        ya, yb, xa = (y0, y1, x0) if y0 < y1 else (y1, y0, x1)
+        live = (rows >= ya) & (rows < yb)
+        xf = (xa << 16) + (rows - ya).astype(np.int64) * slope
+        lo = np.where(live, np.minimum(lo, xf), lo)
+        hi = np.where(live, np.maximum(hi, xf), hi)
+    span = (hi >= lo)
+    m |= span[:, None] & (xx >= (lo >> 16)[:, None]) & (xx <= (hi >> 16)[:, None])
+    return m
+
+
+def _box_score(prob_of, box, H, W):
+    """box_score_fast: mean probability over cv2.fillPoly's raster of the (integer-truncated) box inside its bounding rows / columns"""
+    xa, xb = int(np.clip(np.floor(box[:, 0].min()), 0, W - 1)), int(np.clip(np.ceil(box[:, 0].max()), 0, W - 1))
+    ya, yb = int(np.clip(np.floor(box[:, 1].min()), 0, H - 1)), int(np.clip(np.ceil(box[:, 1].max()), 0, H - 1))
+    q = (box - np.array([xa, ya], np.float32)).astype(np.int32)                        # float32 subtraction, truncation toward zero
+    mask = fill_poly_mask(q, yb - ya + 1, xb - xa + 1)
+    crop = prob_of(ya, yb + 1, xa, xb + 1)
+    return float(crop[mask].astype(np.float64).mean()) if mask.any() else 0.0
+
+
+def _away(v):
+    return int(v - 0.5) if v < 0 else int(v + 0.5)
+
+
+def offset_polygon_round(path, delta):
+    """pyclipper.PyclipperOffset().AddPath(path, JT_ROUND, ET_CLOSEDPOLYGON); Execute(delta) for a convex polygon, delta > 0
+    (ClipperLib 6.4.2: integer-truncated input, unit normals, a corner replaced by an arc of round(steps_per_radian * angle) chords for
+    an arc tolerance of 0.25, every vertex rounded half away from zero) -> list of integer (x, y)"""
+    pts = []
+    for x, y in path:
+        q = (int(x), int(y))
+        if not pts or q != pts[-1]:
+            pts.append(q)
+    if len(pts) > 1 and pts[0] == pts[-1]:
+        pts.pop()
+    n = len(pts)
+    if n < 3:
+        return []
+    twice = sum((pts[i - 1][0] + pts[i][0]) * (pts[i - 1][1] - pts[i][1]) for i in range(n))
+    if twice > 0:                                                     # Clipper's Area() = -twice / 2 < 0: reversed, normals then point outwards
+        pts.reverse()
+    tol = min(0.25, delta * 0.25)
+    steps = min(np.pi / np.arccos(1 - tol / delta), delta * np.pi)
+    rot_s, rot_c, per_rad = np.sin(2 * np.pi / steps), np.cos(2 * np.pi / steps), steps / (2 * np.pi)
+    nrm = []
+    for i in range(n):
+        ex, ey = pts[(i + 1) % n][0] - pts[i][0], pts[(i + 1) % n][1] - pts[i][1]
+        inv = 1.0 / np.sqrt(ex * ex + ey * ey)
+        nrm.append((ey * inv, -ex * inv))
+    res = []
+    put = lambda px, py, nx, ny: res.append((_away(px + nx * delta), _away(py + ny * delta)))
+    for i in range(n):
+        (ax, ay), (bx, by) = nrm[i - 1], nrm[i]
+        sin_t, cos_t = ax * by - bx * ay, ax * bx + ay * by
+        if abs(sin_t * delta) < 1.0 and cos_t > 0:                    # (almost) straight on: one vertex
+            put(*pts[i], ax, ay)
+            continue
+        if abs(sin_t * delta) >= 1.0:
+            sin_t = float(np.clip(sin_t, -1.0, 1.0))
+        if sin_t * delta < 0:                                         # concave corner
+            put(*pts[i], ax, ay)
+            res.append(pts[i])
+            put(*pts[i], bx, by)
+            continue
+        ang = np.arctan2(sin_t, cos_t)
+        cx, cy = ax, ay
+        for _ in range(max(_away(per_rad * abs(ang)), 1)):
+            put(*pts[i], cx, cy)
+            cx, cy = cx * rot_c - rot_s * cy, cx * rot_s + cy * rot_c
+        put(*pts[i], bx, by)
+    return res
+
+
+def box_from_border(border, prob_of, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size):
+    """one iteration of DBPostProcess.boxes_from_bitmap: border points int [n,2] (x, y); prob_of(ya, yb, xa, xb) -> probability crop.
+    -> (box int16 [4,2] in source pixels, score) or None"""
+    corners, w, h = min_area_rect(border)
     if min(w, h) < min_size:
         return None
     box = _order_box(corners)
-    xa, xb = int(np.clip(np.floor(box[:, 0].min()), 0, W - 1)), int(np.clip(np.ceil(box[:, 0].max()), 0, W - 1))
-    ya, yb = int(np.clip(np.floor(box[:, 1].min()), 0, H - 1)), int(np.clip(np.ceil(box[:, 1].max()), 0, H - 1))
-    crop, (oy, ox) = prob_of(ya, yb + 1, xa, xb + 1)
-    score = _box_score(crop, box - np.array([ox, oy], dtype=np.float64))
-    if score < box_thresh:
+    score = _box_score(prob_of, box, H, W)
+    if box_thresh > score:
         return None
-    d = (w * h) * unclip_ratio / (2 * (w + h))                     # unclip: offset the rectangle by area * ratio / perimeter
-    ctr = box.mean(0)
-    u = (box[1] - box[0]) / max(np.hypot(*(box[1] - box[0])), 1e-9)
-    v = (box[3] - box[0]) / max(np.hypot(*(box[3] - box[0])), 1e-9)
-    hw_, hh_ = np.hypot(*(box[1] - box[0])) / 2 + d, np.hypot(*(box[3] - box[0])) / 2 + d
-    if min(2 * hw_, 2 * hh_) < min_size + 2:
+    x, y = box[:, 0].astype(np.float64), box[:, 1].astype(np.float64)
+    area = abs(float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))) * 0.5          # cv2.contourArea
+    seg = box - np.roll(box, 1, axis=0)                                               # cv2.arcLength: float32 segment lengths
+    length = float(np.sqrt(seg[:, 0] * seg[:, 0] + seg[:, 1] * seg[:, 1]).astype(np.float64).sum())
+    if area == 0.0 or length == 0.0:
         return None
-    big = np.array([ctr - hw_ * u - hh_ * v, ctr + hw_ * u - hh_ * v, ctr + hw_ * u + hh_ * v, ctr - hw_ * u + hh_ * v])
-    big[:, 0] = np.clip(np.round(big[:, 0] / W * src_w), 0, src_w)
-    big[:, 1] = np.clip(np.round(big[:, 1] / H * src_h), 0, src_h)
-    return _order_box(big).astype(np.int32), score
+    grown = offset_polygon_round(box.tolist(), area * unclip_ratio / length)
+    if not grown:
+        return None
+    corners, w, h = min_area_rect(np.array(grown))
+    if min(w, h) < min_size + 2:
+        return None
+    big = _order_box(corners).astype(np.float64)
+    big[:, 0] = np.clip(np.round(big[:, 0] * (src_w / W)), 0, src_w)                  # np.round: half to even, as Python's round()
+    big[:, 1] = np.clip(np.round(big[:, 1] * (src_h / H)), 0, src_h)
+    return big.astype(np.int16), score
 
 
 def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
-    """prob [H,W] (host array) -> (boxes int32 [n,4,2] in source-image pixels, scores [n]); everything on the host"""
+    """prob [H,W] (host array) -> (boxes int16 [n,4,2] in source-image pixels, scores [n]); everything on the host"""
+    prob = np.asarray(prob, np.float32)
     H, W = prob.shape
-    labels, n = scipy.ndimage.label(prob > thresh, structure=np.ones((3, 3), dtype=int))        # 8-connected, like findContours
+    whole = lambda ya, yb, xa, xb: prob[ya:yb, xa:xb]
     boxes, scores = [], []
-    whole = lambda ya, yb, xa, xb: (prob[ya:yb, xa:xb], (ya, xa))
-    for lab, sl in enumerate(scipy.ndimage.find_objects(labels)[:max_candidates], start=1):
-        r = _box_of_component(labels[sl] == lab, sl[0].start, sl[1].start, whole, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size)
+    for border in trace_borders(prob > thresh)[:max_candidates]:
+        r = box_from_border(border, whole, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size)
         if r is not None:
             boxes.append(r[0])
             scores.append(r[1])
-    return (np.stack(boxes) if boxes else np.zeros((0, 4, 2), np.int32)), scores
+    return (np.stack(boxes) if boxes else np.zeros((0, 4, 2), np.int16)), scores
 
 
 class DeviceDBPostProcess:
     """DBPostProcess on the GPU, on the probability map where the forward left it (vsr_det_launch_db_boxes): threshold, 8-connected
-    labelling (union-find), per-component bounding box, then per component the hull of its per-row extreme pixels, the minimum-area
-    rectangle, the box score, unclip and the rescale to the source image -- one wave per component.  The host receives one
-    buffer: the component count and a 16-int record per component, i.e. one synchronisation per frame.  Same boxes as
-    db_postprocess on the downloaded map (components are reported in raster order of their first pixel on both sides; the
-    geometry runs in fp64 on both).  More than `cap` components (a noise map, not a subtitle frame) or a component taller than
-    256 rows: the labelling result is downloaded and the numpy statement of the polygon work runs on it (`_host_polygons`)."""
+    labelling (union-find), per-component bounding box, the hole count (Euler number), then per component -- one workgroup -- the
+    steps of box_from_border: hull of its per-row extreme pixels, minimum-area rectangle, cv2.fillPoly-rule score, ClipperLib-rule
+    offset, second rectangle fit, rescale.  The host receives one buffer: a header and a 16-int record per component, i.e. one
+    synchronisation per frame.  Held to oracle/db_postprocess.py in tests/test_gpu_ocr_det.py (boxes equal, scores to 1e-6).
+    The device handles what a subtitle frame looks like; the map goes to the host statement (db_postprocess on the downloaded
+    map) when it has a HOLE (cv2.findContours lists hole borders too, and a component's outer border is then not the only contour
+    it contributes), more than `cap` components (a noise map), a component taller than 256 rows, or an offset polygon beyond
+    the kernel's point buffer."""
 
-    REC = 16
+    REC, HDR = 16, 4
 
     def __init__(self, device, cap=256):
         self.device, self.cap = device, cap
         self._work = {}
+        self.host_fallbacks = 0
 
     def _buffers(self, H, W):
         key = (H, W)
         if key not in self._work:
             dev, i32 = self.device, torch.int32
             self._work[key] = (torch.empty(H * W, dtype=i32, device=dev), torch.empty(H * W * 5, dtype=i32, device=dev),
-                               torch.empty(self.cap * 6, dtype=i32, device=dev), torch.zeros(1, dtype=i32, device=dev),
-                               torch.empty(self.cap * H * 2, dtype=i32, device=dev), torch.zeros(1 + self.cap * self.REC, dtype=i32, device=dev))
+                               torch.empty(self.cap * 6, dtype=i32, device=dev), torch.zeros(4, dtype=i32, device=dev),
+                               torch.empty(self.cap * H * 2, dtype=i32, device=dev), torch.zeros(self.HDR + self.cap * self.REC, dtype=i32, device=dev))
         return self._work[key]
 
     def __call__(self, prob_dev, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
@@ -579,44 +733,20 @@ class DeviceDBPostProcess:
             check(lib.vsr_det_launch_db_boxes(_p(prob_dev), H, W, C.c_float(thresh), src_h, src_w, C.c_float(box_thresh), C.c_float(unclip_ratio),
                                               min_size, _p(labels), _p(stats), _p(comps), _p(count), _p(ext), _p(out), self.cap, _stream()))
             host = torch.cat([out, comps]).cpu().numpy()                             # the one synchronisation of the post-process
-        n = int(host[0])
+        n, holes = int(host[0]), int(host[1])
         if n == 0:
-            return np.zeros((0, 4, 2), np.int32), []
-        rec = host[1:1 + self.cap * self.REC].reshape(self.cap, self.REC)[:min(n, self.cap)]
-        if n > self.cap or (rec[:, 0] < 0).any():
-            return self._host_polygons(prob_dev, labels, count, n, src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
-        first = host[1 + self.cap * self.REC:].reshape(self.cap, 6)[:n, 0]
-        order = np.argsort(first)[:max_candidates]                                   # raster order of the first pixel = findContours' order
+            return np.zeros((0, 4, 2), np.int16), []
+        rec = host[self.HDR:self.HDR + self.cap * self.REC].reshape(self.cap, self.REC)[:min(n, self.cap)]
+        if holes != 0 or n > self.cap or (rec[:, 0] < 0).any():
+            self.host_fallbacks += 1
+            return db_postprocess(prob_dev.cpu().numpy(), src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
+        first = host[self.HDR + self.cap * self.REC:].reshape(self.cap, 6)[:n, 0]
+        order = np.argsort(first)[::-1][:max_candidates]       # cv2.findContours lists the border found LAST by the raster scan first
         rec = rec[order]
         rec = rec[rec[:, 0] == 1]
-        boxes = rec[:, 1:9].reshape(-1, 4, 2).astype(np.int32)
+        boxes = rec[:, 1:9].reshape(-1, 4, 2).astype(np.int16)
         scores = [float(v) for v in np.ascontiguousarray(rec[:, 9]).view(np.float32)]
         return boxes, scores
-
-    def _host_polygons(self, prob_dev, labels, count, n, src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size):
-        """the labelling stays on the device, the polygon work of every component runs in numpy on the downloaded rows"""
-        H, W = prob_dev.shape
-        cap = 4096
-        if n > cap:                          # a noise map: the host labels the downloaded map itself
-            return db_postprocess(prob_dev.cpu().numpy(), src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
-        with torch.cuda.device(self.device):
-            stats = torch.empty(H * W * 5, dtype=torch.int32, device=self.device)
-            comps = torch.empty(cap * 6, dtype=torch.int32, device=self.device)
-            check(lib.vsr_det_launch_ccl(_p(prob_dev), H, W, C.c_float(thresh), _p(labels), _p(stats), _p(comps), cap, _p(count), _stream()))
-            lst = comps[: n * 6].cpu().numpy().reshape(n, 6)
-            lst = lst[np.argsort(lst[:, 0])][:max_candidates]
-            ya0, yb0 = max(0, int(lst[:, 4].min()) - 2), min(H, int(lst[:, 5].max()) + 3)
-            lab_h = labels.view(H, W)[ya0:yb0].cpu().numpy()
-            prob_h = prob_dev[ya0:yb0].cpu().numpy()
-        get_prob = lambda ya, yb, xa, xb: (prob_h[ya - ya0:yb - ya0, xa:xb], (ya, xa))
-        boxes, scores = [], []
-        for lab, _area, x0, x1, y0, y1 in lst.tolist():
-            comp = lab_h[y0 - ya0:y1 + 1 - ya0, x0:x1 + 1] == lab
-            r = _box_of_component(comp, y0, x0, get_prob, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size)
-            if r is not None:
-                boxes.append(r[0])
-                scores.append(r[1])
-        return (np.stack(boxes) if boxes else np.zeros((0, 4, 2), np.int32)), scores
 
 
 def det_resize_shape(H, W, limit_side_len=960, limit_type="max", max_side_limit=4000):

@@ -339,15 +339,22 @@ __global__ void __launch_bounds__(256) k_ccl_compact(int64_t total, const int* _
     }
 }
 
-// ---- DBPostProcess, polygon part on the device (paddleocr DBPostProcess: get_mini_boxes, box_score_fast, unclip; the numpy
-// statement of the same steps is ocr_det._box_of_component).  A minimum-area rectangle only depends on the convex hull, and the
-// hull's vertices are among the leftmost / rightmost pixel of every row of the component: k_db_ext collects those per
-// (component, row) with atomics, k_db_boxes (one wave per component) sorts the <= 2 * rows points by rank, builds the hull with
-// Andrew's monotone chain (integer cross products), runs the calipers with one lane per hull edge, scores the rectangle by the
-// mean probability of the pixels inside it (lanes over its bounding box) and offsets / rescales it.  All geometry in fp64.
+// ---- DBPostProcess, polygon part on the device: the steps of PaddleX's DBPostProcess.boxes_from_bitmap (the numpy statement of the
+// same steps is ocr_det.box_from_border; the reference they are held to is oracle/db_postprocess.py) for maps WITHOUT HOLES, where
+// the borders cv2.findContours(RETR_LIST) returns are exactly the outer borders of the 8-connected components (k_db_quads counts
+// the holes by the Euler number; a map with a hole, more than `cap` components or a component taller than 256 rows goes to the
+// host).  A minimum-area rectangle only depends on the convex hull, and the hull's vertices are among the leftmost / rightmost
+// pixel of every row of the component: k_db_ext collects those per (component, row) with atomics, k_db_boxes (one workgroup per
+// component) sorts the <= 2 * rows points by rank, builds the hull with Andrew's monotone chain (integer cross products), runs the
+// calipers with one thread per hull edge, scores the rectangle over cv2.fillPoly's raster of its integer-truncated corners (outline
+// as 8-connected lines -- membership by the closed form of the line iterator's error recurrence -- plus the 16.16 fixed-point scan
+// lines), grows it the way ClipperLib's rounded offset does (integer-truncated input, arc chords, vertices rounded half away from
+// zero), fits the rectangle of the grown polygon and rescales it (round half to even).  All geometry in fp64 without contraction,
+// the rectangle corners pass through float32 as cv2.boxPoints returns them.
 #define DB_MAXROWS 256
 #define DB_MAXPTS (2 * DB_MAXROWS)
 #define DB_REC 16                                                  // ints per output record: flag, 8 corner coordinates, score bits
+#define DB_HDR 4                                                   // out[0] components found, out[1] holes, out[2..3] reserved
 
 __global__ void __launch_bounds__(256) k_db_slots(const int* __restrict__ comps, const int* __restrict__ count, int cap, int* __restrict__ st)
 {
@@ -376,156 +383,303 @@ __global__ void __launch_bounds__(256) k_db_ext(int H, int W, const int* __restr
     }
 }
 
-__device__ __forceinline__ void db_order_box(const double (*c)[2], double (*o)[2])
-{   // get_mini_boxes: stable sort by x, the left pair and the right pair by y -> top-left, top-right, bottom-right, bottom-left
-    int idx[4] = {0, 1, 2, 3};
-    for (int i = 1; i < 4; ++i)
-        for (int j = i; j > 0 && c[idx[j]][0] < c[idx[j - 1]][0]; --j) { const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
-    int a = idx[0], b = idx[1], d = idx[2], e = idx[3];
-    if (c[b][1] < c[a][1]) { const int t = a; a = b; b = t; }
-    if (c[e][1] < c[d][1]) { const int t = d; d = e; e = t; }
-    const int r[4] = {a, d, e, b};
-    for (int i = 0; i < 4; ++i) { o[i][0] = c[r[i]][0]; o[i][1] = c[r[i]][1]; }
+// Bit-quad counts of the thresholded map (Gray): over all 2x2 windows of the zero-framed image, Q1 = windows with one foreground
+// pixel, Q3 = with three, QD = the two diagonal pairs; Euler number (8-connected foreground) = (Q1 - Q3 - 2 QD) / 4 = components - holes.
+// quads = count + 1 (three ints, zeroed by the launcher).
+__global__ void __launch_bounds__(256) k_db_quads(int H, int W, const int* __restrict__ L, int* __restrict__ quads)
+{
+    const int64_t total = (int64_t)(H + 1) * (W + 1);
+    int q1 = 0, q3 = 0, qd = 0;
+    GRID_STRIDE(i, total) {
+        const int y = (int)(i / (W + 1)), x = (int)(i - (int64_t)y * (W + 1));
+        auto fg = [&](int yy, int xx) { return (yy >= 0 && yy < H && xx >= 0 && xx < W && L[(int64_t)yy * W + xx] >= 0) ? 1 : 0; };
+        const int a = fg(y - 1, x - 1), b = fg(y - 1, x), c = fg(y, x - 1), d = fg(y, x);
+        const int n = a + b + c + d;
+        q1 += n == 1; q3 += n == 3; qd += (n == 2 && a == d);
+    }
+    for (int off = 32; off > 0; off >>= 1) { q1 += __shfl_xor(q1, off); q3 += __shfl_xor(q3, off); qd += __shfl_xor(qd, off); }
+    if ((threadIdx.x & 63) == 0) { if (q1) atomicAdd(quads, q1); if (q3) atomicAdd(quads + 1, q3); if (qd) atomicAdd(quads + 2, qd); }
 }
 
-__global__ void __launch_bounds__(64) k_db_boxes(const float* __restrict__ prob, int H, int W, const int* __restrict__ comps, const int* __restrict__ count, int cap,
-                                                 const int* __restrict__ ext, int src_h, int src_w, float box_thresh, float unclip_ratio, int min_size,
-                                                 int* __restrict__ out)
+struct DbShared {
+    int px[DB_MAXPTS], py[DB_MAXPTS], sx[DB_MAXPTS], sy[DB_MAXPTS], hx[2 * DB_MAXPTS + 2], hy[2 * DB_MAXPTS + 2];   // the two chains share hx / hy
+    int npts, nh, state;
+    double rect[4][2], wh[2];          // minimum-area rectangle (cyclic corner order) and its sides
+    float box[4][2];                   // the same, ordered top-left, top-right, bottom-right, bottom-left, as float32
+    double redA[256]; int redI[256];
+    long long ex[4], eslope[4]; int eya[4], eyb[4], lx0[4], ly0[4], lx1[4], ly1[4];   // edge table of the fill rule
+};
+
+// minimum-area rectangle of the npts distinct integer points in (px, py): rank sort, monotone chain, calipers over every hull edge
+// (first minimum in chain order).  nh <= 2 afterwards: a point or a segment (no rectangle).  Called by the whole workgroup.
+__device__ void db_min_area_rect(DbShared& S, int tid)
 {
-    __shared__ int px[DB_MAXPTS], py[DB_MAXPTS], sx[DB_MAXPTS], sy[DB_MAXPTS], hxI[2 * DB_MAXPTS + 2], hyI[2 * DB_MAXPTS + 2];   // the two chains share hxI / hyI
-    __shared__ int npts, nh;
-    __shared__ double box[4][2], wh[2];
-    __shared__ int state;                                         // 1 = still a candidate
-    const int lane = threadIdx.x, k = blockIdx.x;
-    if (k == 0 && lane == 0) out[0] = *count;
-    if (*count > cap || k >= *count) return;
-    int* o = out + 1 + (int64_t)k * DB_REC;
-    const int y0 = comps[k * 6 + 4], y1 = comps[k * 6 + 5];
-    if (y1 - y0 + 1 > DB_MAXROWS) { if (lane == 0) o[0] = -1; return; }      // a tall component: the host does this map
-    if (lane == 0) {
-        int m = 0;
-        for (int y = y0; y <= y1; ++y) {
-            const int xl = ext[((int64_t)k * H + y) * 2], xr = ext[((int64_t)k * H + y) * 2 + 1];
-            if (xr < 0) continue;
-            px[m] = xl; py[m] = y; ++m;
-            if (xr != xl) { px[m] = xr; py[m] = y; ++m; }
-        }
-        npts = m;
-        state = 1;
-    }
-    __syncthreads();
-    for (int i = lane; i < npts; i += 64) {                        // rank sort by (x, y); the points are distinct
+#pragma clang fp contract(off)
+    const int npts = S.npts;
+    for (int i = tid; i < npts; i += 256) {                        // rank sort by (x, y); the points are distinct
         int r = 0;
-        for (int j = 0; j < npts; ++j) r += (px[j] < px[i] || (px[j] == px[i] && py[j] < py[i])) ? 1 : 0;
-        sx[r] = px[i]; sy[r] = py[i];
+        for (int j = 0; j < npts; ++j) r += (S.px[j] < S.px[i] || (S.px[j] == S.px[i] && S.py[j] < S.py[i])) ? 1 : 0;
+        S.sx[r] = S.px[i]; S.sy[r] = S.py[i];
     }
     __syncthreads();
-    if (lane == 0) {                                               // monotone chain: lower[:-1] + upper[:-1]
+    if (tid == 0) {                                                // monotone chain: lower[:-1] + upper[:-1]
         if (npts <= 2) {
-            nh = npts;
-            for (int i = 0; i < npts; ++i) { hxI[i] = sx[i]; hyI[i] = sy[i]; }
+            S.nh = npts;
+            for (int i = 0; i < npts; ++i) { S.hx[i] = S.sx[i]; S.hy[i] = S.sy[i]; }
         } else {
             auto cross = [](long long ox, long long oy, long long ax, long long ay, long long bx, long long by) {
                 return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
             };
             int n = 0;
             for (int i = 0; i < npts; ++i) {
-                while (n >= 2 && cross(hxI[n - 2], hyI[n - 2], hxI[n - 1], hyI[n - 1], sx[i], sy[i]) <= 0) --n;
-                hxI[n] = sx[i]; hyI[n] = sy[i]; ++n;
+                while (n >= 2 && cross(S.hx[n - 2], S.hy[n - 2], S.hx[n - 1], S.hy[n - 1], S.sx[i], S.sy[i]) <= 0) --n;
+                S.hx[n] = S.sx[i]; S.hy[n] = S.sy[i]; ++n;
             }
-            const int lo = n - 1;                                  // drop lower's last point, upper starts there
-            n = lo;
-            const int base = n;
+            const int base = n - 1;                                // drop lower's last point, upper starts there
+            n = base;
             for (int i = npts - 1; i >= 0; --i) {
-                while (n - base >= 2 && cross(hxI[n - 2], hyI[n - 2], hxI[n - 1], hyI[n - 1], sx[i], sy[i]) <= 0) --n;
-                hxI[n] = sx[i]; hyI[n] = sy[i]; ++n;
+                while (n - base >= 2 && cross(S.hx[n - 2], S.hy[n - 2], S.hx[n - 1], S.hy[n - 1], S.sx[i], S.sy[i]) <= 0) --n;
+                S.hx[n] = S.sx[i]; S.hy[n] = S.sy[i]; ++n;
             }
-            nh = n - 1;                                            // drop upper's last point (= lower's first)
+            S.nh = n - 1;                                          // drop upper's last point (= lower's first)
         }
     }
     __syncthreads();
-    const int h_ = nh;
-    if (h_ <= 2) { if (lane == 0) o[0] = 0; return; }              // a point or a segment: one side is 0 < min_size
-    // calipers: lane i projects the hull on the direction of edge i and on its normal
-    double bestA = 1e300; int bestI = 0x7fffffff;
-    for (int i = lane; i < h_; i += 64) {
+    const int h_ = S.nh;
+    if (h_ <= 2) return;
+    auto project = [&](int i, double& u0, double& u1, double& umin, double& umax, double& vmin, double& vmax) {
         const int j1 = i + 1 == h_ ? 0 : i + 1;
-        const double ex = (double)(hxI[j1] - hxI[i]), ey = (double)(hyI[j1] - hyI[i]);
-        const double nrm = hypot(ex, ey);
-        const double u0 = ex / nrm, u1 = ey / nrm, v0 = -u1, v1 = u0;
-        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+        const double ex = (double)(S.hx[j1] - S.hx[i]), ey = (double)(S.hy[j1] - S.hy[i]);
+        const double nrm = sqrt(ex * ex + ey * ey);               // integer operands: the sum is exact, the root correctly rounded
+        u0 = ex / nrm; u1 = ey / nrm;
+        const double v0 = -u1, v1 = u0;
+        umin = 1e300; umax = -1e300; vmin = 1e300; vmax = -1e300;
         for (int j = 0; j < h_; ++j) {
-            const double pu = (double)hxI[j] * u0 + (double)hyI[j] * u1, pv = (double)hxI[j] * v0 + (double)hyI[j] * v1;
+            const double pu = (double)S.hx[j] * u0 + (double)S.hy[j] * u1, pv = (double)S.hx[j] * v0 + (double)S.hy[j] * v1;
             umin = fmin(umin, pu); umax = fmax(umax, pu); vmin = fmin(vmin, pv); vmax = fmax(vmax, pv);
         }
+    };
+    double bestA = 1e300; int bestI = 0x7fffffff;
+    for (int i = tid; i < h_; i += 256) {
+        double u0, u1, umin, umax, vmin, vmax;
+        project(i, u0, u1, umin, umax, vmin, vmax);
         const double a = (umax - umin) * (vmax - vmin);
         if (a < bestA) { bestA = a; bestI = i; }
     }
-    for (int off = 32; off > 0; off >>= 1) {                       // first minimum over the edges
-        const double a2 = __shfl_xor(bestA, off);
-        const int i2 = __shfl_xor(bestI, off);
-        if (a2 < bestA || (a2 == bestA && i2 < bestI)) { bestA = a2; bestI = i2; }
-    }
-    if (lane == 0) {
-        const int i = bestI, j1 = i + 1 == h_ ? 0 : i + 1;
-        const double ex = (double)(hxI[j1] - hxI[i]), ey = (double)(hyI[j1] - hyI[i]);
-        const double nrm = hypot(ex, ey);
-        const double u0 = ex / nrm, u1 = ey / nrm, v0 = -u1, v1 = u0;
-        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-        for (int j = 0; j < h_; ++j) {
-            const double pu = (double)hxI[j] * u0 + (double)hyI[j] * u1, pv = (double)hxI[j] * v0 + (double)hyI[j] * v1;
-            umin = fmin(umin, pu); umax = fmax(umax, pu); vmin = fmin(vmin, pv); vmax = fmax(vmax, pv);
-        }
-        const double w = umax - umin, h = vmax - vmin;
-        wh[0] = w; wh[1] = h;
-        if (fmin(w, h) < (double)min_size) state = 0;
+    S.redA[tid] = bestA; S.redI[tid] = bestI;
+    __syncthreads();
+    if (tid == 0) {
+        for (int t = 1; t < 256; ++t)
+            if (S.redA[t] < bestA || (S.redA[t] == bestA && S.redI[t] < bestI)) { bestA = S.redA[t]; bestI = S.redI[t]; }
+        double u0, u1, umin, umax, vmin, vmax;
+        project(bestI, u0, u1, umin, umax, vmin, vmax);
+        const double v0 = -u1, v1 = u0;
+        S.wh[0] = umax - umin; S.wh[1] = vmax - vmin;
         const double c[4][2] = {{umin * u0 + vmin * v0, umin * u1 + vmin * v1}, {umax * u0 + vmin * v0, umax * u1 + vmin * v1},
                                 {umax * u0 + vmax * v0, umax * u1 + vmax * v1}, {umin * u0 + vmax * v0, umin * u1 + vmax * v1}};
-        db_order_box(c, box);
+        for (int i = 0; i < 4; ++i) { S.rect[i][0] = c[i][0]; S.rect[i][1] = c[i][1]; }
     }
     __syncthreads();
-    if (!state) { if (lane == 0) o[0] = 0; return; }
-    // box_score_fast: mean probability over the pixels inside the rectangle
-    double bx[4], by[4];
-    for (int i = 0; i < 4; ++i) { bx[i] = box[i][0]; by[i] = box[i][1]; }
-    const double mnx = fmin(fmin(bx[0], bx[1]), fmin(bx[2], bx[3])), mxx = fmax(fmax(bx[0], bx[1]), fmax(bx[2], bx[3]));
-    const double mny = fmin(fmin(by[0], by[1]), fmin(by[2], by[3])), mxy = fmax(fmax(by[0], by[1]), fmax(by[2], by[3]));
-    const int xa = (int)fmin(fmax(floor(mnx), 0.0), (double)(W - 1)), xb = (int)fmin(fmax(ceil(mxx), 0.0), (double)(W - 1));
-    const int ya = (int)fmin(fmax(floor(mny), 0.0), (double)(H - 1)), yb = (int)fmin(fmax(ceil(mxy), 0.0), (double)(H - 1));
-    const int bw = xb - xa + 1, npx = bw * (yb - ya + 1);
-    double sum = 0.0; int cnt = 0;
-    for (int t = lane; t < npx; t += 64) {
-        const int y = ya + t / bw, x = xa + t % bw;
-        bool in = true;
-        for (int i = 0; i < 4; ++i) {
-            const int q = (i + 1) & 3;
-            in = in && ((bx[q] - bx[i]) * ((double)y - by[i]) - (by[q] - by[i]) * ((double)x - bx[i]) >= -1e-6);
+}
+
+// get_mini_boxes' ordering on the float32 corners (cv2.boxPoints): stable sort by x, of the left pair the upper corner first, of the
+// right pair the upper corner second -> top-left, top-right, bottom-right, bottom-left
+__device__ void db_order_box(const double (*c)[2], float (*o)[2])
+{
+    float f[4][2];
+    for (int i = 0; i < 4; ++i) { f[i][0] = (float)c[i][0]; f[i][1] = (float)c[i][1]; }
+    int idx[4] = {0, 1, 2, 3};
+    for (int i = 1; i < 4; ++i)
+        for (int j = i; j > 0 && f[idx[j]][0] < f[idx[j - 1]][0]; --j) { const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+    int i1, i4, i2, i3;
+    if (f[idx[1]][1] > f[idx[0]][1]) { i1 = idx[0]; i4 = idx[1]; } else { i1 = idx[1]; i4 = idx[0]; }
+    if (f[idx[3]][1] > f[idx[2]][1]) { i2 = idx[2]; i3 = idx[3]; } else { i2 = idx[3]; i3 = idx[2]; }
+    const int r[4] = {i1, i2, i3, i4};
+    for (int i = 0; i < 4; ++i) { o[i][0] = f[r[i]][0]; o[i][1] = f[r[i]][1]; }
+}
+
+__device__ __forceinline__ long long db_away(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
+
+__global__ void __launch_bounds__(256) k_db_boxes(const float* __restrict__ prob, int H, int W, const int* __restrict__ comps, const int* __restrict__ count, int cap,
+                                                  const int* __restrict__ ext, int src_h, int src_w, float box_thresh, float unclip_ratio, int min_size,
+                                                  int* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    __shared__ DbShared S;
+    const int tid = threadIdx.x, k = blockIdx.x;
+    if (k == 0 && tid == 0) {
+        out[0] = *count;
+        out[1] = *count - (count[1] - count[2] - 2 * count[3]) / 4;       // holes = components - Euler number
+    }
+    if (*count > cap || k >= *count) return;
+    int* o = out + DB_HDR + (int64_t)k * DB_REC;
+    const int y0 = comps[k * 6 + 4], y1 = comps[k * 6 + 5];
+    if (y1 - y0 + 1 > DB_MAXROWS) { if (tid == 0) o[0] = -1; return; }      // a tall component: the host does this map
+    if (tid == 0) {
+        int m = 0;
+        for (int y = y0; y <= y1; ++y) {
+            const int xl = ext[((int64_t)k * H + y) * 2], xr = ext[((int64_t)k * H + y) * 2 + 1];
+            if (xr < 0) continue;
+            S.px[m] = xl; S.py[m] = y; ++m;
+            if (xr != xl) { S.px[m] = xr; S.py[m] = y; ++m; }
         }
-        if (in) { sum += (double)prob[(int64_t)y * W + x]; ++cnt; }
+        S.npts = m;
+        S.state = 1;
     }
-    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
-    if (lane != 0) return;
-    const float score = cnt ? (float)(sum / cnt) : 0.f;
-    if ((double)score < (double)box_thresh) { o[0] = 0; return; }
-    // unclip: offset the rectangle by area * ratio / perimeter, then rescale to the source image
-    const double w = wh[0], h = wh[1];
-    const double d = (w * h) * (double)unclip_ratio / (2 * (w + h));
-    const double cx = (bx[0] + bx[1] + bx[2] + bx[3]) / 4, cy = (by[0] + by[1] + by[2] + by[3]) / 4;
-    const double e1x = bx[1] - bx[0], e1y = by[1] - by[0], e3x = bx[3] - bx[0], e3y = by[3] - by[0];
-    const double l1 = hypot(e1x, e1y), l3 = hypot(e3x, e3y);
-    const double ux = e1x / fmax(l1, 1e-9), uy = e1y / fmax(l1, 1e-9), vx = e3x / fmax(l3, 1e-9), vy = e3y / fmax(l3, 1e-9);
-    const double hw = l1 / 2 + d, hh = l3 / 2 + d;
-    if (fmin(2 * hw, 2 * hh) < (double)(min_size + 2)) { o[0] = 0; return; }
-    double big[4][2] = {{cx - hw * ux - hh * vx, cy - hw * uy - hh * vy}, {cx + hw * ux - hh * vx, cy + hw * uy - hh * vy},
-                        {cx + hw * ux + hh * vx, cy + hw * uy + hh * vy}, {cx - hw * ux + hh * vx, cy - hw * uy + hh * vy}};
+    __syncthreads();
+    db_min_area_rect(S, tid);
+    if (S.nh <= 2) { if (tid == 0) o[0] = 0; return; }            // a point or a segment: one side is 0 < min_size
+    int xa = 0, ya = 0, bw = 0, bh = 0;
+    if (tid == 0) {
+        if (fmin(S.wh[0], S.wh[1]) < (double)min_size) S.state = 0;
+        db_order_box(S.rect, S.box);
+        // box_score_fast: bounding rows / columns, corners relative to them in float32, truncated; cv2.fillPoly's edge table
+        float mnx = S.box[0][0], mxx = mnx, mny = S.box[0][1], mxy = mny;
+        for (int i = 1; i < 4; ++i) { mnx = fminf(mnx, S.box[i][0]); mxx = fmaxf(mxx, S.box[i][0]); mny = fminf(mny, S.box[i][1]); mxy = fmaxf(mxy, S.box[i][1]); }
+        const int xa_ = (int)fmin(fmax(floor((double)mnx), 0.0), (double)(W - 1)), xb_ = (int)fmin(fmax(ceil((double)mxx), 0.0), (double)(W - 1));
+        const int ya_ = (int)fmin(fmax(floor((double)mny), 0.0), (double)(H - 1)), yb_ = (int)fmin(fmax(ceil((double)mxy), 0.0), (double)(H - 1));
+        S.redI[0] = xa_; S.redI[1] = ya_; S.redI[2] = xb_ - xa_ + 1; S.redI[3] = yb_ - ya_ + 1;
+        int qx[4], qy[4];
+        for (int i = 0; i < 4; ++i) { qx[i] = (int)(S.box[i][0] - (float)xa_); qy[i] = (int)(S.box[i][1] - (float)ya_); }
+        for (int e = 0; e < 4; ++e) {
+            const int p = (e + 3) & 3;
+            const int x0 = qx[p], yy0 = qy[p], x1 = qx[e], yy1 = qy[e];
+            S.lx0[e] = x0; S.ly0[e] = yy0; S.lx1[e] = x1; S.ly1[e] = yy1;
+            if (yy0 == yy1) { S.eya[e] = 1; S.eyb[e] = 0; S.ex[e] = 0; S.eslope[e] = 0; continue; }       // horizontal: outline only
+            S.eslope[e] = (((long long)(x1 - x0)) << 16) / (long long)(yy1 - yy0);                       // C division: toward zero
+            if (yy0 < yy1) { S.eya[e] = yy0; S.eyb[e] = yy1; S.ex[e] = ((long long)x0) << 16; }
+            else { S.eya[e] = yy1; S.eyb[e] = yy0; S.ex[e] = ((long long)x1) << 16; }
+        }
+    }
+    __syncthreads();
+    if (!S.state) { if (tid == 0) o[0] = 0; return; }
+    xa = S.redI[0]; ya = S.redI[1]; bw = S.redI[2]; bh = S.redI[3];
+    __syncthreads();
+    double sum = 0.0; int cnt = 0;
+    const int npx = bw * bh;
+    for (int t = tid; t < npx; t += 256) {
+        const int ly = t / bw, lx = t - ly * bw;
+        bool in = false;
+        long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int x0 = S.lx0[e], yy0 = S.ly0[e], x1 = S.lx1[e], yy1 = S.ly1[e];
+            if (x1 < x0) { int tt = x0; x0 = x1; x1 = tt; tt = yy0; yy0 = yy1; yy1 = tt; }                // the line runs left to right
+            const int dx = x1 - x0, dy = yy1 >= yy0 ? yy1 - yy0 : yy0 - yy1, sy = yy1 >= yy0 ? 1 : -1;
+            if (dy > dx) {
+                const int kk = (ly - yy0) * sy;
+                if (kk >= 0 && kk <= dy && lx == x0 + max(0, (2 * dx * kk + dy - 1) / (2 * dy))) in = true;
+            } else {
+                const int kk = lx - x0;
+                if (kk >= 0 && kk <= dx && ly == yy0 + sy * (dx ? max(0, (2 * dy * kk + dx - 1) / (2 * dx)) : 0)) in = true;
+            }
+            if (ly >= S.eya[e] && ly < S.eyb[e]) {
+                const long long xf = S.ex[e] + (long long)(ly - S.eya[e]) * S.eslope[e];
+                lo = xf < lo ? xf : lo; hi = xf > hi ? xf : hi;
+            }
+        }
+        if (hi >= lo && (long long)lx >= (lo >> 16) && (long long)lx <= (hi >> 16)) in = true;
+        if (in) { sum += (double)prob[(int64_t)(ya + ly) * W + xa + lx]; ++cnt; }
+    }
+    S.redA[tid] = sum; S.redI[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        for (int t = 1; t < 256; ++t) { sum += S.redA[t]; cnt += S.redI[t]; }
+        const double score = cnt ? sum / cnt : 0.0;
+        o[9] = __float_as_int((float)score);
+        if ((double)box_thresh > score) S.state = 0;
+        if (S.state) {
+            // unclip: cv2.contourArea / cv2.arcLength (float32 segment lengths) of the float32 box, then ClipperLib's rounded offset
+            double ar = 0.0, len = 0.0;
+            for (int i = 0; i < 4; ++i) {
+                const int j = (i + 1) & 3;
+                ar += (double)S.box[i][0] * (double)S.box[j][1] - (double)S.box[j][0] * (double)S.box[i][1];
+                const float ddx = S.box[i][0] - S.box[(i + 3) & 3][0], ddy = S.box[i][1] - S.box[(i + 3) & 3][1];
+                len += (double)__fsqrt_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+            }
+            ar = fabs(ar) * 0.5;
+            int n = 0;
+            long long qx[4], qy[4];
+            for (int i = 0; i < 4; ++i) {                          // integer-truncated, consecutive duplicates dropped
+                const long long x = (long long)S.box[i][0], y = (long long)S.box[i][1];
+                if (n && qx[n - 1] == x && qy[n - 1] == y) continue;
+                qx[n] = x; qy[n] = y; ++n;
+            }
+            if (n > 1 && qx[0] == qx[n - 1] && qy[0] == qy[n - 1]) --n;
+            int m = 0;
+            if (ar > 0.0 && len > 0.0 && n >= 3) {
+                const double delta = ar * (double)unclip_ratio / len;
+                long long twice = 0;
+                for (int i = 0; i < n; ++i) { const int p = (i + n - 1) % n; twice += (qx[p] + qx[i]) * (qy[p] - qy[i]); }
+                if (twice > 0)                                    // Clipper's Area() < 0: reversed, the normals then point outwards
+                    for (int i = 0; i < n / 2; ++i) { long long t = qx[i]; qx[i] = qx[n - 1 - i]; qx[n - 1 - i] = t; t = qy[i]; qy[i] = qy[n - 1 - i]; qy[n - 1 - i] = t; }
+                const double PI = 3.14159265358979323846;
+                const double tol = fmin(0.25, delta * 0.25);
+                const double steps = fmin(PI / acos(1 - tol / delta), delta * PI);
+                const double rot_s = sin(2 * PI / steps), rot_c = cos(2 * PI / steps), per_rad = steps / (2 * PI);
+                double nx[4], ny[4];
+                for (int i = 0; i < n; ++i) {
+                    const int j = (i + 1) % n;
+                    const double ex = (double)(qx[j] - qx[i]), ey = (double)(qy[j] - qy[i]);
+                    const double inv = 1.0 / sqrt(ex * ex + ey * ey);
+                    nx[i] = ey * inv; ny[i] = -ex * inv;
+                }
+                auto put = [&](long long px_, long long py_, double ax, double ay) {
+                    if (m < DB_MAXPTS) { S.px[m] = (int)db_away((double)px_ + ax * delta); S.py[m] = (int)db_away((double)py_ + ay * delta); }
+                    ++m;
+                };
+                for (int i = 0; i < n; ++i) {
+                    const int p = (i + n - 1) % n;
+                    const double ax = nx[p], ay = ny[p], bx = nx[i], by = ny[i];
+                    double sin_t = ax * by - bx * ay;
+                    const double cos_t = ax * bx + ay * by;
+                    if (fabs(sin_t * delta) < 1.0 && cos_t > 0) { put(qx[i], qy[i], ax, ay); continue; }
+                    if (fabs(sin_t * delta) >= 1.0) sin_t = fmin(fmax(sin_t, -1.0), 1.0);
+                    if (sin_t * delta < 0) {
+                        put(qx[i], qy[i], ax, ay);
+                        if (m < DB_MAXPTS) { S.px[m] = (int)qx[i]; S.py[m] = (int)qy[i]; }
+                        ++m;
+                        put(qx[i], qy[i], bx, by);
+                        continue;
+                    }
+                    const double ang = atan2(sin_t, cos_t);
+                    long long ns = db_away(per_rad * fabs(ang));
+                    if (ns < 1) ns = 1;
+                    double cx = ax, cy = ay;
+                    for (long long t = 0; t < ns; ++t) {
+                        put(qx[i], qy[i], cx, cy);
+                        const double c2 = cx;
+                        cx = cx * rot_c - rot_s * cy;
+                        cy = c2 * rot_s + cy * rot_c;
+                    }
+                    put(qx[i], qy[i], bx, by);
+                }
+            }
+            if (m == 0 || m > DB_MAXPTS) S.state = m > DB_MAXPTS ? -1 : 0;
+            else {
+                // the rectangle fit wants distinct points: drop duplicates (rounded arc chords may coincide)
+                int u = 0;
+                for (int i = 0; i < m; ++i) {
+                    bool dup = false;
+                    for (int j = 0; j < u && !dup; ++j) dup = S.px[j] == S.px[i] && S.py[j] == S.py[i];
+                    if (!dup) { S.px[u] = S.px[i]; S.py[u] = S.py[i]; ++u; }
+                }
+                S.npts = u;
+            }
+        }
+    }
+    __syncthreads();
+    if (S.state != 1) { if (tid == 0) o[0] = S.state; return; }
+    db_min_area_rect(S, tid);
+    if (tid != 0) return;
+    if (S.nh <= 2 || fmin(S.wh[0], S.wh[1]) < (double)(min_size + 2)) { o[0] = 0; return; }
+    float big[4][2];
+    db_order_box(S.rect, big);
+    const double wsc = (double)src_w / (double)W, hsc = (double)src_h / (double)H;
     for (int i = 0; i < 4; ++i) {
-        big[i][0] = fmin(fmax(rint(big[i][0] / (double)W * (double)src_w), 0.0), (double)src_w);
-        big[i][1] = fmin(fmax(rint(big[i][1] / (double)H * (double)src_h), 0.0), (double)src_h);
+        o[1 + 2 * i] = (int)fmin(fmax(rint((double)big[i][0] * wsc), 0.0), (double)src_w);
+        o[2 + 2 * i] = (int)fmin(fmax(rint((double)big[i][1] * hsc), 0.0), (double)src_h);
     }
-    double ob[4][2];
-    db_order_box(big, ob);
-    for (int i = 0; i < 4; ++i) { o[1 + 2 * i] = (int)ob[i][0]; o[2 + 2 * i] = (int)ob[i][1]; }
-    o[9] = __float_as_int(score);
     o[0] = 1;
 }
 
@@ -634,23 +788,27 @@ int vsr_det_launch_ccl(const float* prob, int H, int W, float thresh, int32_t* l
     DONE();
 }
 
-// The whole DBPostProcess of one probability map on the device: vsr_det_launch_ccl's labelling, then the polygon work per
-// component.  ext int32 [cap][H][2] scratch; out int32 [1 + cap * 16]: out[0] = number of components found, then per component
-// slot k (same order as comps) a record (flag, x0, y0, x1, y1, x2, y2, x3, y3, score bits): flag 1 = box (source-image pixels,
-// ordered top-left, top-right, bottom-right, bottom-left), 0 = rejected (size / score), -1 = taller than 256 rows (not
-// processed).  More than cap components: only out[0] is valid.
+// The whole DBPostProcess of one probability map on the device: vsr_det_launch_ccl's labelling, the hole count, then the polygon
+// work per component.  count int32 [4] (components, then the three bit-quad counts); ext int32 [cap][H][2] scratch; out int32
+// [4 + cap * 16]: out[0] = components found, out[1] = holes (background regions enclosed by foreground: their borders are contours
+// too, such a map is the host's), then per component slot k (same order as comps) a record (flag, x0, y0, x1, y1, x2, y2, x3, y3,
+// score bits): flag 1 = box (source-image pixels, ordered top-left, top-right, bottom-right, bottom-left), 0 = rejected (size /
+// score), -1 = not processed (taller than 256 rows, or an offset polygon beyond the point buffer).  More than cap components: only
+// out[0] is valid.
 int vsr_det_launch_db_boxes(const float* prob, int H, int W, float thresh, int src_h, int src_w, float box_thresh, float unclip_ratio, int min_size,
                             int32_t* labels, int32_t* stats, int32_t* comps, int32_t* count, int32_t* ext, int32_t* out, int cap, void* stream)
 {
     if (!ext || !out || cap <= 0 || cap > 65535) return VSR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, 4 * sizeof(int32_t), s) != hipSuccess) return VSR_ERR_HIP;
     const int rc = vsr_det_launch_ccl(prob, H, W, thresh, labels, stats, comps, cap, count, stream);
     if (rc != 0) return rc;
-    hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)H * W;
+    hipLaunchKernelGGL(k_db_quads, dim3(grid_for((int64_t)(H + 1) * (W + 1))), dim3(256), 0, s, H, W, labels, count + 1);
     hipLaunchKernelGGL(k_db_slots, dim3(grid_for(cap)), dim3(256), 0, s, comps, count, cap, stats);
     hipLaunchKernelGGL(k_db_ext_init, dim3(grid_for((int64_t)cap * H)), dim3(256), 0, s, count, cap, H, ext);
     hipLaunchKernelGGL(k_db_ext, dim3(grid_for(total)), dim3(256), 0, s, H, W, labels, stats, count, cap, ext);
-    hipLaunchKernelGGL(k_db_boxes, dim3(cap), dim3(64), 0, s, prob, H, W, comps, count, cap, ext, src_h, src_w, box_thresh, unclip_ratio, min_size, out);
+    hipLaunchKernelGGL(k_db_boxes, dim3(cap), dim3(256), 0, s, prob, H, W, comps, count, cap, ext, src_h, src_w, box_thresh, unclip_ratio, min_size, out);
     DONE();
 }
 
