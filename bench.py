@@ -100,6 +100,58 @@ def cpu_baseline(sd, clip, mask01, areas):
     return np.stack(ref), dt, net["s"], threads, tried
 
 
+def _parallel_worker(idx, threads, L, start_evt, ready_q, done_q):
+    """one host process of cpu_baseline_parallel: its own chunk (the network part, STTNInpaint.inpaint over L model-resolution
+    frames) on `threads` torch threads"""
+    torch.set_num_threads(threads)
+    import vsr_amd  # noqa: F401
+    from oracle.sttn_auto import STTNInpaintOracle
+    from vsr_amd.synth import make_state_dict
+
+    o = STTNInpaintOracle(make_state_dict(0, "auto"), "auto")
+    frames = list(np.random.default_rng(100 + idx).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8))
+    o.inpaint(frames[:2])                                   # warm: allocator, oneDNN primitives
+    ready_q.put(idx)
+    start_evt.wait()
+    t0 = time.perf_counter()
+    o.inpaint(frames)
+    done_q.put((idx, time.perf_counter() - t0))
+
+
+def cpu_baseline_parallel(L, threads, budget_s=240.0):
+    """The honest 'host cores of the same box' figure: chunks share no state (sttn_auto_inpaint.py:242-328), so the CPU
+    path scales by running one chunk per group of cores.  cpu_count // threads processes, each the network part of one full chunk
+    on `threads` torch threads, started together; aggregate frames/s = processes x L / wall.  None when the box is too small."""
+    import multiprocessing as mp
+
+    ncpu = os.cpu_count() or 1
+    nproc = max(1, ncpu // max(threads, 1))
+    if nproc < 2:
+        return None
+    ctx = mp.get_context("spawn")
+    start_evt, ready_q, done_q = ctx.Event(), ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_parallel_worker, args=(i, threads, L, start_evt, ready_q, done_q), daemon=True) for i in range(nproc)]
+    for p in procs:
+        p.start()
+    try:
+        for _ in procs:
+            ready_q.get(timeout=budget_s)
+        t0 = time.perf_counter()
+        start_evt.set()
+        per = [done_q.get(timeout=budget_s)[1] for _ in procs]
+        wall = time.perf_counter() - t0
+    except Exception as e:                                  # a baseline must not fail the bench line
+        for p in procs:
+            p.terminate()
+        return {"error": f"{type(e).__name__}: {e}"}
+    for p in procs:
+        p.join(timeout=30)
+    return {"value": round(nproc * L / wall, 3), "unit": "frames/s", "processes": nproc, "threads_per_process": threads,
+            "cores": nproc * threads, "wall_s": round(wall, 1), "slowest_process_s": round(max(per), 1), "fastest_process_s": round(min(per), 1),
+            "sample": f"{nproc} independent {L}-frame chunks at once, one per process, STTNInpaint.inpaint (the network: 95 % of a chunk's "
+                      f"CPU time) on {threads} torch threads each -- all {nproc * threads} of the box's {ncpu} hardware threads"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +160,8 @@ def main():
     ap.add_argument("--res", default="1080p", choices=sorted(RES))
     ap.add_argument("--chunk", type=int, default=50, help="frames per chunk (config.sttnMaxLoadNum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-parallel", action="store_true", help="skip cpu_baseline.parallel (one oracle chunk per 16 host threads, all at once)")
+    ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the check of the gathered chunks against each rank's replica result")
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
     ap.add_argument("--precision", default=None, choices=["f32", "split", "split-format", "f16"],
@@ -183,6 +237,7 @@ def main():
         return dt
 
     replicas = None
+    selftest_failed = False
     if world == 1:
         for _ in range(args.warmup):
             step()
@@ -227,6 +282,30 @@ def main():
         if rank == 0:
             checksum = int(sum(int(d[::7, ::5, ::11].sum().item()) for d in dsts))
             replicas["scatter_gather_result_checksum"] = checksum
+        if not args.no_selftest:
+            # the chunk rank k inpainted from rows that travelled over RCCL and back must equal what rank k computes from its own
+            # resident copy of the same clip (same seed): every rank hashes its replica's strip rows, rank 0 hashes what it gathered
+            def digest(t):
+                v = t.to(torch.int64)
+                w = torch.arange(1, v.numel() + 1, dtype=torch.int64, device=t.device).reshape(v.shape) % 1000003
+                return [int(v.sum().item()), int((v * w).sum().item() % (1 << 61))]
+
+            own = src.clone()
+            eng.auto_chunk(own, dmask, areas)
+            torch.cuda.synchronize()
+            mine = torch.tensor(digest(own[:, y_lo:y_hi]), dtype=torch.int64, device="cpu" if dry else device)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            if rank == 0:
+                gathered = [digest(d) for d in dsts]
+                per_rank = [{"rank": k, "replica": [int(x) for x in allr[k].tolist()], "gathered": gathered[k]} for k in range(world)]
+                ok = all(p["replica"] == p["gathered"] for p in per_rank)
+                replicas["selftest"] = {"ok": ok, "ranks": world, "backend": dist.get_backend(),
+                                        "what": "strip rows of chunk k after scatter -> inpaint on rank k -> gather, against rank k's own "
+                                                "resident run of the same clip (sum and position-weighted sum of all bytes)",
+                                        "mismatching_ranks": [p["rank"] for p in per_rank if p["replica"] != p["gathered"]]}
+                if not ok:
+                    replicas["selftest"]["per_rank"] = per_rank
 
     total_frames = args.steps * L * world
     fps = total_frames / elapsed
@@ -336,6 +415,10 @@ def main():
                 "sample": f"oracle chunk body (torch-CPU fp32 restatement of the reference modules + restated cv2 resize / blend) on ONE full "
                           f"{L}-frame {args.res} chunk of the timed clip, end to end in {dt:.1f} s of which STTNInpaint.inpaint "
                           f"(the network, {flops_chunk / 1e12:.2f} TFLOP) {dt_net:.1f} s; thread count picked by a 3-frame probe of the same oracle"}
+            if not args.no_cpu_parallel:
+                par = cpu_baseline_parallel(L, threads)
+                if par is not None:
+                    out["cpu_baseline"]["parallel"] = par
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"
             out["psnr_note"] = (f"masked strip pixels of the full {L}-frame chunk, HIP path vs CPU oracle; max |d| "
                                 f"{int(np.abs(got[:, m].astype(np.int16) - ref[:, m].astype(np.int16)).max())}, "
@@ -397,11 +480,16 @@ def main():
                 out[key] = sp
             eng.set_precision(base_precision)
         print(json.dumps(out), flush=True)
+        if world > 1 and replicas is not None and not replicas.get("selftest", {"ok": True})["ok"]:
+            print("SELFTEST FAILED: gathered chunks differ from the ranks' replica results", file=sys.stderr, flush=True)
+            selftest_failed = True
 
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if selftest_failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -103,6 +103,37 @@ def test_driver_orders_passthrough_and_work_items():
     assert out == []
 
 
+def test_prefetch_admits_a_batch_larger_than_its_budget():
+    """a WORK batch with more frames than `prefetch_frames` (config.sttnMaxLoadNum goes to 300, the budget defaults to
+    256) used to hang the reader thread; it now passes alone, the budget still bounds how far the reader runs ahead"""
+    import threading
+
+    from vsr_amd.backend.tools.batch_parallel import _Prefetch, run_batch_parallel
+
+    items = [("pass", 0)] + [("work", list(range(10 * k, 10 * k + 10)), np.zeros((2, 2), np.uint8)) for k in range(1, 4)] + [("pass", 99)]
+    out = []
+    t = threading.Thread(target=lambda: run_batch_parallel(iter(items), lambda frames, mask: [f + 1000 for f in frames], out.append, prefetch_frames=8),
+                         daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "the prefetcher deadlocked on a batch larger than its budget"
+    assert out == [0] + [f + 1000 for f in range(10, 40)] + [99]
+    # the budget is respected when items fit: never more than 8 frames queued ahead of the consumer
+    peak = [0]
+
+    def gen():
+        for i in range(50):
+            yield ("pass", i)
+
+    pf = _Prefetch(gen(), 8)
+    got = []
+    for v in pf:
+        peak[0] = max(peak[0], pf.q.qsize())
+        got.append(v[1])
+    assert got == list(range(50)) and peak[0] <= 8
+    pf.close()
+
+
 def _bounded_worker(rank, world, port, fail, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist

@@ -99,6 +99,26 @@ def test_lama_plugin_vs_oracle(built_lib, gpu_device):
     plug.close()
 
 
+def test_lama_plugin_overlapping_strips(built_lib, gpu_device):
+    """two subtitle groups closer than split_h give strips that share rows.  The reference crops every strip from the
+    original frames and writes them back afterwards, in order (lama_inpaint.py:88-106); in place, the second strip saw the first
+    one's output."""
+    from vsr_amd.backend.inpaint.lama_inpaint import LamaInpaint
+    from vsr_amd.backend.tools.inpaint_tools import create_mask, get_inpaint_area_by_mask
+
+    H, W = 240, 330
+    clip = make_clip(5, H, W, (60, 70, 40, 290), seed=21)
+    mask = create_mask((H, W), [(40, 290, 62, 68), (60, 270, 112, 118)])
+    areas = get_inpaint_area_by_mask(W, H, int(W * 3 / 16), mask[:, :, None])
+    assert len(areas) == 2 and areas[0][1] > areas[1][0], areas           # the strips overlap
+    sd = make_lama_state_dict(7, 2)
+    plug = LamaInpaint("cuda:0", sd)
+    got = np.stack(plug([f.copy() for f in clip], mask))
+    ref = np.stack(LamaOracle(BigLamaNet(sd, 2))([f for f in clip], mask))
+    _bar(got, ref, "LamaInpaint.__call__ with overlapping strips")
+    plug.close()
+
+
 def test_lama_strip_size_full_network(built_lib, gpu_device):
     """BASELINE config 1's arithmetic at the 1080p strip: all 18 FFC residual blocks (51 M parameters), 1920x360, 2 frames
     (45 x 240 feature maps: DFT lengths 45 = 3^2 5 and 240 = 2^4 3 5)"""

@@ -82,13 +82,19 @@ class LamaInpaint:
         frames = torch.from_numpy(np.ascontiguousarray(np.stack(input_frames))).to(dev)
         dmask = torch.from_numpy(np.ascontiguousarray(input_mask)).to(dev)
         n = frames.shape[0]
+        # The reference crops every strip from the ORIGINAL frames, runs them all, and only then writes them back in order
+        # (:88-106).  Strips of two subtitle groups closer than split_h overlap; in place, the second strip would be fed the
+        # first one's output in the shared rows.  Overlap is rare: only then is a snapshot of the frames kept.
+        spans = sorted((a[0], a[1]) for a in inpaint_area)
+        overlap = any(spans[i][1] > spans[i + 1][0] for i in range(len(spans) - 1))
+        source = frames.clone() if overlap else frames
         for y0, y1, _, _ in inpaint_area:                                    # full-width strips: row slices are contiguous rows
             strip_mask = dmask[y0:y1].contiguous()
             if n == 1:                                                       # :32-33 -> inpaint(): same arithmetic
-                self.engine.inpaint(frames[:, y0:y1], strip_mask, out=frames[:, y0:y1])
+                self.engine.inpaint(source[:, y0:y1], strip_mask, out=frames[:, y0:y1])
                 continue
             for s in range(0, n, self.mini_batch_size):
                 e = min(s + self.mini_batch_size, n)
-                self.engine.inpaint(frames[s:e, y0:y1], strip_mask, out=frames[s:e, y0:y1])
+                self.engine.inpaint(source[s:e, y0:y1], strip_mask, out=frames[s:e, y0:y1])
         out = frames.cpu().numpy()
         return [out[i] for i in range(n)]

@@ -277,8 +277,14 @@ class STTNAutoInpaint:
         return load, store
 
     def __call__(self, input_mask=None, input_sub_remover=None, tbar=None):
+        """The reference swallows every error here and prints it (:329-331); its caller then reports success over a missing or
+        truncated file.  The print is kept, the error is kept too: `last_error` holds it and SubtitleRemover.run() raises it, so
+        that `-o OUT` is written or the run fails.  The writer is opened before the loop, outside the swallowed region
+        of old: a missing sink is an error of the call, not of some chunk."""
+        self.last_error = None
         try:
             self._run(self._distributed(), input_mask, input_sub_remover, tbar)
             gc.collect()
-        except Exception as e:          # the reference swallows every error here (:329-331)
+        except Exception as e:
+            self.last_error = e
             print(f"Error during video processing: {str(e)}")

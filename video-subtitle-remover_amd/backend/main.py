@@ -90,6 +90,10 @@ class SubtitleRemover:
         mask = create_mask(self.mask_size, mask_area_coordinates)
         sttn_video_inpaint = STTNAutoInpaint(self.device, self.model_path, self.video_path)
         sttn_video_inpaint(input_mask=mask, input_sub_remover=self, tbar=tbar)
+        if sttn_video_inpaint.last_error is not None:
+            # the plugin prints and returns like the reference's (sttn_auto_inpaint.py:329-331); the run must not report success
+            # over a file that was not (completely) written
+            raise sttn_video_inpaint.last_error
 
     @staticmethod
     def is_current_frame_no_start(frame_no, continuous_frame_no_list):          # main.py:90-97
@@ -340,6 +344,13 @@ class SubtitleRemover:
         elif mode == InpaintMode.PROPAINTER:
             self.propainter_mode(None, propainter_inpaint=getattr(self, "propainter_inpaint", None),
                                  text_detector=self._default_detector(), scene_div_points=getattr(self, "scene_div_points", None))
+        elif mode == InpaintMode.OPENCV:
+            # main.py:383-384: cv2.inpaint (Telea, radius 3) on the CPU, frame by frame -- not part of the MI355X path (SURVEY 2.1:
+            # surface only).  With opencv-python installed it is the reference's own two lines; without it args_handler has
+            # already refused the mode.
+            from .inpaint.opencv_inpaint import OpenCVInpaint
+
+            self.video_inpaint(None, OpenCVInpaint(), text_detector=self._default_detector())
         else:
             raise Exception(f"inpaint mode: {mode} not implemented")     # main.py:386
         if self._video_writer is not None:

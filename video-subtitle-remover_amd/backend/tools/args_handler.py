@@ -23,6 +23,14 @@ def build_parser():
 def parse_args(argv=None):
     args = build_parser().parse_args(argv)
     args.inpaint_mode = InpaintMode[args.inpaint_mode.replace("-", "_").upper()]
+    if args.inpaint_mode == InpaintMode.OPENCV:
+        from ..inpaint import opencv_inpaint
+
+        if not opencv_inpaint.available():
+            # refused here, before any pass over the video: the mode is cv2.inpaint on the CPU (reference opencv_inpaint.py:9), which
+            # this build neither accelerates nor re-implements
+            build_parser().error("--inpaint-mode opencv is OpenCV's own CPU inpainting (cv2.inpaint): it needs opencv-python, which is "
+                                 "not installed; the MI355X modes are sttn-auto, sttn-det, lama and propainter")
     if args.subtitle_area_coords is None:
         args.subtitle_area_coords = []
     return args

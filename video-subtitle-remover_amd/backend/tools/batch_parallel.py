@@ -31,15 +31,21 @@ def _serve(process, dist, device):
 
 
 class _Prefetch:
-    """Runs the `items` generator (reader + mask construction) in a thread, at most `max_frames` frames ahead -- the role the
-    reference gives FramePrefetcher (tools/video_io.py:12-47): reading the next round overlaps the current round's compute."""
+    """Runs the `items` generator (reader + mask construction) in a thread, about `max_frames` frames ahead -- the role the
+    reference gives FramePrefetcher (tools/video_io.py:12-47): reading the next round overlaps the current round's compute.
+    The budget is a frame counter under a condition variable; an item is ALWAYS admitted when nothing is queued, whatever its
+    size, so a batch larger than the budget (config.sttnMaxLoadNum / propainterMaxLoadNum go up to 300, the default budget is 256
+    frames) passes alone instead of waiting for room that only its own consumption could make (round 2 took the budget frame by
+    frame from a semaphore before queueing the item: such a batch hung the run -- ADVICE r2)."""
 
     def __init__(self, items, max_frames):
         import queue
         import threading
 
         self.q = queue.Queue()
-        self.room = threading.Semaphore(max(1, int(max_frames)))
+        self.budget = max(1, int(max_frames))
+        self.ahead = 0                           # frames queued and not yet consumed
+        self.cv = threading.Condition()
         self.stop = False
         self.t = threading.Thread(target=self._run, args=(items,), daemon=True)
         self.t.start()
@@ -51,10 +57,13 @@ class _Prefetch:
     def _run(self, items):
         try:
             for item in items:
-                for _ in range(self._cost(item)):
-                    self.room.acquire()
-                if self.stop:
-                    return
+                c = self._cost(item)
+                with self.cv:
+                    while not self.stop and self.ahead > 0 and self.ahead + c > self.budget:
+                        self.cv.wait()
+                    if self.stop:
+                        return
+                    self.ahead += c
                 self.q.put(("item", item))
             self.q.put(("end", None))
         except BaseException as e:          # surfaces in the consumer
@@ -68,13 +77,14 @@ class _Prefetch:
             if kind == "error":
                 raise v
             yield v
-            for _ in range(self._cost(v)):
-                self.room.release()
+            with self.cv:
+                self.ahead -= self._cost(v)
+                self.cv.notify_all()
 
     def close(self):
-        self.stop = True
-        for _ in range(1 << 12):
-            self.room.release()
+        with self.cv:
+            self.stop = True
+            self.cv.notify_all()
 
 
 def run_batch_parallel(items, process, write, dist=None, device="cpu", max_pending=64, prefetch_frames=256):

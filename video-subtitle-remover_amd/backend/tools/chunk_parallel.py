@@ -21,6 +21,13 @@ and of the previous result runs under the compute of the current one -- on the p
 thread meanwhile drains round r-2 to the writer and reads round r+2 into pinned memory.  Device buffers form a ring
 of four rounds (288 GB of HBM: a 50-frame 4K strip chunk is 415 MB).  Only the rows that can change (the strips, see
 STTNAutoInpaint._call_chunk_parallel) travel; rank 0 keeps the decoded frames and patches the rows back in.
+
+Failures (round 3).  The ranks meet in matched exchanges, so a rank that left the loop on an exception would leave the others
+blocked in a grouped send / recv until the communicator times out.  Instead a failing callback (the reader or the sink on rank 0,
+the engine on any rank) is recorded, the rank keeps walking the rounds with its callbacks switched off -- every exchange still
+has its partner, the data is just not meaningful any more -- and after the last round the ranks agree on a status word (one
+all-reduce); every rank then raises: the one that failed its own exception, the others a RuntimeError naming the failed rank.
+Before the first round the ring's device memory (RING x owners x a chunk of rows) is checked against hipMemGetInfo.
 """
 import contextlib
 
@@ -96,7 +103,17 @@ def _exchange(dist, ops):
     return dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops])
 
 
-def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, device="cpu", io="host"):
+class ChunkParallelError(RuntimeError):
+    """another rank failed while this one was fine (its own exception is raised there)"""
+
+
+def ring_bytes(maxn, row_shape, world, rank):
+    """device memory of the row ring on `rank`: RING rounds x (every owner on rank 0, itself elsewhere) x one chunk of rows"""
+    h, W, C = row_shape
+    return RING * (world if rank == 0 else 1) * maxn * h * W * C
+
+
+def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, device="cpu", io="host", workspace_bytes=0):
     """Drive the chunks `ranges` = [(start, end)] of one video over the ranks of `dist` (None = single process).
 
     row_shape = (h, W, C): the rows of a frame that travel.
@@ -105,6 +122,9 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
     process(i, t)     on the owner of chunk i: work in place on the device tensor t uint8 [n,h,W,C]; may return while
                       its kernels are still running on the current stream.
     store(i, arr)     rank 0 only, in chunk order: the processed rows (same kind of array as load's).
+    workspace_bytes   what `process` needs besides the ring (the engine's buffers, if not allocated yet): part of the memory check.
+
+    A callback that raises does not break the lock step (module docstring): all ranks finish the rounds, then all raise.
     """
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
@@ -129,6 +149,25 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
                                                # ranks without a chunk in round 0 post nothing in X[0]
     if maxn == 0:
         return
+    if st.gpu:
+        # the ring must fit beside whatever else lives on this device (several ranks may share one in dry runs): fail with the
+        # numbers instead of an allocator error in the middle of round 0
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        need = ring_bytes(maxn, row_shape, world, rank) + int(workspace_bytes)
+        if need > free_b:
+            raise MemoryError(f"chunk ring on rank {rank}: {need / 2**30:.2f} GiB needed ({RING} rounds x {world if rank == 0 else 1} owners x "
+                              f"{maxn} frames of {h}x{W}x{C} rows + {workspace_bytes / 2**30:.2f} GiB workspace), {free_b / 2**30:.2f} GiB of "
+                              f"{total_b / 2**30:.0f} GiB free")
+    failure = []                              # first exception of a callback on this rank
+
+    def guarded(fn, *a):
+        if failure:
+            return
+        try:
+            fn(*a)
+        except BaseException as e:            # noqa: BLE001 -- recorded, re-raised after the last round
+            failure.append(e)
+
     owners = range(world) if rank == 0 else [rank]
     dbuf = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8, device=dev) for q in range(RING) for k in owners}
     if rank == 0 and host_io and st.gpu:
@@ -144,14 +183,14 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
             n, d = nframes(i), dbuf[(r % RING, k)]
             if not host_io:
                 with st.on("io"):
-                    load(i, d[:n])
+                    guarded(load, i, d[:n])
             elif st.gpu:
                 p = pin_in[(r % RING, k)]
-                load(i, p.numpy()[:n])
+                guarded(load, i, p.numpy()[:n])
                 with st.on("io"):
                     d[:n].copy_(p[:n], non_blocking=True)
             else:
-                load(i, d.numpy()[:n])
+                guarded(load, i, d.numpy()[:n])
         staged[r] = st.event("io")
 
     def drain(r):                              # rank 0: results of round r -> sink, in chunk order
@@ -164,14 +203,14 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
                 st.wait("io", computed.get(r))
             if not host_io:
                 with st.on("io"):
-                    store(i, d[:n])
+                    guarded(store, i, d[:n])
             elif st.gpu:
                 with st.on("io"):
                     pin_out[k][:n].copy_(d[:n], non_blocking=True)
                 st.event("io").synchronize()
-                store(i, pin_out[k].numpy()[:n])
+                guarded(store, i, pin_out[k].numpy()[:n])
             else:
-                store(i, d.numpy()[:n])
+                guarded(store, i, d.numpy()[:n])
 
     def compute(r):
         i = chunk_of(r, rank)
@@ -179,7 +218,7 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
             return
         st.wait("cmp", staged.get(r))
         with st.on("cmp"):
-            process(i, dbuf[(r % RING, rank)][:nframes(i)])
+            guarded(process, i, dbuf[(r % RING, rank)][:nframes(i)])
         computed[r] = st.event("cmp")
 
     def post(e):                               # X[e]: scatter round e, gather round e - 2
@@ -226,6 +265,20 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
         staged.pop(r - RING, None)
         computed.pop(r - RING, None)
     if st.gpu:
-        torch.cuda.synchronize(dev)
+        try:
+            torch.cuda.synchronize(dev)
+        except BaseException as e:            # noqa: BLE001 -- an asynchronous kernel error surfaces here
+            if not failure:
+                failure.append(e)
     if dist is not None:
-        dist.barrier()
+        # agree on the outcome: the lowest failed rank + 1, 0 = everybody fine (all-reduce MAX of -(rank + 1) would do too; MIN
+        # over a large sentinel keeps it one collective).  Also the closing barrier.
+        status = torch.tensor([rank + 1 if failure else 1 << 30], dtype=torch.int64, device=dev if st.gpu else "cpu")
+        dist.all_reduce(status, op=dist.ReduceOp.MIN)
+        bad = int(status.item())
+        if failure:
+            raise failure[0]
+        if bad != 1 << 30:
+            raise ChunkParallelError(f"rank {bad - 1} failed in its chunk callbacks; this rank ({rank}) finished its rounds")
+    elif failure:
+        raise failure[0]

@@ -158,6 +158,17 @@ class PaddleGraphRunner:
         self._tape = None                     # launches being recorded: [(C function, argument tuple)]
         self._tapes = {}                      # input shape -> (tape, static input, output, tensors kept alive)
 
+    def _c(self, t):
+        """t as a contiguous tensor.  While a tape is open an implicit torch copy would be a launch the tape does not hold (and
+        whose result nothing keeps alive): the replay would read stale memory.  No op of the two shipped programs needs one;
+        a program that does is refused instead of replayed wrongly."""
+        if t.is_contiguous():
+            return t
+        if self._tape is not None:
+            raise NotImplementedError("detector tape: an operand is not contiguous -- its copy would not be recorded; "
+                                      "run with VSR_DET_TAPE=0 (op-by-op walk) for this program")
+        return t.contiguous()
+
     def _call(self, fn, *args):
         """one launcher call; recorded when a tape is open"""
         check(fn(*args))
@@ -297,7 +308,7 @@ class PaddleGraphRunner:
         else:
             raise NotImplementedError(f"broadcast {tuple(a.shape)} with {tuple(b.shape)}")
         out = self._new(*a.shape)
-        b = b.contiguous()
+        b = self._c(b)
         if self._tape is not None:
             self._keep.append(b)
         self._call(lib.vsr_det_launch_binary, _p(a), _p(b), op, a.numel(), c, hw, mode, _p(out), self._sa)
@@ -324,7 +335,7 @@ class PaddleGraphRunner:
                     val[outs[0]] = folded[i]
                     continue
                 if kind in ("conv2d", "depthwise_conv2d"):
-                    xin, w = g(0).contiguous(), g(1)
+                    xin, w = self._c(g(0)), g(1)
                     n, cin, h, wd = xin.shape
                     cout, _, kh, kw = w.shape
                     sh, sw = a["strides"]
@@ -346,7 +357,7 @@ class PaddleGraphRunner:
                     self._call(lib.vsr_det_launch_conv2d, _p(xin), _p(w), None, n, cin, h, wd, cout, kh, kw, sh, sw, pt, pl, ho, wo, dw, 0, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "conv2d_transpose":
-                    xin, w = g(0).contiguous(), g(1)
+                    xin, w = self._c(g(0)), g(1)
                     n, cin, h, wd = xin.shape
                     if tuple(w.shape[2:]) != (2, 2) or list(a["strides"]) != [2, 2] or list(a["paddings"]) != [0, 0]:
                         raise NotImplementedError("conv2d_transpose other than 2x2 / stride 2")
@@ -356,7 +367,7 @@ class PaddleGraphRunner:
                     self._call(lib.vsr_det_launch_deconv2x2, _p(xin), _p(w), n, cin, h, wd, cout, dw, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "batch_norm_":
-                    xin = g(0).contiguous()
+                    xin = self._c(g(0))
                     s, t = self.bn[i]
                     out = self._new(*xin.shape)
                     self._call(lib.vsr_det_launch_affine, _p(xin), _p(s), _p(t), xin.numel(), xin.shape[1], xin.shape[2] * xin.shape[3], _p(out), self._sa)
@@ -366,25 +377,25 @@ class PaddleGraphRunner:
                 elif kind == "full":
                     val[outs[0]] = a["value"]
                 elif kind == "reshape":
-                    val[outs[0]] = g(0).reshape(g(1))
+                    val[outs[0]] = self._c(g(0)).reshape(g(1))
                 elif kind == "add":
                     val[outs[0]] = self._binary(g(0), g(1), 0)
                 elif kind == "multiply":
                     val[outs[0]] = self._binary(g(0), g(1), 1)
                 elif kind == "relu":
-                    val[outs[0]] = self._unary(g(0).contiguous(), 0)
+                    val[outs[0]] = self._unary(self._c(g(0)), 0)
                 elif kind == "hardswish":
-                    val[outs[0]] = self._unary(g(0).contiguous(), 1)
+                    val[outs[0]] = self._unary(self._c(g(0)), 1)
                 elif kind == "hardsigmoid":
-                    val[outs[0]] = self._unary(g(0).contiguous(), 2, a["slope"], a["offset"])
+                    val[outs[0]] = self._unary(self._c(g(0)), 2, a["slope"], a["offset"])
                 elif kind == "sigmoid":
-                    val[outs[0]] = self._unary(g(0).contiguous(), 3)
+                    val[outs[0]] = self._unary(self._c(g(0)), 3)
                 elif kind == "scale":
                     s = val[ins[1]] if len(ins) > 1 and ins[1] in val else a.get("scale", 1.0)
                     s, b = float(s), float(a.get("bias", 0.0))
-                    val[outs[0]] = self._unary(g(0).contiguous(), 4, s, b if a.get("bias_after_scale", True) else b * s)
+                    val[outs[0]] = self._unary(self._c(g(0)), 4, s, b if a.get("bias_after_scale", True) else b * s)
                 elif kind == "pool2d":
-                    xin, ks = g(0).contiguous(), g(1)
+                    xin, ks = self._c(g(0)), g(1)
                     n, c, h, wd = xin.shape
                     if a["adaptive"]:
                         if list(ks) != [1, 1] or a["pooling_type"] != "avg":
@@ -406,7 +417,7 @@ class PaddleGraphRunner:
                         self._call(lib.vsr_det_launch_maxpool, _p(xin), n * c, h, wd, ks[0], ks[1], sh, sw, pt, pl, ho, wo, _p(out), self._sa)
                     val[outs[0]] = out
                 elif kind == "nearest_interp":
-                    xin = g(0).contiguous()
+                    xin = self._c(g(0))
                     n, c, h, wd = xin.shape
                     s = int(a["scale"][0])
                     if a["scale"][0] != a["scale"][1] or s != a["scale"][0]:

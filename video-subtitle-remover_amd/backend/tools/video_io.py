@@ -502,6 +502,49 @@ def ffmpeg_path():
     return p if p and os.path.exists(p) else None
 
 
+def probe_stream(probe, path):
+    """(width, height, fps, frames) of the first video stream AS DECODED FRAMES ARRIVE: `ffmpeg -i` applies the display-matrix
+    rotation (phone portrait clips) by default -- and so does cv2.VideoCapture, the reference's reader, which reports the rotated
+    size -- so a quarter-turn rotation swaps width and height here (round 2 took the stored size: every frame of such a clip was
+    reshaped with the sides exchanged, silently).  The frame count falls back from the packet count to nb_frames to duration x rate
+    when the container does not know it (`N/A`)."""
+    import json
+
+    out = subprocess.check_output([probe, "-v", "error", "-select_streams", "v:0", "-count_packets", "-show_entries",
+                                   "stream=width,height,r_frame_rate,avg_frame_rate,nb_read_packets,nb_frames,duration:stream_tags=rotate:"
+                                   "stream_side_data=rotation:format=duration", "-of", "json", path], text=True)
+    doc = json.loads(out)
+    st = doc["streams"][0]
+    w, h = int(st["width"]), int(st["height"])
+    num, den = (st.get("r_frame_rate") or st.get("avg_frame_rate") or "0/1").split("/")
+    fps = float(num) / float(den or 1) if float(den or 1) else 0.0
+    rot = 0.0
+    for sd in st.get("side_data_list", []) or []:
+        if "rotation" in sd:
+            rot = float(sd["rotation"])
+    if not rot and (st.get("tags") or {}).get("rotate") not in (None, ""):
+        rot = float(st["tags"]["rotate"])
+    if int(round(abs(rot))) % 180 == 90:
+        w, h = h, w
+
+    def as_int(v):
+        try:
+            return int(v)
+        except (TypeError, ValueError):
+            return None
+
+    n = as_int(st.get("nb_read_packets"))
+    if n is None:
+        n = as_int(st.get("nb_frames"))
+    if n is None:
+        dur = st.get("duration") or (doc.get("format") or {}).get("duration")
+        try:
+            n = int(round(float(dur) * fps))
+        except (TypeError, ValueError):
+            raise RuntimeError(f"{path}: ffprobe reports neither a packet count, nor nb_frames, nor a duration") from None
+    return w, h, fps, n
+
+
 class FFmpegVideo:
     """`ffmpeg -i path -f rawvideo -pix_fmt bgr24 -` as a frame source; stream facts from `ffprobe` next to the binary."""
 
@@ -511,11 +554,7 @@ class FFmpegVideo:
             raise RuntimeError("no ffmpeg binary")
         probe = os.path.join(os.path.dirname(ff), "ffprobe")
         probe = probe if os.path.exists(probe) else (shutil.which("ffprobe") or "ffprobe")
-        out = subprocess.check_output([probe, "-v", "error", "-select_streams", "v:0", "-count_packets", "-show_entries",
-                                       "stream=width,height,r_frame_rate,nb_read_packets", "-of", "csv=p=0", path], text=True).strip()
-        w, h, rate, n = out.split(",")[:4]
-        num, den = rate.split("/")
-        self.w, self.h, self.fps, self.n = int(w), int(h), float(num) / float(den or 1), int(n)
+        self.w, self.h, self.fps, self.n = probe_stream(probe, path)
         self._p = subprocess.Popen([ff, "-loglevel", "error", "-i", path, "-f", "rawvideo", "-pix_fmt", "bgr24", "-"],
                                    stdout=subprocess.PIPE, stdin=subprocess.DEVNULL, bufsize=1 << 24)
 
@@ -539,35 +578,56 @@ class FFmpegVideo:
 
 
 class FFmpegVideoWriter:
-    """Raw bgr24 frames into `ffmpeg ... -c:v libx264 -crf 18 -preset fast` -- the reference's writer (video_io.py:54-103)."""
+    """Raw bgr24 frames into `ffmpeg ... -c:v libx264 -crf 18 -preset fast` -- the reference's writer (video_io.py:54-103).
+    Unlike the reference's, it does not lose errors: a broken pipe (the encoder died) is remembered and raised by the next write /
+    by release(), and release() raises when ffmpeg exits non-zero, with what it wrote to stderr (a run must not print
+    'written' over a truncated file)."""
 
     def __init__(self, output_path, fps, size):
+        import tempfile
+
         ff = ffmpeg_path()
         if ff is None:
             raise RuntimeError("no ffmpeg binary")
         w, h = size
+        self.output_path = output_path
         cmd = [ff, "-y", "-f", "rawvideo", "-vcodec", "rawvideo", "-s", f"{w}x{h}", "-pix_fmt", "bgr24", "-r", str(fps), "-i", "-",
                "-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", "18", "-preset", "fast", "-loglevel", "error", output_path]
-        self._process = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        self._log = tempfile.TemporaryFile()
+        self._process = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=self._log)
+        self._broken = None
+
+    def _fail(self, why):
+        self._log.seek(0)
+        tail = self._log.read()[-2000:].decode("utf-8", "replace").strip()
+        return RuntimeError(f"ffmpeg writing {self.output_path}: {why}" + (f"\n{tail}" if tail else ""))
 
     def write(self, frame):
+        if self._broken is not None:
+            raise self._fail(f"the encoder is gone ({self._broken})")
         if frame.dtype != np.uint8:
             frame = np.clip(frame, 0, 255).astype(np.uint8)
         try:
             self._process.stdin.write(frame.tobytes())
-        except BrokenPipeError:
-            pass
+        except (BrokenPipeError, OSError) as e:
+            self._broken = e
+            raise self._fail(f"the encoder closed its input ({e})") from e
 
     def release(self):
         try:
             self._process.stdin.close()
-        except BrokenPipeError:
-            pass
+        except (BrokenPipeError, OSError) as e:
+            self._broken = self._broken or e
         try:
             self._process.wait(timeout=600)
         except subprocess.TimeoutExpired:
             self._process.terminate()
             self._process.wait(timeout=5)
+            raise self._fail("no exit within 600 s after the last frame") from None
+        if self._process.returncode != 0:
+            raise self._fail(f"exit code {self._process.returncode}")
+        if self._broken is not None:
+            raise self._fail(f"the encoder closed its input early ({self._broken})")
 
 
 class Cv2Video:
