@@ -396,6 +396,13 @@ int vsr_det_launch_ccl(const float* prob_dev, int H, int W, float thresh, int32_
 int vsr_det_launch_db_boxes(const float* prob_dev, int H, int W, float thresh, int src_h, int src_w, float box_thresh, float unclip_ratio,
                             int min_size, int32_t* labels_dev, int32_t* stats_dev, int32_t* comps_dev, int32_t* count_dev, int32_t* ext_dev,
                             int32_t* out_dev, int cap, void* stream);
+/* HOST helper of the post-process (no device work): border following over a thresholded map -- cv2.findContours(RETR_LIST) as
+ * PaddleX's DBPostProcess calls it (Suzuki & Abe, 8-connected foreground; outer and hole borders in raster order of discovery).
+ * bitmap uint8 [H*W] (non-zero = foreground); points_xy int32 [cap_points][2] receives every border's pixels (x, y) back to
+ * back, border_start int64 [cap_borders] the index of each border's first point.  Returns 0, or -100 when a buffer was too small
+ * (*n_borders / *n_points then hold the sizes needed).  Used for the maps the device path hands back (holes, overflow). */
+int vsr_host_trace_borders(const uint8_t* bitmap, int H, int W, int32_t* points_xy, int64_t cap_points, int64_t* border_start,
+                           int32_t cap_borders, int32_t* n_borders, int64_t* n_points);
 int vsr_det_launch_copy(const void* src_dev, int64_t src_pitch, void* dst_dev, int64_t dst_pitch, int64_t width_bytes, int64_t rows, void* stream);   /* channel concat: one strided block copy per part */
 /* layout changes around the dense convolutions that run as gather-GEMMs (vsr_gemm_plan_*): one NCHW image -> zero-padded NHWC
  * [Hp][Wp][Cp] (image origin at (pt, pl), Cp a multiple of 32), and GEMM output [P pixels][Np] -> NCHW [C][P] with an optional

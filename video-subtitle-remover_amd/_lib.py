@@ -135,6 +135,7 @@ SIGNATURES = {
     "vsr_det_launch_nearest": (_I, [_P, _L, _I, _I, _I, _P, _P]),
     "vsr_det_launch_normalize": (_I, [_P, _I, _I, _P, _P]),
     "vsr_det_launch_copy": (_I, [_P, _L, _P, _L, _L, _L, _P]),
+    "vsr_host_trace_borders": (_I, [_P, _I, _I, _P, _L, _P, _I, _P, _P]),
     "vsr_det_launch_ccl": (_I, [_P, _I, _I, C.c_float, _P, _P, _P, _I, _P, _P]),
     "vsr_det_launch_db_boxes": (_I, [_P, _I, _I, C.c_float, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "vsr_det_launch_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

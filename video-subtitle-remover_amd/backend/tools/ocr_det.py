@@ -508,58 +508,28 @@ def _order_box(c):
     return np.array([p[a], p[b], p[e], p[d]], dtype=np.float32)
 
 
-_RING = np.array([(0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1)])      # (dy, dx), counter-clockwise from east
-
-
 def trace_borders(bitmap):
     """cv2.findContours(bitmap, RETR_LIST, ...): every border of the 8-connected foreground by border following (Suzuki & Abe),
     outer and hole borders alike, in cv2's order (the border found last by the raster scan comes first) -> list of int [n,2] (x, y).
-    Straight runs keep their interior points (CHAIN_APPROX_SIMPLE would drop them; the rectangle fit only sees the hull)."""
-    H, W = bitmap.shape
-    g = np.zeros((H + 2, W + 2), np.int32)
-    g[1:-1, 1:-1] = bitmap
-    flat = g.reshape(-1)
-    Wp = W + 2
-    step = (_RING[:, 0] * Wp + _RING[:, 1]).tolist()
-    starts = np.flatnonzero((flat != 0) & ((np.roll(flat, 1) == 0) | (np.roll(flat, -1) == 0))).tolist()
-    mark, out = 1, []
-    for p0 in starts:
-        v = flat[p0]
-        if v == 1 and flat[p0 - 1] == 0:
-            d = 4
-        elif v >= 1 and flat[p0 + 1] == 0:
-            d = 0
-        else:
+    Straight runs keep their interior points (CHAIN_APPROX_SIMPLE would drop them; the rectangle fit only sees the hull).
+    The walk itself is vsr_host_trace_borders (csrc/det_host.cpp): host code, like the reference's, a millisecond per map."""
+    bm = np.ascontiguousarray(bitmap, dtype=np.uint8)
+    H, W = bm.shape
+    cap_p, cap_b = max(4096, 2 * int(bm.sum()) + 16), max(1024, int(bm.sum()) + 16)
+    while True:
+        pts = np.empty((cap_p, 2), np.int32)
+        start = np.empty(cap_b + 1, np.int64)
+        nb, npts = C.c_int32(0), C.c_int64(0)
+        rc = lib.vsr_host_trace_borders(bm.ctypes.data_as(C.c_void_p), H, W, pts.ctypes.data_as(C.c_void_p), cap_p, start.ctypes.data_as(C.c_void_p),
+                                        cap_b, C.byref(nb), C.byref(npts))
+        if rc == -100:                                                  # a border can pass a pixel more than twice: grow and repeat
+            cap_p, cap_b = max(cap_p, int(npts.value)), max(cap_b, int(nb.value))
             continue
-        mark += 1
-        k = 0
-        while k < 8 and flat[p0 + step[(d - k) % 8]] == 0:              # clockwise from the background neighbour
-            k += 1
-        if k == 8:
-            flat[p0] = -mark
-            out.append(np.array([[p0 % Wp - 1, p0 // Wp - 1]], np.int32))
-            continue
-        p1 = p0 + step[(d - k) % 8]
-        prev, cur, pts = p1, p0, []
-        while True:
-            d0 = step.index(prev - cur)
-            east_bg = False
-            for k in range(1, 9):                                       # counter-clockwise, after the pixel we came from
-                dd = (d0 + k) % 8
-                nxt = cur + step[dd]
-                if flat[nxt] != 0:
-                    break
-                east_bg = east_bg or dd == 0
-            if east_bg:
-                flat[cur] = -mark
-            elif flat[cur] == 1:
-                flat[cur] = mark
-            pts.append((cur % Wp - 1, cur // Wp - 1))
-            if nxt == p0 and cur == p1:
-                break
-            prev, cur = cur, nxt
-        out.append(np.array(pts, np.int32))
-    return out[::-1]
+        check(rc)
+        break
+    n = int(nb.value)
+    start[n] = int(npts.value)
+    return [pts[start[k]:start[k + 1]] for k in range(n - 1, -1, -1)]
 
 
 def _line_mask(xx, yy, x0, y0, x1, y1):
@@ -669,6 +639,11 @@ def offset_polygon_round(path, delta):
 def box_from_border(border, prob_of, H, W, src_h, src_w, box_thresh, unclip_ratio, min_size):
     """one iteration of DBPostProcess.boxes_from_bitmap: border points int [n,2] (x, y); prob_of(ya, yb, xa, xb) -> probability crop.
     -> (box int16 [4,2] in source pixels, score) or None"""
+    # a rectangle fit costs a hull; specks are the bulk of a noisy map: the fitted rectangle is never larger in area than the
+    # axis-aligned bounding box, so its short side is at most sqrt(box area)
+    ext = border.max(0) - border.min(0)
+    if float(ext[0]) * float(ext[1]) < float(min_size) * float(min_size):
+        return None
     corners, w, h = min_area_rect(border)
     if min(w, h) < min_size:
         return None
