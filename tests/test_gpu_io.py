@@ -166,3 +166,93 @@ def test_bt601_colour_bars_on_the_device(built_lib, gpu_device, tmp_path, monkey
         assert (int(rec[0, 0, 4 * i]), int(rec[1, 0, 4 * i]), int(rec[2, 0, 4 * i])) == (y, cb, cr)
     back = _read_all(p)[0]
     assert np.abs(back.astype(int) - frame.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("mode", ["sttn-det", "lama", "propainter"])
+def test_resident_detector_modes_write_the_same_file(built_lib, gpu_device, tmp_path, monkeypatch, mode):
+    """*.y4m in -> SubtitleRemover.run() in a detector-driven mode -> *.y4m out (round 3, tools/resident.py): with the decoded video
+    resident in HBM -- planes up once, the detector sampling its frames from the device tensor, the scene-cut kernels reading it, the
+    plugin working in place on slices, planes down once -- the written file is byte for byte the one the host-frame loop writes.
+    The subtitle is on screen in two intervals with a gap (pass-through frames), the second one ends with the clip."""
+    from vsr_amd import synth
+    from vsr_amd.backend.config import config
+    from vsr_amd.backend.main import SubtitleRemover
+    from vsr_amd.backend.tools.constant import InpaintMode
+
+    # (RAFT wants strips of at least 128 rows: the propainter case runs on a larger frame)
+    H, W, N = (480, 852, 34) if mode == "propainter" else (240, 432, 34)
+    box = (400, 450, 100, 760) if mode == "propainter" else (180, 214, 60, 380)        # ymin, ymax, xmin, xmax
+    clip = synth.make_clip(N, H, W, box, seed=5)
+    on = [i for i in range(N) if 3 <= i < 15 or i >= 22]
+    plain = synth.make_clip(N, H, W, (0, 1, 0, 1), seed=5)
+    for i in range(N):
+        if i not in on:
+            clip[i] = plain[i]
+    src = str(tmp_path / "in.y4m")
+    monkeypatch.setenv("VSR_IO_COLOR", "host")
+    w = video_io.Y4mWriter(src, 25.0, (W, H), chroma="420")
+    for f in clip:
+        w.write(f)
+    w.release()
+    quad = np.array([[[box[2], box[0]], [box[3], box[0]], [box[3], box[1]], [box[2], box[1]]]])
+
+    class Det:                                             # the reference's host signature; sees device-decoded or host-decoded frames alike
+        batch_size = 4
+
+        def __init__(self):
+            self.calls = 0
+
+        def predict(self, img):
+            self.calls += 1
+            white = (img[box[0] + 8:box[1] - 8, box[2] + 8:box[3] - 8] > 200).mean()
+            return [{"dt_polys": quad if white > 0.05 else np.zeros((0, 4, 2), np.int32)}]
+
+    if mode == "sttn-det":
+        from vsr_amd.backend.inpaint.sttn_det_inpaint import STTNDetInpaint
+        plugin = STTNDetInpaint("cuda:0", {"netG": synth.make_state_dict(0, "det")})
+    elif mode == "lama":
+        from vsr_amd.backend.inpaint.lama_inpaint import LamaInpaint
+        plugin = LamaInpaint("cuda:0", synth.make_lama_state_dict(3, 2))
+    else:
+        from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+        plugin = PropainterInpaint("cuda:0", {"raft": synth.make_raft_state_dict(0), "rfc": synth.make_rfc_state_dict(0),
+                                              "propainter": synth.make_propainter_state_dict(0)})
+        plugin.raft_iter = 4
+    keys = {"sttnMaxLoadNum": 8, "propainterMaxLoadNum": 8}
+    old = {k: getattr(config, k).value for k in keys}
+    old_mode = config.inpaintMode.value
+    outs, phases = {}, {}
+    try:
+        for k, v in keys.items():
+            getattr(config, k).value = v
+        config.inpaintMode.value = {"sttn-det": InpaintMode.STTN_DET, "lama": InpaintMode.LAMA, "propainter": InpaintMode.PROPAINTER}[mode]
+        for how, color, resident in (("host", "host", "0"), ("resident", "device", "1")):
+            monkeypatch.setenv("VSR_IO_COLOR", color)
+            monkeypatch.setenv("VSR_IO_RESIDENT", resident)
+            sr = SubtitleRemover(src, device="cuda:0")
+            sr.sub_areas = [(0, H, 0, W)]
+            det = Det()
+            sr.video_out_path = str(tmp_path / f"out_{how}.y4m")
+            ticks = []
+            sr.update_progress = lambda tbar, increment: ticks.append(increment)
+            if mode == "propainter":
+                sr.propainter_mode(object(), propainter_inpaint=plugin, text_detector=det, single_frame_inpaint=None)
+            else:
+                sr.video_inpaint(object(), plugin, text_detector=det)
+            sr.video_writer.release()
+            outs[how] = open(sr.video_out_path, "rb").read()
+            phases[how] = dict(sr.phase_seconds)
+            assert sum(ticks) == N and det.calls >= N // 3
+    finally:
+        for k, v in old.items():
+            getattr(config, k).value = v
+        config.inpaintMode.value = old_mode
+        if hasattr(plugin, "close"):
+            plugin.close()
+    assert "read + upload + YUV->BGR" in phases["resident"] and "read + upload + YUV->BGR" not in phases["host"]
+    assert outs["host"] == outs["resident"], "the HBM-resident loop must write the host loop's file"
+    monkeypatch.setenv("VSR_IO_COLOR", "host")
+    got, want = _read_all(str(tmp_path / "out_resident.y4m")), _read_all(src)
+    assert got.shape == want.shape
+    changed = (got != want).any(axis=(1, 2, 3))
+    assert changed[on].mean() > 0.7        # (the timeline expansion / interval merging of main.py decide about the frames around)

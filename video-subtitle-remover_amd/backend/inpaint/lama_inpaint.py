@@ -76,10 +76,11 @@ class LamaInpaint:
         H_ori, W_ori = mask.shape[:2]
         split_h = int(W_ori * 3 / 16)
         inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask)
+        resident = isinstance(input_frames, torch.Tensor)       # a uint8 [n,H,W,3] device tensor (tools/resident.py): in place
         if not inpaint_area or len(input_frames) == 0:
-            return [f.copy() for f in input_frames]
+            return input_frames if resident else [f.copy() for f in input_frames]
         dev = self.engine.device
-        frames = torch.from_numpy(np.ascontiguousarray(np.stack(input_frames))).to(dev)
+        frames = input_frames if resident else torch.from_numpy(np.ascontiguousarray(np.stack(input_frames))).to(dev)
         dmask = torch.from_numpy(np.ascontiguousarray(input_mask)).to(dev)
         n = frames.shape[0]
         # The reference crops every strip from the ORIGINAL frames, runs them all, and only then writes them back in order
@@ -96,5 +97,7 @@ class LamaInpaint:
             for s in range(0, n, self.mini_batch_size):
                 e = min(s + self.mini_batch_size, n)
                 self.engine.inpaint(source[s:e, y0:y1], strip_mask, out=frames[s:e, y0:y1])
+        if resident:
+            return frames
         out = frames.cpu().numpy()
         return [out[i] for i in range(n)]

@@ -97,7 +97,8 @@ class PropainterInpaint:
         _blend_window); one download at the end."""
         n = len(frames)
         dev = self.dev
-        bgr = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in frames]))).to(dev)      # [n,h,w,3] BGR
+        resident = isinstance(frames, torch.Tensor)             # a contiguous uint8 [n,h,w,3] device tensor: a device tensor comes back
+        bgr = frames if resident else torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in frames]))).to(dev)      # [n,h,w,3] BGR
         h, w = int(bgr.shape[1]), int(bgr.shape[2])
         fm, md = read_mask(mask, n, self.mask_dilation, self.mask_dilation)
         fm1, md1 = torch.from_numpy(fm).to(dev).contiguous(), torch.from_numpy(md).to(dev).contiguous()      # uint8 [h,w]
@@ -161,6 +162,8 @@ class PropainterInpaint:
                 check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), stream()))
                 for i in nb:
                     visited[i] = True
+            if resident:
+                return comp
             out = comp.cpu().numpy()                                                        # already BGR (:360)
         return [out[i] for i in range(n)]
 
@@ -169,6 +172,13 @@ class PropainterInpaint:
         H_ori, W_ori = mask.shape[:2]
         split_h = int(W_ori * 3 / 16)
         inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask, multiple=8)
+        if isinstance(input_frames, torch.Tensor):
+            # the HBM-resident loop (tools/resident.py): a uint8 [n,H,W,3] device tensor, inpainted in place.  As in the list form
+            # every strip is cut from the frames as they came in and written back afterwards
+            comps = [self.inpaint(input_frames[:, y0:y1, x0:x1].contiguous(), mask[y0:y1, x0:x1, :]) for y0, y1, x0, x1 in inpaint_area]
+            for (y0, y1, x0, x1), comp in zip(inpaint_area, comps):
+                input_frames[:, y0:y1, x0:x1] = comp
+            return input_frames
         frames_hr = [f.copy() for f in input_frames]
         if not inpaint_area:
             return frames_hr

@@ -27,10 +27,18 @@ class STTNDetInpaint:
         self.model_input_width, self.model_input_height = 432, 240
 
     def __call__(self, input_frames, input_mask):
+        """input_frames: the reference's list of HxWx3 uint8 BGR arrays (fresh arrays come back), or -- the HBM-resident loop of
+        main.SubtitleRemover, tools/resident.py -- a contiguous uint8 [n,H,W,3] device tensor, which is inpainted IN PLACE and
+        returned."""
         mask = input_mask[:, :, None]
         H_ori, W_ori = mask.shape[:2]
         split_h = int(H_ori * 5 / 9) if H_ori > W_ori else int(W_ori * 5 / 18)
         inpaint_area = get_inpaint_area_by_mask(W_ori, H_ori, split_h, mask)
+        if isinstance(input_frames, torch.Tensor):
+            if inpaint_area and input_frames.shape[0]:
+                dmask = torch.from_numpy(np.ascontiguousarray(input_mask)).to(input_frames.device, non_blocking=True)
+                self.engine.det_batch(input_frames, dmask, inpaint_area)
+            return input_frames
         if not inpaint_area or len(input_frames) == 0:
             return [f.copy() for f in input_frames]
         dev = self.engine.device

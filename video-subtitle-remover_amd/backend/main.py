@@ -14,6 +14,8 @@ import sys
 import time
 from pathlib import Path
 
+import numpy as np
+
 from .config import config
 from .inpaint.sttn_auto_inpaint import STTNAutoInpaint
 from .tools.args_handler import parse_args
@@ -59,6 +61,7 @@ class SubtitleRemover:
             "STTN_AUTO_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "sttn-auto", "infer_model.pth"))
         self.progress_total = 0
         self.isFinished = False
+        self.phase_seconds = {}
 
     @property
     def video_writer(self):
@@ -129,6 +132,37 @@ class SubtitleRemover:
 
         run_batch_parallel(items, process, write, dist=self._distributed(), device=self.device if self._distributed() else "cpu")
 
+    def _open_resident(self):
+        """(ResidentClip, writer planes format) when this run can keep the decoded video in HBM (tools/resident.py: raw planar source
+        and sink, one process, the clip fits), else None: the host-frame loop then runs as before."""
+        from .tools.resident import ResidentClip
+
+        if self._distributed() is not None or getattr(self, "gui_mode", False) or not self.is_path:
+            return None
+        reader = open_video(self.video_path)
+        try:
+            fmts = ResidentClip.formats(reader, self.video_writer)
+            info = reader.info()
+            if fmts is None or not ResidentClip.fits(info["len"], info["H_ori"], info["W_ori"]):
+                return None
+            t0 = time.time()
+            clip = ResidentClip.load(reader, fmts[0], info["len"], info["H_ori"], info["W_ori"], self.device)
+            self.phase_seconds["read + upload + YUV->BGR"] = time.time() - t0
+            return clip, fmts[1]
+        finally:
+            reader.release()
+
+    def _timed(self, name, fn, *a, **kw):
+        """phase timer of run(): detector pass / scene cuts / inpainting / writing, reported by main() and scripts/bench_e2e.py"""
+        import torch
+
+        t0 = time.time()
+        r = fn(*a, **kw)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.phase_seconds[name] = self.phase_seconds.get(name, 0.0) + time.time() - t0
+        return r
+
     def propainter_mode(self, tbar, propainter_inpaint=None, text_detector=None, scene_div_points=None, single_frame_inpaint=None):
         """backend/main.py:159-245.  Intervals of frames with the same mask, cut at scene changes, are read whole and
         handed to the plugin in batch_generator batches of propainterMaxLoadNum.  The scene-change frame numbers come
@@ -147,15 +181,53 @@ class SubtitleRemover:
             lama = self.lama_inpaint
             single_frame_inpaint = lama.inpaint if lama is not None else None
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
-        sub_list = detector.find_subtitle_frame_no(sub_remover=self)
+        resident = self._open_resident()
+        clip = resident[0] if resident is not None else None
+        sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self, clip=clip)
         if len(sub_list) == 0:
             self._run_items(tbar, (), propainter_inpaint)                  # releases the peers before failing
             raise Exception(f"No subtitle detected in {self.video_path}")
         ranges = detector.find_continuous_ranges_with_same_mask(sub_list)
         if scene_div_points is None:                 # main.py:165: self.sub_detector.get_scene_div_frame_no(self.video_path)
             dev = self.device
-            scene_div_points = detector.get_scene_div_frame_no(self.video_path, device=int(dev.split(":")[1]) if isinstance(dev, str) and ":" in dev else 0)
+            scene_div_points = self._timed("scene cuts", detector.get_scene_div_frame_no, self.video_path,
+                                           device=int(dev.split(":")[1]) if isinstance(dev, str) and ":" in dev else 0, clip=clip)
         ranges = detector.split_range_by_scene(ranges, list(scene_div_points))
+        if resident is not None:
+            # the same walk over frame numbers as items() below, on the clip in HBM: batches are slices inpainted in place
+            import torch
+
+            clip, wf = resident
+            n, index = len(clip), 0
+
+            def inpaint_all():
+                nonlocal index
+                while index < n:
+                    index += 1
+                    if index not in sub_list or not self.is_current_frame_no_start(index, ranges):
+                        continue
+                    start_frame_no = index
+                    end_frame_no = self.find_frame_no_end(index, ranges)
+                    if end_frame_no == -1:
+                        continue
+                    index = min(end_frame_no, n)
+                    nos = list(range(start_frame_no - 1, index))                          # 0-based indices of the interval
+                    mask = create_mask(self.mask_size, sub_list[start_frame_no])
+                    for batch in ([nos] if len(nos) == 1 else batch_generator(nos, config.propainterMaxLoadNum.value)):
+                        if len(batch) == 1:
+                            if single_frame_inpaint is None:
+                                self.passed_through_single_frames += 1
+                                if self.passed_through_single_frames == 1:
+                                    self.append_output("warning: no LaMa weights configured (LAMA_MODEL_PATH): isolated subtitle frames pass through")
+                            else:                                                          # main.py:217-224: LamaInpaint.inpaint on the whole frame
+                                one = single_frame_inpaint(clip.frames[batch[0]].cpu().numpy(), mask)
+                                clip.frames[batch[0]].copy_(torch.from_numpy(np.ascontiguousarray(one)))
+                        else:
+                            propainter_inpaint(clip.frames[batch[0]:batch[-1] + 1], mask)
+
+            self._timed("inpainting", inpaint_all)
+            self._timed("BGR->YUV + download + write", clip.store, self.video_writer, wf, 0, n, lambda: self.update_progress(tbar, increment=1))
+            return
         reader = open_video(self.video_path)
 
         def items():
@@ -204,7 +276,8 @@ class SubtitleRemover:
         if dist is not None and dist.get_rank() != 0:
             return self._run_items(tbar, (), model)
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
-        sub_list = detector.find_subtitle_frame_no(sub_remover=self)
+        resident = self._open_resident()
+        sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self, clip=resident[0] if resident is not None else None)
         if len(sub_list) == 0:
             self._run_items(tbar, (), model)
             raise Exception(f"No subtitle detected in {self.video_path}")
@@ -213,6 +286,39 @@ class SubtitleRemover:
                                      config.subtitleTimelineForwardFrameCount.value)
         ranges = detector.filter_and_merge_intervals(ranges, config.sttnReferenceLength.value)
         start_end = {s: min(e, self.frame_count) for s, e in ranges}
+
+        def interval_mask(first, last):
+            coords = []
+            for no in range(first, last):                          # NB: the reference's range excludes `last` (:310)
+                for area in sub_list.get(no, []):
+                    xmin, xmax, ymin, ymax = area
+                    if (ymax - ymin) - (xmax - xmin) > config.subtitleYXAxisDifferencePixel.value:
+                        continue                                   # taller than wide: treated as a false detection
+                    if area not in coords:
+                        coords.append(area)
+            return create_mask(self.mask_size, coords)
+
+        if resident is not None:
+            # the same walk over frame numbers as items() below, on the clip in HBM: a batch is a slice, inpainted in place
+            clip, wf = resident
+            n = len(clip)
+
+            def inpaint_all():
+                idx = 0
+                while idx < n:
+                    idx += 1
+                    if idx not in start_end:
+                        continue
+                    first, last = idx, start_end[idx]
+                    idx = min(last, n)                             # frames first .. idx are read (:300-305)
+                    mask = interval_mask(first, last)
+                    for batch in batch_generator(list(range(first - 1, idx)), config.getSttnMaxLoadNum()):
+                        if len(batch) >= 1:
+                            model(clip.frames[batch[0]:batch[-1] + 1], mask)
+
+            self._timed("inpainting", inpaint_all)
+            self._timed("BGR->YUV + download + write", clip.store, self.video_writer, wf, 0, n, lambda: self.update_progress(tbar, increment=1))
+            return
         reader = open_video(self.video_path)
 
         def items():
@@ -233,21 +339,13 @@ class SubtitleRemover:
                         break
                     idx += 1
                     frames.append(frame)
-                coords = []
-                for no in range(first, last):                      # NB: the reference's range excludes `last` (:310)
-                    for area in sub_list.get(no, []):
-                        xmin, xmax, ymin, ymax = area
-                        if (ymax - ymin) - (xmax - xmin) > config.subtitleYXAxisDifferencePixel.value:
-                            continue                               # taller than wide: treated as a false detection
-                        if area not in coords:
-                            coords.append(area)
-                mask = create_mask(self.mask_size, coords)
+                mask = interval_mask(first, last)
                 for batch in batch_generator(frames, config.getSttnMaxLoadNum()):
                     if len(batch) >= 1:
                         yield ("work", batch, mask)
 
         try:
-            self._run_items(tbar, items(), model)
+            self._timed("read + inpainting + write (host frames)", self._run_items, tbar, items(), model)
         finally:
             reader.release()
 

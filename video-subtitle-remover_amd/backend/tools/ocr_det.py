@@ -842,6 +842,31 @@ class TextDetection:
             prob = self.runner.run_taped(x) if self.use_tape else self.runner.run(x)
         return prob[:, 0]
 
+    def probability_maps_device(self, frames_dev):
+        """probability_maps for frames that already live in HBM (uint8 [n,H,W,3] BGR device tensor, tools/resident.py): no upload"""
+        n, H, W, _ = frames_dev.shape
+        rh, rw = det_resize_shape(H, W, self.resize_long, self.limit_type)
+        with torch.cuda.device(self.device):
+            d = frames_dev.contiguous()
+            x = torch.empty((n, 3, rh, rw), dtype=torch.float32, device=self.device)
+            for b in range(n):
+                small = self._resize(d[b], H, W, rh, rw)
+                check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x[b]), _stream()))
+            prob = self.runner.run_taped(x) if self.use_tape else self.runner.run(x)
+        return prob[:, 0]
+
+    def predict_batch_device(self, frames_dev):
+        """predict_batch on device frames: the same dicts"""
+        if frames_dev.shape[0] == 0:
+            return []
+        prob = self.probability_maps_device(frames_dev)
+        H, W = int(frames_dev.shape[1]), int(frames_dev.shape[2])
+        out = []
+        for b in range(frames_dev.shape[0]):
+            boxes, scores = self._post(prob[b], H, W)
+            out.append({"dt_polys": boxes, "dt_scores": scores})
+        return out
+
     def predict_batch(self, imgs):
         """[predict(img)[0] for img in imgs] with one forward for all frames (independent per frame: same results)"""
         if len(imgs) == 0:

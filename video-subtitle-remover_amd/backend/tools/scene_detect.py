@@ -124,10 +124,24 @@ class ContentDetector:
         return cuts
 
 
-def get_scene_div_frame_no(video, device=0, detector=None):
+def get_scene_div_frame_no(video, device=0, detector=None, clip=None):
     """SubtitleDetect.get_scene_div_frame_no (subtitle_detect.py:158-170): `start.frame_num + 1` of every detected scene that
-    does not start at frame 0.  `video`: a path or frame source accepted by video_io.open_video."""
+    does not start at frame 0.  `video`: a path or frame source accepted by video_io.open_video; clip: the same video resident in
+    HBM (tools/resident.ResidentClip) -- the kernels then read it where it is, no third decoding pass."""
     det = detector if detector is not None else ContentDetector(device=device)
+    if clip is not None:
+        n, H, W, _ = clip.frames.shape
+        npix = None
+        out, have_prev = [], False
+        with torch.cuda.device(det.device):
+            _, w, h = det._buffers(H, W)[:3]
+            for s in range(0, n, det.batch_frames):
+                sums = det.device_batch(clip.frames[s:s + det.batch_frames], have_prev)
+                if sums.shape[0]:
+                    out.append(sums.cpu().numpy().copy())
+                have_prev = True
+        sums = np.concatenate(out) if out else np.zeros((0, 3), np.int64)
+        return [c + 1 for c in det.process(sums, h * w)]
     reader = open_video(video)
     info = reader.info()
 

@@ -52,8 +52,12 @@ class SubtitleDetect:
                         break
         return kept
 
-    def find_subtitle_frame_no(self, sub_remover=None):
-        """:84-132 -- {frame_no (1-based): [boxes]}: detect every SAMPLE_STEP-th frame, fill gaps <= 2 steps, unify."""
+    def find_subtitle_frame_no(self, sub_remover=None, clip=None):
+        """:84-132 -- {frame_no (1-based): [boxes]}: detect every SAMPLE_STEP-th frame, fill gaps <= 2 steps, unify.
+        clip: the decoded video resident in HBM (tools/resident.ResidentClip): the sampled frames are taken from it instead of a
+        second decoding pass over the file."""
+        if clip is not None:
+            return self._find_resident(sub_remover, clip)
         reader = open_video(self.video_path)
         sampled = {}
         frame_no = 0
@@ -90,6 +94,30 @@ class SubtitleDetect:
                     flush()
         flush()
         reader.release()
+        return self.fill_and_unify(sampled)
+
+    def _find_resident(self, sub_remover, clip):
+        if self.text_detector is None:
+            raise RuntimeError("no text detector configured (PP-OCRv5 weights are not part of the reference mount)")
+        import torch
+
+        ab = sub_remover.ab_sections if sub_remover is not None else None
+        nos = [no for no in range(1, len(clip) + 1)
+               if is_frame_number_in_ab_sections(no - 1, ab) and ((no - 1) % self.SAMPLE_STEP == 0 or self.SAMPLE_STEP <= 1)]
+        batch = max(1, getattr(self.text_detector, "batch_size", 1))
+        on_device = hasattr(self.text_detector, "predict_batch_device")
+        sampled = {}
+        for s in range(0, len(nos), batch):
+            part = nos[s:s + batch]
+            idx = torch.tensor([no - 1 for no in part], dtype=torch.int64, device=clip.frames.device)
+            if on_device:
+                results = [[r] for r in self.text_detector.predict_batch_device(clip.frames[idx])]
+            else:                                     # an injected detector with the reference's host signature
+                results = [self.text_detector.predict(f) for f in clip.frames[idx].cpu().numpy()]
+            for no, res in zip(part, results):
+                boxes = self._keep_inside(res)
+                if len(boxes) > 0:
+                    sampled[no] = boxes
         return self.fill_and_unify(sampled)
 
     def fill_and_unify(self, sampled):
@@ -154,12 +182,12 @@ class SubtitleDetect:
         return ranges
 
     @staticmethod
-    def get_scene_div_frame_no(v_path, device=0):
+    def get_scene_div_frame_no(v_path, device=0, clip=None):
         """subtitle_detect.py:158-170 -- frame numbers (1-based) where a new scene starts; the ContentDetector pass runs on the GPU
-        (tools/scene_detect.py)"""
+        (tools/scene_detect.py), on the HBM-resident clip when there is one"""
         from . import scene_detect
 
-        return scene_detect.get_scene_div_frame_no(v_path, device=device)
+        return scene_detect.get_scene_div_frame_no(v_path, device=device, clip=clip)
 
     @staticmethod
     def split_range_by_scene(intervals, points):
