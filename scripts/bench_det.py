@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vsr_amd  # noqa: E402,F401
-from oracle.ppocr_det import synthetic_weights  # noqa: E402
+from vsr_amd.synth import make_det_weights as synthetic_weights  # noqa: E402
 from vsr_amd.backend.tools import ocr_det  # noqa: E402
 from vsr_amd.backend.tools.paddle_graph import load_graph  # noqa: E402
 

@@ -447,3 +447,29 @@ def make_lama_state_dict(seed=0, n_blocks=18):
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
     return sd
+
+
+def make_det_weights(graph, seed=0):
+    """Stand-in for the text detector's weights (inference.pdiparams is a missing blob): {parameter name: fp32 array} for every
+    parameter of a loaded PIR program (tools/paddle_graph.load_graph), fan-in scaled convolutions, positive BatchNorm variances.
+    Good for timing and plumbing; the parity tests use oracle/ppocr_det.synthetic_weights, which also calibrates the activations."""
+    rng = np.random.default_rng(seed + 2718)
+    role = {}
+    for kind, ins, _, _ in graph.ops:
+        if kind == "batch_norm_":
+            role[ins[1]], role[ins[2]], role[ins[3]], role[ins[4]] = "mean", "var", "scale", "shift"
+        elif kind in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
+            role[ins[1]] = "weight"
+    out = {}
+    for vid, (name, shape) in graph.params.items():
+        r = role.get(vid, "bias" if len(shape) == 1 else "weight")
+        if r == "weight" and len(shape) == 4:
+            v = rng.standard_normal(shape) * (1.0 / np.sqrt(int(np.prod(shape[1:]))))
+        elif r == "var":
+            v = rng.uniform(0.5, 1.5, shape)
+        elif r == "scale":
+            v = rng.uniform(0.7, 1.3, shape)
+        else:
+            v = rng.normal(0, 0.1, shape)
+        out[name] = np.asarray(v, dtype=np.float32)
+    return out
