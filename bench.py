@@ -100,52 +100,77 @@ def cpu_baseline(sd, clip, mask01, areas):
     return np.stack(ref), dt, net["s"], threads, tried
 
 
-def _parallel_worker(idx, threads, L, start_evt, ready_q, done_q):
-    """one host process of cpu_baseline_parallel: its own chunk (the network part, STTNInpaint.inpaint over L model-resolution
-    frames) on `threads` torch threads"""
-    torch.set_num_threads(threads)
-    import vsr_amd  # noqa: F401
-    from oracle.sttn_auto import STTNInpaintOracle
-    from vsr_amd.synth import make_state_dict
+_PARALLEL_WORKER = r"""
+import importlib.util, os, sys, time
+idx, threads, L, root = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+try:                                        # one group of host threads per process
+    ncpu = os.cpu_count() or 1
+    os.sched_setaffinity(0, {c % ncpu for c in range(idx * threads, (idx + 1) * threads)})
+except (AttributeError, OSError):
+    pass
+import numpy as np
+import torch
+torch.set_num_threads(threads)
+sys.path.insert(0, root)
+spec = importlib.util.spec_from_file_location("vsr_synth", os.path.join(root, "video-subtitle-remover_amd", "synth.py"))
+synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)      # the synthetic checkpoint only: no HIP library in this process
+from oracle.sttn_auto import STTNInpaintOracle
+o = STTNInpaintOracle(synth.make_state_dict(0, "auto"), "auto")
+frames = list(np.random.default_rng(100 + idx).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8))
+o.inpaint(frames[:2])
+print("READY", flush=True)
+sys.stdin.readline()
+t0 = time.perf_counter()
+o.inpaint(frames)
+print("DONE %.3f" % (time.perf_counter() - t0), flush=True)
+"""
 
-    o = STTNInpaintOracle(make_state_dict(0, "auto"), "auto")
-    frames = list(np.random.default_rng(100 + idx).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8))
-    o.inpaint(frames[:2])                                   # warm: allocator, oneDNN primitives
-    ready_q.put(idx)
-    start_evt.wait()
-    t0 = time.perf_counter()
-    o.inpaint(frames)
-    done_q.put((idx, time.perf_counter() - t0))
 
-
-def cpu_baseline_parallel(L, threads, budget_s=240.0):
+def cpu_baseline_parallel(L, threads, budget_s=170.0):
     """The honest 'host cores of the same box' figure: chunks share no state (sttn_auto_inpaint.py:242-328), so the CPU
-    path scales by running one chunk per group of cores.  cpu_count // threads processes, each the network part of one full chunk
-    on `threads` torch threads, started together; aggregate frames/s = processes x L / wall.  None when the box is too small."""
-    import multiprocessing as mp
+    path scales by running one chunk per group of cores.  cpu_count // threads plain Python processes (no GPU library loaded, pinned
+    to their own `threads` hardware threads), each the network part of one full chunk, started together; aggregate frames/s =
+    processes x L / wall.  None when the box is too small; never fails the bench line (a timeout is reported as such)."""
+    import subprocess
 
     ncpu = os.cpu_count() or 1
     nproc = max(1, ncpu // max(threads, 1))
     if nproc < 2:
         return None
-    ctx = mp.get_context("spawn")
-    start_evt, ready_q, done_q = ctx.Event(), ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_parallel_worker, args=(i, threads, L, start_evt, ready_q, done_q), daemon=True) for i in range(nproc)]
-    for p in procs:
-        p.start()
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+               CUDA_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, "-c", _PARALLEL_WORKER, str(i), str(threads), str(L), ROOT], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(nproc)]
+    deadline = time.perf_counter() + budget_s
+
+    def read_line(p):
+        import select
+
+        while time.perf_counter() < deadline:
+            r, _, _ = select.select([p.stdout], [], [], 1.0)
+            if r:
+                return p.stdout.readline().strip()
+            if p.poll() is not None:
+                return p.stdout.readline().strip() or f"EXIT {p.returncode}"
+        return "TIMEOUT"
+
     try:
-        for _ in procs:
-            ready_q.get(timeout=budget_s)
+        ready = [read_line(p) for p in procs]
+        if any(r != "READY" for r in ready):
+            return {"error": f"workers not ready: {sorted(set(ready))}"}
         t0 = time.perf_counter()
-        start_evt.set()
-        per = [done_q.get(timeout=budget_s)[1] for _ in procs]
-        wall = time.perf_counter() - t0
-    except Exception as e:                                  # a baseline must not fail the bench line
         for p in procs:
-            p.terminate()
-        return {"error": f"{type(e).__name__}: {e}"}
-    for p in procs:
-        p.join(timeout=30)
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        done = [read_line(p) for p in procs]
+        wall = time.perf_counter() - t0
+        if not all(d.startswith("DONE") for d in done):
+            return {"error": f"workers did not finish within {budget_s:.0f} s: {sorted(set(d.split()[0] for d in done))}"}
+        per = [float(d.split()[1]) for d in done]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     return {"value": round(nproc * L / wall, 3), "unit": "frames/s", "processes": nproc, "threads_per_process": threads,
             "cores": nproc * threads, "wall_s": round(wall, 1), "slowest_process_s": round(max(per), 1), "fastest_process_s": round(min(per), 1),
             "sample": f"{nproc} independent {L}-frame chunks at once, one per process, STTNInpaint.inpaint (the network: 95 % of a chunk's "
