@@ -230,7 +230,7 @@ def replay(view, packed_weights, frames_u8, masks_u8=None):
         for info, items in view.ops:
             if info.kind == OP_GEMM:
                 for it in items:
-                    gemm_reference(it, info.bmode, bufs, view.tables, tile_m={0: 128, 1: 256, 2: 256, 3: 128}[info.tile_cfg])
+                    gemm_reference(it, info.bmode, bufs, view.tables, tile_m={0: 128, 1: 256, 2: 256, 3: 128, 4: 256}[info.tile_cfg])
             elif info.kind == OP_SOFTMAX:
                 for it in items:
                     softmax_reference(it, bufs)

@@ -21,7 +21,9 @@ from .sttn_auto_inpaint import _device_index
 def _load_lama_state_dict(model_path):
     if isinstance(model_path, dict):
         return model_path
-    path = str(model_path)
+    from ..tools.common_tools import checkpoint_path
+
+    path = checkpoint_path(str(model_path))                                  # big-lama.pt ships in 50 MB parts (model_config.py:24)
     if path.endswith(".npz"):
         with np.load(path) as z:
             return {k: z[k] for k in z.files}
@@ -36,6 +38,8 @@ def _load_lama_state_dict(model_path):
         if ".model." in "." + k or k.startswith("model."):
             k2 = k[k.index("model."):] if not k.startswith("model.") else k
             out[k2] = v
+    if not out:
+        raise KeyError(f"{path}: no generator entries ('model.N...' or 'generator.model.N...') among its {len(sd)} tensors: {list(sd)[:4]}")
     return out
 
 

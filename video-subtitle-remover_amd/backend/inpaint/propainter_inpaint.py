@@ -57,9 +57,13 @@ def get_ref_index(mid_neighbor_id, neighbor_ids, length, ref_stride=10, ref_num=
 
 
 def _load(model_dir, name, file):
+    """one of the three checkpoints of the mode (propainter_inpaint.py:140-146); ProPainter.pth ships in 50 MB parts and is
+    assembled on first use (tools/common_tools.py, reference model_config.py:25)"""
     if isinstance(model_dir, dict):
         return model_dir[name]
-    return torch.load(os.path.join(model_dir, file), map_location="cpu")
+    from ..tools.common_tools import checkpoint_path
+
+    return torch.load(checkpoint_path(os.path.join(model_dir, file)), map_location="cpu")
 
 
 class PropainterInpaint:

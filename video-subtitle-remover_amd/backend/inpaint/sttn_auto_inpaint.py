@@ -26,9 +26,19 @@ from ...engine import SttnEngine
 
 
 def _load_state_dict(model_path):
+    """the generator's state dict: a dict (tests), or a checkpoint file read as the reference reads it
+    (`torch.load(path)['netG']`, sttn_auto_inpaint.py:34).  A DataParallel-saved checkpoint (`module.` on every key) is unwrapped;
+    anything else that does not match the generator's keys and shapes is refused by the engine (strict load)."""
     if isinstance(model_path, dict):
-        return model_path.get("netG", model_path)
-    return torch.load(model_path, map_location="cpu")["netG"]      # sttn_auto_inpaint.py:34
+        sd = model_path.get("netG", model_path)
+    else:
+        ck = torch.load(model_path, map_location="cpu")
+        if not isinstance(ck, dict) or "netG" not in ck:
+            raise KeyError(f"{model_path}: not an STTN checkpoint (no 'netG' entry; keys: {list(ck)[:5] if isinstance(ck, dict) else type(ck).__name__})")
+        sd = ck["netG"]
+    if len(sd) and all(k.startswith("module.") for k in sd):
+        sd = {k[7:]: v for k, v in sd.items()}
+    return sd
 
 
 def _device_index(device):

@@ -355,8 +355,8 @@ class SubtitleRemover:
         object (attribute `_lama_inpaint`) wins; None when no weights can be found."""
         if getattr(self, "_lama_inpaint", None) is None:
             path = os.environ.get("LAMA_MODEL_PATH", os.path.join(os.path.dirname(__file__), "models", "big-lama", "big-lama.pt"))
-            if not os.path.exists(path):
-                return None
+            if not os.path.exists(path) and not os.path.isfile(os.path.join(os.path.dirname(path), "fs_manifest.csv")):
+                return None                                  # neither the checkpoint nor its split parts
             from .inpaint.lama_inpaint import LamaInpaint
 
             self._lama_inpaint = LamaInpaint(self.device, path)

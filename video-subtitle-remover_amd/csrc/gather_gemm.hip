@@ -321,12 +321,12 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
 template <typename K>
-static int resident_blocks(K kernel)
+static int resident_blocks(K kernel, int threads = 256)
 {
     int dev = 0, cus = 0, occ = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0) != hipSuccess || occ <= 0) occ = 1;
     return cus * occ;
 }
 
@@ -360,9 +360,9 @@ template <int BM, int BN, int WM, int WN, int ST>
 static void launch_v6_st(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, int nQueues, unsigned int* rangeFlag,
                          hipStream_t stream)
 {
-    static const int resident = resident_blocks(gather_gemm_f16_v6<BM, BN, WM, WN, ST>);
+    static const int resident = resident_blocks(gather_gemm_f16_v6<BM, BN, WM, WN, ST>, WM * WN * 64);
     const int g = totalBlocks < resident ? totalBlocks : resident;
-    hipLaunchKernelGGL((gather_gemm_f16_v6<BM, BN, WM, WN, ST>), dim3(g), dim3(256), 0, stream, d_probs, nprobs, totalBlocks, queue, nQueues,
+    hipLaunchKernelGGL((gather_gemm_f16_v6<BM, BN, WM, WN, ST>), dim3(g), dim3(WM * WN * 64), 0, stream, d_probs, nprobs, totalBlocks, queue, nQueues,
                        rangeFlag);
 }
 
@@ -440,6 +440,11 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
         return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
     }
     if (variant <= 1) queue = nullptr;
+    if (tileCfg == VSR_TILE_256x128) {         // the 8-wave tile of the fp16-operand mode
+        if (bmode != VSR_BMODE_NK || variant != 6 || !queue) return -1;
+        launch_v6_st<256, 128, 4, 2, 3>(d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag, stream);
+        return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+    }
     if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_NK);
     else if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_KN) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_KN);
     else if (tileCfg == VSR_TILE_256x32 && bmode == VSR_BMODE_NK) GG_LAUNCH(256, 32, 4, 1, VSR_BMODE_NK);

@@ -13,17 +13,23 @@
 #pragma once
 #include <type_traits>
 
+// Round 3: WM x WN = 8 waves (512 threads) runs the 256x128 tile, each wave a 64x64 block: twice the FLOPs per operand byte of the
+// 128x64 tile at the same bytes in flight per CU (one workgroup of three 48 KB stages instead of two of three 24 KB stages) -- the
+// kernel is bound by the latency of its operand pieces, not by bandwidth or by the matrix cores (profiles/r02_f16_ablation_*.log).
 template <int BM, int BN, int WM, int WN, int STAGES GG_ABL_PARAM>
-__global__ void __launch_bounds__(256, (STAGES * (BM + BN) * 128 + 2 * BM * 4 <= 78 * 1024) ? 2 : 1)
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 2 : ((STAGES * (BM + BN) * 128 + 2 * BM * 4 <= 78 * 1024) ? 2 : 1))
 gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue, int nQueues,
                    unsigned int* __restrict__ rangeFlag)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int NT = WM * WN * 64;                            // threads of the workgroup
+    constexpr int RP = NT / 8;                                  // operand rows one pass of LDS-DMA pieces covers (8 lanes per 128-byte row)
+    constexpr int A_IT = BM / RP, B_IT = BN / RP;
     constexpr int AS_FLOATS = BM * 32, BS_FLOATS = BN * 32;     // [rows][128 bytes]
     constexpr int BUF_FLOATS = AS_FLOATS + BS_FLOATS;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile rows in whole DMA passes");
     static_assert(STAGES >= 2 && STAGES <= 4, "2..4 operand stages");
 
     // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA queue in front of every fragment read)
@@ -121,14 +127,14 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             const gci32 rowRt = (gci32)P->rowR;
             const bool hasR = (P->R != nullptr) && (splitK == 1);
 #pragma unroll
-            for (int i = tid; i < 2 * BM; i += 256)
+            for (int i = tid; i < 2 * BM; i += NT)
                 rowTab[i] = i < BM ? rowCt[tm * BM + i] : (hasR ? rowRt[tm * BM + i - BM] : 0);
         }
         int aoff[A_IT], boff[B_IT];
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) aoff[it] = rowA[tm * BM + s_r + 32 * it] + srcSwz;
+        for (int it = 0; it < A_IT; ++it) aoff[it] = rowA[tm * BM + s_r + RP * it] + srcSwz;
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) boff[it] = rowB[tn * BN + s_r + 32 * it] + srcSwz;
+        for (int it = 0; it < B_IT; ++it) boff[it] = rowB[tn * BN + s_r + RP * it] + srcSwz;
 
         V6_STAMP(1)
         f32x16 acc[MI][NI];
@@ -140,20 +146,52 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
         // LDS-DMA of one pair of chunks: ca0 / ca1 (cb0 / cb1) = wave-uniform chunk offsets of the pair in A (B)
-        auto dma_pair = [&](int buf, int ca0, int ca1, int cb0, int cb1) {
+        // byte offsets of the lane's operand rows; narrow: all of them in [0, 2^30) floats (always, except for tensors beyond 4 GB)
+        unsigned aoffB[A_IT], boffB[B_IT];
+        bool narrow = true;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) { narrow = narrow && ((unsigned)aoff[it] < (1u << 30)); aoffB[it] = (unsigned)aoff[it] << 2; }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) { narrow = narrow && ((unsigned)boff[it] < (1u << 30)); boffB[it] = (unsigned)boff[it] << 2; }
+        narrow = __all(narrow) != 0;
+        auto dma_pair = [&](auto bufTag, int ca0, int ca1, int cb0, int cb1) __attribute__((always_inline)) {
+            constexpr int buf = decltype(bufTag)::value;
             float* As = smem + buf * BUF_FLOATS;
             float* Bs = As + AS_FLOATS;
             if constexpr (GG_ABL(2)) { if (buf >= 0) return; }     // ablation: no operand fetch at all
-            const int ca = GG_ABL(8) ? 0 : (second ? ca1 : ca0), cb = GG_ABL(8) ? 0 : (second ? cb1 : cb0);   // 8: one hot chunk
+            if constexpr (GG_ABL(8)) { ca0 = ca1 = cb0 = cb1 = 0; }                                          // 8: one hot chunk
+            if (narrow) {
+                // round 3: the saddr form of global_load_lds -- scalar base = operand + the SMALLER chunk offset of the pair, per-lane
+                // unsigned byte offset = row offset + what its chunk lies above that (one select per operand and pair, one add per piece)
+                typedef const char __attribute__((address_space(1)))* gcc8;
+                const int ma = ca0 < ca1 ? ca0 : ca1, mb = cb0 < cb1 ? cb0 : cb1;
+                const gcc8 baseA = (gcc8)A + (long long)ma * 4, baseB = (gcc8)B + (long long)mb * 4;
+                const unsigned da = (unsigned)((second ? ca1 : ca0) - ma) << 2, db = (unsigned)((second ? cb1 : cb0) - mb) << 2;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    unsigned vo = aoffB[it] + da;
+                    asm volatile("" : "+v"(vo));
+                    glds16((gcf32)(baseA + vo), (lds_vptr)(As + (wave * 8 + RP * it) * 32));
+                }
+#pragma unroll
+                for (int it = 0; it < B_IT; ++it) {
+                    unsigned vo = boffB[it] + db;
+                    asm volatile("" : "+v"(vo));
+                    glds16((gcf32)(baseB + vo), (lds_vptr)(Bs + (wave * 8 + RP * it) * 32));
+                }
+                return;
+            }
+            const int ca = second ? ca1 : ca0, cb = second ? cb1 : cb0;
 #pragma unroll
             for (int it = 0; it < A_IT; ++it)
-                glds16(A + (aoff[it] + ca), (lds_vptr)(As + (wave * 8 + 32 * it) * 32));
+                glds16(A + (aoff[it] + ca), (lds_vptr)(As + (wave * 8 + RP * it) * 32));
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
-                glds16(B + (boff[it] + cb), (lds_vptr)(Bs + (wave * 8 + 32 * it) * 32));
+                glds16(B + (boff[it] + cb), (lds_vptr)(Bs + (wave * 8 + RP * it) * 32));
         };
         struct Frag { f16x8 a[MI], b[NI]; };
-        auto load_frag = [&](int buf, int st, Frag& f) {
+        auto load_frag = [&](auto bufTag, int st, Frag& f) __attribute__((always_inline)) {
+            constexpr int buf = decltype(bufTag)::value;        // compile-time stage: the reads fold it into their offset field
             const char* As = reinterpret_cast<const char*>(smem + buf * BUF_FLOATS);
             const char* Bs = As + AS_FLOATS * 4;
             if constexpr (GG_ABL(16)) {                             // ablation: MFMA on register operands (no fragment reads)
@@ -174,14 +212,14 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     f.b[ni] = *reinterpret_cast<const f16x8*>(Bs + (wn * WTN + ni * 32 + l31) * 128 + rd[st]);
             }
         };
-        auto mfma_frag = [&](const Frag& f) {
+        auto mfma_frag = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0);   // transposed tile: a lane owns an output ROW (epilogue below)
         };
-        auto compute_step = [&](int buf, int st) {
+        auto compute_step = [&](auto buf, int st) __attribute__((always_inline)) {
             if constexpr (GG_ABL(4)) return;                        // ablation: no fragment reads, no MFMA
             Frag f;
             load_frag(buf, st, f);
@@ -205,19 +243,23 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                 const int a = __builtin_amdgcn_readlane(v0, i & 63), b = __builtin_amdgcn_readlane(v1, i & 63);
                 return i < 64 ? a : b;
             };
-            auto issue = [&](int kc, int buf) {                 // pair (kc, kc + 1); a lone last chunk is fetched twice
+            auto issue = [&](int kc, auto bufTag) __attribute__((always_inline)) {     // pair (kc, kc + 1); a lone last chunk is fetched twice
                 const int i = kc - sb, j = kc + 1 < sbEnd ? i + 1 : i;
-                dma_pair(buf, pick(ca0v, ca1v, i), pick(ca0v, ca1v, j), pick(cb0v, cb1v, i), pick(cb0v, cb1v, j));
+                dma_pair(bufTag, pick(ca0v, ca1v, i), pick(ca0v, ca1v, j), pick(cb0v, cb1v, i), pick(cb0v, cb1v, j));
             };
             if (sb != kcBeg) {                                  // stages of the previous super-block are still being read
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-                if (sb + 2 * d < sbEnd) issue(sb + 2 * d, d);
-            int cur = 0, nxt = D % STAGES;
-            for (int kc = sb; kc < sbEnd; kc += 2) {
+            using S0_ = std::integral_constant<int, 0>;
+            using S1_ = std::integral_constant<int, 1>;
+            using S2_ = std::integral_constant<int, 2 % STAGES>;
+            using S3_ = std::integral_constant<int, 3 % STAGES>;
+            if (sb < sbEnd) issue(sb, S0_{});
+            if (D >= 2 && sb + 2 < sbEnd) issue(sb + 2, S1_{});
+            if (D >= 3 && sb + 4 < sbEnd) issue(sb + 4, S2_{});
+            // one pair out of stage `cur` while the DMA of pair kc + 2 D goes into stage `nxt` (the one retired by this step's barrier)
+            auto step = [&](int kc, auto cur, auto nxt) __attribute__((always_inline)) {
                 const int ahead = (sbEnd - 1 - kc) >> 1;        // younger pairs already issued: min(ahead, D - 1)
                 if (D >= 3 && ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (D >= 3 ? 2 : 0)) : "memory");
                 else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (D >= 2 ? 1 : 0)) : "memory");
@@ -231,8 +273,27 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     compute_step(cur, 2);
                     compute_step(cur, 3);
                 }
-                cur = cur + 1 == STAGES ? 0 : cur + 1;
-                nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+            };
+            // the stage a pair lives in is a compile-time constant of a loop unrolled by STAGES (no address arithmetic per read)
+            int kc = sb;
+            if constexpr (STAGES == 2) {
+                for (; kc < sbEnd; kc += 4) {
+                    step(kc, S0_{}, S1_{});
+                    if (kc + 2 < sbEnd) step(kc + 2, S1_{}, S0_{});
+                }
+            } else if constexpr (STAGES == 3) {
+                for (; kc < sbEnd; kc += 6) {
+                    step(kc, S0_{}, S2_{});
+                    if (kc + 2 < sbEnd) step(kc + 2, S1_{}, S0_{});
+                    if (kc + 4 < sbEnd) step(kc + 4, S2_{}, S1_{});
+                }
+            } else {
+                for (; kc < sbEnd; kc += 8) {
+                    step(kc, S0_{}, S3_{});
+                    if (kc + 2 < sbEnd) step(kc + 2, S1_{}, S0_{});
+                    if (kc + 4 < sbEnd) step(kc + 4, S2_{}, S1_{});
+                    if (kc + 6 < sbEnd) step(kc + 6, S3_{}, S2_{});
+                }
             }
         }
         if (tid == 0) {                            // the next tile: the home counter's answer, else steal
@@ -248,7 +309,10 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         __syncthreads();                           // rowTab visible even when the k range is empty; LDS-DMA queue empty
         V6_STAMP(0)
 
-        // ---- epilogue (as v5): C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        // ---- epilogue.  Transposed accumulators (round 3, as gather_gemm_v3.h): lane l31 owns output ROW l31 of its 32x32 block,
+        // register r is column (r & 3) + 8 (r >> 2) + 4 hi -- four runs of four consecutive columns.  In split format a run is 8 bytes
+        // of hi halves and, 64 bytes on, 8 bytes of lo halves: two 8-byte stores where the column-owning layout issued eight 2-byte
+        // ones (the epilogue was a fifth of a tile's time, profiles/r02_f16_ablation_after.log).
         const float alpha = P->alpha;
         const int act = P->act & 0xff;
         const bool postRelu = (P->act & VSR_ACT_POST_RELU) != 0;
@@ -260,80 +324,152 @@ gather_gemm_f16_v6(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const gcf32 R = (partial || GG_ABL(64)) ? (gcf32) nullptr : (gcf32)P->R;
         const cci32 colC = (cci32)P->colC;
         const gf32 C = (gf32)(P->C + (partial ? (int64_t)split * P->splitStride : (int64_t)0));
-        int ccol[NI];
-        float bv[NI];
-        bool nok[NI];
+        int cbase[NI];           // float offset of the 32-column block this lane's columns belong to
+        int ncol[NI];            // global index of the lane's first column (block start + 4 hi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n0 = tn * BN + wn * WTN + ni * 32;
-            ccol[ni] = colC[n0 / VSR_GG_KC] + l31;
-            nok[ni] = (n0 + l31) < N;
-            bv[ni] = (bias != nullptr && nok[ni]) ? bias[n0 + l31] : 0.f;
+            cbase[ni] = colC[n0 / VSR_GG_KC];
+            ncol[ni] = n0 + 4 * hi;
         }
         const bool fullTile = (tm * BM + BM <= M) && (tn * BN + BN <= N);
-        auto epilogue = [&](auto fullTag, auto resTag) {
-            constexpr bool FULL = decltype(fullTag)::value, HASR = decltype(resTag)::value;
+        auto activate = [&](float v) __attribute__((always_inline)) {
+            if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+            else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
+            return v;
+        };
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        // interior tile, 16-byte aligned rows: vector loads / stores.  ACTK: 0 none, 1 LeakyReLU 0.2, -1 run-time
+        auto epilogue_vec = [&](auto resTag, auto actTag) __attribute__((always_inline)) {
+            constexpr bool HASR = decltype(resTag)::value;
+            constexpr int ACTK = decltype(actTag)::value;
+            typedef const f32x4 __attribute__((address_space(1)))* gv4;
+            typedef const f16x4 __attribute__((address_space(1)))* gh4;
+            f32x4 bq[NI][4];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (bias != nullptr) bq[ni][q] = *reinterpret_cast<gv4>(bias + (ncol[ni] + 8 * q));
+                    else bq[ni][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                int rc[16], rr[16];
-                float rv[16][NI];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    rc[r] = rowTab[row];
-                    if constexpr (HASR) rr[r] = rowTab[BM + row];
-                }
+                const int row = wm * WTM + mi * 32 + l31;
+                const int rc = rowTab[row];
+                f16x4 rh[NI][4], rl[NI][4];
                 if constexpr (HASR) {        // residual tensors are GEMM operands too: split format
-                    typedef const _Float16 __attribute__((address_space(1)))* gch;
-                    const gch R16 = (gch)R;
+                    const int rr = rowTab[BM + row];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const gh4 p = reinterpret_cast<gh4>(reinterpret_cast<const char __attribute__((address_space(1)))*>(R) + 4 * (long long)(rr + cbase[ni]) + 8 * hi + 16 * q);
+                            rh[ni][q] = p[0];
+                            rl[ni][q] = p[8];            // + 64 bytes
+                        }
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[mi][ni][4 * q + e] * alpha + bq[ni][q][e];
+                            if constexpr (ACTK == 1) v = v > 0.f ? v : 0.2f * v;
+                            else if constexpr (ACTK < 0) v = activate(v);
+                            if constexpr (HASR) {
+                                v += (float)rh[ni][q][e] + (float)rl[ni][q][e];
+                                if constexpr (ACTK < 0) { if (postRelu) v = fmaxf(v, 0.f); }
+                            }
+                            nonFinite |= !(__builtin_fabsf(v) <= vmax);
+                            o[e] = v;
+                        }
+                        if constexpr (GG_ABL(32)) { if (o[0] == 12345.678f) C[0] = o[1]; }   // ablation: no output stores
+                        else if (cSplit) {
+                            f16x4 h, l;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { h[e] = (_Float16)o[e]; l[e] = (_Float16)(o[e] - (float)h[e]); }
+                            typedef f16x4 __attribute__((address_space(1)))* gwh4;
+                            const gwh4 p = reinterpret_cast<gwh4>(reinterpret_cast<char __attribute__((address_space(1)))*>(C) + 4 * (long long)(rc + cbase[ni]) + 8 * hi + 16 * q);
+                            p[0] = h;
+                            p[8] = l;
+                        } else {
+                            *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(C + (rc + cbase[ni] + 4 * hi + 8 * q)) = o;
+                        }
+                    }
+            }
+        };
+        // border tiles and unaligned outputs: one value at a time, predicated
+        auto epilogue_scalar = [&](auto resTag) __attribute__((always_inline)) {
+            constexpr bool HASR = decltype(resTag)::value;
+            typedef const _Float16 __attribute__((address_space(1)))* gch;
+            typedef _Float16 __attribute__((address_space(1)))* gh;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * WTM + mi * 32 + l31;
+                const int rc = rowTab[row];
+                const int rr = HASR ? rowTab[BM + row] : 0;
+                const bool mok = (tm * BM + row) < M;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool mok = FULL || (tm * BM + row) < M;
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            float x = 0.f;
-                            if (mok && (FULL || nok[ni])) {
-                                const int e = 2 * (rr[r] + ccol[ni] - l31) + l31;
-                                x = (float)R16[e] + (float)R16[e + 32];
-                            }
-                            rv[r][ni] = x;
+                        const int cofs = 4 * hi + (r & 3) + 8 * (r >> 2);          // column inside the 32-block
+                        const bool ok = mok && (ncol[ni] - 4 * hi + cofs) < N;
+                        float v = acc[mi][ni][r] * alpha + ((bias != nullptr && ok) ? bias[ncol[ni] - 4 * hi + cofs] : 0.f);
+                        v = activate(v);
+                        if constexpr (HASR) {
+                            if (ok) { const long long e = 2 * (long long)(rr + cbase[ni]) + cofs; v += (float)((gch)R)[e] + (float)((gch)R)[e + 32]; }
+                            if (postRelu) v = fmaxf(v, 0.f);
                         }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool mok = FULL || (tm * BM + row) < M;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        float v = acc[mi][ni][r] * alpha + bv[ni];
-                        if (act == VSR_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-                        else if (act == VSR_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (act == VSR_ACT_LRELU01) v = v > 0.f ? v : 0.1f * v;
-                        if constexpr (HASR) { v += rv[r][ni]; if (postRelu) v = fmaxf(v, 0.f); }
                         nonFinite |= !(__builtin_fabsf(v) <= vmax);
-                        if constexpr (GG_ABL(32)) { if (v == 12345.678f) C[0] = v; }   // ablation: no output stores
-                        else if (mok && (FULL || nok[ni])) {
+                        if constexpr (GG_ABL(32)) { if (v == 12345.678f) C[0] = v; }
+                        else if (ok) {
                             if (cSplit) {
-                                typedef _Float16 __attribute__((address_space(1)))* gh;
-                                const gh C16 = (gh)C;
-                                const int e = 2 * (rc[r] + ccol[ni] - l31) + l31;
+                                const long long e = 2 * (long long)(rc + cbase[ni]) + cofs;
                                 const _Float16 h = (_Float16)v;
-                                C16[e] = h;
-                                C16[e + 32] = (_Float16)(v - (float)h);
+                                ((gh)C)[e] = h;
+                                ((gh)C)[e + 32] = (_Float16)(v - (float)h);
                             } else {
-                                C[rc[r] + ccol[ni]] = v;
+                                C[rc + cbase[ni] + cofs] = v;
                             }
                         }
                     }
-                }
             }
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-        if (fullTile) { if (R != nullptr) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
-        else          { if (R != nullptr) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
+        bool vec = fullTile && ((reinterpret_cast<uintptr_t>(P->C) | (uintptr_t)(partial ? P->splitStride * 4 : 0)) & 15) == 0 &&
+                   (bias == nullptr || (reinterpret_cast<uintptr_t>(P->bias) & 15) == 0) && (R == nullptr || (reinterpret_cast<uintptr_t>(P->R) & 15) == 0);
+        {
+            int low = 0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) low |= cbase[ni];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                low |= rowTab[wm * WTM + mi * 32 + l31];
+                if (R != nullptr) low |= rowTab[BM + wm * WTM + mi * 32 + l31];
+            }
+            vec = vec && __all((low & 3) == 0);
+        }
+        if (vec) {
+            using IC = std::integral_constant<int, -1>;
+            const int ak = postRelu ? -1 : act;
+            if (R != nullptr) {
+                if (ak == VSR_ACT_NONE) epilogue_vec(T_{}, std::integral_constant<int, 0>{});
+                else if (ak == VSR_ACT_LRELU02) epilogue_vec(T_{}, std::integral_constant<int, 1>{});
+                else epilogue_vec(T_{}, IC{});
+            } else {
+                if (ak == VSR_ACT_NONE) epilogue_vec(F_{}, std::integral_constant<int, 0>{});
+                else if (ak == VSR_ACT_LRELU02) epilogue_vec(F_{}, std::integral_constant<int, 1>{});
+                else epilogue_vec(F_{}, IC{});
+            }
+        } else {
+            if (R != nullptr) epilogue_scalar(T_{}); else epilogue_scalar(F_{});
+        }
         if (rangeFlag != nullptr && __any(nonFinite) && lane == 0) atomicOr(rangeFlag, 1u);
         V6_STAMP(1)
         __syncthreads();

@@ -727,7 +727,7 @@ static void tile_dims(int cfg, int& BM, int& BN)
 {
     BM = cfg == VSR_TILE_128x128 ? 128 : 256;
     BM = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_128x64) ? 128 : 256;
-    BN = cfg == VSR_TILE_128x128 ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
+    BN = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_256x128) ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
 }
 
 static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_);

@@ -255,6 +255,7 @@ static void tileDims(int cfg, int& BM, int& BN)
     if (cfg == VSR_TILE_128x128) { BM = 128; BN = 128; }
     else if (cfg == VSR_TILE_128x64) { BM = 128; BN = 64; }
     else if (cfg == VSR_TILE_256x64) { BM = 256; BN = 64; }
+    else if (cfg == VSR_TILE_256x128) { BM = 256; BN = 128; }
     else { BM = 256; BN = 32; }
 }
 int Plan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : tu_.convTile); }
