@@ -232,6 +232,17 @@ static void stress(const Prob& pr, size_t cElems, float* Cdev, int launches, int
 
 int main(int argc, char** argv)
 {
+    if (argc > 1 && (!strcmp(argv[1], "qk") || !strcmp(argv[1], "conv") || !strcmp(argv[1], "qkv"))) {
+        // one shape, a few launches: for rocprofv3 --pmc passes (FETCH_SIZE, TCC hits) of exactly this problem
+        constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
+        const bool qk = !strcmp(argv[1], "qk"), qkv = !strcmp(argv[1], "qkv");
+        Prob pr = qk ? make_dense<BM, BN>(4800, 4800, 960) : qkv ? make_dense<BM, BN>(72000, 768, 256) : make<BM, BN>(15, 256, 2304, false, true);
+        const int nq = argc > 2 ? atoi(argv[2]) : (qk || qkv ? 1 : 8);
+        const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 6, nq);
+        printf("%s, %d queue(s): %.1f us  %.1f TF\n", argv[1], nq, ms * 1e3, pr.gflop / ms);
+        pr.free_all();
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "stress")) {
         constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
         {
@@ -297,6 +308,8 @@ int main(int argc, char** argv)
         for (int rep = 0; rep < 2; ++rep) {
             { const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 24, 1); printf("  shipped kernel, one global queue                     %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
             { const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 24, 8); printf("  shipped kernel, per-XCD queues                       %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+            { const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 24, 0x108); printf("  shipped kernel, per-XCD queues, grouped tile order   %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
+            { const float ms = time_v3<BM, BN, WM, WN, 0>(pr, 0, 24, 0x101); printf("  shipped kernel, one global queue, grouped tile order %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
             { const float ms = time_v3<BM, BN, WM, WN, 2048>(pr, 0, 24, 1); printf("  no tile pipelining, one global queue                 %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
             { const float ms = time_v3<BM, BN, WM, WN, 128>(pr, 0, 24, 1); printf("  no epilogue, one global queue                        %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }
             { const float ms = time_v3<BM, BN, WM, WN, 2>(pr, 0, 24, 1); printf("  no operand DMA in the loop, one global queue         %8.1f us  %6.1f TF\n", ms * 1e3, pr.gflop / ms); }

@@ -409,7 +409,7 @@ static void launch_v5(const GGProblem* d_probs, int nprobs, int totalBlocks, uns
             static const int resident = resident_blocks(gather_gemm_f32_v3<BM, BN, WM, WN, MODE>);             \
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
             hipLaunchKernelGGL((gather_gemm_f32_v3<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream, d_probs, \
-                               nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1);                              \
+                               nprobs, totalBlocks, queue, ((nQueues & 0xff) == 8 ? 8 : 1) | (nQueues & 0x100));    \
         } else {                                                                                                \
             hipLaunchKernelGGL((gather_gemm_f32<BM, BN, WM, WN, MODE>), dim3(totalBlocks), block, 0, stream,   \
                                d_probs, nprobs);                                                               \

@@ -112,6 +112,10 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
     float* scr = smem + 2 * BUF_FLOATS + 2 * CB_WORDS;
     volatile int* nextTile = reinterpret_cast<volatile int*>(smem + 2 * BUF_FLOATS + 2 * CB_WORDS + BM * WN);
 
+    // nQueues: 8 or 1 tile ranges; bit 8 (VSR_GG_SWIZZLE): problems with many N tiles walk their tiles in groups of 8 M-rows, N
+    // outermost inside a group (see locate())
+    const bool swizzle = (nQueues & 0x100) != 0;
+    nQueues &= 0xff;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,6 +193,21 @@ gather_gemm_f32_v3(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         const int rem = t_ - q.split * tilesMN;
         q.tm = rem / tilesN;
         q.tn = rem - q.tm * tilesN;
+        if (swizzle && tilesN > 4) {
+            // Many N tiles per row block (QK^T: 75, QKV: 12): in plain row-major order the ~96 tiles an XCD works on at a time
+            // are one or two row blocks times ALL column blocks -- every B block is fetched once per row block and the 4 MB L2
+            // holds a fraction of them (rocprofv3: 64 % L2 hits, 788 MB fetched per 4800-token QK^T launch against 37 MB of
+            // operands, profiles/r03_pmc_l2.log).  In groups of 8 row blocks with the column block outermost, the same 96
+            // tiles are an 8 x 12 patch: every A block is shared by 12 and every B block by 8 concurrent tiles.
+            constexpr int G = 8;
+            const int gs = G * tilesN;
+            const int gid = rem / gs;
+            const int r2 = rem - gid * gs;
+            const int first = gid * G;
+            const int gsz = q.P->tilesM - first < G ? q.P->tilesM - first : G;
+            q.tn = r2 / gsz;
+            q.tm = first + (r2 - q.tn * gsz);
+        }
         q.nchunksTotal = q.P->K / VSR_GG_KC;
         q.kcBeg = q.split * q.P->chunksPerSplit;
         q.kcEnd = q.kcBeg + q.P->chunksPerSplit;

@@ -132,6 +132,18 @@ struct vsr_sttn {
 
 static int64_t bufBytes(int buf, int64_t elems) { return (buf == BUF_IN_U8 || buf == BUF_MASK_U8) ? elems : elems * 4; }
 
+// tile queues of a launch whose problems have many N tiles per row block (QK^T, QKV, wide 1x1 convs): one global queue in
+// row-major order (round 2: 101 vs 86 TF against per-XCD ranges on the QKV GEMM).  VSR_GG_SWIZZLE=1 asks the exact-fp32 kernel
+// v3 for per-XCD ranges walked in groups of 8 row blocks instead: it halves the fabric reads of the 4800-token QK^T (788 -> 391 MB
+// per launch, L2 hits 64 -> 80 %, profiles/r03_pmc_l2.log) at the same speed -- the operand latency was hidden either way -- so it
+// stays an option.
+static int gg_wide_queues()
+{
+    static const int v = [] { const char* e = getenv("VSR_GG_SWIZZLE"); return (e && atoi(e) == 1) ? (8 | 0x100) : 1; }();
+    return v;
+}
+
+
 static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 {
     const int key = L * 4 + precision;
@@ -217,7 +229,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
             od.nQueues = 8;
             od.aexp = op.ipar[0] != 0;
             for (const GemmItem& g : op.gemm)
-                if (g.tilesN > 4) od.nQueues = 1;
+                if (g.tilesN > 4) od.nQueues = gg_wide_queues();
             cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
         } else if (op.kind == OP_SOFTMAX) {
             SMProblem* hp = (SMProblem*)(hostDesc.data() + cursor);
@@ -766,7 +778,7 @@ int vsr_gemm_plan_create(const GGProblem* probs, int nprobs, int tile_cfg, int b
         if (q.splitK < 1 || (int64_t)q.splitK * q.chunksPerSplit < q.K / VSR_GG_KC) return fail(VSR_ERR_ARG, "bad split-K");
         q.tileStart = p->total;
         p->total += q.tilesM * q.tilesN * q.splitK;
-        if (q.tilesN > 4) p->nQueues = 1;
+        if (q.tilesN > 4) p->nQueues = gg_wide_queues();
     }
     HIPCHK(hipGetDevice(&p->device));
     const size_t descBytes = (hp.size() * sizeof(GGProblem) + 15) / 16 * 16;
@@ -828,7 +840,7 @@ static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_
     }
     int nQueues = 8;
     for (const auto& p : hp)
-        if (p.tilesN > 4) nQueues = 1;
+        if (p.tilesN > 4) nQueues = gg_wide_queues();
     const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, variant, nQueues, nullptr, stream);
     hipError_t e = hipStreamSynchronize(stream);
     (void)hipFree(d);
