@@ -152,6 +152,11 @@ class SubtitleRemover:
         finally:
             reader.release()
 
+    @staticmethod
+    def _clip_kw(clip):
+        """the HBM-resident clip is handed on only when there is one: without it the calls keep the reference's signatures"""
+        return {} if clip is None else {"clip": clip}
+
     def _timed(self, name, fn, *a, **kw):
         """phase timer of run(): detector pass / scene cuts / inpainting / writing, reported by main() and scripts/bench_e2e.py"""
         import torch
@@ -183,7 +188,7 @@ class SubtitleRemover:
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
         resident = self._open_resident()
         clip = resident[0] if resident is not None else None
-        sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self, clip=clip)
+        sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self, **self._clip_kw(clip))
         if len(sub_list) == 0:
             self._run_items(tbar, (), propainter_inpaint)                  # releases the peers before failing
             raise Exception(f"No subtitle detected in {self.video_path}")
@@ -191,7 +196,7 @@ class SubtitleRemover:
         if scene_div_points is None:                 # main.py:165: self.sub_detector.get_scene_div_frame_no(self.video_path)
             dev = self.device
             scene_div_points = self._timed("scene cuts", detector.get_scene_div_frame_no, self.video_path,
-                                           device=int(dev.split(":")[1]) if isinstance(dev, str) and ":" in dev else 0, clip=clip)
+                                           device=int(dev.split(":")[1]) if isinstance(dev, str) and ":" in dev else 0, **self._clip_kw(clip))
         ranges = detector.split_range_by_scene(ranges, list(scene_div_points))
         if resident is not None:
             # the same walk over frame numbers as items() below, on the clip in HBM: batches are slices inpainted in place
@@ -277,7 +282,8 @@ class SubtitleRemover:
             return self._run_items(tbar, (), model)
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
         resident = self._open_resident()
-        sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self, clip=resident[0] if resident is not None else None)
+        sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self,
+                               **self._clip_kw(resident[0] if resident is not None else None))
         if len(sub_list) == 0:
             self._run_items(tbar, (), model)
             raise Exception(f"No subtitle detected in {self.video_path}")
