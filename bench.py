@@ -441,7 +441,7 @@ def main():
                           f"{L}-frame {args.res} chunk of the timed clip, end to end in {dt:.1f} s of which STTNInpaint.inpaint "
                           f"(the network, {flops_chunk / 1e12:.2f} TFLOP) {dt_net:.1f} s; thread count picked by a 3-frame probe of the same oracle"}
             if not args.no_cpu_parallel:
-                par = cpu_baseline_parallel(L, threads)
+                par = cpu_baseline_parallel(min(L, 20), threads, budget_s=150.0)      # a bounded sample: 20-frame chunks (3 windows each)
                 if par is not None:
                     out["cpu_baseline"]["parallel"] = par
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"
