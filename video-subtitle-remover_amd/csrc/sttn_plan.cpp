@@ -22,6 +22,7 @@ const Tuning& Tuning::get(int precision)
         [] {
             Tuning x;
             x.convTile = envInt("VSR_CONV_TILE", VSR_TILE_128x64);
+            if (x.convTile == VSR_TILE_256x128) x.convTile = VSR_TILE_128x64;      // the 8-wave tile exists in the fp16-operand kernel only
             x.qkTile = envInt("VSR_QK_TILE", VSR_TILE_128x64);
             x.qkvTile = envInt("VSR_QKV_TILE", x.convTile);
             x.pvTile = envInt("VSR_PV_TILE", VSR_TILE_128x64);
