@@ -12,5 +12,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f16_trace -o r -- $B --steps 3 --warmup 1 --precision f16 > $OUT/f16_trace.log 2>&1
 grep '"metric"' $OUT/f16_trace.log > $OUT/f16_bench_under_rocprof.json
 rm -f $OUT/f16_trace/r_kernel_trace.csv
+for b in lama rfc; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${b}_trace -o r -- python scripts/bench_$b.py > $OUT/${b}_trace.log 2>&1
+  rm -f $OUT/${b}_trace/r_kernel_trace.csv; grep '"metric"' $OUT/${b}_trace.log | cut -c1-250
+done
 (timeout 400 python scripts/bench_configs.py 2>&1 | grep '^{') > $OUT/configs.log; cut -c1-300 $OUT/configs.log
 ls $OUT $OUT/trace; du -sh $OUT
