@@ -62,6 +62,42 @@ def cpu_model_name():
     return "unknown"
 
 
+def effective_cpus():
+    """(cpus this process may actually use at once, what limits them): os.cpu_count() counts the machine's hardware threads, but a
+    container may run under an affinity mask or a CFS quota (cgroup cpu.max) far below that -- then more threads or processes only
+    get throttled"""
+    ncpu = os.cpu_count() or 1
+    info = {"cpu_count": ncpu}
+    eff = float(ncpu)
+    try:
+        aff = len(os.sched_getaffinity(0))
+        info["affinity"] = aff
+        eff = min(eff, aff)
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    eff = min(eff, int(txt[0]) / int(txt[1]))
+            else:
+                q = int(txt[0])
+                info["cgroup_cfs_quota_us"] = q
+                if q > 0:
+                    eff = min(eff, q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    try:
+        info["loadavg"] = os.getloadavg()[0]
+    except OSError:
+        pass
+    info["effective_cpus"] = round(eff, 1)
+    return eff, info
+
+
 def cpu_baseline(sd, clip, mask01, areas):
     """The oracle's chunk body (STTNAutoInpaint.__call__ :242-317 restated) on one full chunk of host frames, timed on the host
     cores: end to end, and the network part (STTNInpaint.inpaint) on its own."""
@@ -126,7 +162,7 @@ print("DONE %.3f" % (time.perf_counter() - t0), flush=True)
 """
 
 
-def cpu_baseline_parallel(L, threads, budget_s=170.0):
+def cpu_baseline_parallel(L, threads, budget_s=170.0, flops_sample=None, flops_per_frame=None):
     """The honest 'host cores of the same box' figure: chunks share no state (sttn_auto_inpaint.py:242-328), so the CPU
     path scales by running one chunk per group of cores.  cpu_count // threads plain Python processes (no GPU library loaded, pinned
     to their own `threads` hardware threads), each the network part of one full chunk, started together; aggregate frames/s =
@@ -134,9 +170,10 @@ def cpu_baseline_parallel(L, threads, budget_s=170.0):
     import subprocess
 
     ncpu = os.cpu_count() or 1
-    nproc = max(1, ncpu // max(threads, 1))
+    eff, limits = effective_cpus()
+    nproc = max(1, int(eff) // max(threads, 1))
     if nproc < 2:
-        return None
+        return {"skipped": f"this process may use {eff:.1f} CPUs at once; the single-process figure already runs on {threads} threads", "limits": limits}
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
                CUDA_VISIBLE_DEVICES="")
     procs = [subprocess.Popen([sys.executable, "-c", _PARALLEL_WORKER, str(i), str(threads), str(L), ROOT], stdin=subprocess.PIPE,
@@ -171,10 +208,16 @@ def cpu_baseline_parallel(L, threads, budget_s=170.0):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    return {"value": round(nproc * L / wall, 3), "unit": "frames/s", "processes": nproc, "threads_per_process": threads,
-            "cores": nproc * threads, "wall_s": round(wall, 1), "slowest_process_s": round(max(per), 1), "fastest_process_s": round(min(per), 1),
-            "sample": f"{nproc} independent {L}-frame chunks at once, one per process, STTNInpaint.inpaint (the network: 95 % of a chunk's "
-                      f"CPU time) on {threads} torch threads each -- all {nproc * threads} of the box's {ncpu} hardware threads"}
+    res = {"value": round(nproc * L / wall, 3), "unit": "frames/s", "processes": nproc, "threads_per_process": threads,
+           "cores": nproc * threads, "limits": limits, "wall_s": round(wall, 1), "slowest_process_s": round(max(per), 1), "fastest_process_s": round(min(per), 1),
+           "sample": f"{nproc} independent {L}-frame chunks at once, one per process, STTNInpaint.inpaint (the network: 95 % of a chunk's "
+                     f"CPU time) on {threads} torch threads each -- {nproc * threads} of the box's {ncpu} hardware threads ({eff:.0f} usable by this container)"}
+    if flops_sample and flops_per_frame:
+        # short chunks have short windows (attention cost grows with T^2): the rate that compares with `value` is FLOP-normalised
+        res["tflops"] = round(nproc * flops_sample / wall / 1e12, 3)
+        res["full_chunk_equivalent"] = {"value": round(nproc * flops_sample / wall / flops_per_frame, 3), "unit": "frames/s",
+                                        "note": f"aggregate model FLOP/s of the sample / the {flops_per_frame / 1e9:.1f} GFLOP per frame of full 50-frame chunks"}
+    return res
 
 
 def main():
@@ -286,12 +329,19 @@ def main():
             srcs = [src] + [make_chunk_on_device(L, H, W, box, seed=1 + k, device=device) for k in range(1, world)]
             dsts = [torch.empty((L, y_hi - y_lo, W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
 
+        corrupt = os.environ.get("VSR_BENCH_SELFTEST_CORRUPT") == "1"      # test hook: flip one bit of the last rank's gathered rows
+
+        def store_rows(i, rows):
+            dsts[i % world].copy_(rows)
+            if corrupt and i % world == world - 1:
+                dsts[i % world][0, 0, 0, 0] ^= 1
+
         def run_rounds(n_rounds):
             ranges = [(i * L, (i + 1) * L) for i in range(n_rounds * world)]
             cp.run_chunk_parallel(ranges, (y_hi - y_lo, W, 3),
                                   lambda i, out: out.copy_(srcs[i % world][:, y_lo:y_hi]),
                                   lambda i, rows: eng.auto_chunk(rows, dmask_rows, local_areas),
-                                  lambda i, rows: dsts[i % world].copy_(rows),
+                                  store_rows,
                                   dist=dist, device=device, io="device")
 
         run_rounds(max(1, args.warmup))
@@ -435,13 +485,14 @@ def main():
             out["cpu_baseline"] = {
                 "value": round(L / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
                 "model_only": {"value": round(L / dt_net, 4), "unit": "frames/s", "tflops": round(flops_chunk / dt_net / 1e12, 3)},
-                "host": {"cpu_count": os.cpu_count(), "cpu_model": cpu_model_name(), "torch_threads": threads,
+                "host": {"cpu_count": os.cpu_count(), "limits": effective_cpus()[1], "cpu_model": cpu_model_name(), "torch_threads": threads,
                          "probe_seconds_by_threads": tried},
                 "sample": f"oracle chunk body (torch-CPU fp32 restatement of the reference modules + restated cv2 resize / blend) on ONE full "
                           f"{L}-frame {args.res} chunk of the timed clip, end to end in {dt:.1f} s of which STTNInpaint.inpaint "
                           f"(the network, {flops_chunk / 1e12:.2f} TFLOP) {dt_net:.1f} s; thread count picked by a 3-frame probe of the same oracle"}
             if not args.no_cpu_parallel:
-                par = cpu_baseline_parallel(min(L, 20), threads, budget_s=150.0)      # a bounded sample: 20-frame chunks (3 windows each)
+                Lp = min(L, 10)       # a bounded sample: 10-frame chunks (2 windows each); 16 x 20 frames at once did not finish in 150 s on the box
+                par = cpu_baseline_parallel(Lp, threads, budget_s=150.0, flops_sample=eng.flops(Lp), flops_per_frame=flops_per_frame)
                 if par is not None:
                     out["cpu_baseline"]["parallel"] = par
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"

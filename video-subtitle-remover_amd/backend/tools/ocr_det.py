@@ -835,25 +835,30 @@ class TextDetection:
         rh, rw = det_resize_shape(H, W, self.resize_long, self.limit_type)
         with torch.cuda.device(self.device):
             d = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device)
-            x = torch.empty((n, 3, rh, rw), dtype=torch.float32, device=self.device)
-            for b in range(n):
-                small = self._resize(d[b], H, W, rh, rw)
-                check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x[b]), _stream()))
-            prob = self.runner.run_taped(x) if self.use_tape else self.runner.run(x)
-        return prob[:, 0]
+            prob = self._forward_frames(d, n, H, W, rh, rw)
+        return prob[:n, 0]
+
+    def _forward_frames(self, d, n, H, W, rh, rw):
+        """resize + normalise + forward of n device frames.  A partial batch (the tail of a video) is padded to batch_size with copies of
+        its last frame when launch lists are recorded: every image of a batch comes out exactly as it does alone, so the padding
+        changes nothing, and the runner keeps ONE recorded list (and one set of intermediates) per frame size instead of one per
+        tail length"""
+        nb = self.batch_size if (self.use_tape and 1 < n < self.batch_size) else n
+        x = torch.empty((nb, 3, rh, rw), dtype=torch.float32, device=self.device)
+        for b in range(n):
+            small = self._resize(d[b], H, W, rh, rw)
+            check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x[b]), _stream()))
+        if nb > n:
+            x[n:] = x[n - 1]
+        return self.runner.run_taped(x) if self.use_tape else self.runner.run(x)
 
     def probability_maps_device(self, frames_dev):
         """probability_maps for frames that already live in HBM (uint8 [n,H,W,3] BGR device tensor, tools/resident.py): no upload"""
         n, H, W, _ = frames_dev.shape
         rh, rw = det_resize_shape(H, W, self.resize_long, self.limit_type)
         with torch.cuda.device(self.device):
-            d = frames_dev.contiguous()
-            x = torch.empty((n, 3, rh, rw), dtype=torch.float32, device=self.device)
-            for b in range(n):
-                small = self._resize(d[b], H, W, rh, rw)
-                check(lib.vsr_det_launch_normalize(_p(small), rh, rw, _p(x[b]), _stream()))
-            prob = self.runner.run_taped(x) if self.use_tape else self.runner.run(x)
-        return prob[:, 0]
+            prob = self._forward_frames(frames_dev.contiguous(), n, H, W, rh, rw)
+        return prob[:n, 0]
 
     def predict_batch_device(self, frames_dev):
         """predict_batch on device frames: the same dicts"""
