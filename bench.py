@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=50, help="frames per chunk (config.sttnMaxLoadNum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-parallel", action="store_true", help="skip cpu_baseline.parallel (one oracle chunk per 16 host threads, all at once)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("VSR_STTN_LANES", "2")), choices=[1, 2, 3, 4],
+                    help="streams a chunk's sliding windows are issued on (vsr_sttn_set_lanes; 2 = default of the library)")
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the check of the gathered chunks against each rank's replica result")
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
@@ -273,6 +275,7 @@ def main():
     L = args.chunk
     sd = make_state_dict(0, "auto")
     eng = SttnEngine(sd, "auto", device=local_rank, precision=args.precision)
+    eng.set_lanes(args.lanes)
     base_precision = args.precision or {"1": "split", "s": "split", "2": "split-format", "3": "f16"}.get(
         os.environ.get("VSR_PRECISION", "0")[:1], "f32")
     mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
@@ -310,11 +313,8 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        # HIP events on the launch stream around every launch of the dominant kernel symbol during the timed region (one record
-        # pair per launch, ~410 of the ~1300 launches of a chunk, read back once per chunk) -- feeds the roofline object.  Events
-        # around EVERY launch cost 2.5 % of a chunk; the per-op breakdown is therefore taken on extra chunks after the timed region.
-        eng.timing(2)
-        eng.timing_reset()
+        # the timed region carries no events: with two lanes (vsr_sttn_set_lanes, the default) launches of the two streams overlap,
+        # so per-launch durations are taken in a single-lane pass afterwards (roofline_leg) and the per-op breakdown after that
         elapsed = timed(lambda: [step() for _ in range(args.steps)])
     else:
         # N > 1: the north-star data path.  A step = one round of N chunks: all resident in rank 0's HBM, the rows between the
@@ -345,10 +345,7 @@ def main():
                                   dist=dist, device=device, io="device")
 
         run_rounds(max(1, args.warmup))
-        eng.timing(2)
-        eng.timing_reset()
         elapsed = timed(lambda: run_rounds(args.steps))
-        eng.timing(False)
         for _ in range(max(1, args.warmup)):
             step()
         dt_rep = timed(lambda: [step() for _ in range(args.steps)])
@@ -406,7 +403,27 @@ def main():
         "gflop_per_frame": round(flops_per_frame / 1e9, 2),
     }
 
+    # ---- roofline leg: K steps of the same resident chunk on ONE lane, HIP events on the launch stream around every launch of the
+    # dominant kernel symbol (one record pair per launch, ~410 of the ~1300 launches of a chunk, read back once per chunk).  With
+    # two lanes a launch's event-to-event time contains the other lane's work, and rocprofv3's per-kernel durations do too
+    # (profiles/: the kernel-trace summary that agrees with this leg is the one of `bench.py --lanes 1`).
+    eng.set_lanes(1)
+    step()
+    torch.cuda.synchronize()
+    eng.timing(2)
+    eng.timing_reset()
+    torch.cuda.synchronize()
+    t_leg = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t_leg = time.perf_counter() - t_leg
     eng.timing(False)
+    out["lanes"] = args.lanes
+    out["single_lane"] = {"value": round(args.steps * L / t_leg, 3), "unit": "frames/s (this rank, resident chunk)",
+                          "ms_per_step": round(t_leg / args.steps * 1e3, 3),
+                          "note": "the same step with every op on one stream (vsr_sttn_set_lanes(1)), dominant-kernel launches bracketed by "
+                                  "HIP events: the pass `roofline` is measured on"}
     if replicas is not None:
         out["replicas"] = replicas
     if world > 1:          # the CPU baseline and the informational legs belong to the N = 1 line only
@@ -450,7 +467,9 @@ def main():
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                            "launches": int(n), "avg_launch_ms": round(ms / n, 4) if n else None,
-                           "flops_per_launch": round(fl / n) if n else None}
+                           "flops_per_launch": round(fl / n) if n else None,
+                           "measured_on": f"{args.steps} single-lane steps after the timed region (`single_lane`): with {args.lanes} lanes the "
+                                          "launches of the two streams overlap, so a launch's own duration is taken with one"}
         if world == 1:
             # per-op and per-kernel breakdown: events around every launch of two extra chunks, outside the timed region
             eng.timing_reset()
@@ -470,6 +489,7 @@ def main():
             out["breakdown_note"] = (f"HIP events around every launch of {extra} extra chunks after the timed region (they cost 2.5 % of a "
                                      f"chunk, so the timed region brackets the dominant kernel's launches only)")
 
+        eng.set_lanes(args.lanes)
         refa = None
         if not args.no_cpu_baseline:
             # one full chunk of the timed clip through the oracle on the host cores, and the same chunk through the HIP path

@@ -111,6 +111,12 @@ int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, 
  * Environment default: VSR_PRECISION=split (mode 1) / VSR_PRECISION=2 / VSR_PRECISION=3. */
 int vsr_sttn_set_precision(vsr_sttn_t* h, int mode);
 int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h);
+/* Streams a chunk's sliding windows are issued on (1 .. 4; default 2, environment VSR_STTN_LANES).  The windows of
+ * STTNInpaint.inpaint (sttn_auto_inpaint.py:142-162) share nothing until their decoded frames are averaged into `comps`, so window w
+ * runs on stream w % lanes (engine-owned streams beyond the caller's) in that lane's own window buffers while the averaging stays in window order (events):
+ * the partial last round of tiles of one lane's launch is filled by another lane's kernel.  Results are identical for every
+ * lane count; the caller's stream is joined behind the others before any entry point returns to it. */
+int vsr_sttn_set_lanes(vsr_sttn_t* h, int lanes);
 
 /* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded) */
 double vsr_sttn_flops(vsr_sttn_t* h, int L);
@@ -500,6 +506,7 @@ int64_t vsr_plan_table_len(const vsr_plan_t* p, int t);
 int vsr_plan_table_copy(const vsr_plan_t* p, int t, int32_t* out);
 int vsr_plan_num_ops(const vsr_plan_t* p);
 int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* out);
+int vsr_plan_op_lane(const vsr_plan_t* p, int i);   /* stream the op is issued on (vsr_sttn_set_lanes; 0 for every other plan), -1 on a bad index */
 int vsr_plan_op_gemm(const vsr_plan_t* p, int i, int j, VsrGemmInfo* out);
 int vsr_plan_op_softmax(const vsr_plan_t* p, int i, int j, VsrSoftmaxInfo* out);
 int vsr_plan_counts(const vsr_plan_t* p, int32_t* counts);

@@ -329,3 +329,55 @@ def test_split_format_after_fp32_on_one_engine(built_lib, gpu_device, sd):
     assert torch.equal(a32, b32) and torch.equal(asf, bsf)
     assert (asf - a32).abs().max().item() <= 1.0
     e.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "split-format"])
+def test_two_lanes_equal_one_lane(built_lib, gpu_device, sd, mode):
+    """vsr_sttn_set_lanes: sliding window w on stream w % lanes in that lane's own window buffers, the running average chained in
+    window order -- the same arithmetic in the same order, so comps are identical BIT FOR BIT with one and with two lanes,
+    repeatedly (a race between the lanes would show up as run-to-run differences), for the model-resolution entry and for the
+    strip-level chunk entry; and the caller's stream is joined behind the second one (the result is read on it right away)."""
+    eng = _engine(sd, precision=mode)
+    clip = synth.make_clip(32, 120, 640, (30, 90, 60, 580), seed=5)             # 7 windows: 4 on lane 0, 3 on lane 1
+    d = torch.from_numpy(clip).to(gpu_device)
+    eng.set_lanes(1)
+    ref, counts1 = eng.inpaint(d)
+    ref = ref.clone()
+    for lanes in (2, 2, 3, 4, 2):
+        eng.set_lanes(lanes)
+        got, counts2 = eng.inpaint(d)
+        assert torch.equal(got, ref) and counts1.tolist() == counts2.tolist(), lanes
+    H, W, box = 720, 1280, (620, 700, 192, 1088)
+    frames = torch.from_numpy(synth.make_clip(20, H, W, box, seed=6)).to(gpu_device)
+    from vsr_amd.backend.tools.inpaint_tools import create_mask as cm, get_inpaint_area_by_mask as ga, threshold_mask as tm
+    m01 = tm(cm((H, W), [(box[2], box[3], box[0], box[1])]))
+    areas = ga(W, H, int(W * 3 / 16), m01)
+    dmask = torch.from_numpy(np.ascontiguousarray(m01[:, :, 0])).to(gpu_device)
+    outs = []
+    for lanes in (1, 2, 3):
+        eng.set_lanes(lanes)
+        w = frames.clone()
+        eng.auto_chunk(w, dmask, areas)
+        outs.append(w.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert not torch.equal(outs[0], frames)
+    eng.close()
+
+
+def test_two_lanes_equal_one_lane_det(built_lib, gpu_device, sd_det):
+    from vsr_amd.engine import SttnEngine
+
+    eng = SttnEngine(sd_det, "det", device=0)
+    rng = np.random.default_rng(8)
+    frames = torch.from_numpy(rng.integers(0, 256, size=(17, 240, 432, 3), dtype=np.uint8)).to(gpu_device)
+    masks = torch.zeros((17, 240, 432), dtype=torch.uint8, device=gpu_device)
+    masks[:, 180:230, 40:400] = 255
+    res = []
+    for lanes in (1, 2, 4):
+        eng.set_lanes(lanes)
+        comp, counts = eng.det_inpaint(frames, masks)
+        res.append(comp.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(res[0], res[1]) and torch.equal(res[1], res[2])
+    eng.close()

@@ -121,3 +121,64 @@ def test_plan_tables_stay_inside_buffers(built_lib, host_engine):
                 assert (it.splitK - 1) * it.chunksPerSplit < it.K // 32, "no empty split"
     finally:
         view.close()
+
+
+@pytest.mark.parametrize("nl", [2, 3, 4])
+def test_window_lanes_share_nothing_but_the_running_average(built_lib, nl):
+    """vsr_sttn_set_lanes(n): window w is issued on stream w % n.  What makes that legal is checked here on the plan itself: the
+    op list is the same as with one lane (same kinds, shapes, FLOPs, visit counts), every buffer an op WRITES on lane 1 is a
+    lane-1 instance (ids from BUF_L1_X0 on) and on lane 0 never one, the only shared buffers a window op writes are BUF_COMP
+    -- by OP_DECODE_OUT, which the engine chains from window to window with events -- and the per-instance row maxima, and no
+    lane reads a window buffer of the other.  (That the laned plan computes the right thing is the replay tests above: they run
+    the default, two lanes.)"""
+    from vsr_amd import _lib
+    from vsr_amd.engine import SttnEngine
+
+    BUF_WEIGHTS, BUF_IN_U8, BUF_FEATS, BUF_COMP, BUF_MASK_U8, BUF_ROWMAX, L1_FIRST = 0, 1, 6, 20, 22, 23, 25
+    window_scoped = set(range(7, 20)) | {21, 24}            # X0 .. D4, PVPART, LSUM
+    shared_read = {BUF_WEIGHTS, BUF_IN_U8, BUF_FEATS, BUF_MASK_U8, BUF_ROWMAX}
+    eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None)
+    try:
+        views = {}
+        for lanes in (1, nl):
+            eng.set_lanes(lanes)
+            views[lanes] = PlanView(_lib, eng, 20)
+        one, two = views[1], views[nl]
+
+        def own(buf, lane):
+            return buf in window_scoped if lane == 0 else L1_FIRST + (lane - 1) * 15 <= buf < L1_FIRST + lane * 15
+
+        assert len(one.ops) == len(two.ops) and one.flops == two.flops and list(one.counts) == list(two.counts)
+        assert len(one.buf_elems) == len(two.buf_elems) and all(one.buf_elems[b] == 0 for b in range(L1_FIRST, len(one.buf_elems)))
+        lanes_seen, n_decode = set(), 0
+        first_window_op = next(i for i, (b, _) in enumerate(two.ops) if b.tag == b"attn.qkv")
+        for i, ((a, ai), (b, bi)) in enumerate(zip(one.ops, two.ops)):
+            lane = _lib.lib.vsr_plan_op_lane(two.p, i)
+            assert _lib.lib.vsr_plan_op_lane(one.p, i) == 0 and 0 <= lane < nl
+            assert (a.kind, a.nitems, a.tile_cfg, a.bmode, a.flops, a.tag) == (b.kind, b.nitems, b.tile_cfg, b.bmode, b.flops, b.tag)
+            if i < first_window_op:                              # the encoder: the caller's stream, before the lanes fork
+                assert lane == 0
+                continue
+            lanes_seen.add(lane)
+            reads, writes = [], []
+            if b.kind == 1:
+                for x, y in zip(ai, bi):
+                    assert (x.M, x.N, x.K, x.splitK, x.act) == (y.M, y.N, y.K, y.splitK, y.act)
+                    reads += [y.bufA, y.bufB] + ([y.bufR] if y.bufR >= 0 else [])
+                    writes.append(y.bufC)
+            elif b.kind == 2:
+                reads += [y.bufS for y in bi]
+                writes += [y.bufP for y in bi]
+            else:
+                reads += [v for v in (b.buf_src, b.ibuf[0]) if v >= 0]
+                writes += [b.buf_dst] if b.buf_dst >= 0 else []
+            n_decode += b.kind == 4
+            for buf in writes:                                   # a lane writes its own window buffers; shared state: the running average only
+                assert own(buf, lane) or (buf == BUF_COMP and b.kind == 4), (i, b.tag, lane, buf)
+            for buf in reads:                                    # ... and reads its own window buffers and read-only shared ones
+                assert own(buf, lane) or buf in shared_read, (i, b.tag, lane, buf)
+        assert lanes_seen == set(range(nl)) and n_decode == 4               # L = 20, stride 5: four windows, one decode_out each
+        for v in views.values():
+            v.close()
+    finally:
+        eng.close()

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vsr_sttn_det_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_sttn_set_precision": (_I, [_P, _I]),
+    "vsr_sttn_set_lanes": (_I, [_P, _I]),
     "vsr_sttn_fallbacks": (_L, [_P]),
     "vsr_sttn_flops": (_D, [_P, _I]),
     "vsr_sttn_timing": (_I, [_P, _I]),
@@ -185,6 +186,7 @@ SIGNATURES = {
     "vsr_plan_table_copy": (_I, [_P, _I, _P]),
     "vsr_plan_num_ops": (_I, [_P]),
     "vsr_plan_op": (_I, [_P, _I, C.POINTER(VsrOpInfo)]),
+    "vsr_plan_op_lane": (_I, [_P, _I]),
     "vsr_plan_op_gemm": (_I, [_P, _I, _I, C.POINTER(VsrGemmInfo)]),
     "vsr_plan_op_softmax": (_I, [_P, _I, _I, C.POINTER(VsrSoftmaxInfo)]),
     "vsr_plan_counts": (_I, [_P, _P]),

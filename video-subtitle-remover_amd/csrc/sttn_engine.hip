@@ -67,6 +67,7 @@ struct OpDev {
     const float* lsum = nullptr; // reduce_scatter of a fused attention: partial row sums [nsplit][ldL]
     int ldL = 0;
     double flops = 0;
+    int lane = 0;                // stream the op is issued on (Plan::lanes)
     std::string tag;
 };
 
@@ -118,6 +119,13 @@ struct vsr_sttn {
     float* weightsSplit = nullptr;     // mode 2: the packed weights in split format (biases are read from BUF_WEIGHTS)
     unsigned int* dRangeFlag = nullptr;
     int64_t fallbacks = 0;             // chunks recomputed in fp32 because the range guard fired
+    // lanes: the sliding windows of a chunk are independent until their decoded frames are averaged into BUF_COMP, so odd
+    // windows are issued on a second stream with their own window buffers -- the tail of one lane's launch (a partial last round
+    // of tiles) is filled by the other lane's kernel.  Same arithmetic in the same order: results do not change.
+    int lanes = 2;               // VSR_STTN_LANES / vsr_sttn_set_lanes: 1 = everything on the caller's stream
+    hipStream_t laneStream[kMaxLanes] = {};     // [0] unused (the caller's stream)
+    hipEvent_t evFork = nullptr, evJoin[kMaxLanes] = {};
+    std::vector<hipEvent_t> evDecode;
     int timing = 0;              // 0 off; 1 every op; 2 only the launches of the 128x64 NK gather-GEMM (the dominant kernel symbol)
     std::vector<TimingRec> pending;
     std::map<std::string, std::pair<double, std::pair<int, double>>> timed; // tag -> (ms, (launches, flops))
@@ -125,6 +133,8 @@ struct vsr_sttn {
     {
         const char* e = getenv("VSR_PRECISION");
         precision = !e ? 0 : (e[0] == '3' ? 3 : (e[0] == '2' ? 2 : ((e[0] == '1' || e[0] == 's') ? 1 : 0)));   // "1" / "split" / "2" / "3"
+        const char* l = getenv("VSR_STTN_LANES");
+        lanes = (l && l[0] >= '1' && l[0] <= '0' + kMaxLanes) ? l[0] - '0' : 2;
     }
 };
 
@@ -146,9 +156,9 @@ static int gg_wide_queues()
 
 static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
 {
-    const int key = L * 4 + precision;
+    const int key = (L * 4 + precision) * 8 + h->lanes;
     const bool fmt = precision >= 2;       // split-format tensors: everything a GEMM reads (see gather_gemm_v5.h)
-    auto plainF32 = [](int buf) { return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
+    auto plainF32 = [](int buf) { buf = baseBuf(buf); return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
     if (fmt && !h->weightsSplit) {
         const int64_t n = (int64_t)h->model.packed.size();
         HIPCHK(hipMalloc((void**)&h->weightsSplit, (size_t)n * sizeof(float)));
@@ -160,7 +170,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     if (it != h->plans.end()) { *out = it->second.get(); return 0; }
     std::unique_ptr<PlanDev> pd(new PlanDev);
     try {
-        pd->plan.reset(new Plan(h->model, L, precision));
+        pd->plan.reset(new Plan(h->model, L, precision, h->lanes));
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
     }
@@ -204,7 +214,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     size_t cursor = 0;
     for (const Op& op : P.ops) {
         OpDev od;
-        od.kind = op.kind; od.tileCfg = op.tileCfg; od.bmode = op.bmode; od.flops = op.flops; od.tag = op.tag;
+        od.kind = op.kind; od.tileCfg = op.tileCfg; od.bmode = op.bmode; od.flops = op.flops; od.tag = op.tag; od.lane = op.lane;
         if (op.kind == OP_GEMM) {
             GGProblem* hp = (GGProblem*)(hostDesc.data() + cursor);
             int tileStart = 0;
@@ -305,10 +315,34 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
     if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
     if (pd->plan->bufElems[BUF_ROWMAX] > 0)     // fused attention: every instance's row maxima start below every float
         HIPCHK(hipMemsetAsync(h->bufs[BUF_ROWMAX], 0, (size_t)pd->plan->bufElems[BUF_ROWMAX] * sizeof(unsigned int), stream));
+    // lanes: everything up to the first window op (the memsets above, the encoder) is on the caller's stream; lane 1 starts
+    // behind it (evFork); OP_DECODE_OUT -- the one op of a window that touches shared state, the running average in BUF_COMP --
+    // is chained from window to window across the lanes (evDecode); the caller's stream ends behind lane 1 (evJoin)
+    const bool laned = pd->plan->lanes > 1;
+    hipStream_t laneOf[kMaxLanes] = {stream, stream, stream, stream};
+    if (laned) {
+        if (!h->evFork) HIPCHK(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+        for (int l = 1; l < pd->plan->lanes; ++l) {
+            if (!h->laneStream[l]) HIPCHK(hipStreamCreateWithFlags(&h->laneStream[l], hipStreamNonBlocking));
+            if (!h->evJoin[l]) HIPCHK(hipEventCreateWithFlags(&h->evJoin[l], hipEventDisableTiming));
+            laneOf[l] = h->laneStream[l];
+        }
+    }
+    bool forked[kMaxLanes] = {};
+    int lastDecodeLane = -1;
+    size_t nDecode = 0;
     size_t opIndex = 0;
     for (const OpDev& od : pd->ops) {
         unsigned int* queue = persistent ? pd->dQueues + 8 * opIndex : nullptr;
+        if (laned && (int)opIndex == pd->plan->firstWindowOp) HIPCHK(hipEventRecord(h->evFork, laneOf[0]));
         ++opIndex;
+        hipStream_t const stream = laneOf[od.lane];            // shadows the caller's stream for this op
+        if (laned && od.lane > 0 && !forked[od.lane]) {
+            HIPCHK(hipStreamWaitEvent(stream, h->evFork, 0));
+            forked[od.lane] = true;
+        }
+        if (laned && od.kind == OP_DECODE_OUT && lastDecodeLane >= 0 && lastDecodeLane != od.lane)
+            HIPCHK(hipStreamWaitEvent(stream, h->evDecode[nDecode - 1], 0));
         TimingRec tr;
         const bool timed = h->timing == 1 || (h->timing == 2 && od.kind == OP_GEMM && od.tileCfg == VSR_TILE_128x64 && od.bmode == VSR_BMODE_NK);
         if (timed) {
@@ -352,7 +386,22 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             HIPCHK(hipEventRecord(tr.b, stream));
             h->pending.push_back(tr);
         }
+        if (laned && od.kind == OP_DECODE_OUT) {
+            if (h->evDecode.size() <= nDecode) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->evDecode.push_back(e);
+            }
+            HIPCHK(hipEventRecord(h->evDecode[nDecode], stream));
+            lastDecodeLane = od.lane;
+            ++nDecode;
+        }
     }
+    for (int l = 1; l < kMaxLanes; ++l)
+        if (forked[l]) {
+            HIPCHK(hipEventRecord(h->evJoin[l], laneOf[l]));
+            HIPCHK(hipStreamWaitEvent(laneOf[0], h->evJoin[l], 0));
+        }
     return 0;
 }
 
@@ -499,6 +548,12 @@ void vsr_sttn_destroy(vsr_sttn_t* h)
         if (h->dRangeFlag) (void)hipFree(h->dRangeFlag);
         if (h->weightsSplit) (void)hipFree(h->weightsSplit);
         if (h->dSel) (void)hipFree(h->dSel);
+        for (hipEvent_t e : h->evDecode) (void)hipEventDestroy(e);
+        if (h->evFork) (void)hipEventDestroy(h->evFork);
+        for (int l = 1; l < kMaxLanes; ++l) {
+            if (h->evJoin[l]) (void)hipEventDestroy(h->evJoin[l]);
+            if (h->laneStream[l]) (void)hipStreamDestroy(h->laneStream[l]);
+        }
     }
     delete h;
 }
@@ -689,6 +744,13 @@ int vsr_sttn_set_precision(vsr_sttn_t* h, int mode)
     if (!h || mode < 0 || mode > 3)
         return fail(VSR_ERR_ARG, "precision mode must be 0 (f32), 1 (split-half f16 MFMA), 2 (split-half on split-format tensors) or 3 (fp16 operands)");
     h->precision = mode;
+    return 0;
+}
+
+int vsr_sttn_set_lanes(vsr_sttn_t* h, int lanes)
+{
+    if (!h || lanes < 1 || lanes > kMaxLanes) return fail(VSR_ERR_ARG, "lanes must be 1 .. 4");
+    h->lanes = lanes;                  // plans are cached per (L, precision, lanes)
     return 0;
 }
 
@@ -888,7 +950,7 @@ int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out)
     if (!h->model.packed_ready()) return fail(VSR_ERR_STATE, "model not finalized");
     try {
         std::unique_ptr<vsr_plan> p(new vsr_plan);
-        p->plan.reset(new Plan(h->model, L));
+        p->plan.reset(new Plan(h->model, L, 0, h->lanes));
         *out = p.release();
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
@@ -928,6 +990,8 @@ int vsr_plan_op(const vsr_plan_t* p, int i, VsrOpInfo* o)
     strncpy(o->tag, op.tag.c_str(), sizeof(o->tag) - 1);
     return 0;
 }
+int vsr_plan_op_lane(const vsr_plan_t* p, int i) { return (p && i >= 0 && i < (int)p->plan->ops.size()) ? p->plan->ops[i].lane : -1; }
+
 int vsr_plan_op_gemm(const vsr_plan_t* p, int i, int j, VsrGemmInfo* o)
 {
     if (!p || !o || i < 0 || i >= (int)p->plan->ops.size()) return fail(VSR_ERR_ARG, "bad op");

@@ -500,7 +500,7 @@ void Plan::addAttention(int T, const BlockW&)
 {
     const Tuning& tu = tu_;
     const int C = g.channels, dk = C / g.nscales;
-    const Act att{BUF_ATT, T, g.featH, g.featW, C, 1};
+    const Act att{lb(BUF_ATT), T, g.featH, g.featW, C, 1};
     Op qk, sm, pv;
     qk.kind = OP_GEMM; qk.tag = "attn.qk"; qk.tileCfg = tu.qkTile; qk.bmode = VSR_BMODE_NK;
     sm.kind = OP_SOFTMAX; sm.tag = "attn.softmax";
@@ -529,13 +529,13 @@ void Plan::addAttention(int T, const BlockW&)
         a.tilesM = cdiv(Ntok, qBM); a.tilesN = cdiv(Ntok, qBN);
         a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
         a.alpha = 1.f; a.act = VSR_ACT_NONE;
-        a.bufA = BUF_QKV; a.offA = 0;
+        a.bufA = lb(BUF_QKV); a.offA = 0;
         a.tRowA = tRowsTokens(T, s, dk * s, Ntok, qBM);
         a.tColA = tColsPatch(s, nchunks);
-        a.bufB = BUF_QKV; a.offB = 0;
+        a.bufB = lb(BUF_QKV); a.offB = 0;
         a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN);
         a.tColB = a.tColA;
-        a.bufC = BUF_S; a.offC = sOff;
+        a.bufC = lb(BUF_S); a.offC = sOff;
         a.tRowC = tRowsLinear(Ntok, ldS, qBM);
         a.tColC = tColsLinear(a.tilesN * qBN / VSR_GG_KC, a.tilesN * qBN / VSR_GG_KC);
         a.bufR = -1; a.tRowR = -1; a.offBias = -1;
@@ -558,8 +558,8 @@ void Plan::addAttention(int T, const BlockW&)
 
         if (!fused) {
             SoftmaxItem m{};
-            m.bufS = BUF_S; m.offS = sOff; m.splitStride = plane; m.nsplit = splitK;
-            m.bufP = BUF_P; m.offP = pOff;
+            m.bufS = lb(BUF_S); m.offS = sOff; m.splitStride = plane; m.nsplit = splitK;
+            m.bufP = lb(BUF_P); m.offP = pOff;
             m.M = Ntok; m.N = Ntok; m.ldS = ldS; m.ldP = ldS;
             m.scale = scale;
             sm.softmax.push_back(m);
@@ -577,27 +577,27 @@ void Plan::addAttention(int T, const BlockW&)
         b.tilesM = cdiv(Ntok, pBM); b.tilesN = cdiv(D, pBN);
         b.splitK = pvSplit; b.chunksPerSplit = pvCps;
         b.alpha = 1.f; b.act = VSR_ACT_NONE;
-        b.bufA = fused ? BUF_S : BUF_P; b.offA = fused ? sOff : pOff;
+        b.bufA = fused ? lb(BUF_S) : lb(BUF_P); b.offA = fused ? sOff : pOff;
         b.tRowA = tRowsLinear(Ntok, ldS, pBM);
         b.tColA = tColsLinear(kchunks, kchunks);
-        b.bufB = BUF_QKV; b.offB = 0;
+        b.bufB = lb(BUF_QKV); b.offB = 0;
         b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
         b.tColB = tColsPatch(s, b.tilesN * pBN / VSR_GG_KC);
         const int tRowAtt = tRowsTokensAct(att, T, s, pBM);
         const int tColAtt = tColsPatchAct(att, s, b.tilesN * pBN / VSR_GG_KC);
         if (pvSplit == 1) {
-            b.bufC = BUF_ATT; b.offC = 0; b.splitStride = 0;
+            b.bufC = lb(BUF_ATT); b.offC = 0; b.splitStride = 0;
             b.tRowC = tRowAtt;
             b.tColC = tColAtt;
         } else {        // partial planes [pvSplit][Ntok][D], combined + scattered by the reduce op
-            b.bufC = BUF_PVPART; b.offC = partOff; b.splitStride = (int64_t)Ntok * D;
+            b.bufC = lb(BUF_PVPART); b.offC = partOff; b.splitStride = (int64_t)Ntok * D;
             b.tRowC = tRowsLinear(Ntok, D, pBM);
             b.tColC = tColsLinear(D / VSR_GG_KC, b.tilesN * pBN / VSR_GG_KC);
             Op r;
             r.kind = OP_REDUCE_SCATTER; r.tag = "attn.pv.reduce";
-            r.bufSrc = BUF_PVPART; r.offSrc = partOff; r.splitStride = b.splitStride; r.nsplit = pvSplit;
-            r.bufDst = BUF_ATT; r.offDst = 0; r.M = Ntok; r.N = D; r.tRowC = tRowAtt; r.tColC = tColAtt;
-            if (fused) { r.ibuf[0] = BUF_LSUM; r.ioff[0] = lOff; r.ipar[0] = b.tilesM * pBM; }
+            r.bufSrc = lb(BUF_PVPART); r.offSrc = partOff; r.splitStride = b.splitStride; r.nsplit = pvSplit;
+            r.bufDst = lb(BUF_ATT); r.offDst = 0; r.M = Ntok; r.N = D; r.tRowC = tRowAtt; r.tColC = tColAtt;
+            if (fused) { r.ibuf[0] = lb(BUF_LSUM); r.ioff[0] = lOff; r.ipar[0] = b.tilesM * pBM; }
             reduces.push_back(std::move(r));
             partOff += rup(b.splitStride * pvSplit, 32);
         }
@@ -605,7 +605,7 @@ void Plan::addAttention(int T, const BlockW&)
         if (fused) {
             b.act |= VSR_ACT_A_EXP;
             b.bufBias = BUF_ROWMAX; b.offBias = rmaxOff;
-            if (pvSplit > 1) { b.bufR = BUF_LSUM; b.offR = lOff; lOff += rup((int64_t)pvSplit * b.tilesM * pBM, 32); }
+            if (pvSplit > 1) { b.bufR = lb(BUF_LSUM); b.offR = lOff; lOff += rup((int64_t)pvSplit * b.tilesM * pBM, 32); }
             pvFused = true;
         }
         pv.gemm.push_back(b);
@@ -615,12 +615,12 @@ void Plan::addAttention(int T, const BlockW&)
         if (!fused) pOff += rup(plane, 32);
     }
     if (pvFused) pv.ipar[0] = 1;       // the launch may carry VSR_ACT_A_EXP problems: kernel variant 1 | VSR_VARIANT_A_EXP
-    need(BUF_S, sOff);
-    need(BUF_P, pOff);
+    need(lb(BUF_S), sOff);
+    need(lb(BUF_P), pOff);
     need(BUF_ROWMAX, rowmaxElems_);
-    need(BUF_LSUM, lOff);
-    need(BUF_PVPART, partOff);
-    need(BUF_ATT, att.elems());
+    need(lb(BUF_LSUM), lOff);
+    need(lb(BUF_PVPART), partOff);
+    need(lb(BUF_ATT), att.elems());
     flops += qk.flops + pv.flops;
     ops.push_back(std::move(qk));
     if (!sm.softmax.empty()) ops.push_back(std::move(sm));
@@ -637,8 +637,8 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     ids.insert(ids.end(), refs.begin(), refs.end());
     const int T = (int)ids.size(), nn = (int)neighbors.size();
     const Act feats{BUF_FEATS, L, fh, fw, C, 2};
-    const Act x0{BUF_X0, T, fh, fw, C, 2}, x1{BUF_X1, T, fh, fw, C, 2};
-    const Act att{BUF_ATT, T, fh, fw, C, 1}, f1{BUF_F1, T, fh, fw, C, 1};
+    const Act x0{lb(BUF_X0), T, fh, fw, C, 2}, x1{lb(BUF_X1), T, fh, fw, C, 2};
+    const Act att{lb(BUF_ATT), T, fh, fw, C, 1}, f1{lb(BUF_F1), T, fh, fw, C, 1};
     const std::vector<int> idT = iota(T);
 
     Act cur = feats;
@@ -660,7 +660,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
             it.bufB = BUF_WEIGHTS; it.offB = bw.qkv.w;
             it.tRowB = tRowsLinear(it.N, it.K, BN);
             it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
-            it.bufC = BUF_QKV; it.offC = 0;
+            it.bufC = lb(BUF_QKV); it.offC = 0;
             it.tRowC = tRowsLinear(it.M, 3 * C, BM);
             it.tColC = tColsLinear(it.N / VSR_GG_KC, it.tilesN * BN / VSR_GG_KC);
             it.offBias = bw.qkv.b;
@@ -668,7 +668,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
             op.flops = 2.0 * it.M * (double)it.N * it.K;
             flops += op.flops;
             op.gemm.push_back(it);
-            need(BUF_QKV, (int64_t)it.M * 3 * C);
+            need(lb(BUF_QKV), (int64_t)it.M * 3 * C);
             ops.push_back(std::move(op));
         }
         addAttention(T, bw);
@@ -682,8 +682,8 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     }
 
     // decoder on the neighbour frames only (sttn_auto_inpaint.py:150; auto_sttn.py:87-95,118-127)
-    const Act up1{BUF_UP1, nn, 2 * fh, 2 * fw, C, 1}, d1{BUF_D1, nn, 2 * fh, 2 * fw, 128, 1};
-    const Act d2{BUF_D2, nn, 2 * fh, 2 * fw, 64, 0}, up2{BUF_UP2, nn, mh, mw, 64, 1}, d3{BUF_D3, nn, mh, mw, 64, 1};
+    const Act up1{lb(BUF_UP1), nn, 2 * fh, 2 * fw, C, 1}, d1{lb(BUF_D1), nn, 2 * fh, 2 * fw, 128, 1};
+    const Act d2{lb(BUF_D2), nn, 2 * fh, 2 * fw, 64, 0}, up2{lb(BUF_UP2), nn, mh, mw, 64, 1}, d3{lb(BUF_D3), nn, mh, mw, 64, 1};
     const std::vector<int> idN = iota(nn);
     {
         Op op;
@@ -739,7 +739,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         it.bufB = BUF_WEIGHTS; it.offB = w.w;
         it.tRowB = tRowsLinear(it.N, it.K, BN);
         it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
-        it.bufC = BUF_D4; it.offC = 0;
+        it.bufC = lb(BUF_D4); it.offC = 0;
         it.tRowC = tRowsLinear(it.M, 32, BM);
         it.tColC = tColsLinear(1, 1);
         it.offBias = w.b;
@@ -747,7 +747,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.flops = 2.0 * (double)nn * mh * mw * 3.0 * (9.0 * d3.C);     // the algorithmic work of the 3x3 conv, not the padded window's
         flops += op.flops;
         op.gemm.push_back(it);
-        need(BUF_D4, (int64_t)it.tilesM * BM * 32);
+        need(lb(BUF_D4), (int64_t)it.tilesM * BM * 32);
         ops.push_back(std::move(op));
     } else
     {   // 64 -> 3 conv into a plain [M][32] buffer (columns 0..2 valid)
@@ -765,7 +765,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         it.bufB = BUF_WEIGHTS; it.offB = w.w;
         it.tRowB = tRowsLinear(it.N, it.K, BN);
         it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
-        it.bufC = BUF_D4; it.offC = 0;
+        it.bufC = lb(BUF_D4); it.offC = 0;
         it.tRowC = tRowsLinear(it.M, 32, BM);
         it.tColC = tColsLinear(1, 1);
         it.offBias = w.b;
@@ -773,13 +773,13 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.flops = 2.0 * it.M * (double)it.N * it.K;
         flops += op.flops;
         op.gemm.push_back(it);
-        need(BUF_D4, (int64_t)it.M * 32);
+        need(lb(BUF_D4), (int64_t)it.M * 32);
         ops.push_back(std::move(op));
     }
     {
         Op op;
         op.kind = OP_DECODE_OUT; op.tag = "dec.out";
-        op.bufSrc = BUF_D4; op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
+        op.bufSrc = lb(BUF_D4); op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
         if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) op.W = mw;   // src rows are 2x4 blocks of a mw-wide image
         op.bufMask = g.variant == 1 ? BUF_MASK_U8 : -1;   // sttn-det: model-resolution blend with the input frames
         std::vector<int32_t> fi, fs;
@@ -795,14 +795,14 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.tFirst = table(k2, std::move(fs));
         ops.push_back(std::move(op));
     }
-    need(BUF_X0, x0.elems());
-    need(BUF_X1, x1.elems());
-    need(BUF_F1, f1.elems());
+    need(lb(BUF_X0), x0.elems());
+    need(lb(BUF_X1), x1.elems());
+    need(lb(BUF_F1), f1.elems());
     ++nwindows;
 }
 
-Plan::Plan(const Model& model, int L_, int precision_)
-    : L(L_), precision(precision_), g(model.g), m_(model), tu_(Tuning::get(precision_))
+Plan::Plan(const Model& model, int L_, int precision_, int lanes_)
+    : L(L_), precision(precision_), lanes(lanes_ < 1 ? 1 : (lanes_ > kMaxLanes ? kMaxLanes : lanes_)), g(model.g), m_(model), tu_(Tuning::get(precision_))
 {
     if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
     if (L <= 0) throw std::runtime_error("empty frame list");
@@ -865,8 +865,15 @@ Plan::Plan(const Model& model, int L_, int precision_)
             for (int n : neighbors) inN |= (n == i);
             if (!inN) refs.push_back(i);
         }
+        // windows are independent until OP_DECODE_OUT averages their frames into BUF_COMP (in window order): window w works in
+        // lane w % lanes' buffers and is issued on that lane's stream
+        lane_ = nwindows % lanes;
+        const size_t first = ops.size();
+        if (firstWindowOp < 0) firstWindowOp = (int)first;
         buildWindow(neighbors, refs, visits);
+        for (size_t i = first; i < ops.size(); ++i) ops[i].lane = lane_;
     }
+    lane_ = 0;
     compCount = visits;
 }
 

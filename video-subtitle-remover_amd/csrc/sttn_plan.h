@@ -77,8 +77,24 @@ enum BufId {
     BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2, BUF_D3, BUF_D4, BUF_COMP, BUF_PVPART, BUF_MASK_U8,
     BUF_ROWMAX,   // fused attention: row maxima of the scores (uint32 images of floats, one array per attention instance of the plan; zeroed per run)
     BUF_LSUM,     // fused attention: partial row sums of the exponentials [split][rows] of a split P.V
-    BUF_COUNT
+    // further instances of every buffer a sliding window works in: the windows of a chunk are independent until their decoded
+    // frames are averaged into BUF_COMP, so window w runs on stream ("lane") w % lanes in lane-owned instances (Plan::lanes, laneBuf())
+    BUF_LANE_FIRST,
+    BUF_COUNT = BUF_LANE_FIRST + 15 * 3      // kLaneBufs * (kMaxLanes - 1)
 };
+constexpr int kLaneBufs = 15, kMaxLanes = 4;
+// the window-scoped buffers, in the order of their lane instances
+constexpr int kLaneBufList[kLaneBufs] = {BUF_X0, BUF_X1, BUF_QKV, BUF_S, BUF_P, BUF_ATT, BUF_F1, BUF_UP1, BUF_D1, BUF_D2, BUF_UP2,
+                                         BUF_D3, BUF_D4, BUF_PVPART, BUF_LSUM};
+// lane instance of a window-scoped buffer (every other buffer is shared: weights, encoder stages, features, comp, masks, row maxima)
+inline int laneBuf(int buf, int lane)
+{
+    if (lane == 0) return buf;
+    for (int i = 0; i < kLaneBufs; ++i)
+        if (kLaneBufList[i] == buf) return BUF_LANE_FIRST + (lane - 1) * kLaneBufs + i;
+    return buf;
+}
+inline int baseBuf(int buf) { return buf >= BUF_LANE_FIRST ? kLaneBufList[(buf - BUF_LANE_FIRST) % kLaneBufs] : buf; }   // the lane-0 buffer an instance mirrors
 
 enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5,
               OP_EW = 6 /* RAFT's elementwise / gather kernels, sub-kind in Op::ew (raft_plan.h) */ };
@@ -115,6 +131,7 @@ struct Op {
     int M = 0, N = 0, nsplit = 0, tRowC = -1, tColC = -1;
     int64_t offSrc = 0, offDst = 0, splitStride = 0;
     double flops = 0;                    // algorithmic flops of this op (2*M*N*K, unpadded)
+    int lane = 0;                        // STTN: the stream this op is issued on (0 = the caller's; ops in list order are a valid serial schedule)
     std::string tag;
     // OP_EW: sub-kind + generic operands (buffers, element offsets, integer / float parameters; meaning per sub-kind)
     int ew = 0;
@@ -165,14 +182,18 @@ protected:
 
 class Plan : public PlanBuilder {
 public:
-    Plan(const Model& model, int L, int precision = 0);
+    Plan(const Model& model, int L, int precision = 0, int lanes = 1);
     int L;
     int precision;
+    int lanes;                           // 1 .. kMaxLanes: window w runs on lane w % lanes
+    int firstWindowOp = -1;              // index of the first op that is not the encoder's: lane 1 may start once everything before it is done
     Geometry g;
     int nwindows = 0;
 private:
     const Model& m_;
     const Tuning& tu_;
+    int lane_ = 0;                       // lane of the window being built
+    int lb(int buf) const { return laneBuf(buf, lane_); }
     int64_t rowmaxElems_ = 0;            // BUF_ROWMAX handed out so far: every fused attention instance of the plan has its own array
     int pickTile(int N) const;
     int tRowsTokens(int T, int s, int choff, int count, int padTo);

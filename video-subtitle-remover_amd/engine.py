@@ -73,6 +73,10 @@ class SttnEngine:
     def set_precision(self, precision):
         check(lib.vsr_sttn_set_precision(self._h, PRECISION_MODES[precision]))
 
+    def set_lanes(self, lanes):
+        """1: every op of a chunk on the caller's stream; n (default 2, up to 4): sliding window w on stream w % n (same results)"""
+        check(lib.vsr_sttn_set_lanes(self._h, int(lanes)))
+
     def fallbacks(self):
         return int(lib.vsr_sttn_fallbacks(self._h))
 
