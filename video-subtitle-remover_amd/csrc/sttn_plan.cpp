@@ -259,7 +259,11 @@ static void tileDims(int cfg, int& BM, int& BN)
     else if (cfg == VSR_TILE_256x128) { BM = 256; BN = 128; }
     else { BM = 256; BN = 32; }
 }
-int Plan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : tu_.convTile); }
+int Plan::pickTile(int N) const
+{
+    static const int n64 = envInt("VSR_N64_TILE", VSR_TILE_256x64);      // A/B knob: tile of the N = 64 convs (decoder, encoder)
+    return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64 : tu_.convTile);
+}
 
 static void checkFits(int64_t v)
 {
