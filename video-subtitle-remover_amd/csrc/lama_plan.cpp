@@ -251,7 +251,7 @@ bool LamaModel::pack(std::string& err)
 // ------------------------------------------------------------------------------------
 // LamaPlan
 // ------------------------------------------------------------------------------------
-int LamaPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : VSR_TILE_128x64); }
+int LamaPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : VSR_TILE_128x64); }
 
 Op& LamaPlan::ew(int kind, const char* tag)
 {

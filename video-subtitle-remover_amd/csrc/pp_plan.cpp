@@ -264,7 +264,7 @@ void PpGenPlan::token_grid(int H, int W, int& fh, int& fw, int& gh, int& gw)
     gh = cdiv(fh, 5) * 5; gw = cdiv(fw, 9) * 9;                   // window (5, 9)
 }
 
-int PpGenPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : VSR_TILE_128x64); }
+int PpGenPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : VSR_TILE_128x64); }
 
 Op& PpGenPlan::ew(int kind, const char* tag)
 {

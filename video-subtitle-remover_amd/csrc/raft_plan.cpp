@@ -199,7 +199,7 @@ bool RaftModel::pack(std::string& err)
 // ------------------------------------------------------------------------------------
 // RaftPlan
 // ------------------------------------------------------------------------------------
-int RaftPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : VSR_TILE_128x64); }
+int RaftPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : VSR_TILE_128x64); }
 
 Op& RaftPlan::ew(int kind, const char* tag)
 {

@@ -132,7 +132,7 @@ bool RfcModel::pack(std::string& err)
 // ------------------------------------------------------------------------------------
 // RfcPlan
 // ------------------------------------------------------------------------------------
-int RfcPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? VSR_TILE_256x64 : VSR_TILE_128x64); }
+int RfcPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : VSR_TILE_128x64); }
 
 // Frames are stored step-major, sequence-minor (frame = i*S + s); buffers read by a temporal conv carry two zero
 // steps before and after the sequence, so a +-2 step shift is a constant offset and never crosses into the other sequence.

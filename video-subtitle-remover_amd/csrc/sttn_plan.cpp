@@ -259,13 +259,14 @@ static void tileDims(int cfg, int& BM, int& BN)
     else if (cfg == VSR_TILE_256x128) { BM = 256; BN = 128; }
     else { BM = 256; BN = 32; }
 }
-int Plan::pickTile(int N) const
+int n64Tile()
 {
-    // N = 64 convs (decoder, encoder): 128x64 since round 3 -- the 256x64 instance of the rebuilt v3 kernel needs 385 VGPRs (one wave
-    // per SIMD): decoder 99 -> 104 TF (profiles/r03_n64_tile_ab.log); VSR_N64_TILE=2 restores 256x64
-    static const int n64 = envInt("VSR_N64_TILE", VSR_TILE_128x64);
-    return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64 : tu_.convTile);
+    static const int t = envInt("VSR_N64_TILE", VSR_TILE_128x64);
+    return t;
 }
+
+// N = 64 convs (decoder, encoder): 128x64 since round 3 (decoder 99 -> 104 TF; VSR_N64_TILE=2 restores 256x64)
+int Plan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : tu_.convTile); }
 
 static void checkFits(int64_t v)
 {

@@ -208,6 +208,10 @@ private:
                      std::vector<int32_t>& visits);
 };
 
+// tile of the N <= 64 convs of every plan (VSR_N64_TILE, A/B knob): 128x64 -- the 256x64 instance of the rebuilt v3 kernel needs 385
+// VGPRs, one wave per SIMD (profiles/r03_n64_tile_ab.log)
+int n64Tile();
+
 // cv2.resize INTER_LINEAR coefficient tables (OpenCV 4.11 imgproc/resize.cpp, resize()):
 // ofs[d], fixed-point (x2048, round-half-even) and float taps {1-f, f}.  clampX selects the
 // horizontal rule (index clamped, f reset to 0 at the borders); vertical keeps f and lets
