@@ -44,6 +44,8 @@ def _load_lama_state_dict(model_path):
 
 
 class LamaInpaint:
+    accepts_device_frames = True      # __call__ also takes a uint8 [n,H,W,3] device tensor and inpaints it in place (tools/resident.py)
+
     mini_batch_size = 4                                                      # lama_inpaint.py:37
 
     def __init__(self, device="cuda:0", model_path="big-lama.pt"):

@@ -67,6 +67,8 @@ def _load(model_dir, name, file):
 
 
 class PropainterInpaint:
+    accepts_device_frames = True      # __call__ also takes a uint8 [n,H,W,3] device tensor and inpaints it in place (tools/resident.py)
+
     def __init__(self, device, model_dir, sub_video_length=80, use_fp16=True, precision=None):
         self.device = device
         self.model_dir = model_dir

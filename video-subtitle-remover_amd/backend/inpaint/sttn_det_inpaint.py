@@ -18,6 +18,8 @@ from .sttn_auto_inpaint import _device_index, _load_state_dict
 
 
 class STTNDetInpaint:
+    accepts_device_frames = True      # __call__ also takes a uint8 [n,H,W,3] device tensor and inpaints it in place (tools/resident.py)
+
     def __init__(self, device, model_path):
         self.device = device
         self.neighbor_stride = config.sttnNeighborStride.value

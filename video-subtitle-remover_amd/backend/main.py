@@ -186,7 +186,8 @@ class SubtitleRemover:
             lama = self.lama_inpaint
             single_frame_inpaint = lama.inpaint if lama is not None else None
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
-        resident = self._open_resident()
+        # the clip stays in HBM only for a plugin that takes device tensors (an injected callable, or the cv2 plugin, gets host frames)
+        resident = self._open_resident() if getattr(propainter_inpaint, "accepts_device_frames", False) else None
         clip = resident[0] if resident is not None else None
         sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self, **self._clip_kw(clip))
         if len(sub_list) == 0:
@@ -281,7 +282,7 @@ class SubtitleRemover:
         if dist is not None and dist.get_rank() != 0:
             return self._run_items(tbar, (), model)
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
-        resident = self._open_resident()
+        resident = self._open_resident() if getattr(model, "accepts_device_frames", False) else None
         sub_list = self._timed("detector pass", detector.find_subtitle_frame_no, sub_remover=self,
                                **self._clip_kw(resident[0] if resident is not None else None))
         if len(sub_list) == 0:
