@@ -401,6 +401,7 @@ def main():
                    "weights": "synthetic variance-preserving (no checkpoint in the reference mount)"},
         "model_tflops": round(flops_per_frame * fps / 1e12, 3),
         "gflop_per_frame": round(flops_per_frame / 1e9, 2),
+        "model_frac_of_peak": round(flops_per_frame * fps / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),   # whole step, per GPU, vs the fp32-MFMA spec
     }
 
     # ---- roofline leg: K steps of the same resident chunk on ONE lane, HIP events on the launch stream around every launch of the
