@@ -182,3 +182,100 @@ def test_window_lanes_share_nothing_but_the_running_average(built_lib, nl):
             v.close()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("nl", [2, 3])
+def test_lane_schedule_orders_every_conflict(built_lib, nl):
+    """Race freedom of the laned schedule, by construction.  The engine (sttn_engine.hip run_plan) orders the streams with three kinds of
+    events: every lane starts behind everything issued before the first window op (fork), every OP_DECODE_OUT waits for the previous
+    one (chain), and the caller's stream ends behind all lanes (join).  Here those edges plus program order per lane are turned into
+    vector clocks over the op list, every op's reads and writes are taken from its descriptors (buffer, and for the row-maxima array
+    the instance offset), and for every pair of accesses to the same location on DIFFERENT lanes with at least one write the earlier
+    op must happen-before the later one."""
+    from vsr_amd import _lib
+    from vsr_amd.engine import SttnEngine
+
+    BUF_WEIGHTS, BUF_ROWMAX = 0, 23
+    ACT_ROW_MAX, ACT_A_EXP = 0x400, 0x800
+    eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None)
+    try:
+        eng.set_lanes(nl)
+        view = PlanView(_lib, eng, 30)                          # six windows
+        lanes = [_lib.lib.vsr_plan_op_lane(view.p, i) for i in range(len(view.ops))]
+        first_window = next(i for i, (b, _) in enumerate(view.ops) if b.tag == b"attn.qkv")
+
+        def accesses(info, items):
+            """[(location, is_write)]: location = buffer id, or (BUF_ROWMAX, offset) -- every attention instance has its own array"""
+            acc = []
+            if info.kind == 1:
+                for y in items:
+                    acc += [(y.bufA, False), (y.bufC, True)]
+                    if y.bufB != BUF_WEIGHTS:
+                        acc.append((y.bufB, False))
+                    if y.act & ACT_ROW_MAX:                     # the epilogue leaves row maxima in R (atomic max)
+                        acc.append(((BUF_ROWMAX, y.offR), True))
+                    elif y.act & ACT_A_EXP:                     # reads the row maxima through the bias pointer, writes partial row sums to R
+                        acc.append(((BUF_ROWMAX, y.offBias), False))
+                        if y.bufR >= 0:
+                            acc.append((y.bufR, True))
+                    elif y.bufR >= 0:
+                        acc.append((y.bufR, False))
+            elif info.kind == 2:
+                for y in items:
+                    acc += [(y.bufS, False), (y.bufP, True)]
+            else:
+                if info.buf_src >= 0:
+                    acc.append((info.buf_src, False))
+                if info.ibuf[0] >= 0:
+                    acc.append((info.ibuf[0], False))
+                if info.buf_mask >= 0:
+                    acc.append((info.buf_mask, False))
+                if info.buf_dst >= 0:
+                    acc.append((info.buf_dst, True))
+                    if info.kind == 4:                          # decode_out averages into comps: read-modify-write
+                        acc.append((info.buf_dst, False))
+            return acc
+
+        # ---- happens-before: vc[i][lane] = largest op index on `lane` known to precede op i (inclusive of i on its own lane)
+        vc, last_on_lane, last_decode = [], {}, None
+        for i, (info, _) in enumerate(view.ops):
+            lane = lanes[i]
+            clock = dict(vc[last_on_lane[lane]]) if lane in last_on_lane else {}
+            if lane != 0 and lane not in last_on_lane:          # fork: behind everything before the first window op
+                assert first_window > 0
+                for k, v in vc[first_window - 1].items():
+                    clock[k] = max(clock.get(k, -1), v)
+            if info.kind == 4 and last_decode is not None and lanes[last_decode] != lane:      # decode chain
+                for k, v in vc[last_decode].items():
+                    clock[k] = max(clock.get(k, -1), v)
+            clock[lane] = i
+            vc.append(clock)
+            last_on_lane[lane] = i
+            if info.kind == 4:
+                last_decode = i
+
+        def ordered(j, i):
+            return vc[i].get(lanes[j], -1) >= j
+
+        last_write, reads_since, checked = {}, {}, 0
+        for i, (info, items) in enumerate(view.ops):
+            for loc, is_write in accesses(info, items):
+                w = last_write.get(loc)
+                if w is not None and w != i and lanes[w] != lanes[i]:
+                    checked += 1
+                    assert ordered(w, i), (i, info.tag, "after write by", w, view.ops[w][0].tag, loc)
+                if is_write:
+                    for r in reads_since.get(loc, []):
+                        if r != i and lanes[r] != lanes[i]:
+                            checked += 1
+                            assert ordered(r, i), (i, info.tag, "overwrites what", r, view.ops[r][0].tag, "reads", loc)
+            for loc, is_write in accesses(info, items):
+                if is_write:
+                    last_write[loc] = i
+                    reads_since[loc] = []
+                else:
+                    reads_since.setdefault(loc, []).append(i)
+        assert checked > 20                                     # the features every lane reads, the running average every window updates
+        view.close()
+    finally:
+        eng.close()
