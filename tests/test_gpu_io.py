@@ -1,6 +1,8 @@
 """The GPU colour conversion of the *.y4m transport (csrc/io_kernels.hip through backend/tools/video_io.py) against the numpy
 statement of the same BT.601 integer matrices (video_io._yuv_to_bgr / _bgr_to_yuv): bit-exact, every chroma layout the reader
 accepts, odd sizes (edge replication of the 4:2:0 sub-sampler), both ranges."""
+import os
+
 import numpy as np
 import pytest
 
@@ -226,9 +228,14 @@ def test_resident_detector_modes_write_the_same_file(built_lib, gpu_device, tmp_
         for k, v in keys.items():
             getattr(config, k).value = v
         config.inpaintMode.value = {"sttn-det": InpaintMode.STTN_DET, "lama": InpaintMode.LAMA, "propainter": InpaintMode.PROPAINTER}[mode]
-        for how, color, resident in (("host", "host", "0"), ("resident", "device", "1")):
+        # opt-in third pass (VSR_TEST_BATCH_LANES=1): the resident run again over two batch lanes (tools/batch_lanes.py, off by default)
+        passes = [("host", "host", "0", "1"), ("resident", "device", "1", "1")]
+        if os.environ.get("VSR_TEST_BATCH_LANES") == "1":
+            passes.append(("lanes", "device", "1", "2"))
+        for how, color, resident, lanes in passes:
             monkeypatch.setenv("VSR_IO_COLOR", color)
             monkeypatch.setenv("VSR_IO_RESIDENT", resident)
+            monkeypatch.setenv("VSR_BATCH_LANES", lanes)
             sr = SubtitleRemover(src, device="cuda:0")
             sr.sub_areas = [(0, H, 0, W)]
             det = Det()
@@ -251,6 +258,8 @@ def test_resident_detector_modes_write_the_same_file(built_lib, gpu_device, tmp_
             plugin.close()
     assert "read + upload + YUV->BGR" in phases["resident"] and "read + upload + YUV->BGR" not in phases["host"]
     assert outs["host"] == outs["resident"], "the HBM-resident loop must write the host loop's file"
+    if "lanes" in outs:
+        assert outs["lanes"] == outs["resident"], "batch lanes must not change a byte"
     monkeypatch.setenv("VSR_IO_COLOR", "host")
     got, want = _read_all(str(tmp_path / "out_resident.y4m")), _read_all(src)
     assert got.shape == want.shape

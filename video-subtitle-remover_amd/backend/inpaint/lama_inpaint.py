@@ -51,6 +51,11 @@ class LamaInpaint:
     def __init__(self, device="cuda:0", model_path="big-lama.pt"):
         self.device = device
         self.engine = LamaEngine(_load_lama_state_dict(model_path), device=_device_index(device))
+        self._model_path = model_path
+
+    def clone(self):
+        """a second instance on the same device from the same weights: its own engine and workspace (tools/batch_lanes.py)"""
+        return LamaInpaint(self.device, self._model_path)
 
     def close(self):
         self.engine.close()

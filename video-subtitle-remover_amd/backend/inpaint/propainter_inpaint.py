@@ -92,6 +92,12 @@ class PropainterInpaint:
             for e in (self.fix_raft, self.fix_flow_complete, self.model):
                 e.set_precision(self.precision)
 
+    def clone(self):
+        """a second instance on the same device from the same checkpoints: its own three engines and workspaces (tools/batch_lanes.py)"""
+        other = PropainterInpaint(self.device, self.model_dir, self.sub_video_length, self.use_fp16, self.precision)
+        other.raft_iter = self.raft_iter
+        return other
+
     def close(self):
         for e in (self.fix_raft, self.fix_flow_complete, self.model):
             e.close()

@@ -27,6 +27,11 @@ class STTNDetInpaint:
         self.engine = SttnEngine(_load_state_dict(model_path), "det", device=_device_index(device),
                                  neighbor_stride=self.neighbor_stride, ref_length=self.ref_length)
         self.model_input_width, self.model_input_height = 432, 240
+        self._model_path = model_path
+
+    def clone(self):
+        """a second instance on the same device from the same checkpoint: its own engine and workspace (tools/batch_lanes.py)"""
+        return STTNDetInpaint(self.device, self._model_path)
 
     def __call__(self, input_frames, input_mask):
         """input_frames: the reference's list of HxWx3 uint8 BGR arrays (fresh arrays come back), or -- the HBM-resident loop of

@@ -152,6 +152,14 @@ class SubtitleRemover:
         finally:
             reader.release()
 
+    def _run_resident_jobs(self, jobs, plugin, clip):
+        """the independent batches of a resident run: one after the other, or over VSR_BATCH_LANES plugin instances (tools/batch_lanes.py)"""
+        from .tools import batch_lanes
+
+        if not hasattr(self, "_lane_cache"):
+            self._lane_cache = {}
+        batch_lanes.run_jobs(jobs, batch_lanes.lane_plugins(plugin, batch_lanes.lanes_from_env(), self._lane_cache), clip.frames.device)
+
     @staticmethod
     def _clip_kw(clip):
         """the HBM-resident clip is handed on only when there is one: without it the calls keep the reference's signatures"""
@@ -205,6 +213,7 @@ class SubtitleRemover:
 
             clip, wf = resident
             n, index = len(clip), 0
+            jobs = []                              # (slice of the clip, mask): independent batches, run by tools/batch_lanes.py
 
             def inpaint_all():
                 nonlocal index
@@ -229,7 +238,8 @@ class SubtitleRemover:
                                 one = single_frame_inpaint(clip.frames[batch[0]].cpu().numpy(), mask)
                                 clip.frames[batch[0]].copy_(torch.from_numpy(np.ascontiguousarray(one)))
                         else:
-                            propainter_inpaint(clip.frames[batch[0]:batch[-1] + 1], mask)
+                            jobs.append((clip.frames[batch[0]:batch[-1] + 1], mask))
+                self._run_resident_jobs(jobs, propainter_inpaint, clip)
 
             self._timed("inpainting", inpaint_all)
             self._timed("BGR->YUV + download + write", clip.store, self.video_writer, wf, 0, n, lambda: self.update_progress(tbar, increment=1))
@@ -311,7 +321,7 @@ class SubtitleRemover:
             n = len(clip)
 
             def inpaint_all():
-                idx = 0
+                idx, jobs = 0, []
                 while idx < n:
                     idx += 1
                     if idx not in start_end:
@@ -321,7 +331,8 @@ class SubtitleRemover:
                     mask = interval_mask(first, last)
                     for batch in batch_generator(list(range(first - 1, idx)), config.getSttnMaxLoadNum()):
                         if len(batch) >= 1:
-                            model(clip.frames[batch[0]:batch[-1] + 1], mask)
+                            jobs.append((clip.frames[batch[0]:batch[-1] + 1], mask))
+                self._run_resident_jobs(jobs, model, clip)
 
             self._timed("inpainting", inpaint_all)
             self._timed("BGR->YUV + download + write", clip.store, self.video_writer, wf, 0, n, lambda: self.update_progress(tbar, increment=1))

@@ -1,0 +1,83 @@
+"""Batch lanes of the HBM-resident detector-driven modes (opt-in: VSR_BATCH_LANES=2; default 1 = the plain loop).
+
+The batches `batch_generator` cuts out of a detected interval are independent units (main.py:229-245, :323-332: every call of the
+plugin starts from the frames of its own batch), and on the resident path they are disjoint slices of one device tensor that the
+plugin rewrites in place.  A plugin call is a long sequence of dependent launches with host work between its stages (the
+propainter plugin runs three engines back to back), so one stream leaves the GPU idle at every launch tail and every host step;
+with L lanes, L host threads -- each with its own plugin instance (own engines and workspaces) and its own stream -- pull
+batches from one queue.  Every batch is computed by the same code on the same inputs as in the plain loop, so the frames are
+identical whatever the interleaving.  The same idea one level down: the window lanes inside the STTN engine.
+"""
+import os
+import queue
+import threading
+
+
+def lanes_from_env():
+    try:
+        return max(1, min(4, int(os.environ.get("VSR_BATCH_LANES", "1"))))
+    except ValueError:
+        return 1
+
+
+def lane_plugins(plugin, lanes, cache):
+    """[plugin] + clones for the other lanes (kept in `cache`, a dict owned by the caller, so a run builds them once).  A plugin
+    without clone() -- an injected callable -- stays on one lane."""
+    if lanes <= 1 or not hasattr(plugin, "clone"):
+        return [plugin]
+    have = cache.setdefault(id(plugin), [])
+    while len(have) < lanes - 1:
+        have.append(plugin.clone())
+    return [plugin] + have[:lanes - 1]
+
+
+def run_jobs(jobs, plugins, device=None):
+    """jobs: [(frames, mask)] with disjoint `frames`; plugins: one per lane.  One plugin: the plain loop in the caller's thread.
+    More: one thread per plugin, each on its own stream of `device` (a torch.device; None / cpu: plain threads), all pulling from
+    one queue; the caller's stream is joined behind every lane; the first exception stops the queue and is re-raised here."""
+    if len(plugins) <= 1 or len(jobs) <= 1:
+        for frames, mask in jobs:
+            plugins[0](frames, mask)
+        return
+    todo = queue.Queue()
+    for j in jobs:
+        todo.put(j)
+    errors = []
+    cuda = device is not None and getattr(device, "type", "cpu") == "cuda"
+    if cuda:
+        import torch
+
+        caller = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device) for _ in plugins]
+        for s in streams:
+            s.wait_stream(caller)                   # the frames the caller prepared (upload, colour conversion) are ready
+
+    def lane(k):
+        def pull():
+            while not errors:
+                try:
+                    frames, mask = todo.get_nowait()
+                except queue.Empty:
+                    return
+                plugins[k](frames, mask)
+
+        try:
+            if cuda:
+                with torch.cuda.device(device), torch.cuda.stream(streams[k]):
+                    pull()
+                    streams[k].synchronize()
+            else:
+                pull()
+        except BaseException as e:                  # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=lane, args=(k,), name=f"vsr-batch-lane-{k}") for k in range(len(plugins))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if cuda:
+        for s in streams:
+            caller.wait_stream(s)
+    if errors:
+        raise errors[0]
