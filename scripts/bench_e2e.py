@@ -68,8 +68,19 @@ class InjectedDetection(ocr_det.TextDetection):
         m = torch.full((rh, rw), 0.02, dtype=torch.float32, device=self.device)
         m[int(ymin * sy + inset):int(ymax * sy - inset) + 1, int(xmin * sx + inset):int(xmax * sx - inset) + 1] = 0.93
         self._on, self._off = m, torch.full((rh, rw), 0.02, dtype=torch.float32, device=self.device)
-        self._box = box
+        self._box, self._hw = box, (H, W)
         self.forwards = self.frames_seen = self.positives = 0
+        self._family = getattr(self, "_family", [self])
+
+    def clone(self):                                        # a detector lane (VSR_DET_LANES): armed like this one, counted with it
+        other = super().clone()
+        other._family = self._family
+        other.arm(self._box, *self._hw)
+        self._family.append(other)
+        return other
+
+    def total(self, name):
+        return sum(getattr(d, name) for d in self._family)
 
     def _verdicts(self, frames_dev):
         ymin, ymax, xmin, xmax = self._box
@@ -161,10 +172,12 @@ def main():
     res = {"metric": f"frames/s, file to file through SubtitleRemover.run(), --inpaint-mode {args.mode}", "value": round(args.frames / wall, 2),
            "unit": "frames/s", "frames": args.frames, "res": args.res, "wall_s": round(wall, 2), "n_gpus": 1,
            "phases_s": {k: round(v, 2) for k, v in sr.phase_seconds.items()},
-           "detector": {"program": args.det_program, "forwards": det.forwards, "frames_sampled": det.frames_seen, "frames_with_text": det.positives,
+           "detector": {"program": args.det_program, "forwards": det.total("forwards"), "frames_sampled": det.total("frames_seen"),
+                        "frames_with_text": det.total("positives"), "lanes": len(det._family),
                         "frames_per_forward": det.batch_size, "postprocess_host_fallbacks": post.host_fallbacks if post is not None else None,
                         "map": "injected at the graph output (synthetic weights find no text); forward executed in full"},
            "frames_written": out_frames, "resident": args.resident == "1",
+           "batch_lanes": int(os.environ.get("VSR_BATCH_LANES", "1")), "sttn_window_lanes": int(os.environ.get("VSR_STTN_LANES", "2")),
            "precision": os.environ.get("VSR_PP_PRECISION", "f32") if args.mode == "propainter" else "f32",
            "clip": f"synthetic {W}x{H} y4m 4:2:0, subtitle on 100 of every 120 frames in box {box}; generated in {t_gen:.0f} s (not timed)"}
     print(json.dumps(res), flush=True)

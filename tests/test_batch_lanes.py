@@ -83,3 +83,54 @@ def test_a_callable_without_clone_stays_on_one_lane():
     arr = np.repeat(np.arange(6, dtype=np.int64)[:, None], 2, axis=1)
     batch_lanes.run_jobs(jobs_over(arr, 3), plugins)
     assert calls == [0, 2, 4]
+
+
+def test_detector_lanes_give_the_same_subtitle_frames(monkeypatch):
+    """SubtitleDetect's pass over a resident clip (tools/subtitle_detect.py _find_resident) with VSR_DET_LANES=2: the sampled batches
+    are spread over two detector instances and come back in order -- the same {frame_no: boxes} as on one lane."""
+    import torch
+
+    from vsr_amd.backend.tools.subtitle_detect import SubtitleDetect
+
+    N, H, W = 61, 40, 120
+    frames = torch.zeros((N, H, W, 3), dtype=torch.uint8)
+    on = [i for i in range(N) if 5 <= i < 23 or 31 <= i < 48]
+    for i in on:
+        frames[i, 28:36, 20:100] = 255
+
+    class Clip:
+        pass
+
+    clip = Clip()
+    clip.frames = frames
+    clip.__class__.__len__ = lambda self: N
+    quad = np.array([[20, 28], [100, 28], [100, 36], [20, 36]])
+
+    class Det:
+        batch_size = 4
+        made = 0
+
+        def __init__(self):
+            Det.made += 1
+            self.batches = 0
+
+        def clone(self):
+            return Det()
+
+        def predict_batch_device(self, fr):
+            self.batches += 1
+            time.sleep(0.002)
+            return [{"dt_polys": quad[None] if int(f[30, 50, 0]) > 200 else np.zeros((0, 4, 2), np.int32)} for f in fr]
+
+    got = {}
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("VSR_DET_LANES", lanes)
+        Det.made = 0
+        det = Det()
+        sd = SubtitleDetect(None, [(0, H, 0, W)], text_detector=det)
+        got[lanes] = sd._find_resident(None, clip)
+        assert Det.made == int(lanes)
+        if lanes == "2":
+            others = sd._det_lanes[id(det)]
+            assert det.batches > 0 and others[0].batches > 0 and det.batches + others[0].batches == -(-len(range(0, N, sd.SAMPLE_STEP)) // 4)
+    assert got["1"] == got["2"] and len(got["1"]) > 20

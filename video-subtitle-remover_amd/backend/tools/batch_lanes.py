@@ -13,9 +13,9 @@ import queue
 import threading
 
 
-def lanes_from_env():
+def lanes_from_env(name="VSR_BATCH_LANES"):
     try:
-        return max(1, min(4, int(os.environ.get("VSR_BATCH_LANES", "1"))))
+        return max(1, min(4, int(os.environ.get(name, "1"))))
     except ValueError:
         return 1
 
@@ -31,35 +31,33 @@ def lane_plugins(plugin, lanes, cache):
     return [plugin] + have[:lanes - 1]
 
 
-def run_jobs(jobs, plugins, device=None):
-    """jobs: [(frames, mask)] with disjoint `frames`; plugins: one per lane.  One plugin: the plain loop in the caller's thread.
-    More: one thread per plugin, each on its own stream of `device` (a torch.device; None / cpu: plain threads), all pulling from
+def run_map(jobs, workers, call, device=None):
+    """[call(worker, job) for job in jobs], the jobs spread over the workers.  One worker: a plain loop in the caller's thread.
+    More: one thread per worker, each on its own stream of `device` (a torch.device; None / cpu: plain threads), all pulling from
     one queue; the caller's stream is joined behind every lane; the first exception stops the queue and is re-raised here."""
-    if len(plugins) <= 1 or len(jobs) <= 1:
-        for frames, mask in jobs:
-            plugins[0](frames, mask)
-        return
+    if len(workers) <= 1 or len(jobs) <= 1:
+        return [call(workers[0], job) for job in jobs]
     todo = queue.Queue()
-    for j in jobs:
-        todo.put(j)
-    errors = []
+    for item in enumerate(jobs):
+        todo.put(item)
+    results, errors = [None] * len(jobs), []
     cuda = device is not None and getattr(device, "type", "cpu") == "cuda"
     if cuda:
         import torch
 
         caller = torch.cuda.current_stream(device)
-        streams = [torch.cuda.Stream(device) for _ in plugins]
+        streams = [torch.cuda.Stream(device) for _ in workers]
         for s in streams:
-            s.wait_stream(caller)                   # the frames the caller prepared (upload, colour conversion) are ready
+            s.wait_stream(caller)                   # what the caller prepared (upload, colour conversion) is ready
 
     def lane(k):
         def pull():
             while not errors:
                 try:
-                    frames, mask = todo.get_nowait()
+                    i, job = todo.get_nowait()
                 except queue.Empty:
                     return
-                plugins[k](frames, mask)
+                results[i] = call(workers[k], job)
 
         try:
             if cuda:
@@ -71,7 +69,7 @@ def run_jobs(jobs, plugins, device=None):
         except BaseException as e:                  # noqa: BLE001 -- re-raised in the caller's thread
             errors.append(e)
 
-    threads = [threading.Thread(target=lane, args=(k,), name=f"vsr-batch-lane-{k}") for k in range(len(plugins))]
+    threads = [threading.Thread(target=lane, args=(k,), name=f"vsr-batch-lane-{k}") for k in range(len(workers))]
     for t in threads:
         t.start()
     for t in threads:
@@ -81,3 +79,9 @@ def run_jobs(jobs, plugins, device=None):
             caller.wait_stream(s)
     if errors:
         raise errors[0]
+    return results
+
+
+def run_jobs(jobs, plugins, device=None):
+    """jobs: [(frames, mask)] with disjoint `frames`, each rewritten in place by plugin(frames, mask); plugins: one per lane"""
+    run_map(jobs, plugins, lambda plugin, job: plugin(*job), device)

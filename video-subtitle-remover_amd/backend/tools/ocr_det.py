@@ -773,6 +773,7 @@ class TextDetection:
         if isinstance(model, (str, os.PathLike)) and os.path.isdir(model):
             model = os.path.join(model, "inference.json")
         self.graph = model if hasattr(model, "ops") else load_graph(model)
+        self._weights = weights
         self.runner = PaddleGraphRunner(self.graph, weights, device)
         self.resize_long = resize_long
         self.limit_type = limit_type
@@ -783,6 +784,12 @@ class TextDetection:
         self.use_tape = os.environ.get("VSR_DET_TAPE", "1") != "0"
         self.device = self.runner.device
         self._tables = {}
+
+    def clone(self):
+        """a second detector on the same device from the same program and weights: its own runner (recorded launch lists,
+        intermediates) and post-process buffers -- one per lane of SubtitleDetect's resident pass (VSR_DET_LANES, tools/batch_lanes.py)"""
+        return type(self)(self.graph, self._weights, device=self.device.index if hasattr(self.device, "index") else self.device,
+                          resize_long=self.resize_long, limit_type=self.limit_type)
 
     def _resize(self, img_dev, H, W, rh, rw):
         """cv2.resize(img, (rw, rh)) INTER_LINEAR on uint8 -- the fixed-point kernel of the inpainting path"""

@@ -104,16 +104,25 @@ class SubtitleDetect:
         ab = sub_remover.ab_sections if sub_remover is not None else None
         nos = [no for no in range(1, len(clip) + 1)
                if is_frame_number_in_ab_sections(no - 1, ab) and ((no - 1) % self.SAMPLE_STEP == 0 or self.SAMPLE_STEP <= 1)]
+        from . import batch_lanes
+
         batch = max(1, getattr(self.text_detector, "batch_size", 1))
         on_device = hasattr(self.text_detector, "predict_batch_device")
-        sampled = {}
-        for s in range(0, len(nos), batch):
-            part = nos[s:s + batch]
+        parts = [nos[s:s + batch] for s in range(0, len(nos), batch)]
+
+        def detect(detector, part):
             idx = torch.tensor([no - 1 for no in part], dtype=torch.int64, device=clip.frames.device)
             if on_device:
-                results = [[r] for r in self.text_detector.predict_batch_device(clip.frames[idx])]
-            else:                                     # an injected detector with the reference's host signature
-                results = [self.text_detector.predict(f) for f in clip.frames[idx].cpu().numpy()]
+                return [[r] for r in detector.predict_batch_device(clip.frames[idx])]
+            return [detector.predict(f) for f in clip.frames[idx].cpu().numpy()]       # an injected detector with the reference's host signature
+
+        # the sampled frames are independent: VSR_DET_LANES detectors (own runner, own stream, own host thread) share the batches
+        # (opt-in, default 1 = this thread alone; the results do not depend on it)
+        if not hasattr(self, "_det_lanes"):
+            self._det_lanes = {}
+        detectors = batch_lanes.lane_plugins(self.text_detector, batch_lanes.lanes_from_env("VSR_DET_LANES") if on_device else 1, self._det_lanes)
+        sampled = {}
+        for part, results in zip(parts, batch_lanes.run_map(parts, detectors, detect, clip.frames.device)):
             for no, res in zip(part, results):
                 boxes = self._keep_inside(res)
                 if len(boxes) > 0:
