@@ -311,6 +311,80 @@ def test_gather_gemm_fp16_operands(built_lib, gpu_device, out_split, cfg, bm, bn
     assert np.array_equal(rest, s16), f"{what}: store footprint differs"
 
 
+def _split_case(rng, M, N, K, bm, bn, representable=True):
+    """an NK problem on split-format operands (bias, LeakyReLU, residual) and its fp32 reference"""
+    c = _make_gemm_case(rng, M, N, K, bm, bn, 0, 1, True, 1, True)
+    if representable:
+        c.Abuf[:] = c.Abuf.astype(np.float16).astype(np.float32)
+        c.Bbuf[:] = c.Bbuf.astype(np.float16).astype(np.float32)
+    ref = _reference(c) if representable else None
+    _to_split_inplace(c.Abuf, _starts(c.rowA, c.colA))
+    _to_split_inplace(c.Bbuf, _starts(c.rowB, c.colB))
+    _to_split_inplace(c.Rbuf, _starts(c.rowR[:M], c.colC))
+    return c, ref
+
+
+@pytest.mark.parametrize("out_split", [0, 1])
+@pytest.mark.parametrize("M,N,K,tilesM", [
+    (300, 256, 576, None),
+    (513, 257, 2304, None),            # N not a multiple of 32: the element-wise epilogue; a partial last M tile
+    (260, 130, 96, None),              # 3 chunks: one full pair + a lone chunk; N = 130
+    (1000, 512, 320, 8),               # tile height 128 (tilesM given: 8 tiles of roundup32(125) rows), two N tiles
+    (200, 64, 352, 7),                 # tile height 32: the second wave row owns no block
+    (448, 256, 128, 2),                # tile height 224: 4 + 3 blocks over the two wave rows
+    (700, 320, 64, 3),                 # second N tile 64 columns wide
+    (4800, 256, 32 * 150, None),       # 150 chunks: crosses a 128-chunk super-block
+])
+def test_gather_gemm_fp16_256x256(built_lib, gpu_device, out_split, M, N, K, tilesM):
+    """TILE_256x256 (variant 6, NK) = gather_gemm_f16_v7: 8 waves, 256 x 256 tile of dynamic height, output turned through LDS.  With
+    fp16-representable operands the result is the fp32-accumulated product itself; the store footprint is exact."""
+    rng = np.random.default_rng(7000 + M + N + K + out_split)
+    c, ref = _split_case(rng, M, N, K, 256, 256)
+    if tilesM is not None:
+        c.tilesM = tilesM
+    sentinel = c.Cbuf.copy()
+    if out_split:
+        c.act |= 0x100
+    got = _run_cases(built_lib, gpu_device, [c], built_lib.TILE_256x256, 0, 6)[0]
+    what = f"v7 256x256 {M}x{N}x{K} tilesM={tilesM} out_split={out_split}"
+    if not out_split:
+        _assert_close(got, ref, K, what, case=c)
+        return
+    m, n = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    chunk = c.rowC[m] + c.colC[n // 32]
+    hi_i, lo_i = 2 * chunk + n % 32, 2 * chunk + 32 + n % 32
+    g16 = got.view(np.uint16)
+    val = g16[hi_i].view(np.float16).astype(np.float32) + g16[lo_i].view(np.float16).astype(np.float32)
+    err = np.abs(val - ref[chunk + n % 32]).max()
+    tol = 2e-5 * np.sqrt(K) * 4 + 1e-5
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e}"
+    s16 = sentinel.view(np.uint16)
+    rest = g16.copy()
+    rest[hi_i] = s16[hi_i]
+    rest[lo_i] = s16[lo_i]
+    assert np.array_equal(rest, s16), f"{what}: store footprint differs"
+
+
+@pytest.mark.parametrize("out_split", [0, 1])
+def test_gather_gemm_fp16_256x256_equals_128x64(built_lib, gpu_device, out_split):
+    """Same k order, same MFMA: on ANY split-format operands (not only fp16-representable ones) the 256 x 256 kernel writes the
+    bytes the 128 x 64 kernel writes -- also as two problems of one launch (a body and a remainder with offset row tables)."""
+    rng = np.random.default_rng(7100 + out_split)
+    outs = {}
+    for cfg, bm, bn in (("TILE_128x64", 128, 64), ("TILE_256x256", 256, 256)):
+        rng = np.random.default_rng(7100 + out_split)
+        cases = []
+        for (M, N, K) in ((1300, 256, 576), (900, 384, 960)):
+            c, _ = _split_case(rng, M, N, K, 256, 256, representable=False)
+            c.tilesM, c.tilesN = -(-M // bm), -(-N // bn)
+            if out_split:
+                c.act |= 0x100
+            cases.append(c)
+        outs[cfg] = _run_cases(built_lib, gpu_device, cases, getattr(built_lib, cfg), 0, 6)
+    for a, b in zip(outs["TILE_128x64"], outs["TILE_256x256"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_to_split_bit_exact(built_lib, gpu_device):
     rng = np.random.default_rng(8)
     x = (rng.standard_normal(32 * 1000) * np.exp(rng.uniform(-8, 8, 32 * 1000))).astype(np.float32)

@@ -17,3 +17,8 @@
 extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int tileCfg,
                                           int bmode, unsigned int* queue, int variant, int nQueues,
                                           unsigned int* rangeFlag, void* stream);
+
+// the 256 x 256 fp16-operand kernel (tile config VSR_TILE_256x256, variant 6, NK; gather_gemm_v7.h): cuts one problem into a body of
+// whole rounds of 256-row tiles and a remainder of short tiles (out: room for 2 problems; returns how many); CUs of the device
+extern "C" int vsr_v7_split(const GGProblem* p, int cus, GGProblem* out);
+extern "C" int vsr_gg_cus(void);

@@ -317,6 +317,7 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #include "gather_gemm_v4.h"
 #include "gather_gemm_v5.h"
 #include "gather_gemm_v6.h"
+#include "gather_gemm_v7.h"
 
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
@@ -364,6 +365,51 @@ static void launch_v6_st(const GGProblem* d_probs, int nprobs, int totalBlocks, 
     const int g = totalBlocks < resident ? totalBlocks : resident;
     hipLaunchKernelGGL((gather_gemm_f16_v6<BM, BN, WM, WN, ST>), dim3(g), dim3(WM * WN * 64), 0, stream, d_probs, nprobs, totalBlocks, queue, nQueues,
                        rangeFlag);
+}
+
+// How a problem is cut for the 256 x 256 kernel (one workgroup per CU: a launch runs in whole rounds).  out[0] = the body, whole
+// rounds of 256-row tiles; out[1] = the remaining rows as one short tile per workgroup of a round (tile height =
+// roundup32(ceil(M / tilesM)), which the kernel derives again from M and tilesM).  Returns the number of problems written (1 or 2);
+// tileStart is left to the caller.
+extern "C" int vsr_v7_split(const GGProblem* p, int cus, GGProblem* out)
+{
+    if (cus <= 0) cus = 256;
+    const int tilesN = (p->N + 255) / 256;
+    const int perRound = cus / tilesN > 0 ? cus / tilesN : 1;          // M tiles of one round
+    const int body = (p->M / 256) / perRound * perRound;               // whole 256-row tiles in whole rounds
+    int n = 0;
+    if (body > 0) {
+        out[n] = *p;
+        out[n].tilesN = tilesN; out[n].M = body * 256; out[n].tilesM = body;
+        ++n;
+    }
+    const int rem = p->M - body * 256;
+    if (rem > 0) {
+        out[n] = *p;
+        out[n].tilesN = tilesN; out[n].M = rem;
+        out[n].rowA = p->rowA + (size_t)body * 256; out[n].rowC = p->rowC + (size_t)body * 256;
+        out[n].rowR = p->rowR ? p->rowR + (size_t)body * 256 : nullptr;
+        int rows = ((rem + perRound - 1) / perRound + 31) & ~31;       // rows per tile when every workgroup of a round takes one
+        if (rows > 256) rows = 256;
+        out[n].tilesM = (rem + rows - 1) / rows;
+        ++n;
+    }
+    return n;
+}
+extern "C" int vsr_gg_cus(void)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+}
+
+// fp16-operand mode, large NK problems: the 256 x 256 tile of 8 waves, one workgroup per CU (gather_gemm_v7.h)
+static void launch_v7(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, unsigned int* rangeFlag, hipStream_t stream)
+{
+    static const int resident = resident_blocks(gather_gemm_f16_v7<1>, 512);
+    const int g = totalBlocks < resident ? totalBlocks : resident;
+    hipLaunchKernelGGL((gather_gemm_f16_v7<1>), dim3(g), dim3(512), 0, stream, d_probs, nprobs, totalBlocks, queue, rangeFlag);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
@@ -443,6 +489,11 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
     if (tileCfg == VSR_TILE_256x128) {         // the 8-wave tile of the fp16-operand mode
         if (bmode != VSR_BMODE_NK || variant != 6 || !queue) return -1;
         launch_v6_st<256, 128, 4, 2, 3>(d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag, stream);
+        return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+    }
+    if (tileCfg == VSR_TILE_256x256) {         // the 8-wave 256 x 256 tile of the fp16-operand mode (dynamic tile height, see gather_gemm_v7.h)
+        if (bmode != VSR_BMODE_NK || variant != 6 || !queue) return -1;
+        launch_v7(d_probs, nprobs, totalBlocks, queue, rangeFlag, stream);
         return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
     }
     if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_NK);

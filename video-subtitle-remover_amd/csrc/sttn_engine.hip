@@ -49,6 +49,8 @@ struct OpDev {
     const void* dDesc = nullptr; // GGProblem* / SMProblem* (device)
     int nitems = 0, total = 0;   // total = workgroups (GEMM) or padded rows (softmax)
     int nQueues = 1;             // persistent gather-GEMM: 8 = per-XCD tile ranges, 1 = global queue
+    const void* dDesc7 = nullptr; // fp16-operand mode: the large NK problems of the op, cut for the 256 x 256 kernel (gather_gemm_v7.h)
+    int nitems7 = 0, total7 = 0;
     // elementwise
     const void* src = nullptr;
     void* dst = nullptr;
@@ -204,9 +206,19 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     auto F = [&](int buf, int64_t off) -> float* { return buf < 0 ? nullptr : (float*)h->bufs[buf] + off; };
 
     // ---- descriptors: one allocation, 64-byte aligned records
+    // fp16-operand mode: the large NK problems of an op (convs, QKV, the fine attention scales) go to the 256 x 256 kernel, each cut
+    // into whole rounds + a remainder (vsr_v7_split: up to two descriptors); the rest of the op stays on the 128 x 64 kernel
+    static const bool v7on = [] { const char* e = getenv("VSR_F16_V7"); return !(e && atoi(e) == 0); }();
+    const int cus = vsr_gg_cus();
+    auto forV7 = [&](const Op& op, const GemmItem& g) {
+        return v7on && precision == 3 && op.bmode == VSR_BMODE_NK && g.splitK == 1 && !(g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP)) && g.N >= 192 && g.K >= 256 && g.M >= 16 * 256 &&
+               (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * 2 >= cus;
+    };
     size_t descBytes = 0;
     for (const Op& op : P.ops) {
-        descBytes += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+        size_t n7 = 0;
+        if (op.kind == OP_GEMM) for (const GemmItem& g : op.gemm) if (forV7(op, g)) ++n7;
+        descBytes += ((op.gemm.size() + n7) * sizeof(GGProblem) + 63) / 64 * 64 + 64;
         descBytes += (op.softmax.size() * sizeof(SMProblem) + 63) / 64 * 64;
     }
     std::vector<char> hostDesc(descBytes + 64, 0);
@@ -216,11 +228,10 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
         OpDev od;
         od.kind = op.kind; od.tileCfg = op.tileCfg; od.bmode = op.bmode; od.flops = op.flops; od.tag = op.tag; od.lane = op.lane;
         if (op.kind == OP_GEMM) {
-            GGProblem* hp = (GGProblem*)(hostDesc.data() + cursor);
-            int tileStart = 0;
+            std::vector<GGProblem> small, big;
             for (size_t j = 0; j < op.gemm.size(); ++j) {
                 const GemmItem& g = op.gemm[j];
-                GGProblem& q = hp[j];
+                GGProblem q{};
                 q.A = F(g.bufA, g.offA); q.B = F(g.bufB, g.offB); q.C = F(g.bufC, g.offC);
                 if (fmt && g.bufB == BUF_WEIGHTS) q.B = h->weightsSplit + g.offB;
                 q.bias = g.offBias >= 0 ? F(g.bufBias, g.offBias) : nullptr;      // bufBias 0 = BUF_WEIGHTS; BUF_ROWMAX for VSR_ACT_A_EXP
@@ -228,19 +239,37 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
                 q.rowA = T(g.tRowA); q.colA = T(g.tColA); q.rowB = T(g.tRowB); q.colB = T(g.tColB);
                 q.rowC = T(g.tRowC); q.colC = T(g.tColC); q.rowR = T(g.tRowR);
                 q.M = g.M; q.N = g.N; q.K = g.K; q.tilesM = g.tilesM; q.tilesN = g.tilesN;
-                q.splitK = g.splitK; q.chunksPerSplit = g.chunksPerSplit; q.tileStart = tileStart;
+                q.splitK = g.splitK; q.chunksPerSplit = g.chunksPerSplit;
                 q.act = g.act | ((fmt && !plainF32(g.bufC)) ? VSR_ACT_OUT_SPLIT : 0);
                 q.alpha = g.alpha; q.splitStride = g.splitStride;
-                tileStart += g.tilesM * g.tilesN * g.splitK;
+                if (forV7(op, g)) {
+                    GGProblem two[2];
+                    const int n = vsr_v7_split(&q, cus, two);
+                    for (int k = 0; k < n; ++k) big.push_back(two[k]);
+                } else {
+                    small.push_back(q);
+                }
             }
+            int tileStart = 0;
+            for (GGProblem& q : small) { q.tileStart = tileStart; tileStart += q.tilesM * q.tilesN * q.splitK; }
+            int tileStart7 = 0;
+            for (GGProblem& q : big) { q.tileStart = tileStart7; tileStart7 += q.tilesM * q.tilesN; }
+            GGProblem* hp = (GGProblem*)(hostDesc.data() + cursor);
+            for (size_t j = 0; j < small.size(); ++j) hp[j] = small[j];
+            const size_t smallBytes = (small.size() * sizeof(GGProblem) + 63) / 64 * 64;
+            GGProblem* hp7 = (GGProblem*)(hostDesc.data() + cursor + smallBytes);
+            for (size_t j = 0; j < big.size(); ++j) hp7[j] = big[j];
+            od.dDesc7 = (char*)pd->dDescs + cursor + smallBytes;
+            od.nitems7 = (int)big.size();
+            od.total7 = tileStart7;
             od.dDesc = (char*)pd->dDescs + cursor;
-            od.nitems = (int)op.gemm.size();
+            od.nitems = (int)small.size();
             od.total = tileStart;
             od.nQueues = 8;
             od.aexp = op.ipar[0] != 0;
-            for (const GemmItem& g : op.gemm)
-                if (g.tilesN > 4) od.nQueues = gg_wide_queues();
-            cursor += (op.gemm.size() * sizeof(GGProblem) + 63) / 64 * 64;
+            for (const GGProblem& q : small)
+                if (q.tilesN > 4) od.nQueues = gg_wide_queues();
+            cursor += smallBytes + (big.size() * sizeof(GGProblem) + 63) / 64 * 64;
         } else if (op.kind == OP_SOFTMAX) {
             SMProblem* hp = (SMProblem*)(hostDesc.data() + cursor);
             int rowStart = 0;
@@ -280,7 +309,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     for (int i = 0; i < L; ++i) isf[i] = P.compCount[i] > 1 ? 1 : 0;
     HIPCHK(hipMalloc((void**)&pd->dIsFloat, (size_t)L * sizeof(int32_t)));
     HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 8 * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 16 * sizeof(unsigned int)));
     *out = pd.get();
     h->plans[key] = std::move(pd);
     return 0;
@@ -312,7 +341,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
 {
     const int prec = pd->plan->precision;
     const bool persistent = prec ? true : use_persistent();
-    if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
+    if (persistent) HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 16 * sizeof(unsigned int), stream));
     if (pd->plan->bufElems[BUF_ROWMAX] > 0)     // fused attention: every instance's row maxima start below every float
         HIPCHK(hipMemsetAsync(h->bufs[BUF_ROWMAX], 0, (size_t)pd->plan->bufElems[BUF_ROWMAX] * sizeof(unsigned int), stream));
     // lanes: everything up to the first window op (the memsets above, the encoder) is on the caller's stream; lane 1 starts
@@ -333,7 +362,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
     size_t nDecode = 0;
     size_t opIndex = 0;
     for (const OpDev& od : pd->ops) {
-        unsigned int* queue = persistent ? pd->dQueues + 8 * opIndex : nullptr;
+        unsigned int* queue = persistent ? pd->dQueues + 16 * opIndex : nullptr;   // [0..7] tile ranges, [8] the 256 x 256 kernel's counter
         if (laned && (int)opIndex == pd->plan->firstWindowOp) HIPCHK(hipEventRecord(h->evFork, laneOf[0]));
         ++opIndex;
         hipStream_t const stream = laneOf[od.lane];            // shadows the caller's stream for this op
@@ -357,9 +386,13 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         int rc = 0;
         switch (od.kind) {
         case OP_GEMM:
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue,
-                                            gg_variant(od.bmode, prec) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
-                                            prec ? h->dRangeFlag : nullptr, stream);
+            if (od.total7 > 0)
+                rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_256x256, VSR_BMODE_NK, queue + 8, 6, 1,
+                                                h->dRangeFlag, stream);
+            if (rc == 0 && od.total > 0)
+                rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue,
+                                                gg_variant(od.bmode, prec) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
+                                                prec ? h->dRangeFlag : nullptr, stream);
             break;
         case OP_SOFTMAX:
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);
@@ -799,9 +832,8 @@ int vsr_sttn_timing_get(vsr_sttn_t* h, const char* prefix, double* total_ms, int
 // ---- kernel-level entry points -----------------------------------------------------------
 static void tile_dims(int cfg, int& BM, int& BN)
 {
-    BM = cfg == VSR_TILE_128x128 ? 128 : 256;
     BM = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_128x64) ? 128 : 256;
-    BN = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_256x128) ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
+    BN = cfg == VSR_TILE_256x256 ? 256 : (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_256x128) ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
 }
 
 static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_);
@@ -887,6 +919,12 @@ static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_
     int total = 0;
     for (auto& p : hp) {
         if (p.K % VSR_GG_KC) return fail(VSR_ERR_ARG, "K must be a multiple of 32");
+        if (tile_cfg == VSR_TILE_256x256) {
+            // dynamic tile height: any tilesM whose tiles of roundup32(ceil(M / tilesM)) <= 256 rows cover M (gather_gemm_v7.h)
+            const int rows = p.tilesM > 0 ? (((p.M + p.tilesM - 1) / p.tilesM) + 31) / 32 * 32 : 0;
+            if (p.tilesM <= 0 || rows > 256 || (int64_t)rows * p.tilesM < p.M || p.tilesN != (p.N + BN - 1) / BN || p.splitK != 1)
+                return fail(VSR_ERR_ARG, "256x256 tile: tilesM must give tiles of at most 256 rows that cover M; no split-K");
+        } else
         if (p.tilesM != (p.M + BM - 1) / BM || p.tilesN != (p.N + BN - 1) / BN) return fail(VSR_ERR_ARG, "tile counts do not match the tile config");
         if (p.splitK < 1 || (int64_t)p.splitK * p.chunksPerSplit < p.K / VSR_GG_KC) return fail(VSR_ERR_ARG, "bad split-K");
         p.tileStart = total;
