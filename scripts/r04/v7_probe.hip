@@ -44,7 +44,7 @@ static void v7_split(const GGProblem& p, std::vector<GGProblem>& out)
     }
 }
 
-template <int SPREAD, int ABL>
+template <int SPLIT, int ABL>
 static float time_v7(const GGProblem* d, int nprobs, int blocks, int iters)
 {
     hipEvent_t a, b;
@@ -57,7 +57,7 @@ static float time_v7(const GGProblem* d, int nprobs, int blocks, int iters)
         hipMemset(q, 0, 64 * sizeof(unsigned int));
         hipEventRecord(a, 0);
         for (int i = 0; i < iters; ++i)
-            hipLaunchKernelGGL((gather_gemm_f16_v7<SPREAD, ABL>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q + i, (unsigned int*)nullptr);
+            hipLaunchKernelGGL((gather_gemm_f16_v7<SPLIT, ABL>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q + i, (unsigned int*)nullptr);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;
@@ -93,13 +93,38 @@ static float time_v6(const GGProblem* d, int blocks, int iters)
     return best;
 }
 
+static float time_v5(const GGProblem* d, int blocks, int iters)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    unsigned int* q;
+    hipMalloc(&q, 64 * 8 * sizeof(unsigned int));
+    int occ = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v5<128, 64, 2, 2, VSR_BMODE_NK, 2, false, 0>, 256, 0);
+    const int grid = blocks < g_cus * occ ? blocks : g_cus * occ;
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(q, 0, 64 * 8 * sizeof(unsigned int));
+        hipEventRecord(a, 0);
+        for (int i = 0; i < iters; ++i)
+            hipLaunchKernelGGL((gather_gemm_f32_v5<128, 64, 2, 2, VSR_BMODE_NK, 2, false, 0>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8, (unsigned int*)nullptr);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms / iters < best) best = ms / iters;
+    }
+    hipFree(q);
+    return best;
+}
+
 static void timeline(const GGProblem* d, int nprobs, int blocks)
 {
     std::vector<unsigned long long> z(1024 * 256, 0), h(1024 * 256);
     hipMemcpyToSymbol(HIP_SYMBOL(gg_trace), z.data(), z.size() * 8);
     unsigned int* q; hipMalloc(&q, 32); hipMemset(q, 0, 32);
     const int grid = blocks < g_cus ? blocks : g_cus;
-    hipLaunchKernelGGL((gather_gemm_f16_v7<0, 256>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q, (unsigned int*)nullptr);
+    hipLaunchKernelGGL((gather_gemm_f16_v7<1, 256>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q, (unsigned int*)nullptr);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gg_trace), h.size() * 8);
     hipFree(q);
@@ -207,33 +232,33 @@ static int conv_case(int T)
     for (auto& q : v7) printf(" [M=%d tilesM=%d]", q.M, q.tilesM);
     printf("\n");
     float ms6 = time_v6(d6, blocks6, 10);
-    printf("  v6 128x64 x3      %8.1f us  %7.1f TF\n", ms6 * 1e3, gf / ms6);
+    printf("  fp16 operands:  v6 128x64 x3   %8.1f us  %7.1f TF\n", ms6 * 1e3, gf / ms6);
     float ms7 = time_v7<0, 0>(d7, (int)v7.size(), blocks7, 10);
-    printf("  v7 256x256 spread0 %8.1f us  %7.1f TF\n", ms7 * 1e3, gf / ms7);
+    printf("  fp16 operands:  v7 256x256     %8.1f us  %7.1f TF\n", ms7 * 1e3, gf / ms7);
     CK(hipDeviceSynchronize());
-    int bad = compare(C6, C7, actElems, "conv output (split format), spread 0");
-    CK(hipMemset(C7, 0, actElems * 4));
+    int bad = compare(C6, C7, actElems, "conv output (split format), fp16 operands");
+    CK(hipMemset(C6, 0, actElems * 4)); CK(hipMemset(C7, 0, actElems * 4));
+    float ms5 = time_v5(d6, blocks6, 10);
+    printf("  split-half:     v5 128x64 x2   %8.1f us  %7.1f TF-equivalent\n", ms5 * 1e3, gf / ms5);
     ms7 = time_v7<1, 0>(d7, (int)v7.size(), blocks7, 10);
-    printf("  v7 256x256 spread1 %8.1f us  %7.1f TF\n", ms7 * 1e3, gf / ms7);
+    printf("  split-half:     v7 256x256     %8.1f us  %7.1f TF-equivalent (x3 = %.0f TF of MFMA work)\n", ms7 * 1e3, gf / ms7, 3 * gf / ms7);
     CK(hipDeviceSynchronize());
-    bad |= compare(C6, C7, actElems, "conv output (split format), spread 1");
+    bad |= compare(C6, C7, actElems, "conv output (split format), split-half");
     {   // one body-only problem (no remainder): what the in-tile rate is
         GGProblem* d1; CK(hipMalloc(&d1, sizeof(p)));
         GGProblem b = v7[0]; b.tileStart = 0;
         CK(hipMemcpy(d1, &b, sizeof(p), hipMemcpyHostToDevice));
         const double gfb = 2.0 * b.M * N * (double)K / 1e9;
         float ms = time_v7<0, 0>(d1, 1, b.tilesM * b.tilesN, 10);
-        printf("  v7 body only (%d tiles), spread 0        %8.1f us  %7.1f TF\n", b.tilesM * b.tilesN, ms * 1e3, gfb / ms);
+        printf("  fp16 body only (%d tiles)                 %8.1f us  %7.1f TF\n", b.tilesM * b.tilesN, ms * 1e3, gfb / ms);
         ms = time_v7<1, 0>(d1, 1, b.tilesM * b.tilesN, 10);
-        printf("  v7 body only (%d tiles), spread 1        %8.1f us  %7.1f TF\n", b.tilesM * b.tilesN, ms * 1e3, gfb / ms);
-        ms = time_v7<0, 2>(d1, 1, b.tilesM * b.tilesN, 10);
-        printf("  v7 body, no operand fetch                 %8.1f us  %7.1f TF\n", ms * 1e3, gfb / ms);
-        ms = time_v7<0, 8>(d1, 1, b.tilesM * b.tilesN, 10);
-        printf("  v7 body, one hot chunk (L2 hits)          %8.1f us  %7.1f TF\n", ms * 1e3, gfb / ms);
-        ms = time_v7<0, 4>(d1, 1, b.tilesM * b.tilesN, 10);
-        printf("  v7 body, fetch + barriers only            %8.1f us\n", ms * 1e3);
-        ms = time_v7<0, 32 + 64>(d1, 1, b.tilesM * b.tilesN, 10);
-        printf("  v7 body, no residual read, no stores      %8.1f us  %7.1f TF\n", ms * 1e3, gfb / ms);
+        printf("  split body only (%d tiles)                %8.1f us  %7.1f TF-equivalent\n", b.tilesM * b.tilesN, ms * 1e3, gfb / ms);
+        ms = time_v7<1, 2>(d1, 1, b.tilesM * b.tilesN, 10);
+        printf("  split: no operand fetch                   %8.1f us  %7.1f\n", ms * 1e3, gfb / ms);
+        ms = time_v7<1, 4>(d1, 1, b.tilesM * b.tilesN, 10);
+        printf("  split: fetch + barriers only              %8.1f us\n", ms * 1e3);
+        ms = time_v7<1, 32 + 64>(d1, 1, b.tilesM * b.tilesN, 10);
+        printf("  split: no residual read, no stores        %8.1f us  %7.1f\n", ms * 1e3, gfb / ms);
         hipFree(d1);
     }
     timeline(d7, (int)v7.size(), blocks7);
@@ -280,16 +305,18 @@ static int qk_case(int T)
     for (auto& q : v7) printf(" [M=%d tilesM=%d tilesN=%d]", q.M, q.tilesM, q.tilesN);
     printf("\n");
     float ms6 = time_v6(d6, blocks6, 10);
-    printf("  v6 128x64 x3      %8.1f us  %7.1f TF\n", ms6 * 1e3, gf / ms6);
+    printf("  fp16 operands:  v6 128x64 x3   %8.1f us  %7.1f TF\n", ms6 * 1e3, gf / ms6);
     float ms7 = time_v7<0, 0>(d7, (int)v7.size(), blocks7, 10);
-    printf("  v7 256x256 spread0 %8.1f us  %7.1f TF\n", ms7 * 1e3, gf / ms7);
+    printf("  fp16 operands:  v7 256x256     %8.1f us  %7.1f TF\n", ms7 * 1e3, gf / ms7);
     CK(hipDeviceSynchronize());
-    int bad = compare(C6, C7, (size_t)M * N, "scores (fp32), spread 0");
-    CK(hipMemset(C7, 0, (size_t)M * N * 4));
+    int bad = compare(C6, C7, (size_t)M * N, "scores (fp32), fp16 operands");
+    CK(hipMemset(C6, 0, (size_t)M * N * 4)); CK(hipMemset(C7, 0, (size_t)M * N * 4));
+    float ms5 = time_v5(d6, blocks6, 10);
+    printf("  split-half:     v5 128x64 x2   %8.1f us  %7.1f TF-equivalent\n", ms5 * 1e3, gf / ms5);
     ms7 = time_v7<1, 0>(d7, (int)v7.size(), blocks7, 10);
-    printf("  v7 256x256 spread1 %8.1f us  %7.1f TF\n", ms7 * 1e3, gf / ms7);
+    printf("  split-half:     v7 256x256     %8.1f us  %7.1f TF-equivalent\n", ms7 * 1e3, gf / ms7);
     CK(hipDeviceSynchronize());
-    bad |= compare(C6, C7, (size_t)M * N, "scores (fp32), spread 1");
+    bad |= compare(C6, C7, (size_t)M * N, "scores (fp32), split-half");
     timeline(d7, (int)v7.size(), blocks7);
     hipFree(Q); hipFree(Kt); hipFree(C6); hipFree(C7); hipFree(d6); hipFree(d7);
     hipFree(dRowQ); hipFree(dColK); hipFree(dColC); hipFree(dRowC);
@@ -303,7 +330,7 @@ int main(int argc, char** argv)
     hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev);
     printf("CUs: %d\n", g_cus);
     int bad = 0;
-    for (int T : {15, 10, 11}) bad |= conv_case(T);
+    for (int T : {15, 10}) bad |= conv_case(T);
     for (int T : {15, 10}) bad |= qk_case(T);
     printf(bad ? "RESULT: MISMATCH\n" : "RESULT: all outputs identical\n");
     return bad;

@@ -226,6 +226,7 @@ def _starts(row, col):
     ("TILE_256x32", 256, 32, 0, 700, 3, 64, 1),
     ("TILE_128x128", 128, 128, 1, 200, 192, 96, 1), ("TILE_128x64", 128, 64, 1, 1440, 960, 320, 3),
     ("TILE_128x64", 128, 64, 1, 129, 960, 4800 // 32 * 32, 1),
+    ("TILE_256x256", 256, 256, 0, 513, 257, 2304, 1), ("TILE_256x256", 256, 256, 0, 700, 320, 96, 1),     # gather_gemm_f16_v7<1>
 ])
 def test_gather_gemm_split_format(built_lib, gpu_device, out_split, cfg, bm, bn, bmode, M, N, K, splitK):
     """Variant 5: A, B and R arrive in split format ([32 fp16 hi | 32 fp16 lo] per 32-float chunk); C leaves in
@@ -366,9 +367,11 @@ def test_gather_gemm_fp16_256x256(built_lib, gpu_device, out_split, M, N, K, til
 
 
 @pytest.mark.parametrize("out_split", [0, 1])
-def test_gather_gemm_fp16_256x256_equals_128x64(built_lib, gpu_device, out_split):
-    """Same k order, same MFMA: on ANY split-format operands (not only fp16-representable ones) the 256 x 256 kernel writes the
-    bytes the 128 x 64 kernel writes -- also as two problems of one launch (a body and a remainder with offset row tables)."""
+@pytest.mark.parametrize("variant", [6, 5])
+def test_gather_gemm_fp16_256x256_equals_128x64(built_lib, gpu_device, out_split, variant):
+    """Same k order, same MFMAs in the same order: on ANY split-format operands (not only fp16-representable ones) the 256 x 256 kernel
+    writes the bytes the 128 x 64 kernel of the same variant (6: fp16 operands, 5: split-half, three MFMAs per product) writes --
+    also as two problems of one launch."""
     rng = np.random.default_rng(7100 + out_split)
     outs = {}
     for cfg, bm, bn in (("TILE_128x64", 128, 64), ("TILE_256x256", 256, 256)):
@@ -380,7 +383,7 @@ def test_gather_gemm_fp16_256x256_equals_128x64(built_lib, gpu_device, out_split
             if out_split:
                 c.act |= 0x100
             cases.append(c)
-        outs[cfg] = _run_cases(built_lib, gpu_device, cases, getattr(built_lib, cfg), 0, 6)
+        outs[cfg] = _run_cases(built_lib, gpu_device, cases, getattr(built_lib, cfg), 0, variant)
     for a, b in zip(outs["TILE_128x64"], outs["TILE_256x256"]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 

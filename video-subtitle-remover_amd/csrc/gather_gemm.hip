@@ -405,11 +405,17 @@ extern "C" int vsr_gg_cus(void)
 }
 
 // fp16-operand mode, large NK problems: the 256 x 256 tile of 8 waves, one workgroup per CU (gather_gemm_v7.h)
-static void launch_v7(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, unsigned int* rangeFlag, hipStream_t stream)
+static void launch_v7(const GGProblem* d_probs, int nprobs, int totalBlocks, unsigned int* queue, unsigned int* rangeFlag, bool hiOnly, hipStream_t stream)
 {
-    static const int resident = resident_blocks(gather_gemm_f16_v7<1>, 512);
-    const int g = totalBlocks < resident ? totalBlocks : resident;
-    hipLaunchKernelGGL((gather_gemm_f16_v7<1>), dim3(g), dim3(512), 0, stream, d_probs, nprobs, totalBlocks, queue, rangeFlag);
+    if (hiOnly) {
+        static const int resident = resident_blocks(gather_gemm_f16_v7<0>, 512);
+        const int g = totalBlocks < resident ? totalBlocks : resident;
+        hipLaunchKernelGGL((gather_gemm_f16_v7<0>), dim3(g), dim3(512), 0, stream, d_probs, nprobs, totalBlocks, queue, rangeFlag);
+    } else {
+        static const int resident = resident_blocks(gather_gemm_f16_v7<1>, 512);
+        const int g = totalBlocks < resident ? totalBlocks : resident;
+        hipLaunchKernelGGL((gather_gemm_f16_v7<1>), dim3(g), dim3(512), 0, stream, d_probs, nprobs, totalBlocks, queue, rangeFlag);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
@@ -491,9 +497,9 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
         launch_v6_st<256, 128, 4, 2, 3>(d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag, stream);
         return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
     }
-    if (tileCfg == VSR_TILE_256x256) {         // the 8-wave 256 x 256 tile of the fp16-operand mode (dynamic tile height, see gather_gemm_v7.h)
-        if (bmode != VSR_BMODE_NK || variant != 6 || !queue) return -1;
-        launch_v7(d_probs, nprobs, totalBlocks, queue, rangeFlag, stream);
+    if (tileCfg == VSR_TILE_256x256) {         // the 8-wave 256 x 256 tile of the split-format modes (variant 5: split-half, 6: fp16 operands; dynamic tile height, see gather_gemm_v7.h)
+        if (bmode != VSR_BMODE_NK || (variant != 6 && variant != 5) || !queue) return -1;
+        launch_v7(d_probs, nprobs, totalBlocks, queue, rangeFlag, variant == 6, stream);
         return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
     }
     if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_NK);

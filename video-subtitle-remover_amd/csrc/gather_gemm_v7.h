@@ -30,7 +30,7 @@
 #pragma once
 #include <type_traits>
 
-template <int PIPE GG_ABL_PARAM>
+template <int SPLIT GG_ABL_PARAM>
 __global__ void __launch_bounds__(512, 2)
 gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue,
                    unsigned int* __restrict__ rangeFlag)
@@ -39,7 +39,7 @@ gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTil
     constexpr int MI = 4, NI = 2;
     constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
     constexpr int A_IT = 4, B_IT = 4;                            // LDS-DMA passes of 64 rows
-    static_assert(PIPE == 0 || PIPE == 1, "0: two stages of a PAIR of chunks; 1: a ring of four 32-deep stages");
+    static_assert(SPLIT == 0 || SPLIT == 1, "0: fp16 hi halves as operands (variant 6); 1: split-half operands, three MFMAs per product (variant 5)");
 
     // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA queue in front of every fragment read)
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_BYTES / 4 + 2 * BM + 4];
@@ -53,11 +53,13 @@ gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTil
     const int l31 = lane & 31, hi = lane >> 5;
     const int s_r = tid >> 3, s_q = tid & 7;                    // LDS-DMA: row-in-pass (0..63), piece slot
     const int lp = s_q ^ ((s_r >> 1) & 7);                      // logical piece this lane fetches
-    const bool second = (lp & 4) != 0;                          // ... of the second chunk of the pair
-    const int srcSwz = (lp & 3) << 2;                           // float offset of the 16-byte group inside the chunk's hi half
-    int rd[4];                                                  // k-step st: lane (l31, hi) reads logical piece 2 st + hi
+    // SPLIT 0: a row holds the hi halves of a PAIR of chunks (pieces 0-3 chunk 2j, 4-7 chunk 2j+1); SPLIT 1: ONE chunk, its 128
+    // bytes as they lie in memory (pieces 0-3 hi halves, 4-7 lo halves)
+    const bool second = SPLIT == 0 && (lp & 4) != 0;            // the piece belongs to the second chunk of the pair
+    const int srcSwz = (SPLIT ? lp : (lp & 3)) << 2;            // float offset of the 16-byte group inside its chunk
+    int rd[4];                                                  // logical piece p of a row lies at rd-style offset (p ^ swizzle) << 4
 #pragma unroll
-    for (int st = 0; st < 4; ++st) rd[st] = (((2 * st + hi) ^ ((l31 >> 1) & 7)) << 4);
+    for (int st = 0; st < 4; ++st) rd[st] = (((2 * st + hi) ^ ((l31 >> 1) & 7)) << 4);   // SPLIT 0: k-step st reads piece 2 st + hi; SPLIT 1: k-step st < 2 reads hi piece rd[st] and lo piece rd[2 + st]
 
 #ifdef GG_ABLATE
     int tr_ = 0;                                     // 256: wall-clock stamps of wave 0 (100 MHz), 4 per tile
@@ -144,7 +146,7 @@ gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             narrow = narrow && ((unsigned)o < (1u << 30));
             boffB[it] = (unsigned)o << 2;
         }
-        if (PIPE == 0 && rangeFlag != nullptr && !narrow) atomicOr(rangeFlag, 2u);
+        if (rangeFlag != nullptr && !narrow) atomicOr(rangeFlag, 2u);
         const int aPasses = (R + 63) >> 6;                      // 64-row passes that hold rows of this tile
 
         V7_STAMP(1)
@@ -261,132 +263,88 @@ gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             }
         };
 
-        // ---- PIPE 1: a ring of FOUR 32-deep stages ([256 A rows | 256 B rows] x 64 bytes = 32 KB each), three stages ahead.
-        // Measured on the pair pipeline (profiles/r04_v7_probe_b.log): a 64 KB burst issued behind a barrier lands 1.5 us later, and
-        // one burst in flight per CU is all two 64 KB stages allow -- the loop cannot run below 1.55 us per pair whatever the MFMAs
-        // do (0.85 us), and a 32-row tile takes half the time of a 256-row one.  Four half-size stages hold 96 KB in flight with the
-        // same LDS: a stage is waited for (counted vmcnt) three steps after it was issued.  One barrier per chunk; a lane fetches
-        // the same two A rows and two B rows in every stage (4 offset registers), a wave instruction fills 16 rows x 64 bytes;
-        // bank-conflict XOR on (row >> 2) & 3, source side and fragment read alike.
-        const int r_row = lane >> 2, r_slot = lane & 3;
-        const int lpR = r_slot ^ ((r_row >> 2) & 3);               // logical 16-byte piece of the chunk's hi half this lane fetches
-        unsigned aoffR[2] = {0, 0}, boffR[2] = {0, 0};
-        int rdR[2] = {0, 0};
-        if constexpr (PIPE == 1) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int m = m0 + (wave * 2 + i) * 16 + r_row;
-                if (m > M - 1) m = M - 1;
-                int n = n0 + (wave * 2 + i) * 16 + r_row;
-                if (n > N - 1) n = N - 1;
-                const int oa = rowA[m] + 4 * lpR, ob = rowB[n] + 4 * lpR;
-                narrow = narrow && ((unsigned)oa < (1u << 30)) && ((unsigned)ob < (1u << 30));
-                aoffR[i] = (unsigned)oa << 2;
-                boffR[i] = (unsigned)ob << 2;
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st) rdR[st] = (((2 * st + hi) ^ ((l31 >> 2) & 3)) << 4);
-            if (rangeFlag != nullptr && !narrow) atomicOr(rangeFlag, 2u);
-        }
-        auto main_loop_ring = [&](auto miaTag) __attribute__((always_inline)) {
+        // ---- SPLIT 1 (kernel variant 5): split-half operands, a.b = a_lo.b_hi + a_hi.b_lo + a_hi.b_hi in that order per k-step (the
+        // order of gather_gemm_f32_v5, so the two kernels agree bit for bit).  A stage is ONE 32-deep chunk -- its 128-byte rows are
+        // the tensor's own [32 hi | 32 lo] lines, no byte fetched in vain -- and carries 48 MFMAs per wave: three times the matrix
+        // work of the fp16-operand form per LDS byte and per barrier.
+        auto main_loop_split = [&](auto miaTag) __attribute__((always_inline)) {
             constexpr int MIA = decltype(miaTag)::value;
-            constexpr int RSTAGE = 32 * 1024, RA = 16 * 1024;
-            struct Frag { f16x8 a[MIA > 0 ? MIA : 1], b[NI]; };
+            struct Frag { f16x8 ah[MIA > 0 ? MIA : 1], al[MIA > 0 ? MIA : 1], bh[NI], bl[NI]; };
             auto read_frag = [&](auto bufTag, int st, Frag& f) __attribute__((always_inline)) {
                 constexpr int buf = decltype(bufTag)::value;
-                const char* As = reinterpret_cast<const char*>(smem) + buf * RSTAGE;
-                const char* Bs = As + RA;
+                const char* As = reinterpret_cast<const char*>(smem) + buf * STAGE_BYTES;
+                const char* Bs = As + A_BYTES;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    f.b[ni] = *reinterpret_cast<const f16x8*>(Bs + (wn * 64 + ni * 32 + l31) * 64 + rdR[st]);
+                for (int ni = 0; ni < NI; ++ni) {
+                    const char* row = Bs + (wn * 64 + ni * 32 + l31) * 128;
+                    f.bh[ni] = *reinterpret_cast<const f16x8*>(row + rd[st]);
+                    f.bl[ni] = *reinterpret_cast<const f16x8*>(row + rd[2 + st]);
+                }
 #pragma unroll
-                for (int mi = 0; mi < MIA; ++mi)
-                    f.a[mi] = *reinterpret_cast<const f16x8*>(As + ((wm + 2 * mi) * 32 + l31) * 64 + rdR[st]);
+                for (int mi = 0; mi < MIA; ++mi) {
+                    const char* row = As + ((wm + 2 * mi) * 32 + l31) * 128;
+                    f.ah[mi] = *reinterpret_cast<const f16x8*>(row + rd[st]);
+                    f.al[mi] = *reinterpret_cast<const f16x8*>(row + rd[2 + st]);
+                }
             };
             auto mfma_frag = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
                 for (int mi = 0; mi < MIA; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0);
-            };
-            auto dma_stage = [&](auto bufTag, int ca, int cb) __attribute__((always_inline)) {
-                constexpr int buf = decltype(bufTag)::value;
-                char* As = reinterpret_cast<char*>(smem) + buf * RSTAGE;
-                char* Bs = As + RA;
-                if constexpr (GG_ABL(2)) { if (buf >= 0) return; }     // ablation: no operand fetch at all
-                if constexpr (GG_ABL(8)) { ca = cb = 0; }              // 8: one hot chunk
-                typedef const char __attribute__((address_space(1)))* gcc8;
-                const gcc8 baseA = (gcc8)A + (long long)ca * 4, baseB = (gcc8)B + (long long)cb * 4;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    unsigned vo = aoffR[i];
-                    asm volatile("" : "+v"(vo));
-                    glds16((gcf32)(baseA + vo), (lds_vptr)(As + (wave * 2 + i) * 1024));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    unsigned vo = boffR[i];
-                    asm volatile("" : "+v"(vo));
-                    glds16((gcf32)(baseB + vo), (lds_vptr)(Bs + (wave * 2 + i) * 1024));
-                }
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ni], f.al[mi], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[ni], f.ah[mi], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ni], f.ah[mi], acc[mi][ni], 0, 0, 0);
+                    }
             };
             using S0_ = std::integral_constant<int, 0>;
             using S1_ = std::integral_constant<int, 1>;
-            using S2_ = std::integral_constant<int, 2>;
-            using S3_ = std::integral_constant<int, 3>;
-            // chunk offsets: lane i of v0 holds entry tb + i, of v1 entry tb + 64 + i (refreshed every 64 chunks)
-            int tb = kcBeg;
-            auto fetch_tab = [&](int base, int& va, int& vb) __attribute__((always_inline)) {
-                const int idx = base + lane < nchunksTotal ? base + lane : nchunksTotal - 1;
-                va = colA[idx]; vb = colB[idx];
-            };
-            int ca0v, cb0v, ca1v, cb1v;
-            fetch_tab(tb, ca0v, cb0v);
-            fetch_tab(tb + 64, ca1v, cb1v);
-            asm volatile("" ::"v"(ca0v), "v"(ca1v), "v"(cb0v), "v"(cb1v));
-            auto pick = [&](int v0, int v1, int i) {           // both halves read, scalar select: no branch in the loop
-                const int a_ = __builtin_amdgcn_readlane(v0, i & 63), b_ = __builtin_amdgcn_readlane(v1, i & 63);
-                return i < 64 ? a_ : b_;
-            };
-            if (kcBeg < kcEnd) dma_stage(S0_{}, pick(ca0v, ca1v, 0), pick(cb0v, cb1v, 0));
-            if (kcBeg + 1 < kcEnd) dma_stage(S1_{}, pick(ca0v, ca1v, 1), pick(cb0v, cb1v, 1));
-            if (kcBeg + 2 < kcEnd) dma_stage(S2_{}, pick(ca0v, ca1v, 2), pick(cb0v, cb1v, 2));
-            // chunk kc out of stage `cur`; the DMA of chunk kc + 3 goes into stage `nxt` (chunk kc - 1's, retired by this step's barrier)
-            auto step = [&](int kc, auto cur, auto nxt) __attribute__((always_inline)) {
-                const int ahead = kcEnd - 1 - kc;                  // younger stages already issued: min(ahead, 2), 4 pieces each
-                if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (!GG_ABL(1)) __builtin_amdgcn_s_barrier();
-                Frag f;
-                if constexpr (!GG_ABL(4)) read_frag(cur, 0, f);
-                if (kc + 3 < kcEnd) dma_stage(nxt, pick(ca0v, ca1v, kc + 3 - tb), pick(cb0v, cb1v, kc + 3 - tb));
-                if constexpr (GG_ABL(4)) return;
-                mfma_frag(f);
-                read_frag(cur, 1, f);
-                mfma_frag(f);
-            };
-            for (int kc = kcBeg; kc < kcEnd; kc += 4) {
-                step(kc, S0_{}, S3_{});
-                if (kc + 1 < kcEnd) step(kc + 1, S1_{}, S0_{});
-                if (kc + 2 < kcEnd) step(kc + 2, S2_{}, S1_{});
-                if (kc + 3 < kcEnd) step(kc + 3, S3_{}, S2_{});
-                if (kc + 4 - tb >= 64 && kc + 4 < kcEnd) {        // the next 64 table entries become current
-                    tb += 64;
-                    ca0v = ca1v; cb0v = cb1v;
-                    fetch_tab(tb + 64, ca1v, cb1v);
-                    asm volatile("" ::"v"(ca1v), "v"(cb1v));
+            using PA_ = std::integral_constant<int, 0>;
+            using PB_ = std::integral_constant<int, 1>;
+            for (int sb = kcBeg; sb < kcEnd; sb += 128) {
+                const int sbEnd = sb + 128 < kcEnd ? sb + 128 : kcEnd;
+                const int i0 = sb + lane < nchunksTotal ? sb + lane : nchunksTotal - 1;
+                const int i1 = sb + 64 + lane < nchunksTotal ? sb + 64 + lane : nchunksTotal - 1;
+                const int ca0v = colA[i0], ca1v = colA[i1], cb0v = colB[i0], cb1v = colB[i1];
+                asm volatile("" ::"v"(ca0v), "v"(ca1v), "v"(cb0v), "v"(cb1v));
+                auto pick = [&](int v0, int v1, int i) {
+                    const int a_ = __builtin_amdgcn_readlane(v0, i & 63), b_ = __builtin_amdgcn_readlane(v1, i & 63);
+                    return i < 64 ? a_ : b_;
+                };
+                if (sb != kcBeg) {                                  // stages of the previous super-block are still being read
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                {
+                    const int ca = pick(ca0v, ca1v, 0), cb = pick(cb0v, cb1v, 0);
+                    dma_part(S0_{}, PA_{}, ca, ca);
+                    dma_part(S0_{}, PB_{}, cb, cb);
+                }
+                auto step = [&](int kc, auto cur, auto nxt) __attribute__((always_inline)) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if constexpr (!GG_ABL(1)) __builtin_amdgcn_s_barrier();
+                    const int i = kc + 1 - sb;
+                    const int na = pick(ca0v, ca1v, i), nb = pick(cb0v, cb1v, i);
+                    if (kc + 1 < sbEnd) { dma_part(nxt, PA_{}, na, na); dma_part(nxt, PB_{}, nb, nb); }
+                    if constexpr (GG_ABL(4)) return;
+                    Frag f;
+                    read_frag(cur, 0, f);
+                    mfma_frag(f);
+                    read_frag(cur, 1, f);
+                    mfma_frag(f);
+                };
+                for (int kc = sb; kc < sbEnd; kc += 2) {
+                    step(kc, S0_{}, S1_{});
+                    if (kc + 1 < sbEnd) step(kc + 1, S1_{}, S0_{});
                 }
             }
         };
-        if constexpr (PIPE == 1) {
-            if (MIact >= 4) main_loop_ring(std::integral_constant<int, 4>{});
-            else if (MIact == 3) main_loop_ring(std::integral_constant<int, 3>{});
-            else if (MIact == 2) main_loop_ring(std::integral_constant<int, 2>{});
-            else if (MIact == 1) main_loop_ring(std::integral_constant<int, 1>{});
-            else main_loop_ring(std::integral_constant<int, 0>{});
+        if constexpr (SPLIT == 1) {
+            if (MIact >= 4) main_loop_split(std::integral_constant<int, 4>{});
+            else if (MIact == 3) main_loop_split(std::integral_constant<int, 3>{});
+            else if (MIact == 2) main_loop_split(std::integral_constant<int, 2>{});
+            else if (MIact == 1) main_loop_split(std::integral_constant<int, 1>{});
+            else main_loop_split(std::integral_constant<int, 0>{});
         } else
         if (MIact >= 4) main_loop(std::integral_constant<int, 4>{});
         else if (MIact == 3) main_loop(std::integral_constant<int, 3>{});

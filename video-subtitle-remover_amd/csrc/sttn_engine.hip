@@ -206,12 +206,12 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     auto F = [&](int buf, int64_t off) -> float* { return buf < 0 ? nullptr : (float*)h->bufs[buf] + off; };
 
     // ---- descriptors: one allocation, 64-byte aligned records
-    // fp16-operand mode: the large NK problems of an op (convs, QKV, the fine attention scales) go to the 256 x 256 kernel, each cut
+    // split-format modes (precision 2, 3): the large NK problems of an op (convs, QKV, the fine attention scales) go to the 256 x 256 kernel, each cut
     // into whole rounds + a remainder (vsr_v7_split: up to two descriptors); the rest of the op stays on the 128 x 64 kernel
     static const bool v7on = [] { const char* e = getenv("VSR_F16_V7"); return !(e && atoi(e) == 0); }();
     const int cus = vsr_gg_cus();
     auto forV7 = [&](const Op& op, const GemmItem& g) {
-        return v7on && precision == 3 && op.bmode == VSR_BMODE_NK && g.splitK == 1 && !(g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP)) && g.N >= 192 && g.K >= 256 && g.M >= 16 * 256 &&
+        return v7on && precision >= 2 && op.bmode == VSR_BMODE_NK && g.splitK == 1 && !(g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP)) && g.N >= 192 && g.K >= 256 && g.M >= 16 * 256 &&
                (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * 2 >= cus;
     };
     size_t descBytes = 0;
@@ -387,8 +387,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         switch (od.kind) {
         case OP_GEMM:
             if (od.total7 > 0)
-                rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_256x256, VSR_BMODE_NK, queue + 8, 6, 1,
-                                                h->dRangeFlag, stream);
+                rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_256x256, VSR_BMODE_NK, queue + 8,
+                                                prec == 3 ? 6 : 5, 1, h->dRangeFlag, stream);
             if (rc == 0 && od.total > 0)
                 rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue,
                                                 gg_variant(od.bmode, prec) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
