@@ -208,6 +208,11 @@ int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
 /* fp32 -> split format (variant 5 operands): dst[32c .. 32c+31] as bytes = fp16 hi[0..31] | fp16 lo[0..31] of
  * src[32c .. 32c+31]; n a multiple of 32 */
 int vsr_launch_to_split(const float* src_dev, float* dst_dev, int64_t n, void* stream);
+/* a KN operand in split format, B(k, n) = B[rowB[k] + colB[n / 32] + n % 32], as the dense NK operand dst[n * ld + k] in split format
+ * (the P.V product of the split-format modes runs on the NK kernels: V of auto_sttn.py:195-203 is turned once per product);
+ * K, N multiples of 32, ld >= K */
+int vsr_launch_kn_to_nk_split(const float* B_dev, const int32_t* rowB_dev, const int32_t* colB_dev, int K, int N, int64_t ld,
+                              float* dst_dev, void* stream);
 
 /* cv2.resize(..., INTER_LINEAR) on uint8 (fixed-point path), tables from vsr_cv2_linear_tables;
  * frame_idx (device, nullable) gathers source frames (sttn_auto_inpaint.py:269-271) */

@@ -388,6 +388,47 @@ def test_gather_gemm_fp16_256x256_equals_128x64(built_lib, gpu_device, out_split
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("variant", [6, 5])
+@pytest.mark.parametrize("M,N,K,splitK,tilesM", [(1440, 960, 1472, 3, None), (700, 320, 480, 2, 5)])
+def test_gather_gemm_256x256_split_k(built_lib, gpu_device, variant, M, N, K, splitK, tilesM):
+    """split-K on the 256 x 256 kernel: every (tile, slice) writes its own fp32 partial plane, as on the 128 x 64 kernel"""
+    outs = {}
+    for cfg, bm, bn in (("TILE_128x64", 128, 64), ("TILE_256x256", 256, 256)):
+        rng = np.random.default_rng(7300 + M + splitK)
+        c = _make_gemm_case(rng, M, N, K, 256, 256, 0, splitK, False, 0, False)
+        _to_split_inplace(c.Abuf, _starts(c.rowA, c.colA))
+        _to_split_inplace(c.Bbuf, _starts(c.rowB, c.colB))
+        c.tilesM, c.tilesN = -(-M // bm), -(-N // bn)
+        if cfg == "TILE_256x256" and tilesM is not None:
+            c.tilesM = tilesM
+        outs[cfg] = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), 0, variant)[0]
+    assert np.array_equal(outs["TILE_128x64"].view(np.uint32), outs["TILE_256x256"].view(np.uint32))
+
+
+def test_kn_to_nk_split(built_lib, gpu_device):
+    """vsr_launch_kn_to_nk_split: a gathered KN operand in split format becomes the dense NK operand dst[n * ld + k] in split format"""
+    rng = np.random.default_rng(7400)
+    K, N, ld = 96, 64, 128
+    rowstride = (N // 32 + 2) * 32
+    rowB = (rng.permutation(K + 3)[:K] * rowstride).astype(np.int64)
+    colB = (rng.permutation(N // 32 + 2)[: N // 32] * 32).astype(np.int64)
+    src = rng.integers(0, 2 ** 32, size=(K + 3) * rowstride + 64, dtype=np.uint32)
+    dst = np.zeros(N * ld + 32, dtype=np.uint32)
+    d_src, d_dst = _dev(src.view(np.float32), gpu_device), _dev(dst.view(np.float32), gpu_device)
+    t_row, t_col = _dev(rowB.astype(np.int32), gpu_device), _dev(colB.astype(np.int32), gpu_device)
+    built_lib.check(built_lib.lib.vsr_launch_kn_to_nk_split(_ptr(d_src), _ptr(t_row), _ptr(t_col), K, N, C.c_int64(ld), _ptr(d_dst), None))
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy().view(np.uint16)
+    s16 = src.view(np.uint16)
+    want = np.zeros_like(got)
+    k, n = np.meshgrid(np.arange(K), np.arange(N), indexing="ij")
+    src_chunk = rowB[k] + colB[n // 32]                       # float offset of the source chunk
+    dst_chunk = n * ld + 32 * (k // 32)
+    want[2 * dst_chunk + k % 32] = s16[2 * src_chunk + n % 32]                 # hi halves
+    want[2 * dst_chunk + 32 + k % 32] = s16[2 * src_chunk + 32 + n % 32]       # lo halves
+    assert np.array_equal(got, want)
+
+
 def test_to_split_bit_exact(built_lib, gpu_device):
     rng = np.random.default_rng(8)
     x = (rng.standard_normal(32 * 1000) * np.exp(rng.uniform(-8, 8, 32 * 1000))).astype(np.float32)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "vsr_run_gather_gemm_variant": (_I, [C.POINTER(GGProblem), _I, _I, _I, _I, _P]),
     "vsr_run_softmax": (_I, [C.POINTER(SMProblem), _I, _P]),
     "vsr_launch_to_split": (_I, [_P, _P, C.c_int64, _P]),
+    "vsr_launch_kn_to_nk_split": (_I, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "vsr_launch_resize_u8": (_I, [_P, _L, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsr_launch_norm_im2col": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_launch_reduce_scatter": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P]),

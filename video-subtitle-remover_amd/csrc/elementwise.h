@@ -19,3 +19,5 @@ extern "C" int vsr_launch_decode_out_blk(const float* y, int ldy, int pix, int n
                                          int blkW, void* stream);
 extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
                                          int nframes, int split, void* stream);
+// KN operand (B(k, n) = B[rowB[k] + colB[n / 32] + n % 32], split format) -> NK operand dst[n * ld + k] in split format; K, N multiples of 32
+extern "C" int vsr_launch_kn_to_nk_split(const float* B, const int32_t* rowB, const int32_t* colB, int K, int N, int64_t ld, float* dst, void* stream);

@@ -557,3 +557,42 @@ extern "C" int vsr_launch_to_split(const float* src, float* dst, int64_t n, void
     hipLaunchKernelGGL(k_to_split, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
+
+// ---- KN operand -> NK operand, split format (the P.V product of the split-format modes on the 256 x 256 NK kernel) ----------------
+// The KN form reads B(k, n) = B[rowB[k] + colB[n / 32] + n % 32] (V: k = token, n = position in the patch x channel vector); the
+// LDS-DMA kernels want the contraction index contiguous.  One workgroup turns a 32 (k) x 32 (n) block: 32 gathered 128-byte chunks
+// ([32 hi | 32 lo] of 32 n-values of one token) in, 32 chunks of the transposed tensor out -- dst chunk (n, k / 32) at float offset
+// n * ld + 32 (k / 32) holds [32 hi | 32 lo] of 32 k-values of one n.  K is a multiple of 32 (the caller's row table is padded the
+// way the KN kernel's is: pad rows repeat row 0, and the A operand's pad columns are zero); N a multiple of 32.
+__global__ void __launch_bounds__(256) k_kn_to_nk_split(const float* __restrict__ B, const int32_t* __restrict__ rowB, const int32_t* __restrict__ colB,
+                                                        int K, int N, int64_t ld, float* __restrict__ dst)
+{
+    __shared__ unsigned short tile[32][64 + 2];                   // [k][32 hi | 32 lo] (+ pad: column reads hit 32 banks)
+    const int kc = blockIdx.x, nc = blockIdx.y, t = threadIdx.x;
+    {
+        const int k = t >> 3, piece = t & 7;                       // 8 threads fetch the 128-byte chunk of token k
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(B + (rowB[kc * 32 + k] + colB[nc])) + 16 * piece);
+        unsigned short* d = &tile[k][8 * piece];
+        d[0] = (unsigned short)v.x; d[1] = (unsigned short)(v.x >> 16); d[2] = (unsigned short)v.y; d[3] = (unsigned short)(v.y >> 16);
+        d[4] = (unsigned short)v.z; d[5] = (unsigned short)(v.z >> 16); d[6] = (unsigned short)v.w; d[7] = (unsigned short)(v.w >> 16);
+    }
+    __syncthreads();
+    {
+        const int n = t >> 3, piece = t & 7;                       // 8 threads write the 128-byte chunk of position n
+        const int half = piece >> 2, k0 = 8 * (piece & 3);         // pieces 0-3: hi halves of k0..k0+7, 4-7: lo halves
+        unsigned short h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = tile[k0 + j][32 * half + n];
+        uint4 o;
+        o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16); o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst + ((int64_t)(nc * 32 + n) * ld + 32 * kc)) + 16 * piece) = o;
+    }
+}
+
+extern "C" int vsr_launch_kn_to_nk_split(const float* B, const int32_t* rowB, const int32_t* colB, int K, int N, int64_t ld, float* dst, void* stream)
+{
+    if (K <= 0 || N <= 0) return 0;
+    if (K % 32 || N % 32 || ld < K) return VSR_ERR_ARG;
+    hipLaunchKernelGGL(k_kn_to_nk_split, dim3(K / 32, N / 32), dim3(256), 0, (hipStream_t)stream, B, rowB, colB, K, N, ld, dst);
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}

@@ -375,8 +375,11 @@ extern "C" int vsr_v7_split(const GGProblem* p, int cus, GGProblem* out)
 {
     if (cus <= 0) cus = 256;
     const int tilesN = (p->N + 255) / 256;
-    const int perRound = cus / tilesN > 0 ? cus / tilesN : 1;          // M tiles of one round
-    const int body = (p->M / 256) / perRound * perRound;               // whole 256-row tiles in whole rounds
+    const int splitK = p->splitK > 0 ? p->splitK : 1;
+    const int perM = tilesN * splitK;                                  // workgroups one M tile needs (N tiles x K slices)
+    const int perRound = cus / perM > 0 ? cus / perM : 1;              // M tiles of one round
+    // split-K problems write partial planes indexed by the split: they stay one problem (tilesM is free, see the kernel)
+    const int body = splitK > 1 ? 0 : (p->M / 256) / perRound * perRound;   // whole 256-row tiles in whole rounds
     int n = 0;
     if (body > 0) {
         out[n] = *p;
@@ -389,7 +392,8 @@ extern "C" int vsr_v7_split(const GGProblem* p, int cus, GGProblem* out)
         out[n].tilesN = tilesN; out[n].M = rem;
         out[n].rowA = p->rowA + (size_t)body * 256; out[n].rowC = p->rowC + (size_t)body * 256;
         out[n].rowR = p->rowR ? p->rowR + (size_t)body * 256 : nullptr;
-        int rows = ((rem + perRound - 1) / perRound + 31) & ~31;       // rows per tile when every workgroup of a round takes one
+        const int rounds = (rem + 256 * perRound - 1) / (256 * perRound);                 // rounds the remainder needs at full height
+        int rows = ((rem + rounds * perRound - 1) / (rounds * perRound) + 31) & ~31;      // rows per tile when those rounds are full
         if (rows > 256) rows = 256;
         out[n].tilesM = (rem + rows - 1) / rows;
         ++n;

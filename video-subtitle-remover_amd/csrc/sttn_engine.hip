@@ -51,6 +51,8 @@ struct OpDev {
     int nQueues = 1;             // persistent gather-GEMM: 8 = per-XCD tile ranges, 1 = global queue
     const void* dDesc7 = nullptr; // fp16-operand mode: the large NK problems of the op, cut for the 256 x 256 kernel (gather_gemm_v7.h)
     int nitems7 = 0, total7 = 0;
+    struct Vt { const float* B; const int32_t* rowB; const int32_t* colB; int K, N; int64_t ld; float* dst; };
+    std::vector<Vt> vts;          // KN problems among them (P.V): their B operand is turned to NK form first (vsr_launch_kn_to_nk_split)
     // elementwise
     const void* src = nullptr;
     void* dst = nullptr;
@@ -79,9 +81,13 @@ struct PlanDev {
     void* dDescs = nullptr;
     int32_t* dIsFloat = nullptr;
     unsigned int* dQueues = nullptr;   // 8 tile-queue counters (one per XCD) per op (persistent gather-GEMM), zeroed per run
+    int32_t* dTables7 = nullptr;       // row tables of the transposed P.V operands (n -> n * ld)
+    float* dVt = nullptr;              // the transposed operands themselves, one region per lane
     std::vector<OpDev> ops;
     ~PlanDev()
     {
+        if (dTables7) (void)hipFree(dTables7);
+        if (dVt) (void)hipFree(dVt);
         if (dQueues) (void)hipFree(dQueues);
         if (dTables) (void)hipFree(dTables);
         if (dDescs) (void)hipFree(dDescs);
@@ -210,10 +216,31 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     // into whole rounds + a remainder (vsr_v7_split: up to two descriptors); the rest of the op stays on the 128 x 64 kernel
     static const bool v7on = [] { const char* e = getenv("VSR_F16_V7"); return !(e && atoi(e) == 0); }();
     const int cus = vsr_gg_cus();
+    // NK problems as they are; KN problems (P.V: B = V, n-contiguous) after their B operand has been turned to NK form into a
+    // scratch tensor (one pass over V per product, ~2 % of the product's own time).  Split-K problems keep their partial planes.
     auto forV7 = [&](const Op& op, const GemmItem& g) {
-        return v7on && precision >= 2 && op.bmode == VSR_BMODE_NK && g.splitK == 1 && !(g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP)) && g.N >= 192 && g.K >= 256 && g.M >= 16 * 256 &&
-               (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * 2 >= cus;
+        if (!v7on || precision < 2 || (g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP))) return false;
+        if (op.bmode == VSR_BMODE_KN && (g.K % 32 || g.N % 32)) return false;
+        const int64_t units = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitK;
+        return g.N >= 192 && g.K >= 256 && g.M >= 1024 && units * 2 >= cus;
     };
+    // scratch for the transposed operands: per lane the largest sum over one op's KN problems; row tables n -> n * ld
+    std::vector<int64_t> vtLane(kMaxLanes, 0);
+    int64_t tab7 = 0;
+    for (const Op& op : P.ops) {
+        if (op.kind != OP_GEMM || op.bmode != VSR_BMODE_KN) continue;
+        int64_t sum = 0;
+        for (const GemmItem& g : op.gemm)
+            if (forV7(op, g)) { sum += (int64_t)g.N * g.K; tab7 += (g.N + 3) / 4 * 4; }
+        if (sum > vtLane[op.lane]) vtLane[op.lane] = sum;
+    }
+    std::vector<int64_t> vtBase(kMaxLanes, 0);
+    int64_t vtTotal = 0;
+    for (int l = 0; l < kMaxLanes; ++l) { vtBase[l] = vtTotal; vtTotal += (vtLane[l] + 31) / 32 * 32; }
+    if (vtTotal > 0) HIPCHK(hipMalloc((void**)&pd->dVt, (size_t)vtTotal * sizeof(float)));
+    std::vector<int32_t> hostTab7((size_t)tab7, 0);
+    if (tab7 > 0) HIPCHK(hipMalloc((void**)&pd->dTables7, (size_t)tab7 * sizeof(int32_t)));
+    int64_t tab7Cursor = 0;
     size_t descBytes = 0;
     for (const Op& op : P.ops) {
         size_t n7 = 0;
@@ -229,6 +256,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
         od.kind = op.kind; od.tileCfg = op.tileCfg; od.bmode = op.bmode; od.flops = op.flops; od.tag = op.tag; od.lane = op.lane;
         if (op.kind == OP_GEMM) {
             std::vector<GGProblem> small, big;
+            int64_t vtCursor = 0;
             for (size_t j = 0; j < op.gemm.size(); ++j) {
                 const GemmItem& g = op.gemm[j];
                 GGProblem q{};
@@ -243,6 +271,18 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
                 q.act = g.act | ((fmt && !plainF32(g.bufC)) ? VSR_ACT_OUT_SPLIT : 0);
                 q.alpha = g.alpha; q.splitStride = g.splitStride;
                 if (forV7(op, g)) {
+                    if (op.bmode == VSR_BMODE_KN) {
+                        // B(k, n) = V[rowB[k] + colB[n / 32] + n % 32]  ->  Vt[n * K + k], K = the padded token count (A's chunk table
+                        // 32 kc serves as Vt's too)
+                        OpDev::Vt vt;
+                        vt.B = q.B; vt.rowB = q.rowB; vt.colB = q.colB; vt.K = g.K; vt.N = g.N; vt.ld = g.K;
+                        vt.dst = pd->dVt + vtBase[op.lane] + vtCursor;
+                        vtCursor += (int64_t)g.N * g.K;
+                        for (int n = 0; n < g.N; ++n) hostTab7[(size_t)(tab7Cursor + n)] = (int32_t)((int64_t)n * g.K);
+                        q.B = vt.dst; q.rowB = pd->dTables7 + tab7Cursor; q.colB = q.colA;
+                        tab7Cursor += (g.N + 3) / 4 * 4;
+                        od.vts.push_back(vt);
+                    }
                     GGProblem two[2];
                     const int n = vsr_v7_split(&q, cus, two);
                     for (int k = 0; k < n; ++k) big.push_back(two[k]);
@@ -253,7 +293,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
             int tileStart = 0;
             for (GGProblem& q : small) { q.tileStart = tileStart; tileStart += q.tilesM * q.tilesN * q.splitK; }
             int tileStart7 = 0;
-            for (GGProblem& q : big) { q.tileStart = tileStart7; tileStart7 += q.tilesM * q.tilesN; }
+            for (GGProblem& q : big) { q.tileStart = tileStart7; tileStart7 += q.tilesM * q.tilesN * q.splitK; }
             GGProblem* hp = (GGProblem*)(hostDesc.data() + cursor);
             for (size_t j = 0; j < small.size(); ++j) hp[j] = small[j];
             const size_t smallBytes = (small.size() * sizeof(GGProblem) + 63) / 64 * 64;
@@ -305,6 +345,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
         pd->ops.push_back(std::move(od));
     }
     HIPCHK(hipMemcpy(pd->dDescs, hostDesc.data(), descBytes, hipMemcpyHostToDevice));
+    if (tab7 > 0) HIPCHK(hipMemcpy(pd->dTables7, hostTab7.data(), (size_t)tab7 * sizeof(int32_t), hipMemcpyHostToDevice));
     std::vector<int32_t> isf(L);
     for (int i = 0; i < L; ++i) isf[i] = P.compCount[i] > 1 ? 1 : 0;
     HIPCHK(hipMalloc((void**)&pd->dIsFloat, (size_t)L * sizeof(int32_t)));
@@ -386,7 +427,9 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         int rc = 0;
         switch (od.kind) {
         case OP_GEMM:
-            if (od.total7 > 0)
+            for (const OpDev::Vt& vt : od.vts)
+                if (rc == 0) rc = vsr_launch_kn_to_nk_split(vt.B, vt.rowB, vt.colB, vt.K, vt.N, vt.ld, vt.dst, stream);
+            if (rc == 0 && od.total7 > 0)
                 rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_256x256, VSR_BMODE_NK, queue + 8,
                                                 prec == 3 ? 6 : 5, 1, h->dRangeFlag, stream);
             if (rc == 0 && od.total > 0)
@@ -922,8 +965,8 @@ static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_
         if (tile_cfg == VSR_TILE_256x256) {
             // dynamic tile height: any tilesM whose tiles of roundup32(ceil(M / tilesM)) <= 256 rows cover M (gather_gemm_v7.h)
             const int rows = p.tilesM > 0 ? (((p.M + p.tilesM - 1) / p.tilesM) + 31) / 32 * 32 : 0;
-            if (p.tilesM <= 0 || rows > 256 || (int64_t)rows * p.tilesM < p.M || p.tilesN != (p.N + BN - 1) / BN || p.splitK != 1)
-                return fail(VSR_ERR_ARG, "256x256 tile: tilesM must give tiles of at most 256 rows that cover M; no split-K");
+            if (p.tilesM <= 0 || rows > 256 || (int64_t)rows * p.tilesM < p.M || p.tilesN != (p.N + BN - 1) / BN)
+                return fail(VSR_ERR_ARG, "256x256 tile: tilesM must give tiles of at most 256 rows that cover M");
         } else
         if (p.tilesM != (p.M + BM - 1) / BM || p.tilesN != (p.N + BN - 1) / BN) return fail(VSR_ERR_ARG, "tile counts do not match the tile config");
         if (p.splitK < 1 || (int64_t)p.splitK * p.chunksPerSplit < p.K / VSR_GG_KC) return fail(VSR_ERR_ARG, "bad split-K");
