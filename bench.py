@@ -15,9 +15,11 @@ under the compute: backend/tools/chunk_parallel.py), are inpainted there and ret
 chunk, nothing exchanged) is reported beside it as `replicas`.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (gather_gemm_f32<128,128,NK> running the 3x3 256->256 convs:
-                  59 % of the model FLOPs), algorithmic FLOPs / HIP-event time on the launch stream
-                  against the 157.3 TFLOP/s fp32 MFMA peak of MI355X_MICROARCH.md.
+  roofline     -- the dominant kernel symbol (the gather-GEMM instantiation with the largest total time:
+                  since round 4 gather_gemm_f32_v8<9>, the 3x3 256->256 convs = 59 % of the model FLOPs),
+                  algorithmic FLOPs / HIP-event time on the launch stream against the 157.3 TFLOP/s fp32
+                  MFMA peak of MI355X_MICROARCH.md; `every_gemm_launch` beside it is the same ratio over
+                  ALL gather-GEMM launches of a chunk (every symbol).
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference modules, "port") timed on
                   this box's host cores on ONE full 50-frame chunk of the same clip, end to end (crop,
                   cv2-style resize, network, resize back, blend) with the network-only time beside it.
@@ -450,6 +452,9 @@ def main():
                 a, b, c = eng.timing_get(f"kernel:gg:{cfg}:1:v1x")          # P.V of the fused attention (gather_gemm_pvx.h)
                 if b:
                     per_kernel[f"gather_gemm_f32_aexp<{bm}, {bn}, {wm}, {wn}>"] = (a, b, c)
+            a, b, c = eng.timing_get("kernel:gg:6:0:v8")                    # the 288 x 256 tile of the long-K convolutions (gather_gemm_v8.h)
+            if b:
+                per_kernel["gather_gemm_f32_v8<9>"] = (a, b, c)
             return per_kernel
 
         per_kernel = kernels_timed()
@@ -487,6 +492,12 @@ def main():
             out["op_breakdown"] = breakdown
             out["kernel_breakdown"] = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_launch_ms": round(v[0] / v[1], 4),
                                            "tflops": round(v[2] / v[0] / 1e9, 2)} for k, v in kernels_timed().items()}
+            kb_ms = sum(v[0] for v in kernels_timed().values())
+            kb_fl = sum(v[2] for v in kernels_timed().values())
+            if kb_ms > 0:
+                out["roofline"]["every_gemm_launch"] = {
+                    "achieved": round(kb_fl / kb_ms / 1e9, 2), "frac": round(kb_fl / kb_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "note": "all gather-GEMM launches of a chunk, every kernel symbol (kernel_breakdown), single lane, events around every launch"}
             out["breakdown_note"] = (f"HIP events around every launch of {extra} extra chunks after the timed region (they cost 2.5 % of a "
                                      f"chunk, so the timed region brackets the dominant kernel's launches only)")
 

@@ -15,6 +15,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 static int g_cus = 256;
+static int g_order = 1;          // tile order of the 256 x 256 kernel: 1 XCD-aware static slots, 0 plain (argv[1])
 
 // how the host cuts one problem for the 256 x 256 kernel: whole rounds of 256-row tiles, then the remaining rows spread over
 // one short tile per CU (tile height = roundup32(ceil(M / tilesM)), derived again in the kernel)
@@ -57,7 +58,7 @@ static float time_v7(const GGProblem* d, int nprobs, int blocks, int iters)
         hipMemset(q, 0, 64 * sizeof(unsigned int));
         hipEventRecord(a, 0);
         for (int i = 0; i < iters; ++i)
-            hipLaunchKernelGGL((gather_gemm_f16_v7<SPLIT, ABL>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q + i, (unsigned int*)nullptr);
+            hipLaunchKernelGGL((gather_gemm_f16_v7<SPLIT, ABL>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q + i, (unsigned int*)nullptr, g_order);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;
@@ -124,7 +125,7 @@ static void timeline(const GGProblem* d, int nprobs, int blocks)
     hipMemcpyToSymbol(HIP_SYMBOL(gg_trace), z.data(), z.size() * 8);
     unsigned int* q; hipMalloc(&q, 32); hipMemset(q, 0, 32);
     const int grid = blocks < g_cus ? blocks : g_cus;
-    hipLaunchKernelGGL((gather_gemm_f16_v7<1, 256>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q, (unsigned int*)nullptr);
+    hipLaunchKernelGGL((gather_gemm_f16_v7<1, 256>), dim3(grid), dim3(512), 0, 0, d, nprobs, blocks, q, (unsigned int*)nullptr, g_order);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gg_trace), h.size() * 8);
     hipFree(q);
@@ -328,7 +329,8 @@ int main(int argc, char** argv)
     int dev = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev);
-    printf("CUs: %d\n", g_cus);
+    if (argc > 1) g_order = atoi(argv[1]);
+    printf("CUs: %d, tile order %d\n", g_cus, g_order);
     int bad = 0;
     for (int T : {15, 10}) bad |= conv_case(T);
     for (int T : {15, 10}) bad |= qk_case(T);

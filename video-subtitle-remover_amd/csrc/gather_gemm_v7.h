@@ -33,7 +33,7 @@
 template <int SPLIT GG_ABL_PARAM>
 __global__ void __launch_bounds__(512, 2)
 gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue,
-                   unsigned int* __restrict__ rangeFlag)
+                   unsigned int* __restrict__ rangeFlag, int order)
 {
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int MI = 4, NI = 2;
@@ -73,12 +73,28 @@ gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #define V7_STAMP(drain)
 #endif
 
-    int bid = blockIdx.x;                            // first round: static
+    // Tile order.  order 0: first round static (tile id = workgroup id), later rounds from one atomic counter.  order 1 (XCD-aware,
+    // static): workgroup b runs on XCD b % 8 (observed placement, used for locality only) and takes slot b of every round of
+    // gridDim.x tile ids; within a round XCD x owns the x-th eighth of the ids, so the ~32 tiles an XCD works on at a time are
+    // NEIGHBOURS in id space -- they share A row blocks (the N tiles of one M tile) or sit in adjacent M tiles -- and meet in that
+    // XCD's L2.  In plain order a tile's 31 neighbours on its XCD are ids 8 apart: different M tile and different N tile, nothing
+    // shared, every operand block crosses the fabric once per tile (the split-format modes are bound by exactly that stream).
+    const int G = (int)gridDim.x;
+    auto xcd_slot = [&](int id) -> int {
+        const int r = id / G, s = id - r * G;
+        const int cnt = totalTiles - r * G < G ? totalTiles - r * G : G;      // ids of this round
+        const int x = s & 7, k = s >> 3, q = cnt >> 3, rm = cnt & 7;
+        if (s >= cnt) return totalTiles;                                      // a slot beyond a partial last round
+        // XCD x owns q + (x < rm) ids starting at x q + min(x, rm); slot (x, k) exists for k < ceil((cnt - x) / 8) = that count
+        return r * G + x * q + (x < rm ? x : rm) + k;
+    };
+    int slotId = blockIdx.x;                         // order 1: the slot sequence b, b + G, b + 2 G, ...
+    int bid = order ? xcd_slot(slotId) : (int)blockIdx.x;      // first round: static
     for (;;) {
         if (bid >= totalTiles) break;
         V7_STAMP(0)
         unsigned int pend = 0;
-        if (tid == 0) pend = atomicAdd(queue, 1u);   // the tile after this one; the answer is read after the main loop
+        if (tid == 0 && !order) pend = atomicAdd(queue, 1u);   // the tile after this one; the answer is read after the main loop
 
         int pi = 0;
         for (int lo_ = 0, hi_ = nprobs - 1; lo_ < hi_;) {
@@ -351,7 +367,18 @@ gather_gemm_f16_v7(const GGProblem* __restrict__ probs, int nprobs, int totalTil
         else if (MIact == 2) main_loop(std::integral_constant<int, 2>{});
         else if (MIact == 1) main_loop(std::integral_constant<int, 1>{});
         else main_loop(std::integral_constant<int, 0>{});   // a wave without a block in this tile (R = 32, wm = 1) still fetches its share of the operands and meets every barrier
-        if (tid == 0) *nextTile = (int)gridDim.x + (int)pend;
+        if (tid == 0) {
+            if (order) {
+                int nx = totalTiles;
+                for (slotId += G; slotId < (totalTiles + G - 1) / G * G; slotId += G) {      // (a slot beyond a partial round has no tile)
+                    nx = xcd_slot(slotId);
+                    if (nx < totalTiles) break;
+                }
+                *nextTile = nx < totalTiles ? nx : totalTiles;
+            } else {
+                *nextTile = (int)gridDim.x + (int)pend;
+            }
+        }
         __syncthreads();                           // rowTab visible even when the k range is empty; LDS-DMA queue empty; nextTile published
         V7_STAMP(0)
 
