@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--color", default="device", choices=["device", "host"])
     ap.add_argument("--chroma-out", default="420", choices=["420", "444"])
     ap.add_argument("--resident", default="1", choices=["0", "1"], help="0: host-frame chunk loop (VSR_IO_RESIDENT=0)")
+    ap.add_argument("--profile", action="store_true", help="cProfile around run(): where the start-up goes (stderr)")
     args = ap.parse_args()
     os.environ["VSR_IO_COLOR"] = args.color
     os.environ["VSR_IO_RESIDENT"] = args.resident
@@ -76,10 +77,21 @@ def main():
     sr.video_out_path = dst
     sr.append_output = lambda *a: None
     torch.cuda.synchronize()
+    prof = None
+    if args.profile:
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     sr.run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     out_bytes = os.path.getsize(dst)
     rd = video_io.Y4mVideo(dst)
     assert rd.info()["len"] == N

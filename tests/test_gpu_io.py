@@ -121,7 +121,12 @@ def test_resident_chunk_loop_writes_the_same_file(built_lib, gpu_device, tmp_pat
         for k, v in keys.items():
             getattr(config, k).value = v
         config.inpaintMode.value = InpaintMode.STTN_AUTO
-        for mode, color, resident in (("host", "host", "0"), ("device-frames", "device", "0"), ("resident", "device", "1")):
+        from vsr_amd.backend.tools.pinned import PinnedPool
+
+        # (the "-late-pins" passes hold the page-locking thread back, so that the first transfers of the loop take the pageable path)
+        for mode, color, resident in (("host", "host", "0"), ("device-frames", "device", "0"), ("resident", "device", "1"),
+                                      ("device-frames-late-pins", "device", "0"), ("resident-late-pins", "device", "1")):
+            monkeypatch.setattr(PinnedPool, "test_delay", 0.25 if mode.endswith("late-pins") else 0.0)
             monkeypatch.setenv("VSR_IO_COLOR", color)
             monkeypatch.setenv("VSR_IO_RESIDENT", resident)
             sr = SubtitleRemover(src, model_path={"netG": synth.make_state_dict(0, "auto")})
@@ -139,7 +144,7 @@ def test_resident_chunk_loop_writes_the_same_file(built_lib, gpu_device, tmp_pat
         for k, v in old.items():
             getattr(config, k).value = v
         config.inpaintMode.value = old_mode
-    assert outs["host"] == outs["device-frames"] == outs["resident"]
+    assert outs["host"] == outs["device-frames"] == outs["resident"] == outs["device-frames-late-pins"] == outs["resident-late-pins"]
     monkeypatch.setenv("VSR_IO_COLOR", "host")
     got, want = _read_all(str(tmp_path / "out_resident.y4m")), _read_all(src)
     assert got.shape == want.shape

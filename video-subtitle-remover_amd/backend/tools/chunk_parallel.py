@@ -171,8 +171,24 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
     owners = range(world) if rank == 0 else [rank]
     dbuf = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8, device=dev) for q in range(RING) for k in owners}
     if rank == 0 and host_io and st.gpu:
-        pin_in = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8).pin_memory() for q in range(RING) for k in range(world)}
-        pin_out = {k: torch.empty((maxn, h, W, C), dtype=torch.uint8).pin_memory() for k in range(world)}
+        # pinned staging, page-locked by a helper thread in the order of first use (tools/pinned.py): rounds 0 and 1 in, the results
+        # out, then the rest of the ring; a transfer whose buffer is not there yet goes through pageable memory once
+        from .pinned import PinnedPool
+
+        order = [("in", q, k) for q in (0, 1) for k in range(world)] + [("out", 0, k) for k in range(world)] + \
+                [("in", q, k) for q in range(2, RING) for k in range(world)]
+        pool = PinnedPool([(maxn, h, W, C)] * len(order), device=dev)
+        slot = {key: j for j, key in enumerate(order)}
+        pageable = {}
+
+        def host_buf(kind, q, k):
+            """(tensor, pinned?) for this transfer"""
+            t = pool.get(slot[(kind, q, k)])
+            if t is not None:
+                return t, True
+            if kind not in pageable:
+                pageable[kind] = torch.empty((maxn, h, W, C), dtype=torch.uint8)
+            return pageable[kind], False
     staged, computed = {}, {}                 # (round) -> event after upload of the own chunk / after its compute
 
     def stage(r):                              # rank 0: read round r and bring it to the device (io stream)
@@ -185,10 +201,10 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
                 with st.on("io"):
                     guarded(load, i, d[:n])
             elif st.gpu:
-                p = pin_in[(r % RING, k)]
+                p, pinned = host_buf("in", r % RING, k)
                 guarded(load, i, p.numpy()[:n])
                 with st.on("io"):
-                    d[:n].copy_(p[:n], non_blocking=True)
+                    d[:n].copy_(p[:n], non_blocking=pinned)     # (a pageable source is copied before the call returns)
             else:
                 guarded(load, i, d.numpy()[:n])
         staged[r] = st.event("io")
@@ -205,10 +221,11 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
                 with st.on("io"):
                     guarded(store, i, d[:n])
             elif st.gpu:
+                p, pinned = host_buf("out", 0, k)
                 with st.on("io"):
-                    pin_out[k][:n].copy_(d[:n], non_blocking=True)
+                    p[:n].copy_(d[:n], non_blocking=pinned)
                 st.event("io").synchronize()
-                guarded(store, i, pin_out[k].numpy()[:n])
+                guarded(store, i, p.numpy()[:n])
             else:
                 guarded(store, i, d.numpy()[:n])
 

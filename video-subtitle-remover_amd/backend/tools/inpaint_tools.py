@@ -48,9 +48,72 @@ def threshold_mask(input_mask):
 
 
 def _islands(binary):
+    """8-connected components of the mask as (top, bottom, centre row, area, label) -- the statistics the reference reads off
+    cv2.connectedComponentsWithStats (inpaint_tools.py:151-160), labels numbered in raster order of their first pixel.
+
+    Run-based: a subtitle mask is a union of a few rectangles, i.e. one to three runs of set pixels per row; the components are
+    the classes of a union-find over those runs (two runs of neighbouring rows belong together when they touch or overlap by a
+    corner), and top / bottom / area / row sum add up per run.  scipy.ndimage.label does the same per pixel -- importing it cost
+    90 ms in front of the first chunk (profiles/r04_cli_startup.log); it stays the path for masks with a great many runs."""
+    b = np.asarray(binary) > 0
+    H, W = b.shape
+    edge = np.diff(b.astype(np.int8), axis=1, prepend=0, append=0)          # [H, W + 1]: +1 where a run starts, -1 one past its end
+    ry, rs = np.nonzero(edge == 1)
+    _, re_ = np.nonzero(edge == -1)                                          # row-major on both sides: the k-th start meets the k-th end
+    n = int(ry.size)
+    if n == 0:
+        return []
+    if n > 50000:
+        return _islands_scipy(b)
+    ry, rs, re_ = ry.tolist(), rs.tolist(), re_.tolist()
+    parent = list(range(n))
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    first = {}                                                               # row -> index of its first run
+    for k, y in enumerate(ry):
+        first.setdefault(y, k)
+    for k in range(n):
+        y = ry[k]
+        j = first.get(y - 1)
+        if j is None:
+            continue
+        while j < n and ry[j] == y - 1:
+            if rs[j] <= re_[k] and rs[k] <= re_[j]:                          # [rs - 1, re + 1) overlaps: 8-connectivity
+                a, c = find(j), find(k)
+                if a != c:
+                    parent[max(a, c)] = min(a, c)                            # the root is the component's first run in raster order
+            j += 1
+    comps = {}
+    for k in range(n):
+        r = find(k)
+        ln = re_[k] - rs[k]
+        c = comps.get(r)
+        if c is None:
+            comps[r] = [ry[k], ry[k] + 1, ln, ln * ry[k]]
+        else:
+            if ry[k] + 1 > c[1]:
+                c[1] = ry[k] + 1
+            c[2] += ln
+            c[3] += ln * ry[k]
+    out = []
+    for label, r in enumerate(sorted(comps), start=1):
+        top, bottom, area, ysum = comps[r]
+        if area < 10:
+            continue
+        cy = int(((ysum - area * top) / area) + top)                          # int(mean of the rows relative to the top + top), as before
+        out.append((top, bottom, cy, area, label))
+    return out
+
+
+def _islands_scipy(b):
     from scipy import ndimage
 
-    labels, n = ndimage.label(binary > 0, structure=np.ones((3, 3), dtype=bool))
+    labels, n = ndimage.label(b, structure=np.ones((3, 3), dtype=bool))
     out = []
     if n == 0:
         return out
