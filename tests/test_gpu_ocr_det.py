@@ -142,6 +142,46 @@ def test_batched_forward_equals_single_frames(built_lib, gpu_device, fixture):
         assert torch.equal(maps[b], det.probability_map(img)[0])
 
 
+def test_detector_lanes_on_the_device(built_lib, gpu_device, monkeypatch):
+    """SubtitleDetect's resident pass with two REAL detectors (TextDetection + clone(): own recorded launch lists, intermediates and
+    post-process buffers, own stream, own host thread -- the default since round 4) gives the {frame_no: boxes} of one lane, and the
+    probability maps of the two instances are bit-equal on the same frames."""
+    from vsr_amd.backend.tools.subtitle_detect import SubtitleDetect
+
+    g = load_graph(os.path.join(GOLD, "ppocr_det_fast_graph.json"))
+    det = ocr_det.TextDetection(g, synthetic_weights(g), device=0)
+    rng = np.random.default_rng(29)
+    N, H, W = 41, 270, 480
+    frames = torch.from_numpy(rng.integers(0, 256, size=(N, H, W, 3), dtype=np.uint8)).to(gpu_device)
+
+    class Clip:
+        def __len__(self):
+            return N
+
+    clip = Clip()
+    clip.frames = frames
+    other = det.clone()
+    a, b = det.probability_maps_device(frames[:5]).clone(), other.probability_maps_device(frames[:5]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # the same batches over one and over two instances running side by side (own streams, own host threads): bit-equal maps
+    from vsr_amd.backend.tools import batch_lanes
+
+    parts = [list(range(s, min(s + 8, N))) for s in range(0, N, 8)]
+    fwd = lambda d, part: d.probability_maps_device(frames[torch.tensor(part, device=gpu_device)]).clone()
+    one = batch_lanes.run_map(parts, [det], fwd, frames.device)
+    two = batch_lanes.run_map(parts, [det, other], fwd, frames.device)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(one, two))
+    got = {}
+    for lanes in ("1", "2", "3"):
+        monkeypatch.setenv("VSR_DET_LANES", lanes)
+        sd = SubtitleDetect(None, [(0, H, 0, W)], text_detector=det)
+        sd.SAMPLE_STEP = 1
+        got[lanes] = sd._find_resident(None, clip)
+    assert got["1"] == got["2"] == got["3"]
+
+
 from oracle import db_postprocess as dbo
 from test_db_postprocess import blob_map
 

@@ -152,13 +152,30 @@ class SubtitleRemover:
         finally:
             reader.release()
 
-    def _run_resident_jobs(self, jobs, plugin, clip):
-        """the independent batches of a resident run: one after the other, or over VSR_BATCH_LANES plugin instances (tools/batch_lanes.py)"""
+    def _run_resident_jobs(self, jobs, plugin, clip, store=None):
+        """the independent batches of a resident run: one after the other, or over VSR_BATCH_LANES plugin instances (tools/batch_lanes.py).
+        store: a tools/resident.StreamingStore -- with one lane the frames in front of the next batch are handed to it as each batch
+        is enqueued (behind an event on the compute stream), so that they are converted, downloaded and written under the batches
+        that follow; jobs are slices of clip.frames in frame order."""
+        import torch
+
         from .tools import batch_lanes
 
         if not hasattr(self, "_lane_cache"):
             self._lane_cache = {}
-        batch_lanes.run_jobs(jobs, batch_lanes.lane_plugins(plugin, batch_lanes.lanes_from_env(), self._lane_cache), clip.frames.device)
+        plugins = batch_lanes.lane_plugins(plugin, batch_lanes.lanes_from_env(), self._lane_cache)
+        if store is None or len(plugins) > 1 or os.environ.get("VSR_STREAM_STORE", "1") == "0":      # (0: everything is written after the last batch)
+            batch_lanes.run_jobs(jobs, plugins, clip.frames.device)
+            return
+        dev = clip.frames.device
+        frame_elems = clip.frames[0].numel()
+        first = [(job[0].data_ptr() - clip.frames.data_ptr()) // frame_elems for job in jobs]     # first frame of every batch
+        store.ready(first[0] if jobs else len(clip))
+        for j, job in enumerate(jobs):
+            plugin(*job)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            store.ready(first[j + 1] if j + 1 < len(jobs) else len(clip), ev)
 
     @staticmethod
     def _clip_kw(clip):
@@ -194,6 +211,10 @@ class SubtitleRemover:
             lama = self.lama_inpaint
             single_frame_inpaint = lama.inpaint if lama is not None else None
         detector = SubtitleDetect(self.video_path, self.sub_areas, text_detector=text_detector)
+        # one detector lane here unless VSR_DET_LANES says otherwise: with two, the detector pass of config 4 gains 0.45 s and the
+        # propainter inpainting that follows loses 2-4 s (62.9-63.1 -> 65.0-67.5 s, same box, profiles/r04_pp_e2e_ab.log; the
+        # sttn-det inpainting does not care) -- the second instance's streams stay alive beside the plugin's
+        detector.det_lanes_default = 1
         # the clip stays in HBM only for a plugin that takes device tensors (an injected callable, or the cv2 plugin, gets host frames)
         resident = self._open_resident() if getattr(propainter_inpaint, "accepts_device_frames", False) else None
         clip = resident[0] if resident is not None else None
@@ -239,10 +260,17 @@ class SubtitleRemover:
                                 clip.frames[batch[0]].copy_(torch.from_numpy(np.ascontiguousarray(one)))
                         else:
                             jobs.append((clip.frames[batch[0]:batch[-1] + 1], mask))
-                self._run_resident_jobs(jobs, propainter_inpaint, clip)
+                self._run_resident_jobs(jobs, propainter_inpaint, clip, store)
 
-            self._timed("inpainting", inpaint_all)
-            self._timed("BGR->YUV + download + write", clip.store, self.video_writer, wf, 0, n, lambda: self.update_progress(tbar, increment=1))
+            from .tools.resident import StreamingStore
+
+            store = StreamingStore(clip, self.video_writer, wf, lambda: self.update_progress(tbar, increment=1))
+            try:
+                self._timed("inpainting", inpaint_all)
+            except BaseException:
+                store.abort()
+                raise
+            self._timed("BGR->YUV + download + write (what is left after the last batch)", store.finish)
             return
         reader = open_video(self.video_path)
 
@@ -332,10 +360,17 @@ class SubtitleRemover:
                     for batch in batch_generator(list(range(first - 1, idx)), config.getSttnMaxLoadNum()):
                         if len(batch) >= 1:
                             jobs.append((clip.frames[batch[0]:batch[-1] + 1], mask))
-                self._run_resident_jobs(jobs, model, clip)
+                self._run_resident_jobs(jobs, model, clip, store)
 
-            self._timed("inpainting", inpaint_all)
-            self._timed("BGR->YUV + download + write", clip.store, self.video_writer, wf, 0, n, lambda: self.update_progress(tbar, increment=1))
+            from .tools.resident import StreamingStore
+
+            store = StreamingStore(clip, self.video_writer, wf, lambda: self.update_progress(tbar, increment=1))
+            try:
+                self._timed("inpainting", inpaint_all)
+            except BaseException:
+                store.abort()
+                raise
+            self._timed("BGR->YUV + download + write (what is left after the last batch)", store.finish)
             return
         reader = open_video(self.video_path)
 

@@ -1,4 +1,5 @@
-"""Batch lanes of the HBM-resident detector-driven modes (opt-in: VSR_BATCH_LANES=2; default 1 = the plain loop).
+"""Batch lanes of the HBM-resident detector-driven modes (opt-in: VSR_BATCH_LANES=2; default 1 = the plain loop) and detector lanes of
+their sampling pass (VSR_DET_LANES, default 2 since round 4).
 
 The batches `batch_generator` cuts out of a detected interval are independent units (main.py:229-245, :323-332: every call of the
 plugin starts from the frames of its own batch), and on the resident path they are disjoint slices of one device tensor that the
@@ -13,11 +14,17 @@ import queue
 import threading
 
 
-def lanes_from_env(name="VSR_BATCH_LANES"):
+DEFAULT_LANES = {"VSR_BATCH_LANES": 1,      # plugin instances over the batches of a resident run: measured, no gain (profiles/r04_lanes_e2e.log)
+                 "VSR_DET_LANES": 2}        # detectors over the sampled batches: 4.55 -> 4.10 s per 600 frames (r04_lanes_e2e.log, r04_e2e_store.log)
+
+
+def lanes_from_env(name="VSR_BATCH_LANES", default=None):
+    """the lane count `name` asks for; `default` (when given) replaces the table's default for a caller that measured otherwise"""
+    dflt = DEFAULT_LANES.get(name, 1) if default is None else default
     try:
-        return max(1, min(4, int(os.environ.get(name, "1"))))
+        return max(1, min(4, int(os.environ.get(name, dflt))))
     except ValueError:
-        return 1
+        return dflt
 
 
 def lane_plugins(plugin, lanes, cache):

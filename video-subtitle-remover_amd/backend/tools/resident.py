@@ -76,8 +76,11 @@ class ResidentClip:
         """frames [lo, hi) -> the writer's planes, converted on the device, in order"""
         dev = self.frames.device
         n, H, W, _ = self.frames.shape
-        pins = [torch.empty((self.BATCH, wf["frame_bytes"]), dtype=torch.uint8).pin_memory() for _ in range(2)]
-        dout = [torch.empty((self.BATCH, wf["frame_bytes"]), dtype=torch.uint8, device=dev) for _ in range(2)]
+        if getattr(self, "_store_bufs", None) is None or self._store_bufs[0] != wf["frame_bytes"]:      # (kept: store() may be called range by range)
+            self._store_bufs = (wf["frame_bytes"],
+                                [torch.empty((self.BATCH, wf["frame_bytes"]), dtype=torch.uint8).pin_memory() for _ in range(2)],
+                                [torch.empty((self.BATCH, wf["frame_bytes"]), dtype=torch.uint8, device=dev) for _ in range(2)])
+        _, pins, dout = self._store_bufs
         b = 0
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
@@ -94,3 +97,62 @@ class ResidentClip:
                     for _ in range(k):
                         tick()
                 b ^= 1
+
+
+class StreamingStore:
+    """Writes the frames of a ResidentClip in order AS THEY BECOME FINAL, on its own thread and stream.
+
+    The batches of a detector-driven run are inpainted in frame order and nothing after batch j touches a frame in front of batch
+    j + 1, so the conversion, download and file write of what is finished run under the inpainting of what is not -- the
+    reference writes every batch as soon as its plugin call returns (main.py:239-245, :326-332); round 3's resident path wrote the
+    whole clip after the last batch (1.0 s of a 12.3 s run at 1080p x 1200, profiles/r03_e2e_configs_3_4.log).
+
+        st = StreamingStore(clip, writer, wf, tick)
+        st.ready(hi, event)      frames [.., hi) are final once `event` (a torch.cuda.Event, or None = now) has completed
+        st.finish()              everything up to len(clip); joins the thread, re-raises its error"""
+
+    def __init__(self, clip, writer, wf, tick=None):
+        import queue
+        import threading
+
+        self.clip, self.writer, self.wf, self.tick = clip, writer, wf, tick
+        self._q = queue.Queue()
+        self._error = None
+        self._thread = threading.Thread(target=self._run, name="vsr-streaming-store", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        dev = self.clip.frames.device
+        lo = 0
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
+                while True:
+                    item = self._q.get()
+                    if item is None:
+                        return
+                    hi, event = item
+                    if self._error is not None:
+                        continue
+                    if event is not None:
+                        event.synchronize()
+                    hi = min(int(hi), len(self.clip))
+                    if hi > lo:
+                        self.clip.store(self.writer, self.wf, lo, hi, self.tick)
+                        lo = hi
+        except BaseException as e:                # noqa: BLE001 -- re-raised by finish() in the caller's thread
+            self._error = e
+
+    def ready(self, hi, event=None):
+        self._q.put((hi, event))
+
+    def abort(self):
+        """the run failed: stop writing, release the thread"""
+        self._q.put(None)
+        self._thread.join()
+
+    def finish(self):
+        self._q.put((len(self.clip), None))
+        self._q.put(None)
+        self._thread.join()
+        if self._error is not None:
+            raise self._error

@@ -117,10 +117,13 @@ class SubtitleDetect:
             return [detector.predict(f) for f in clip.frames[idx].cpu().numpy()]       # an injected detector with the reference's host signature
 
         # the sampled frames are independent: VSR_DET_LANES detectors (own runner, own stream, own host thread) share the batches
-        # (opt-in, default 1 = this thread alone; the results do not depend on it)
+        # (default 2 since round 4, VSR_DET_LANES=1 = this thread alone; the results do not depend on it: tests/test_batch_lanes.py,
+        # tests/test_gpu_ocr_det.py::test_detector_lanes_on_the_device)
         if not hasattr(self, "_det_lanes"):
             self._det_lanes = {}
-        detectors = batch_lanes.lane_plugins(self.text_detector, batch_lanes.lanes_from_env("VSR_DET_LANES") if on_device else 1, self._det_lanes)
+        detectors = batch_lanes.lane_plugins(self.text_detector,
+                                             batch_lanes.lanes_from_env("VSR_DET_LANES", getattr(self, "det_lanes_default", None)) if on_device else 1,
+                                             self._det_lanes)
         sampled = {}
         for part, results in zip(parts, batch_lanes.run_map(parts, detectors, detect, clip.frames.device)):
             for no, res in zip(part, results):

@@ -67,8 +67,9 @@ def make_state_dict(seed=0, variant="auto"):
     return sd
 
 
-def make_clip(n, H, W, box, seed=0):
-    """box = (ymin, ymax, xmin, xmax) of the subtitle area (CLI order, args_handler.py:19)."""
+def make_clip(n, H, W, box, seed=0, glyph_frames=None):
+    """box = (ymin, ymax, xmin, xmax) of the subtitle area (CLI order, args_handler.py:19).  glyph_frames: per-frame booleans --
+    frames without the glyph blocks are the background alone (what make_clip gives for an empty box with the same seed)."""
     rng = np.random.default_rng(seed)
     gh, gw = H // 40 + 3, W // 40 + 3
     base = rng.random((gh, gw, 3)).astype(np.float32)
@@ -92,7 +93,7 @@ def make_clip(n, H, W, box, seed=0):
         gh_px = max((ymax - ymin) // 2, 4)
         gy = ymin + (ymax - ymin - gh_px) // 2
         x = xmin + 8
-        while x + gh_px < xmax - 8:
+        while (glyph_frames is None or glyph_frames[i]) and x + gh_px < xmax - 8:
             wpx = int(grng.integers(gh_px // 2, gh_px + 1))
             if grng.random() < 0.8:
                 img[gy:gy + gh_px, x:x + wpx] = 16
