@@ -40,6 +40,7 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0          # ... dense f16 / bf16 MFMA (the --precision modes only)
 RES = {"720p": (720, 1280, (620, 700, 192, 1088)), "1080p": (1080, 1920, (950, 1070, 288, 1632)),
        "4k": (2160, 3840, (1900, 2140, 576, 3264))}
 
@@ -455,6 +456,9 @@ def main():
             a, b, c = eng.timing_get("kernel:gg:6:0:v8")                    # the 288 x 256 tile of the long-K convolutions (gather_gemm_v8.h)
             if b:
                 per_kernel["gather_gemm_f32_v8<9>"] = (a, b, c)
+            a, b, c = eng.timing_get("kernel:gg:5:0:v7")                    # split-format modes: the 256 x 256 tile (gather_gemm_v7.h)
+            if b:
+                per_kernel["gather_gemm_f16_v7<%d>" % (0 if base_precision == "f16" else 1)] = (a, b, c)
             return per_kernel
 
         per_kernel = kernels_timed()
@@ -469,9 +473,12 @@ def main():
             except Exception:
                 traffic = None
         ach = fl / ms / 1e9 if ms > 0 else 0.0
+        # --precision split / split-format / f16 (never the default line): the products run on the f16 matrix cores; FLOPs stay the
+        # algorithmic 2 per product (three MFMAs each in the split modes), the peak is the dense f16 one
+        peak = PEAK_FP32_MFMA_TFLOPS if base_precision == "f32" else PEAK_F16_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": dom + " (3x3 / 1x1 convs as implicit GEMM: bias + LeakyReLU + residual fused)",
-                           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": traffic,
                            "launches": int(n), "avg_launch_ms": round(ms / n, 4) if n else None,
                            "flops_per_launch": round(fl / n) if n else None,
                            "measured_on": f"{args.steps} single-lane steps after the timed region (`single_lane`): with {args.lanes} lanes the "
@@ -496,7 +503,7 @@ def main():
             kb_fl = sum(v[2] for v in kernels_timed().values())
             if kb_ms > 0:
                 out["roofline"]["every_gemm_launch"] = {
-                    "achieved": round(kb_fl / kb_ms / 1e9, 2), "frac": round(kb_fl / kb_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "achieved": round(kb_fl / kb_ms / 1e9, 2), "frac": round(kb_fl / kb_ms / 1e9 / peak, 4),
                     "note": "all gather-GEMM launches of a chunk, every kernel symbol (kernel_breakdown), single lane, events around every launch"}
             out["breakdown_note"] = (f"HIP events around every launch of {extra} extra chunks after the timed region (they cost 2.5 % of a "
                                      f"chunk, so the timed region brackets the dominant kernel's launches only)")

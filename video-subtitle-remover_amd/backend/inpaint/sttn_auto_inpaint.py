@@ -207,6 +207,7 @@ class STTNAutoInpaint:
                 cp.run_chunk_parallel(ranges, (y_hi - y_lo, W_ori, 3), load, process, store, dist=dist, device=engine.device,
                                       io="device" if resident is not None else "host")
         finally:
+            getattr(store, "close", lambda: None)()      # the resident path's page-locking thread (tools/pinned.py)
             reader.release()
             if writer:
                 writer.release()
@@ -301,6 +302,7 @@ class STTNAutoInpaint:
                     tick(None, None)
             free.append(kf.full)
 
+        store.close = pool.close                         # called by _run when the loop is over
         return load, store
 
     def __call__(self, input_mask=None, input_sub_remover=None, tbar=None):

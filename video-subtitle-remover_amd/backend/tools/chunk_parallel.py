@@ -287,6 +287,8 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
         except BaseException as e:            # noqa: BLE001 -- an asynchronous kernel error surfaces here
             if not failure:
                 failure.append(e)
+        if rank == 0 and host_io:
+            pool.close()                       # (a short run ends before the page-locking thread does)
     if dist is not None:
         # agree on the outcome: the lowest failed rank + 1, 0 = everybody fine (all-reduce MAX of -(rank + 1) would do too; MIN
         # over a large sentinel keeps it one collective).  Also the closing barrier.

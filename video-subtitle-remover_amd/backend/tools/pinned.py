@@ -22,6 +22,7 @@ class PinnedPool:
         self._bufs = [None] * len(self._shapes)
         self._ready = [threading.Event() for _ in self._shapes]
         self._error = None
+        self._stop = False
         self._device = device
         self._thread = threading.Thread(target=self._fill, name="vsr-pinned-pool", daemon=True)
         self._thread.start()
@@ -33,6 +34,8 @@ class PinnedPool:
             for i, shp in enumerate(self._shapes):
                 if self.test_delay:
                     time.sleep(self.test_delay)
+                if self._stop:                       # the loop is over: nobody will ask for the rest
+                    return
                 self._bufs[i] = torch.empty(shp, dtype=self._dtype).pin_memory()
                 self._ready[i].set()
         except BaseException as e:            # noqa: BLE001 -- surfaced by get(); the callers fall back to pageable memory
@@ -50,5 +53,8 @@ class PinnedPool:
         return self._shapes[i]
 
     def close(self):
+        """the loop is over: stop page-locking (a short run ends before the thread does) and wait for the thread, so that no
+        allocation is in flight when the process tears the runtime down"""
+        self._stop = True
         self._thread.join()
         self._bufs = [None] * len(self._shapes)
