@@ -384,8 +384,10 @@ def main():
 
     total_frames = args.steps * L * world
     fps = total_frames / elapsed
-    flops_chunk = eng.flops(L)
+    flops_chunk = eng.chunk_flops(L, dmask, areas)      # what the HIP path contracts: the last block of a window on its neighbour frames
+                                                        # only, the decoder on the rows the mask's strip rows are resized from only
     flops_per_frame = flops_chunk / L
+    flops_chunk_ref = eng.flops(L, reference=True)      # what the reference's modules (and the CPU oracle) compute: SURVEY 8(d)
 
     out = {
         "metric": "inpainted frames/sec @1080p (STTN, 5-frame window)" if args.res == "1080p"
@@ -404,6 +406,8 @@ def main():
                    "weights": "synthetic variance-preserving (no checkpoint in the reference mount)"},
         "model_tflops": round(flops_per_frame * fps / 1e12, 3),
         "gflop_per_frame": round(flops_per_frame / 1e9, 2),
+        "gflop_per_frame_reference": round(flops_chunk_ref / L / 1e9, 2),      # incl. what the reference computes and nothing reads: the last-block
+                                                                               # rows of the reference frames, the decoder rows outside the mask
         "model_frac_of_peak": round(flops_per_frame * fps / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),   # whole step, per GPU, vs the fp32-MFMA spec
     }
 
@@ -523,15 +527,15 @@ def main():
             psnr = float("inf") if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
             out["cpu_baseline"] = {
                 "value": round(L / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-                "model_only": {"value": round(L / dt_net, 4), "unit": "frames/s", "tflops": round(flops_chunk / dt_net / 1e12, 3)},
+                "model_only": {"value": round(L / dt_net, 4), "unit": "frames/s", "tflops": round(flops_chunk_ref / dt_net / 1e12, 3)},
                 "host": {"cpu_count": os.cpu_count(), "limits": effective_cpus()[1], "cpu_model": cpu_model_name(), "torch_threads": threads,
                          "probe_seconds_by_threads": tried},
                 "sample": f"oracle chunk body (torch-CPU fp32 restatement of the reference modules + restated cv2 resize / blend) on ONE full "
                           f"{L}-frame {args.res} chunk of the timed clip, end to end in {dt:.1f} s of which STTNInpaint.inpaint "
-                          f"(the network, {flops_chunk / 1e12:.2f} TFLOP) {dt_net:.1f} s; thread count picked by a 3-frame probe of the same oracle"}
+                          f"(the network, {flops_chunk_ref / 1e12:.2f} TFLOP) {dt_net:.1f} s; thread count picked by a 3-frame probe of the same oracle"}
             if not args.no_cpu_parallel:
                 Lp = min(L, 10)       # a bounded sample: 10-frame chunks (2 windows each); 16 x 20 frames at once did not finish in 150 s on the box
-                par = cpu_baseline_parallel(Lp, threads, budget_s=150.0, flops_sample=eng.flops(Lp), flops_per_frame=flops_per_frame)
+                par = cpu_baseline_parallel(Lp, threads, budget_s=150.0, flops_sample=eng.flops(Lp, reference=True), flops_per_frame=flops_chunk_ref / L)
                 if par is not None:
                     out["cpu_baseline"]["parallel"] = par
             out["psnr_db_vs_oracle"] = round(psnr, 2) if np.isfinite(psnr) else "inf"

@@ -80,6 +80,18 @@ int vsr_sttn_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, int L, float* com
  * ------------------------------------------------------------------------------------- */
 int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                         int n_areas, const int32_t* areas, const int32_t* sel, int nsel, void* stream);
+/* The same with a promise about the mask: mask_rows host [n_areas][2] = for every area the rows [lo, hi) of its strip
+ * (0 = the strip's first row) outside which mask_dev is zero.  The strip is written back only where the mask is set
+ * (:312-315), so of the model-resolution output only the rows those strip rows are resized from are ever read: the decoder
+ * computes these rows and what they depend on and nothing else -- the frames come out bit for bit as from vsr_sttn_auto_chunk
+ * (a subtitle line in a 360-row strip: ~40 % of the decoder's rows, 4 % of the chunk).  lo >= hi for an area = no promise.
+ * A mask that is set outside the promised rows gets undefined pixels there.  VSR_DECODE_ROWS=0 ignores the promise. */
+int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
+                             int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* sel, int nsel, void* stream);
+/* model-resolution rows [*row_lo, *row_hi) decoded for a strip of strip_h rows whose mask lives in rows [mask_row_lo, mask_row_hi),
+ * and the FLOPs of one L-frame call decoded that way (vsr_sttn_flops = the whole image) */
+int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_row_hi, int32_t* row_lo, int32_t* row_hi);
+double vsr_sttn_flops_rows(vsr_sttn_t* h, int L, int row_lo, int row_hi);
 
 /* ---------------------------------------------------------------------------------------
  * sttn-det (backend/inpaint/sttn_det_inpaint.py; model created with VSR_VARIANT_STTN_DET).
@@ -118,8 +130,12 @@ int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h);
  * lane count; the caller's stream is joined behind the others before any entry point returns to it. */
 int vsr_sttn_set_lanes(vsr_sttn_t* h, int lanes);
 
-/* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded) */
+/* algorithmic model FLOPs of one inpaint(L) call (2*M*N*K over every conv / GEMM, unpadded): what this library contracts.  The
+ * last transformer block of a window is computed for the neighbour frames only -- the decoder reads nothing else
+ * (sttn_auto_inpaint.py:150) --; vsr_sttn_flops_reference counts those rows too, i.e. what the reference's modules compute
+ * (642.8 GFLOP per frame of a 50-frame chunk) */
 double vsr_sttn_flops(vsr_sttn_t* h, int L);
+double vsr_sttn_flops_reference(vsr_sttn_t* h, int L);
 
 /* GPU timing of the next calls with hipEvents on the launch stream, per op tag and per kernel symbol: enable = 1 brackets every op
  * (about 2.5 % of a chunk's wall time: 1 300 launches), 2 only the launches of the 128x64 NK gather-GEMM -- the dominant kernel
@@ -501,6 +517,7 @@ typedef struct VsrSoftmaxInfo {
 } VsrSoftmaxInfo;
 
 int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
+int vsr_plan_create_rows(const vsr_sttn_t* h, int L, int row_lo, int row_hi, vsr_plan_t** out);   /* the decoder on model rows [row_lo, row_hi) only */
 int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out);
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);

@@ -16,12 +16,15 @@ BUF_WEIGHTS, BUF_IN_U8 = 0, 1
 
 
 class PlanView:
-    def __init__(self, _lib, engine, L, plan_ptr=None):
-        """STTN: PlanView(_lib, engine, L).  Any other plan: pass the vsr_plan_t pointer (L = length of the counts array, 0 = none)."""
+    def __init__(self, _lib, engine, L, plan_ptr=None, rows=None):
+        """STTN: PlanView(_lib, engine, L[, rows=(lo, hi): the decoder on these model rows only]).  Any other plan: pass the
+        vsr_plan_t pointer (L = length of the counts array, 0 = none)."""
         self._lib = _lib
         lib = _lib.lib
         self.p = plan_ptr if plan_ptr is not None else C.c_void_p()
-        if plan_ptr is None:
+        if plan_ptr is None and rows is not None:
+            _lib.check(lib.vsr_plan_create_rows(engine.handle, L, int(rows[0]), int(rows[1]), C.byref(self.p)))
+        elif plan_ptr is None:
             _lib.check(lib.vsr_plan_create(engine.handle, L, C.byref(self.p)))
         self.L = L
         self.buf_elems = [lib.vsr_plan_buffer_elems(self.p, b) for b in range(lib.vsr_plan_num_buffers(self.p))]
@@ -140,7 +143,10 @@ def upsample_reference(info, bufs):
     x = torch.from_numpy(np.ascontiguousarray(src)).permute(0, 3, 1, 2)
     y = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
     dst = bufs[info.buf_dst][: n * Hd * Wd * Cc].reshape(n, Hd, Wd, Cc)
-    dst[:, hd:hd + 2 * H, hd:hd + 2 * W, :] = y.permute(0, 2, 3, 1).numpy()
+    lo, hi = int(info.ipar[1]), int(info.ipar[2])       # output rows written (a plan with a decoder row range); 0, 0 = all
+    if hi <= lo:
+        lo, hi = 0, 2 * H
+    dst[:, hd + lo:hd + hi, hd:hd + 2 * W, :] = y.permute(0, 2, 3, 1).numpy()[:, lo:hi]
 
 
 def norm_im2col_reference(info, bufs):
@@ -173,17 +179,22 @@ def decode_out_reference(info, bufs, tables):
     det_mask = bufs[info.buf_mask] if getattr(info, "buf_mask", -1) >= 0 else None
     idx = tables[info.t_frame_idx]
     first = tables[info.t_first]
+    p0, p1 = 0, pix                                      # pixels decoded: whole image rows [ipar[1], ipar[2]) of a W-wide image
+    if getattr(info, "W", 0) > 0 and int(info.ipar[2]) > int(info.ipar[1]):
+        p0, p1 = int(info.ipar[1]) * info.W, int(info.ipar[2]) * info.W
     for i in range(n):
         if det_mask is not None:
             f = int(idx[i])
             b = (det_mask[f * pix:(f + 1) * pix] > 0)[:, None]
             rgb = bufs[BUF_IN_U8][f * pix * 3:(f + 1) * pix * 3].reshape(pix, 3)[:, ::-1].astype(np.float32)
             img[i] = np.where(b, img[i], rgb)
-        sl = slice(int(idx[i]) * pix * 3, (int(idx[i]) + 1) * pix * 3)
+        base = int(idx[i]) * pix * 3
+        sl = slice(base + p0 * 3, base + p1 * 3)
+        new = img[i].reshape(-1)[p0 * 3:p1 * 3]
         if first[i]:
-            comp[sl] = img[i].reshape(-1)
+            comp[sl] = new
         else:
-            comp[sl] = comp[sl] * np.float32(0.5) + img[i].reshape(-1) * np.float32(0.5)
+            comp[sl] = comp[sl] * np.float32(0.5) + new * np.float32(0.5)
 
 
 def reduce_scatter_reference(info, bufs, tables):

@@ -365,6 +365,37 @@ def test_two_lanes_equal_one_lane(built_lib, gpu_device, sd, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("H,W,boxes", [
+    (720, 1280, [(620, 700, 192, 1088)]),                          # a subtitle line at the bottom of its strip
+    (720, 1280, [(10, 40, 100, 900)]),                             # at the very top of the frame: rows 0.. of the model image
+    (1080, 1920, [(500, 560, 300, 1600), (940, 1060, 288, 1632)]), # two areas, two row ranges
+    (480, 852, [(200, 340, 50, 800)]),                             # a mask about as tall as the strip (h = 159): nearly every row is needed
+])
+def test_decoder_rows_give_the_same_frames(built_lib, gpu_device, sd, mode, H, W, boxes):
+    """vsr_sttn_auto_chunk_rows: with the promise that the mask lives in rows [lo, hi) of every strip the decoder runs on the
+    model-resolution rows those strip rows are resized from (and what they depend on) only -- the written frames are the ones of
+    the call without the promise BIT FOR BIT, also with A/B selections, two lanes, and the fp16-operand mode."""
+    from vsr_amd.backend.tools.inpaint_tools import create_mask as cm, get_inpaint_area_by_mask as ga, threshold_mask as tm
+
+    eng = _engine(sd, precision=mode)
+    frames = torch.from_numpy(synth.make_clip(12, H, W, boxes[0], seed=9)).to(gpu_device)
+    m01 = tm(cm((H, W), [(b[2], b[3], b[0], b[1]) for b in boxes]))
+    areas = ga(W, H, int(W * 3 / 16), m01)
+    dmask = torch.from_numpy(np.ascontiguousarray(m01[:, :, 0])).to(gpu_device)
+    rows = eng.mask_rows(dmask, areas)
+    assert len(rows) == len(areas) and all(hi > lo for lo, hi in rows)
+    for sel in (None, [1, 2, 3, 7, 8, 10]):
+        a, b = frames.clone(), frames.clone()
+        eng.auto_chunk(a, dmask, areas, sel=sel, decode_rows=False)
+        eng.auto_chunk(b, dmask, areas, sel=sel)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert not torch.equal(a, frames)
+    assert eng.chunk_flops(12, dmask, areas) <= len(areas) * eng.flops(12)
+    eng.close()
+
+
 def test_two_lanes_equal_one_lane_det(built_lib, gpu_device, sd_det):
     from vsr_amd.engine import SttnEngine
 

@@ -69,6 +69,32 @@ def test_mask_helpers_match_oracle(size, boxes):
                 assert (ymax - ymin) % mult == 0 and (xmax - xmin) % mult == 0 and xmin == (W % mult) // 2
 
 
+def test_mask_islands_without_scipy_equal_scipy_label():
+    """inpaint_tools._islands (round 4: union-find over the runs of set pixels per row, no scipy import in front of the first chunk)
+    gives the statistics and the label order of scipy.ndimage.label with 8-connectivity -- rectangles, specks touching by corners,
+    diagonals, noise -- and hands masks with a great many runs to scipy."""
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        H, W = int(rng.integers(20, 160)), int(rng.integers(20, 240))
+        m = np.zeros((H, W), np.uint8)
+        if trial % 3 == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                y0, x0 = int(rng.integers(0, H - 2)), int(rng.integers(0, W - 2))
+                m[y0:y0 + int(rng.integers(1, 40)), x0:x0 + int(rng.integers(1, 80))] = 255
+        elif trial % 3 == 1:
+            m = (rng.random((H, W)) < rng.uniform(0.02, 0.6)).astype(np.uint8) * 255
+        else:
+            for _ in range(int(rng.integers(1, 12))):
+                y0, x0 = int(rng.integers(0, H - 1)), int(rng.integers(0, W - 1))
+                m[y0:y0 + int(rng.integers(1, 6)), x0:x0 + int(rng.integers(1, 6))] = 1
+            for i in range(min(H, W) // 2):
+                m[i, i] = 1
+        assert t._islands(m) == t._islands_scipy(m > 0)
+    assert t._islands(np.zeros((8, 8), np.uint8)) == []
+    noisy = (np.indices((400, 400)).sum(0) % 2).astype(np.uint8)          # 80 000 one-pixel runs: the scipy path
+    assert t._islands(noisy) == t._islands_scipy(noisy > 0)
+
+
 def test_inpaint_area_1080p_value():
     mask = t.create_mask((1080, 1920), [(288, 1632, 950, 1070)])
     assert mask[940, 278] == 255 and mask[939, 278] == 0 and mask[1079, 1642] == 255 and mask[1079, 1643] == 0

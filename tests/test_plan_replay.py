@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +33,35 @@ def test_plan_replay_matches_oracle(built_lib):
     assert res["counts"] == [2, 2, 2, 1]
 
 
+@pytest.mark.parametrize("rows", [(76, 118), (0, 7), (41, 80), (113, 120), (59, 61)])
+def test_plan_replay_decoder_rows(built_lib, host_engine, rows):
+    """A plan that was told which rows of the model-resolution output its caller reads (vsr_sttn_auto_chunk_rows: the strip is blended
+    back only where the mask is set) runs its decoder on those rows and on what they depend on -- and nothing else: the replay writes
+    ONLY the row ranges the ops carry (what lies outside stays zero), so a range that is one row too small anywhere in the chain
+    (3x3 convs, two align_corners upsamplings, the 2-row blocks of the output conv) shows up as a difference.  Inside the range
+    the comps equal the full plan's bit for bit; the FLOPs go down."""
+    from vsr_amd import _lib
+    from _replay import PlanView, replay
+
+    sd, eng = host_engine
+    L = 4
+    frames = np.random.default_rng(21).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8)
+    full = PlanView(_lib, eng, L)
+    part = PlanView(_lib, eng, L, rows=rows)
+    try:
+        want, counts, _ = replay(full, eng.packed_weights(), frames)
+        got, counts2, _ = replay(part, eng.packed_weights(), frames)
+        lo, hi = rows[0] // 2 * 2, (rows[1] + 1) // 2 * 2            # whole 2-row blocks
+        assert list(counts) == list(counts2)
+        assert np.array_equal(got[:, lo:hi], want[:, lo:hi])
+        assert part.flops < full.flops
+        dec = [(i.H, int(i.ipar[1]), int(i.ipar[2])) for i, _ in part.ops if i.kind == 3]      # OP_UPSAMPLE2X
+        assert dec and all(0 <= a < b <= 2 * H for H, a, b in dec) and any(b - a < 2 * H for H, a, b in dec)
+    finally:
+        full.close()
+        part.close()
+
+
 def test_plan_replay_degenerate_chunks(built_lib):
     """a 1-frame and a 2-frame chunk with the reference's default stride 5 / references every 10 (the ragged tail of a video,
     sttn_auto_inpaint.py:240-245): one window of T = 1 / T = 2, every frame visited once and returned as uint8"""
@@ -56,10 +86,11 @@ def test_plan_flops_det_matches_survey(built_lib):
 
     eng = SttnEngine(make_state_dict(1, "det"), "det", device=None)
     try:
-        f50 = eng.flops(50)
+        f50, x50 = eng.flops(50, reference=True), eng.flops(50)
     finally:
         eng.close()
     assert abs(f50 / 50 / 1e9 - 733.8) < 1.5, f50 / 50 / 1e9
+    assert 0.95 * f50 < x50 < 0.985 * f50          # the last block of a window runs on its neighbour frames only
 
 
 def test_plan_replay_split_pv_and_square_tiles():
@@ -81,10 +112,13 @@ def test_plan_flops_L50_matches_survey(built_lib, host_engine):
     sd, _ = host_engine
     eng = SttnEngine(sd, "auto", device=None)
     try:
-        f50 = eng.flops(50)
+        f50, x50 = eng.flops(50, reference=True), eng.flops(50)
     finally:
         eng.close()
     assert abs(f50 / 50 / 1e9 - 642.8) < 1.0, f50 / 50 / 1e9
+    # what is contracted: the reference's count minus the reference-frame rows of every window's last block (Plan::buildWindow) --
+    # windows of 10 / 14 / 15 frames with 6 / 10-11 / 11 neighbours: (T - nn) / T of one block in eight, QKV excepted
+    assert 0.96 * f50 < x50 < 0.975 * f50, x50 / f50
 
 
 def test_plan_tables_stay_inside_buffers(built_lib, host_engine):

@@ -86,12 +86,16 @@ SIGNATURES = {
     "vsr_sttn_packed_weights": (_L, [_P, _P, _L]),
     "vsr_sttn_inpaint": (_I, [_P, _P, _I, _P, _P, _P]),
     "vsr_sttn_auto_chunk": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
+    "vsr_sttn_auto_chunk_rows": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "vsr_sttn_decode_rows": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vsr_sttn_flops_rows": (_D, [_P, _I, _I, _I]),
     "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vsr_sttn_det_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "vsr_sttn_set_precision": (_I, [_P, _I]),
     "vsr_sttn_set_lanes": (_I, [_P, _I]),
     "vsr_sttn_fallbacks": (_L, [_P]),
     "vsr_sttn_flops": (_D, [_P, _I]),
+    "vsr_sttn_flops_reference": (_D, [_P, _I]),
     "vsr_sttn_timing": (_I, [_P, _I]),
     "vsr_sttn_timing_get": (_I, [_P, C.c_char_p, C.POINTER(_D), C.POINTER(C.c_int32), C.POINTER(_D)]),
     "vsr_sttn_timing_reset": (_I, [_P]),
@@ -108,6 +112,7 @@ SIGNATURES = {
     "vsr_launch_upscale_blend": (_I, [_P, _I, _I, _P, _P, _L, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsr_cv2_linear_tables": (_I, [_I, _I, _I, _P, _P, _P]),
     "vsr_plan_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "vsr_plan_create_rows": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
     "vsr_raft_plan_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_raft_create": (_I, [C.POINTER(_P)]),
     "vsr_raft_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),

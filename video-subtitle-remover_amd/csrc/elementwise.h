@@ -21,3 +21,10 @@ extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, 
                                          int nframes, int split, void* stream);
 // KN operand (B(k, n) = B[rowB[k] + colB[n / 32] + n % 32], split format) -> NK operand dst[n * ld + k] in split format; K, N multiples of 32
 extern "C" int vsr_launch_kn_to_nk_split(const float* B, const int32_t* rowB, const int32_t* colB, int K, int N, int64_t ld, float* dst, void* stream);
+// the same with a range: output rows [oyLo, oyHi) of the upsampled image / pixels [pLo, pLo + pCnt) of every decoded frame (whole image
+// rows, whole 2-row blocks in the blocked form) -- the decoder of a plan that was given the rows its caller will read (Plan::decLo)
+extern "C" int vsr_launch_upsample2x_rows(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
+                                          int nframes, int split, int oyLo, int oyHi, void* stream);
+extern "C" int vsr_launch_decode_out_rows(const float* y, int ldy, int pix, int nframes, const int32_t* frameIdx,
+                                          const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
+                                          int blkW, int pLo, int pCnt, void* stream);

@@ -267,18 +267,18 @@ k_softmax_rows(const SMProblem* __restrict__ probs, int nprobs)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_upsample2x_nhwc(const float* __restrict__ src, int H, int W, int C, int haloS,
-                  float* __restrict__ dst, int haloD, int nframes, int split)
+                  float* __restrict__ dst, int haloD, int nframes, int split, int oyLo, int oyHi /* output rows [oyLo, oyHi) are written */)
 {
-    const int OH = 2 * H, OW = 2 * W, C4 = C / 4;
+    const int OH = 2 * H, OW = 2 * W, C4 = C / 4, RH = oyHi - oyLo;
     const int Hs = H + 2 * haloS, Ws = W + 2 * haloS, Hd = OH + 2 * haloD, Wd = OW + 2 * haloD;
     const float rh = (float)(H - 1) / (float)(OH - 1);
     const float rw = (float)(W - 1) / (float)(OW - 1);
-    const int64_t total = (int64_t)nframes * OH * OW * C4;
+    const int64_t total = (int64_t)nframes * RH * OW * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const int ox = (int)((i / C4) % OW);
-        const int oy = (int)((i / ((int64_t)C4 * OW)) % OH);
-        const int f = (int)(i / ((int64_t)C4 * OW * OH));
+        const int oy = oyLo + (int)((i / ((int64_t)C4 * OW)) % RH);
+        const int f = (int)(i / ((int64_t)C4 * OW * RH));
         const float fy = rh * (float)oy, fx = rw * (float)ox;
         int y0 = (int)fy; if (y0 > H - 1) y0 = H - 1;
         int x0 = (int)fx; if (x0 > W - 1) x0 = W - 1;
@@ -311,12 +311,14 @@ k_decode_out(const float* __restrict__ y /*[n*pix][ldy] first 3 cols = RGB pre-t
              float* __restrict__ comp /*[L][pix][3]*/,
              const uint8_t* __restrict__ inBGR /*[L][pix][3] model-res input frames, sttn-det only*/,
              const uint8_t* __restrict__ mask /*[L][pix] resized 0..255 mask, sttn-det only (null = sttn-auto)*/,
-             int blkW /*0: y row = pixel; image width: y row = 2x4 pixel block, columns (dy, dx, channel) -- the blocked output conv*/)
+             int blkW /*0: y row = pixel; image width: y row = 2x4 pixel block, columns (dy, dx, channel) -- the blocked output conv*/,
+             int pLo, int pCnt /* pixels [pLo, pLo + pCnt) of every frame are decoded (a range of whole image rows) */)
 {
-    const int64_t total = (int64_t)nframes * pix;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / pix);
-        const int p = (int)(i - (int64_t)f * pix);
+    const int64_t total = (int64_t)nframes * pCnt;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(j / pCnt);
+        const int p = pLo + (int)(j - (int64_t)f * pCnt);
+        const int64_t i = (int64_t)f * pix + p;
         const int idx = frameIdx[f];
         const bool fst = first[f] != 0;
         const float* s = y + i * ldy;
@@ -511,10 +513,16 @@ extern "C" int vsr_launch_upsample2x(const float* src, int H, int W, int C, int 
 extern "C" int vsr_launch_upsample2x_fmt(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
                                          int nframes, int split, void* stream)
 {
-    const int64_t total = (int64_t)nframes * 4 * H * W * (C / 4);
+    return vsr_launch_upsample2x_rows(src, H, W, C, haloS, dst, haloD, nframes, split, 0, 2 * H, stream);
+}
+extern "C" int vsr_launch_upsample2x_rows(const float* src, int H, int W, int C, int haloS, float* dst, int haloD,
+                                          int nframes, int split, int oyLo, int oyHi, void* stream)
+{
+    if (oyLo < 0 || oyHi > 2 * H || oyLo > oyHi) return VSR_ERR_ARG;
+    const int64_t total = (int64_t)nframes * (oyHi - oyLo) * 2 * W * (C / 4);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_upsample2x_nhwc, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, C,
-                       haloS, dst, haloD, nframes, split);
+                       haloS, dst, haloD, nframes, split, oyLo, oyHi);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 
@@ -528,11 +536,18 @@ extern "C" int vsr_launch_decode_out_blk(const float* y, int ldy, int pix, int n
                                          const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
                                          int blkW, void* stream)
 {
-    const int64_t total = (int64_t)nframes * pix;
+    return vsr_launch_decode_out_rows(y, ldy, pix, nframes, frameIdx, first, comp, inBGR, mask, blkW, 0, pix, stream);
+}
+extern "C" int vsr_launch_decode_out_rows(const float* y, int ldy, int pix, int nframes, const int32_t* frameIdx,
+                                          const int32_t* first, float* comp, const uint8_t* inBGR, const uint8_t* mask,
+                                          int blkW, int pLo, int pCnt, void* stream)
+{
+    const int64_t total = (int64_t)nframes * pCnt;
     if (total <= 0) return 0;
     if (blkW < 0 || (blkW > 0 && (blkW % 4 || pix % blkW || (pix / blkW) % 2 || ldy < 24))) return VSR_ERR_ARG;
+    if (pLo < 0 || pCnt < 0 || pLo + pCnt > pix || (blkW > 0 && (pLo % (2 * blkW) || pCnt % (2 * blkW)))) return VSR_ERR_ARG;
     hipLaunchKernelGGL(k_decode_out, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, pix, nframes,
-                       frameIdx, first, comp, inBGR, mask, blkW);
+                       frameIdx, first, comp, inBGR, mask, blkW, pLo, pCnt);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 

@@ -66,6 +66,7 @@ struct OpDev {
     int64_t splitStride = 0;
     const int32_t* tRowC = nullptr;
     const int32_t* tColC = nullptr;
+    int rowLo = 0, rowHi = 0;    // UPSAMPLE2X: output rows written; DECODE_OUT: image rows decoded (Plan::decLo)
     int split = 0;               // precision mode 2: this elementwise op reads / writes split-format tensors
     bool aexp = false;           // GEMM: the launch carries VSR_ACT_A_EXP problems (P.V of a fused attention)
     const float* lsum = nullptr; // reduce_scatter of a fused attention: partial row sums [nsplit][ldL]
@@ -116,7 +117,7 @@ struct vsr_sttn {
     bool finalized = false;
     void* bufs[BUF_COUNT] = {};
     int64_t cap[BUF_COUNT] = {};
-    std::map<int, std::unique_ptr<PlanDev>> plans;
+    std::map<int64_t, std::unique_ptr<PlanDev>> plans;
     std::map<std::pair<int, int>, StripTables> strips;
     float* compAreas = nullptr;
     int64_t compAreasCap = 0;
@@ -162,9 +163,10 @@ static int gg_wide_queues()
 }
 
 
-static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
+// decLo / decHi: the rows of the model-resolution output the caller will read (Plan::decLo; 0, 0 = all)
+static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int decLo = 0, int decHi = 0)
 {
-    const int key = (L * 4 + precision) * 8 + h->lanes;
+    const int64_t key = ((((int64_t)L * 4 + precision) * 8 + h->lanes) * 4096 + decLo) * 4096 + decHi;
     const bool fmt = precision >= 2;       // split-format tensors: everything a GEMM reads (see gather_gemm_v5.h)
     auto plainF32 = [](int buf) { buf = baseBuf(buf); return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
     if (fmt && !h->weightsSplit) {
@@ -178,7 +180,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
     if (it != h->plans.end()) { *out = it->second.get(); return 0; }
     std::unique_ptr<PlanDev> pd(new PlanDev);
     try {
-        pd->plan.reset(new Plan(h->model, L, precision, h->lanes));
+        pd->plan.reset(new Plan(h->model, L, precision, h->lanes, decLo, decHi));
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
     }
@@ -351,6 +353,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out)
             od.dst = op.bufDst >= 0 ? h->bufs[op.bufDst] : nullptr;
             od.H = op.H; od.W = op.W; od.C = op.C; od.haloS = op.haloS; od.haloD = op.haloD; od.n = op.n;
             od.ldy = op.ldy; od.pix = op.pix; od.premask = op.premask;
+            od.rowLo = op.ipar[1]; od.rowHi = op.ipar[2];
             od.tFrameIdx = T(op.tFrameIdx); od.tFirst = T(op.tFirst);
             od.maskU8 = op.bufMask >= 0 ? (const uint8_t*)h->bufs[op.bufMask] : nullptr;
             od.inU8 = (const uint8_t*)h->bufs[BUF_IN_U8];
@@ -465,11 +468,16 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             rc = vsr_launch_norm_im2col_fmt((const uint8_t*)od.src, od.H, od.W, od.n, (float*)od.dst, od.premask, od.maskU8, od.split, stream);
             break;
         case OP_UPSAMPLE2X:
-            rc = vsr_launch_upsample2x_fmt((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, od.split, stream);
+            rc = vsr_launch_upsample2x_rows((const float*)od.src, od.H, od.W, od.C, od.haloS, (float*)od.dst, od.haloD, od.n, od.split,
+                                            od.rowLo, od.rowHi > od.rowLo ? od.rowHi : 2 * od.H, stream);
             break;
         case OP_DECODE_OUT:
-            rc = vsr_launch_decode_out_blk((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
-                                           od.maskU8 ? od.inU8 : nullptr, od.maskU8, od.W, stream);
+            if (od.rowHi > od.rowLo && od.W > 0)
+                rc = vsr_launch_decode_out_rows((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
+                                                od.maskU8 ? od.inU8 : nullptr, od.maskU8, od.W, od.rowLo * od.W, (od.rowHi - od.rowLo) * od.W, stream);
+            else
+                rc = vsr_launch_decode_out_blk((const float*)od.src, od.ldy, od.pix, od.n, od.tFrameIdx, od.tFirst, (float*)od.dst,
+                                               od.maskU8 ? od.inU8 : nullptr, od.maskU8, od.W, stream);
             break;
         case OP_REDUCE_SCATTER:
             rc = vsr_launch_reduce_scatter_fmt((const float*)od.src, od.nsplit, od.splitStride, od.M, od.N, od.tRowC, od.tColC,
@@ -747,8 +755,11 @@ int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t
 // shared body of the strip-level entries: crop + resize down, inpaint, resize up + write back.
 //   det == false: sttn-auto (mask01 thresholded, blend only where the mask is set)
 //   det == true : sttn-det  (raw 0..255 mask resized with the frames, whole strip overwritten)
+//   maskRows (sttn-auto, nullable): per area, the strip rows [lo, hi) outside which the caller's mask is zero.  The strip is blended
+//   back only where the mask is set (vsr_launch_upscale_blend), so only the model-resolution rows those strip rows are resized
+//   from are ever read: the decoder computes them and what they depend on (Plan::decLo), the same values as before.
 static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
-                         const int32_t* areas, const int32_t* sel, int nsel, hipStream_t stream)
+                         const int32_t* areas, const int32_t* sel, int nsel, hipStream_t stream, const int32_t* maskRows = nullptr)
 {
     if (!frames_dev || !mask_dev || L <= 0 || H <= 0 || W <= 0 || n_areas < 0 || (n_areas > 0 && !areas))
         return fail(VSR_ERR_ARG, "bad argument");
@@ -769,8 +780,30 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
         HIPCHK(hipStreamSynchronize(stream)); // `sel` is caller memory
         dSel = h->dSel;
     }
+    // model-resolution rows every area needs (0, 0 = all)
+    static const bool rowsOn = [] { const char* e = getenv("VSR_DECODE_ROWS"); return !(e && atoi(e) == 0); }();
+    std::vector<int> decLo((size_t)n_areas, 0), decHi((size_t)n_areas, 0);
+    if (!det && maskRows && rowsOn) {
+        for (int k = 0; k < n_areas; ++k) {
+            const int sh = areas[4 * k + 1] - areas[4 * k];
+            const int r0 = maskRows[2 * k], r1 = maskRows[2 * k + 1];
+            if (sh <= 0 || r0 < 0 || r1 > sh || r0 >= r1) continue;          // no promise for this strip: the whole image
+            std::vector<int32_t> ofs;
+            std::vector<int16_t> ic;
+            std::vector<float> fc;
+            cv2_linear_tables(mh, sh, false, ofs, ic, fc);                   // the vertical taps of the resize back (k_upscale_blend)
+            auto clampRow = [&](int y) { return y < 0 ? 0 : (y < mh ? y : mh - 1); };
+            int lo = mh, hi = 0;
+            for (int dy = r0; dy < r1; ++dy) {
+                const int a = clampRow(ofs[dy]), b = clampRow(ofs[dy] + 1);
+                lo = a < lo ? a : lo;
+                hi = b + 1 > hi ? b + 1 : hi;
+            }
+            decLo[k] = lo; decHi[k] = hi;
+        }
+    }
     PlanDev* pd = nullptr;
-    RCCHK(build_plan_dev(h, Ls, h->precision, &pd));
+    RCCHK(build_plan_dev(h, Ls, h->precision, &pd, decLo[0], decHi[0]));
     const int64_t compElems = (int64_t)Ls * mh * mw * 3;
     if (n_areas > 1 && h->compAreasCap < compElems * n_areas) {
         if (h->compAreas) HIPCHK(hipFree(h->compAreas));
@@ -795,6 +828,7 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
             if (vsr_launch_resize_u8(mask_dev + (int64_t)ymin * W, 0, W, W, sh, (uint8_t*)h->bufs[BUF_MASK_U8], mw, mh, Ls, 1,
                                      nullptr, st->dxofs, st->dialpha, st->dyofs, st->dibeta, stream) != 0)
                 return fail(VSR_ERR_HIP, "mask resize launch failed");
+        if (k > 0 || attempt > 0) RCCHK(build_plan_dev(h, Ls, attempt ? 0 : h->precision, &pd, decLo[k], decHi[k]));
         RCCHK(run_plan(h, pd, stream));
         if (n_areas > 1)
             HIPCHK(hipMemcpyAsync(h->compAreas + compElems * k, h->bufs[BUF_COMP], (size_t)compElems * sizeof(float),
@@ -802,8 +836,7 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
     }
     bool fired = false;
     if (attempt == 0) RCCHK(guard_end(h, stream, &fired));
-    if (!fired) break;
-    RCCHK(build_plan_dev(h, Ls, 0, &pd));          // the frames are still untouched: redo pass 1 in exact fp32
+    if (!fired) break;                             // (fired: the frames are still untouched, pass 1 is redone in exact fp32)
     }
     for (int k = 0; k < n_areas; ++k) {
         const int ymin = areas[4 * k], ymax = areas[4 * k + 1];
@@ -826,6 +859,47 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
     RCCHK(need_gpu(h));
     if (h->model.g.variant != VSR_VARIANT_STTN_AUTO) return fail(VSR_ERR_STATE, "not an sttn-auto model");
     return strips_common(h, false, frames_dev, L, H, W, mask_dev, n_areas, areas, sel, nsel, (hipStream_t)stream_);
+}
+
+int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                             const int32_t* areas, const int32_t* mask_rows, const int32_t* sel, int nsel, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (h->model.g.variant != VSR_VARIANT_STTN_AUTO) return fail(VSR_ERR_STATE, "not an sttn-auto model");
+    return strips_common(h, false, frames_dev, L, H, W, mask_dev, n_areas, areas, sel, nsel, (hipStream_t)stream_, mask_rows);
+}
+
+double vsr_sttn_flops_rows(vsr_sttn_t* h, int L, int row_lo, int row_hi)
+{
+    if (!h || !h->model.packed_ready() || L <= 0) { fail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        Plan p(h->model, L, 0, 1, row_lo, row_hi);
+        return p.flops;
+    } catch (const std::exception& e) {
+        fail(VSR_ERR_ARG, e.what());
+        return -1.0;
+    }
+}
+
+int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_row_hi, int32_t* row_lo, int32_t* row_hi)
+{
+    if (!h || !row_lo || !row_hi || strip_h <= 0 || mask_row_lo < 0 || mask_row_hi > strip_h || mask_row_lo >= mask_row_hi)
+        return fail(VSR_ERR_ARG, "bad argument");
+    const int mh = h->model.g.modelH;
+    std::vector<int32_t> ofs;
+    std::vector<int16_t> ic;
+    std::vector<float> fc;
+    cv2_linear_tables(mh, strip_h, false, ofs, ic, fc);
+    auto clampRow = [&](int y) { return y < 0 ? 0 : (y < mh ? y : mh - 1); };
+    int lo = mh, hi = 0;
+    for (int dy = mask_row_lo; dy < mask_row_hi; ++dy) {
+        const int a = clampRow(ofs[dy]), b = clampRow(ofs[dy] + 1);
+        lo = a < lo ? a : lo;
+        hi = b + 1 > hi ? b + 1 : hi;
+    }
+    Plan p(h->model, 1, 0, 1, lo, hi);                   // (the widening to whole output-conv blocks)
+    *row_lo = p.decLo; *row_hi = p.decHi;
+    return 0;
 }
 
 int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
@@ -859,6 +933,18 @@ double vsr_sttn_flops(vsr_sttn_t* h, int L)
     try {
         Plan p(h->model, L);
         return p.flops;
+    } catch (const std::exception& e) {
+        fail(VSR_ERR_ARG, e.what());
+        return -1.0;
+    }
+}
+
+double vsr_sttn_flops_reference(vsr_sttn_t* h, int L)
+{
+    if (!h || !h->model.packed_ready() || L <= 0) { fail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        Plan p(h->model, L);
+        return p.refFlops;
     } catch (const std::exception& e) {
         fail(VSR_ERR_ARG, e.what());
         return -1.0;
@@ -1055,6 +1141,19 @@ int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out)
     try {
         std::unique_ptr<vsr_plan> p(new vsr_plan);
         p->plan.reset(new Plan(h->model, L, 0, h->lanes));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
+    }
+    return 0;
+}
+int vsr_plan_create_rows(const vsr_sttn_t* h, int L, int row_lo, int row_hi, vsr_plan_t** out)
+{
+    if (!h || !out || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return fail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new Plan(h->model, L, 0, h->lanes, row_lo, row_hi));
         *out = p.release();
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());

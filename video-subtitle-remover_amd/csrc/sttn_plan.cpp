@@ -31,6 +31,7 @@ const Tuning& Tuning::get(int precision)
             // the fused path needs the kernels it was written into: v3 for the scores, v1 (+ A_EXP) for P.V -- the defaults
             x.fuseSoftmax = envInt("VSR_FUSE_SOFTMAX", 1) && envInt("VSR_GG_VARIANT", 3) == 3 && envInt("VSR_PV_VARIANT", 1) == 1;
             x.outConvBlocked = envInt("VSR_OUT_CONV_BLOCKED", 1);
+            x.trimLastBlock = envInt("VSR_TRIM_LAST_BLOCK", 1);
             return x;
         }(),
         [] {
@@ -43,6 +44,7 @@ const Tuning& Tuning::get(int precision)
             x.convChannelMajor = envInt("VSR_CONV_KORDER", 1);
             x.fuseSoftmax = 0;      // split-format tensors: the probabilities are a GEMM operand in that format, k_softmax_rows writes it
             x.outConvBlocked = envInt("VSR_OUT_CONV_BLOCKED", 1);
+            x.trimLastBlock = envInt("VSR_TRIM_LAST_BLOCK", 1);
             return x;
         }()};
     return t[precision ? 1 : 0];
@@ -452,8 +454,11 @@ static std::vector<int> iota(int n)
 // conv (ksz 1 or 3, stride, dilation) + bias + optional LeakyReLU(0.2) + optional residual,
 // as one gather-GEMM: M = nOut*out.H*out.W pixels, N = cout, K = ksz*ksz*cin.
 void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut, int ksz,
-                   int stride, int dil, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds)
+                   int stride, int dil, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds, int ylo, int yhi)
 {
+    if (yhi < 0) yhi = out.H;
+    if (ylo < 0 || yhi > out.H || ylo >= yhi || (stride != 1 && (ylo != 0 || yhi != out.H))) throw std::runtime_error(std::string("conv row range: ") + tag);
+    const int oh = yhi - ylo;           // a row range is a row offset: pix(f, y + ylo, x) = pix(f, y, x) + ylo * Wp * C
     if (w.K != ksz * ksz * in.C) throw std::runtime_error(std::string("conv K mismatch: ") + tag);
     if ((int)inIds.size() != nOut) throw std::runtime_error("conv frame list mismatch");
     Op op;
@@ -464,7 +469,7 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
     int BM, BN;
     tileDims(op.tileCfg, BM, BN);
     GemmItem it{};
-    it.M = nOut * out.H * out.W;
+    it.M = nOut * oh * out.W;
     it.N = w.cout;
     it.K = w.K;
     it.tilesM = cdiv(it.M, BM);
@@ -475,18 +480,18 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
     it.alpha = 1.f;
     it.act = act;
     it.bufA = in.buf; it.offA = 0;
-    it.tRowA = tRowsAct(in, inIds, out.H, out.W, stride, BM, 0);
+    it.tRowA = tRowsAct(in, inIds, oh, out.W, stride, BM, (int64_t)ylo * in.Wp() * in.C);
     it.tColA = tColsConv(in, ksz, dil);
     it.bufB = BUF_WEIGHTS; it.offB = w.w;
     it.tRowB = tRowsLinear(it.N, it.K, BN);
     it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
     it.bufC = out.buf; it.offC = 0;
-    it.tRowC = tRowsAct(out, iota(nOut), out.H, out.W, 1, BM, 0);
+    it.tRowC = tRowsAct(out, iota(nOut), oh, out.W, 1, BM, (int64_t)ylo * out.Wp() * out.C);
     it.tColC = tColsLinear(cdiv(it.N, VSR_GG_KC), it.tilesN * BN / VSR_GG_KC);
     it.offBias = w.b;
     if (res) {
         it.bufR = res->buf; it.offR = 0;
-        it.tRowR = tRowsAct(*res, *resIds, out.H, out.W, 1, BM, 0);
+        it.tRowR = tRowsAct(*res, *resIds, oh, out.W, 1, BM, (int64_t)ylo * res->Wp() * res->C);
     } else {
         it.bufR = -1; it.offR = 0; it.tRowR = -1;
     }
@@ -503,7 +508,9 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
 // so that the long workgroups are dispatched first and the short ones fill the tail; a PV
 // whose token contraction is long is split into slices (fewer, longer workgroups than CUs
 // would otherwise leave half the chip idle) and combined by a reduce-scatter pass.
-void Plan::addAttention(int T, const BlockW&)
+// Tq <= T: the QUERY frames are the first Tq of the T frames (the keys and values are all T): the last block of a window only needs
+// the rows of its neighbour frames (Plan::buildWindow)
+void Plan::addAttention(int Tq, int T, const BlockW&)
 {
     const Tuning& tu = tu_;
     const int C = g.channels, dk = C / g.nscales;
@@ -521,7 +528,8 @@ void Plan::addAttention(int T, const BlockW&)
     for (int s = g.nscales - 1; s >= 0; --s) { // finest scale (most tokens, most work) first
         const int pw = g.patchW[s], ph = g.patchH[s];
         const int Pn = (g.featW / pw) * (g.featH / ph);
-        const int Ntok = T * Pn;
+        const int Ntok = T * Pn;        // key / value tokens
+        const int Mtok = Tq * Pn;       // query tokens (frame-major: the first Tq frames)
         const int D = dk * pw * ph;
         const int ldS = (int)rup(Ntok, VSR_GG_KC);
         const int nchunks = D / VSR_GG_KC;
@@ -529,21 +537,21 @@ void Plan::addAttention(int T, const BlockW&)
         int splitK = cdiv(nchunks, cps);
         cps = cdiv(nchunks, splitK);
         splitK = cdiv(nchunks, cps);
-        const int64_t plane = (int64_t)Ntok * ldS;
+        const int64_t plane = (int64_t)Mtok * ldS;
 
         GemmItem a{};
-        a.M = Ntok; a.N = Ntok; a.K = D;
-        a.tilesM = cdiv(Ntok, qBM); a.tilesN = cdiv(Ntok, qBN);
+        a.M = Mtok; a.N = Ntok; a.K = D;
+        a.tilesM = cdiv(Mtok, qBM); a.tilesN = cdiv(Ntok, qBN);
         a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
         a.alpha = 1.f; a.act = VSR_ACT_NONE;
         a.bufA = lb(BUF_QKV); a.offA = 0;
-        a.tRowA = tRowsTokens(T, s, dk * s, Ntok, qBM);
+        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM);
         a.tColA = tColsPatch(s, nchunks);
         a.bufB = lb(BUF_QKV); a.offB = 0;
         a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN);
         a.tColB = a.tColA;
         a.bufC = lb(BUF_S); a.offC = sOff;
-        a.tRowC = tRowsLinear(Ntok, ldS, qBM);
+        a.tRowC = tRowsLinear(Mtok, ldS, qBM);
         a.tColC = tColsLinear(a.tilesN * qBN / VSR_GG_KC, a.tilesN * qBN / VSR_GG_KC);
         a.bufR = -1; a.tRowR = -1; a.offBias = -1;
         // Fused softmax (exact-fp32 mode): a scale whose scores are not split along K and whose token count is whole chunks keeps
@@ -555,19 +563,19 @@ void Plan::addAttention(int T, const BlockW&)
         int64_t rmaxOff = -1;
         if (fused) {
             rmaxOff = rowmaxElems_;
-            rowmaxElems_ += rup((int64_t)a.tilesM * qBM > (int64_t)cdiv(Ntok, pBM) * pBM ? (int64_t)a.tilesM * qBM : (int64_t)cdiv(Ntok, pBM) * pBM, 32);
+            rowmaxElems_ += rup((int64_t)a.tilesM * qBM > (int64_t)cdiv(Mtok, pBM) * pBM ? (int64_t)a.tilesM * qBM : (int64_t)cdiv(Mtok, pBM) * pBM, 32);
             a.alpha = (float)((double)scale * 1.4426950408889634);   // log2(e): the P.V kernel exponentiates with v_exp_f32 (2^x)
             a.act |= VSR_ACT_ROW_MAX;
             a.bufR = BUF_ROWMAX; a.offR = rmaxOff;
         }
         qk.gemm.push_back(a);
-        qk.flops += 2.0 * Ntok * (double)Ntok * D;
+        qk.flops += 2.0 * Mtok * (double)Ntok * D;
 
         if (!fused) {
             SoftmaxItem m{};
             m.bufS = lb(BUF_S); m.offS = sOff; m.splitStride = plane; m.nsplit = splitK;
             m.bufP = lb(BUF_P); m.offP = pOff;
-            m.M = Ntok; m.N = Ntok; m.ldS = ldS; m.ldP = ldS;
+            m.M = Mtok; m.N = Ntok; m.ldS = ldS; m.ldP = ldS;
             m.scale = scale;
             sm.softmax.push_back(m);
         }
@@ -580,30 +588,30 @@ void Plan::addAttention(int T, const BlockW&)
             pvSplit = cdiv(kchunks, pvCps);
         }
         GemmItem b{};
-        b.M = Ntok; b.N = D; b.K = ldS;
-        b.tilesM = cdiv(Ntok, pBM); b.tilesN = cdiv(D, pBN);
+        b.M = Mtok; b.N = D; b.K = ldS;
+        b.tilesM = cdiv(Mtok, pBM); b.tilesN = cdiv(D, pBN);
         b.splitK = pvSplit; b.chunksPerSplit = pvCps;
         b.alpha = 1.f; b.act = VSR_ACT_NONE;
         b.bufA = fused ? lb(BUF_S) : lb(BUF_P); b.offA = fused ? sOff : pOff;
-        b.tRowA = tRowsLinear(Ntok, ldS, pBM);
+        b.tRowA = tRowsLinear(Mtok, ldS, pBM);
         b.tColA = tColsLinear(kchunks, kchunks);
         b.bufB = lb(BUF_QKV); b.offB = 0;
         b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
         b.tColB = tColsPatch(s, b.tilesN * pBN / VSR_GG_KC);
-        const int tRowAtt = tRowsTokensAct(att, T, s, pBM);
+        const int tRowAtt = tRowsTokensAct(att, Tq, s, pBM);
         const int tColAtt = tColsPatchAct(att, s, b.tilesN * pBN / VSR_GG_KC);
         if (pvSplit == 1) {
             b.bufC = lb(BUF_ATT); b.offC = 0; b.splitStride = 0;
             b.tRowC = tRowAtt;
             b.tColC = tColAtt;
         } else {        // partial planes [pvSplit][Ntok][D], combined + scattered by the reduce op
-            b.bufC = lb(BUF_PVPART); b.offC = partOff; b.splitStride = (int64_t)Ntok * D;
-            b.tRowC = tRowsLinear(Ntok, D, pBM);
+            b.bufC = lb(BUF_PVPART); b.offC = partOff; b.splitStride = (int64_t)Mtok * D;
+            b.tRowC = tRowsLinear(Mtok, D, pBM);
             b.tColC = tColsLinear(D / VSR_GG_KC, b.tilesN * pBN / VSR_GG_KC);
             Op r;
             r.kind = OP_REDUCE_SCATTER; r.tag = "attn.pv.reduce";
             r.bufSrc = lb(BUF_PVPART); r.offSrc = partOff; r.splitStride = b.splitStride; r.nsplit = pvSplit;
-            r.bufDst = lb(BUF_ATT); r.offDst = 0; r.M = Ntok; r.N = D; r.tRowC = tRowAtt; r.tColC = tColAtt;
+            r.bufDst = lb(BUF_ATT); r.offDst = 0; r.M = Mtok; r.N = D; r.tRowC = tRowAtt; r.tColC = tColAtt;
             if (fused) { r.ibuf[0] = lb(BUF_LSUM); r.ioff[0] = lOff; r.ipar[0] = b.tilesM * pBM; }
             reduces.push_back(std::move(r));
             partOff += rup(b.splitStride * pvSplit, 32);
@@ -616,7 +624,7 @@ void Plan::addAttention(int T, const BlockW&)
             pvFused = true;
         }
         pv.gemm.push_back(b);
-        pv.flops += 2.0 * Ntok * (double)Ntok * D;
+        pv.flops += 2.0 * Mtok * (double)Ntok * D;
 
         sOff += rup(plane * splitK, 32);
         if (!fused) pOff += rup(plane, 32);
@@ -678,12 +686,24 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
             need(lb(BUF_QKV), (int64_t)it.M * 3 * C);
             ops.push_back(std::move(op));
         }
-        addAttention(T, bw);
+        // The LAST block of a window is read by the decoder alone, and the decoder takes the neighbour frames only
+        // (sttn_auto_inpaint.py:150: pred_feat[:len(neighbor_ids)]).  Everything behind the K / V projection is per query row and
+        // per frame -- a score row, its softmax and its P.V row belong to one query token, the 3x3 convs stay inside a frame -- so
+        // the rows of the reference frames (the last T - nn of the window: `ids` lists the neighbours first) are computed by the
+        // reference and never read.  They are not computed here (Tuning::trimLastBlock): the neighbour rows come out bit for bit as
+        // before (same tiles' worth of products in the same order), 3 % of the chunk's FLOPs are not spent.  `refFlops` keeps the
+        // reference's count.
+        const int Tq = (tu_.trimLastBlock && b == g.blocks - 1) ? nn : T;
+        const std::vector<int> idQ = iota(Tq);
+        const std::vector<int> curIdsQ(curIds.begin(), curIds.begin() + Tq);
+        const double before = flops;
+        addAttention(Tq, T, bw);
         // x = x + LeakyReLU(conv3x3(att))            (auto_sttn.py:162-164,237)
-        addConv("attn.out", att, idT, x0, T, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIds);
+        addConv("attn.out", att, idQ, x0, Tq, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIdsQ);
         // x = x + LeakyReLU(conv3x3(LeakyReLU(conv3x3 dil2(x))))   (auto_sttn.py:214-218,238)
-        addConv("ffn.1", x0, idT, f1, T, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr);
-        addConv("ffn.2", f1, idT, x1, T, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idT);
+        addConv("ffn.1", x0, idQ, f1, Tq, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr);
+        addConv("ffn.2", f1, idQ, x1, Tq, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idQ);
+        trimmedFlops_ += (flops - before) * (double)(T - Tq) / Tq;          // every one of these ops is linear in its query frames
         cur = x1;
         curIds = idT;
     }
@@ -692,25 +712,47 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     const Act up1{lb(BUF_UP1), nn, 2 * fh, 2 * fw, C, 1}, d1{lb(BUF_D1), nn, 2 * fh, 2 * fw, 128, 1};
     const Act d2{lb(BUF_D2), nn, 2 * fh, 2 * fw, 64, 0}, up2{lb(BUF_UP2), nn, mh, mw, 64, 1}, d3{lb(BUF_D3), nn, mh, mw, 64, 1};
     const std::vector<int> idN = iota(nn);
+    // Rows of every decoder stage that the output rows [decLo, decHi) depend on (the whole image when no range was given): a 3x3
+    // conv widens by one row, the align_corners x2 upsampling of H source rows reads rows floor(y (H - 1) / (2 H - 1)) and the
+    // next one for output row y -- exactly the kernel's float arithmetic is not needed here, one row of slack on each side covers
+    // its rounding.  Rows outside a stage's range keep whatever an earlier launch left there; nothing inside the ranges reads them.
+    struct Rng { int lo, hi; };
+    auto widen = [](Rng r, int by, int H) { return Rng{r.lo - by > 0 ? r.lo - by : 0, r.hi + by < H ? r.hi + by : H}; };
+    auto below = [](Rng r, int Hsrc) {          // source rows of the x2 upsampling that produces rows r of 2 * Hsrc
+        const int OH = 2 * Hsrc;
+        int lo = (int)((int64_t)r.lo * (Hsrc - 1) / (OH - 1)) - 1, hi = (int)((int64_t)(r.hi - 1) * (Hsrc - 1) / (OH - 1)) + 3;
+        return Rng{lo > 0 ? lo : 0, hi < Hsrc ? hi : Hsrc};
+    };
+    const bool ranged = decHi > decLo && (decLo > 0 || decHi < mh);
+    const Rng rOut = ranged ? Rng{decLo, decHi} : Rng{0, mh};
+    const Rng rD3 = widen(rOut, 1, mh), rUp2 = widen(rD3, 1, mh);
+    const Rng rD2 = below(rUp2, 2 * fh), rD1 = widen(rD2, 1, 2 * fh), rUp1 = widen(rD1, 1, 2 * fh);
     {
         Op op;
         op.kind = OP_UPSAMPLE2X; op.tag = "dec.up1";
         op.bufSrc = x1.buf; op.H = fh; op.W = fw; op.C = C; op.haloS = x1.halo; op.bufDst = up1.buf; op.haloD = up1.halo;
         op.n = nn;
+        op.ipar[1] = rUp1.lo; op.ipar[2] = rUp1.hi;       // output rows
         need(up1.buf, up1.elems());
         ops.push_back(std::move(op));
     }
-    addConv("dec.1", up1, idN, d1, nn, 3, 1, 1, m_.dec[0], VSR_ACT_LRELU02, nullptr, nullptr);
-    addConv("dec.2", d1, idN, d2, nn, 3, 1, 1, m_.dec[1], VSR_ACT_LRELU02, nullptr, nullptr);
+    // (refFlops keeps the reference's count: what a ranged conv leaves out is its flops x (H / rows - 1))
+    auto skipped = [&](Rng r, int H) { trimmedFlops_ += ops.back().flops * (double)(H - (r.hi - r.lo)) / (r.hi - r.lo); };
+    addConv("dec.1", up1, idN, d1, nn, 3, 1, 1, m_.dec[0], VSR_ACT_LRELU02, nullptr, nullptr, rD1.lo, rD1.hi);
+    skipped(rD1, 2 * fh);
+    addConv("dec.2", d1, idN, d2, nn, 3, 1, 1, m_.dec[1], VSR_ACT_LRELU02, nullptr, nullptr, rD2.lo, rD2.hi);
+    skipped(rD2, 2 * fh);
     {
         Op op;
         op.kind = OP_UPSAMPLE2X; op.tag = "dec.up2";
         op.bufSrc = d2.buf; op.H = 2 * fh; op.W = 2 * fw; op.C = 64; op.haloS = d2.halo; op.bufDst = up2.buf;
         op.haloD = up2.halo; op.n = nn;
+        op.ipar[1] = rUp2.lo; op.ipar[2] = rUp2.hi;
         need(up2.buf, up2.elems());
         ops.push_back(std::move(op));
     }
-    addConv("dec.3", up2, idN, d3, nn, 3, 1, 1, m_.dec[2], VSR_ACT_LRELU02, nullptr, nullptr);
+    addConv("dec.3", up2, idN, d3, nn, 3, 1, 1, m_.dec[2], VSR_ACT_LRELU02, nullptr, nullptr, rD3.lo, rD3.hi);
+    skipped(rD3, mh);
     if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) {
         // 64 -> 3 conv over 2x4 output blocks (Model::pack_conv_blocked): row = block, columns (dy, dx, c) in a [blocks][32] buffer
         const ConvW& w = m_.dec4blk;
@@ -719,17 +761,22 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.kind = OP_GEMM; op.tag = "dec.4"; op.tileCfg = VSR_TILE_256x32; op.bmode = VSR_BMODE_NK;
         const int BM = 256, BN = 32;
         GemmItem it{};
-        it.M = nn * (mh / bh) * (mw / bw); it.N = w.cout; it.K = w.K;
+        const int by0 = rOut.lo / bh, by1 = rOut.hi / bh;      // (decLo / decHi are whole blocks: Plan::Plan)
+        it.M = nn * (by1 - by0) * (mw / bw); it.N = w.cout; it.K = w.K;
         it.tilesM = cdiv(it.M, BM); it.tilesN = 1;
         it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
         it.bufA = d3.buf; it.offA = 0;
+        std::vector<int32_t> crows;          // where a block's 32 columns go: the [frame][block row][block col] slot of the FULL image
         {   // rows: the block's top-left pixel; columns: the (bh+2) x (bw+2) window around the block, K order as packed
             std::vector<int32_t> rows;
             for (int f = 0; f < nn; ++f)
-                for (int by = 0; by < mh / bh; ++by)
-                    for (int bx = 0; bx < mw / bw; ++bx) rows.push_back((int32_t)d3.pix(f, by * bh, bx * bw));
-            while ((int)rows.size() % BM) rows.push_back(rows[0]);
-            it.tRowA = table("RBLK:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw), std::move(rows));
+                for (int by = by0; by < by1; ++by)
+                    for (int bx = 0; bx < mw / bw; ++bx) {
+                        rows.push_back((int32_t)d3.pix(f, by * bh, bx * bw));
+                        crows.push_back((int32_t)((((int64_t)f * (mh / bh) + by) * (mw / bw) + bx) * 32));
+                    }
+            while ((int)rows.size() % BM) { rows.push_back(rows[0]); crows.push_back(crows[0]); }
+            it.tRowA = table("RBLK:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw) + ":" + std::to_string(by0) + "-" + std::to_string(by1), std::move(rows));
             std::vector<int32_t> cols;
             auto off = [&](int wy, int wx, int c) { return (int32_t)(((int64_t)(wy - 1) * d3.Wp() + (wx - 1)) * d3.C + c); };
             if (tu_.convChannelMajor) {
@@ -747,15 +794,16 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         it.tRowB = tRowsLinear(it.N, it.K, BN);
         it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
         it.bufC = lb(BUF_D4); it.offC = 0;
-        it.tRowC = tRowsLinear(it.M, 32, BM);
+        it.tRowC = table("CBLKROW:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw) + ":" + std::to_string(by0) + "-" + std::to_string(by1), std::move(crows));
         it.tColC = tColsLinear(1, 1);
         it.offBias = w.b;
         it.bufR = -1; it.tRowR = -1;
-        op.flops = 2.0 * (double)nn * mh * mw * 3.0 * (9.0 * d3.C);     // the algorithmic work of the 3x3 conv, not the padded window's
+        op.flops = 2.0 * (double)nn * (rOut.hi - rOut.lo) * mw * 3.0 * (9.0 * d3.C);     // the algorithmic work of the 3x3 conv, not the padded window's
         flops += op.flops;
         op.gemm.push_back(it);
-        need(lb(BUF_D4), (int64_t)it.tilesM * BM * 32);
+        need(lb(BUF_D4), (int64_t)cdiv(nn * (mh / bh) * (mw / bw), BM) * BM * 32);
         ops.push_back(std::move(op));
+        skipped(rOut, mh);
     } else
     {   // 64 -> 3 conv into a plain [M][32] buffer (columns 0..2 valid)
         const ConvW& w = m_.dec[3];
@@ -763,6 +811,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.kind = OP_GEMM; op.tag = "dec.4"; op.tileCfg = VSR_TILE_256x32; op.bmode = VSR_BMODE_NK;
         const int BM = 256, BN = 32;
         GemmItem it{};
+        if (ranged) throw std::runtime_error("a decoder row range needs the blocked output conv (VSR_OUT_CONV_BLOCKED=1)");
         it.M = nn * mh * mw; it.N = w.cout; it.K = w.K;
         it.tilesM = cdiv(it.M, BM); it.tilesN = 1;
         it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
@@ -787,6 +836,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         Op op;
         op.kind = OP_DECODE_OUT; op.tag = "dec.out";
         op.bufSrc = lb(BUF_D4); op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
+        op.ipar[1] = rOut.lo; op.ipar[2] = rOut.hi;       // rows of the mw-wide image that are decoded and averaged
         if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) op.W = mw;   // src rows are 2x4 blocks of a mw-wide image
         op.bufMask = g.variant == 1 ? BUF_MASK_U8 : -1;   // sttn-det: model-resolution blend with the input frames
         std::vector<int32_t> fi, fs;
@@ -808,9 +858,16 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     ++nwindows;
 }
 
-Plan::Plan(const Model& model, int L_, int precision_, int lanes_)
+Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, int decHi_)
     : L(L_), precision(precision_), lanes(lanes_ < 1 ? 1 : (lanes_ > kMaxLanes ? kMaxLanes : lanes_)), g(model.g), m_(model), tu_(Tuning::get(precision_))
 {
+    if (decHi_ > decLo_ && tu_.outConvBlocked && g.modelH % Model::kOutBlkH == 0 && g.modelW % Model::kOutBlkW == 0) {
+        // whole 2-row blocks of the output conv, inside the image (the per-pixel form of that conv keeps the whole image)
+        decLo = (decLo_ < 0 ? 0 : decLo_) / Model::kOutBlkH * Model::kOutBlkH;
+        decHi = (decHi_ > g.modelH ? g.modelH : decHi_);
+        decHi = (decHi + Model::kOutBlkH - 1) / Model::kOutBlkH * Model::kOutBlkH;
+        if (decHi > g.modelH) decHi = g.modelH;
+    }
     if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
     if (L <= 0) throw std::runtime_error("empty frame list");
     bufElems.assign(BUF_COUNT, 0);
@@ -882,6 +939,7 @@ Plan::Plan(const Model& model, int L_, int precision_, int lanes_)
     }
     lane_ = 0;
     compCount = visits;
+    refFlops = flops + trimmedFlops_;
 }
 
 // ------------------------------------------------------------------------------------

@@ -36,6 +36,8 @@ struct Tuning {
                          //   chunks when it has at least twice as many (0 = never split)
     int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
     int outConvBlocked;  // VSR_OUT_CONV_BLOCKED: 1 = the 64 -> 3 output conv runs over 2x4 output blocks (Model::pack_conv_blocked)
+    int trimLastBlock;   // VSR_TRIM_LAST_BLOCK: 1 = the last transformer block of a window computes its attention output, out-conv and
+                         //   FFN for the NEIGHBOUR frames only -- the decoder reads nothing else (Plan::buildWindow); same bits
     int fuseSoftmax;     // VSR_FUSE_SOFTMAX: 1 = exact-fp32 mode keeps no probability matrix for the scales whose scores are not
                          //   split along K: row max in the QK^T epilogue, exp + row sum while P.V stages its A tiles (0 = k_softmax_rows)
     // precision 0: exact fp32 MFMA kernels; 1: split-half f16 MFMA kernels (larger tiles pay there)
@@ -161,7 +163,9 @@ struct PlanIR {
     std::vector<std::vector<int32_t>> tables;
     std::vector<Op> ops;
     std::vector<int32_t> compCount;       // STTN: decodes per frame (1 => comp stays u8)
-    double flops = 0;                     // algorithmic model flops of the whole call
+    double flops = 0;                     // algorithmic model flops of the whole call (what the plan's GEMMs contract)
+    double refFlops = 0;                  // STTN: flops of the call as the reference computes it -- `flops` + the rows of the last block
+                                          // that nothing reads (Plan::buildWindow); equal to `flops` for every other plan
     virtual ~PlanIR() {}
 };
 
@@ -182,7 +186,11 @@ protected:
 
 class Plan : public PlanBuilder {
 public:
-    Plan(const Model& model, int L, int precision = 0, int lanes = 1);
+    // decLo / decHi: rows [decLo, decHi) of the model-resolution output are all the caller will read (sttn-auto blends the strip back
+    // only where the mask is set: vsr_sttn_auto_chunk) -- the decoder computes those rows and what they depend on, nothing else
+    // (buildWindow); decHi <= decLo = the whole image
+    Plan(const Model& model, int L, int precision = 0, int lanes = 1, int decLo = 0, int decHi = 0);
+    int decLo = 0, decHi = 0;            // as given, clipped to the image and widened to whole 2-row blocks of the output conv
     int L;
     int precision;
     int lanes;                           // 1 .. kMaxLanes: window w runs on lane w % lanes
@@ -195,6 +203,7 @@ private:
     int lane_ = 0;                       // lane of the window being built
     int lb(int buf) const { return laneBuf(buf, lane_); }
     int64_t rowmaxElems_ = 0;            // BUF_ROWMAX handed out so far: every fused attention instance of the plan has its own array
+    double trimmedFlops_ = 0;            // what the reference spends on last-block rows nobody reads (buildWindow)
     int pickTile(int N) const;
     int tRowsTokens(int T, int s, int choff, int count, int padTo);
     int tColsPatch(int s, int padTo);
@@ -202,8 +211,8 @@ private:
     int tColsPatchAct(const Act& a, int s, int padTo);
     void addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut,
                  int ksz, int stride, int dil, const ConvW& w, int act, const Act* res,
-                 const std::vector<int>* resIds);
-    void addAttention(int T, const BlockW& bw);
+                 const std::vector<int>* resIds, int ylo = 0, int yhi = -1);     // [ylo, yhi): output rows computed (stride 1; default all)
+    void addAttention(int Tq, int T, const BlockW& bw);
     void buildWindow(const std::vector<int>& neighbors, const std::vector<int>& refs,
                      std::vector<int32_t>& visits);
 };

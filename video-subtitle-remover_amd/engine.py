@@ -5,6 +5,7 @@ raw pointers), the current HIP stream and, for multi-GPU, torch.distributed.  Al
 of the hot path happens inside the library's hand-written kernels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -85,8 +86,10 @@ class SttnEngine:
         check(lib.vsr_sttn_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
 
-    def flops(self, L):
-        v = lib.vsr_sttn_flops(self._h, int(L))
+    def flops(self, L, reference=False):
+        """FLOPs of one inpaint(L) call as contracted here; reference=True: as the reference's modules compute it (the rows of the
+        last block that nothing reads included)"""
+        v = (lib.vsr_sttn_flops_reference if reference else lib.vsr_sttn_flops)(self._h, int(L))
         if v < 0:
             raise _lib.VsrError(_lib.VSR_ERR_ARG, _lib.last_error())
         return v
@@ -109,18 +112,58 @@ class SttnEngine:
                                        counts.ctypes.data_as(C.c_void_p), _stream_ptr()))
         return comp, counts
 
-    def auto_chunk(self, frames_dev, mask_dev, areas, sel=None):
-        """One chunk of STTNAutoInpaint.__call__, in place on frames_dev uint8 [L,H,W,3] BGR."""
+    def mask_rows(self, mask_dev, areas):
+        """int32 [n_areas, 2]: for every area the rows [lo, hi) of its strip that hold the mask's set pixels (lo = hi = 0: none) --
+        the promise vsr_sttn_auto_chunk_rows takes.  Read off the device mask once per mask (one row-flag reduction and a
+        download of H bytes) and kept while the same tensor object stays unmodified (its version counter)."""
+        ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
+        ent = getattr(self, "_mask_rows_cache", None)
+        if ent is not None and ent[0]() is mask_dev and ent[1] == mask_dev._version and np.array_equal(ent[2], ar):
+            return ent[3]
+        import weakref
+
+        H, W = int(mask_dev.shape[0]), int(mask_dev.shape[1])
+        flags = mask_dev.reshape(H, W).ne(0).any(dim=1).cpu().numpy()
+        rows = np.zeros((ar.shape[0], 2), dtype=np.int32)
+        for k, (ymin, ymax, _, _) in enumerate(ar):
+            nz = np.flatnonzero(flags[int(ymin):int(ymax)])
+            if nz.size:
+                rows[k] = (int(nz[0]), int(nz[-1]) + 1)
+        self._mask_rows_cache = (weakref.ref(mask_dev), mask_dev._version, ar.copy(), rows)
+        return rows
+
+    def chunk_flops(self, L, mask_dev, areas):
+        """FLOPs of one auto_chunk call on this mask: every area's plan decodes only the rows its mask rows are resized from"""
+        ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
+        total = 0.0
+        for (ymin, ymax, _, _), (lo, hi) in zip(ar, self.mask_rows(mask_dev, ar)):
+            if hi > lo and os.environ.get("VSR_DECODE_ROWS", "1") != "0":
+                a, b = C.c_int32(), C.c_int32()
+                check(lib.vsr_sttn_decode_rows(self._h, int(ymax - ymin), int(lo), int(hi), C.byref(a), C.byref(b)))
+                v = lib.vsr_sttn_flops_rows(self._h, int(L), a.value, b.value)
+            else:
+                v = lib.vsr_sttn_flops(self._h, int(L))
+            if v < 0:
+                raise _lib.VsrError(_lib.VSR_ERR_ARG, _lib.last_error())
+            total += v
+        return total
+
+    def auto_chunk(self, frames_dev, mask_dev, areas, sel=None, decode_rows=True):
+        """One chunk of STTNAutoInpaint.__call__, in place on frames_dev uint8 [L,H,W,3] BGR.  The rows of every strip that hold the
+        mask go along (mask_rows): the decoder then computes only what the blend reads -- same frames (vsr_sttn_auto_chunk_rows)."""
         assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
         assert mask_dev.dtype == torch.uint8 and mask_dev.is_cuda and mask_dev.is_contiguous()
         L, H, W, _ = frames_dev.shape
         assert tuple(mask_dev.shape[:2]) == (H, W)
         ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
         sel_arr = None if sel is None else np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
+        # decode_rows=False: no promise about the mask, the whole model-resolution image is decoded (tests compare the two)
+        rows = np.ascontiguousarray(self.mask_rows(mask_dev, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
         with torch.cuda.device(frames_dev.device):
-            check(lib.vsr_sttn_auto_chunk(
+            check(lib.vsr_sttn_auto_chunk_rows(
                 self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()), ar.shape[0],
-                ar.ctypes.data_as(C.c_void_p), None if sel_arr is None else sel_arr.ctypes.data_as(C.c_void_p),
+                ar.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p),
+                None if sel_arr is None else sel_arr.ctypes.data_as(C.c_void_p),
                 0 if sel_arr is None else int(sel_arr.size), _stream_ptr()))
         return frames_dev
 
