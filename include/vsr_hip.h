@@ -106,6 +106,11 @@ int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t
                          int32_t* counts, void* stream);
 int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
                        const int32_t* areas, void* stream);
+/* with the promise of vsr_sttn_auto_chunk_rows (mask_rows host [n_areas][2]: strip rows outside which mask_dev is zero): the
+ * prediction is taken only where the resized mask is non-zero (:132,168), every other pixel of the composite is the input
+ * frame -- the decoder runs on the model rows the mask rows are resized to; same frames */
+int vsr_sttn_det_batch_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                            const int32_t* areas, const int32_t* mask_rows, void* stream);
 
 /* Arithmetic of the contractions.  0 (default): exact fp32 -- v_mfma_f32_32x32x2_f32, bitwise an fmaf chain.
  * 1: split-half -- fp32 data and fp32 accumulation, each fp32 operand fed to the f16 matrix cores as

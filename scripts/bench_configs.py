@@ -49,7 +49,7 @@ def run_auto(name, res, precision, steps=4, warmup=1, L=50):
     dt = timed(step, steps, warmup)
     fps = steps * L / dt
     out = {"config": name, "mode": "sttn-auto", "res": res, "precision": precision, "chunk_frames": L, "fps": round(fps, 2),
-           "ms_per_chunk": round(dt / steps * 1e3, 2), "model_tflops": round(eng.flops(L) / L * fps / 1e12, 2),
+           "ms_per_chunk": round(dt / steps * 1e3, 2), "model_tflops": round(eng.chunk_flops(L, dmask, areas) / L * fps / 1e12, 2),
            "fp32_fallback_chunks": eng.fallbacks()}
     eng.close()
     print(json.dumps(out), flush=True)
@@ -79,7 +79,7 @@ def run_det(name, res, precision, total=1200, reps=1):
         per[L] = dt / (3 if L == Lmax else 2)
     wall = sum(per[L] for L in sizes)
     fps = total / wall
-    flops = sum(eng.flops(L) for L in sizes)
+    flops = sum(eng.chunk_flops(L, dmask, areas) for L in sizes)          # what is contracted (last block / decoder rows trimmed to what is read)
     out = {"config": name, "mode": "sttn-det", "res": res, "precision": precision, "batches": f"{sizes.count(Lmax)}x{Lmax}+{sizes[-1]}",
            "fps": round(fps, 2), "ms_per_batch": {str(L): round(per[L] * 1e3, 2) for L in sample},
            "model_tflops": round(flops / wall / 1e12, 2), "gflop_per_frame": round(flops / total / 1e9, 1)}

@@ -396,6 +396,30 @@ def test_decoder_rows_give_the_same_frames(built_lib, gpu_device, sd, mode, H, W
     eng.close()
 
 
+@pytest.mark.parametrize("H,W,box", [(720, 1280, (620, 700, 192, 1088)), (1080, 1920, (40, 160, 288, 1632)), (480, 852, (150, 400, 50, 800))])
+def test_decoder_rows_give_the_same_frames_det(built_lib, gpu_device, sd_det, H, W, box):
+    """vsr_sttn_det_batch_rows: the prediction is taken where the resized mask is non-zero, every other composite pixel is the input
+    frame -- with the promise about the mask rows the decoder (and the last block) run on the model rows the mask is resized to only;
+    the frames are the ones of the call without the promise bit for bit; the host-mask and the device-mask route give the same rows."""
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.backend.tools.inpaint_tools import create_mask as cm, get_inpaint_area_by_mask as ga
+
+    eng = SttnEngine(sd_det, "det", device=0)
+    frames = torch.from_numpy(synth.make_clip(9, H, W, box, seed=12)).to(gpu_device)
+    mask = cm((H, W), [(box[2], box[3], box[0], box[1])])
+    areas = ga(W, H, int(W * 5 / 18), mask[:, :, None])
+    dmask = torch.from_numpy(np.ascontiguousarray(mask)).to(gpu_device)
+    assert np.array_equal(eng.mask_rows(dmask, areas), eng.mask_rows(mask, areas))
+    a, b, c = frames.clone(), frames.clone(), frames.clone()
+    eng.det_batch(a, dmask, areas, decode_rows=False)
+    eng.det_batch(b, dmask, areas)
+    eng.det_batch(c, dmask, areas, mask_host=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert not torch.equal(a, frames)
+    eng.close()
+
+
 def test_two_lanes_equal_one_lane_det(built_lib, gpu_device, sd_det):
     from vsr_amd.engine import SttnEngine
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     "vsr_sttn_flops_rows": (_D, [_P, _I, _I, _I]),
     "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vsr_sttn_det_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "vsr_sttn_det_batch_rows": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "vsr_sttn_set_precision": (_I, [_P, _I]),
     "vsr_sttn_set_lanes": (_I, [_P, _I]),
     "vsr_sttn_fallbacks": (_L, [_P]),

@@ -68,7 +68,7 @@ class STTNInpaint:
         dev = self.engine.device
         frames = torch.from_numpy(np.ascontiguousarray(np.stack(input_frames))).to(dev, non_blocking=True)
         dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(dev, non_blocking=True)
-        self.engine.auto_chunk(frames, dmask, inpaint_area)
+        self.engine.auto_chunk(frames, dmask, inpaint_area, mask_host=mask[:, :, 0])
         out = frames.cpu().numpy()
         return [out[i] for i in range(out.shape[0])]
 
@@ -148,6 +148,7 @@ class STTNAutoInpaint:
         y_hi = max((a[1] for a in inpaint_area), default=0)
         local_areas = [(a[0] - y_lo, a[1] - y_lo, a[2], a[3]) for a in inpaint_area]
         dmask = torch.from_numpy(np.ascontiguousarray(mask[y_lo:y_hi, :, 0])).to(engine.device) if inpaint_area else None
+        mask_rows_host = mask[y_lo:y_hi, :, 0] if inpaint_area else None     # the engine reads the rows that hold the mask off this copy
         kept = {}
 
         def tick(original, frame):
@@ -179,7 +180,7 @@ class STTNAutoInpaint:
             n = len(kept[i]) if i in kept else e - s     # the owner of the frame source knows how many frames were read
             sel = [j - s for j in range(s, s + n) if is_frame_number_in_ab_sections(j, ab_sections)]
             if sel:
-                engine.auto_chunk(rows[:n], dmask, local_areas, sel=None if len(sel) == n else sel)
+                engine.auto_chunk(rows[:n], dmask, local_areas, sel=None if len(sel) == n else sel, mask_host=mask_rows_host)
 
         def store(i, rows):
             for j, frame in enumerate(kept.pop(i)):

@@ -44,14 +44,14 @@ class STTNDetInpaint:
         if isinstance(input_frames, torch.Tensor):
             if inpaint_area and input_frames.shape[0]:
                 dmask = torch.from_numpy(np.ascontiguousarray(input_mask)).to(input_frames.device, non_blocking=True)
-                self.engine.det_batch(input_frames, dmask, inpaint_area)
+                self.engine.det_batch(input_frames, dmask, inpaint_area, mask_host=input_mask)
             return input_frames
         if not inpaint_area or len(input_frames) == 0:
             return [f.copy() for f in input_frames]
         dev = self.engine.device
         frames = torch.from_numpy(np.ascontiguousarray(np.stack(input_frames))).to(dev, non_blocking=True)
         dmask = torch.from_numpy(np.ascontiguousarray(input_mask)).to(dev, non_blocking=True)
-        self.engine.det_batch(frames, dmask, inpaint_area)
+        self.engine.det_batch(frames, dmask, inpaint_area, mask_host=input_mask)
         out = frames.cpu().numpy()
         return [out[i] for i in range(out.shape[0])]
 

@@ -783,7 +783,7 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
     // model-resolution rows every area needs (0, 0 = all)
     static const bool rowsOn = [] { const char* e = getenv("VSR_DECODE_ROWS"); return !(e && atoi(e) == 0); }();
     std::vector<int> decLo((size_t)n_areas, 0), decHi((size_t)n_areas, 0);
-    if (!det && maskRows && rowsOn) {
+    if (maskRows && rowsOn) {
         for (int k = 0; k < n_areas; ++k) {
             const int sh = areas[4 * k + 1] - areas[4 * k];
             const int r0 = maskRows[2 * k], r1 = maskRows[2 * k + 1];
@@ -791,15 +791,28 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
             std::vector<int32_t> ofs;
             std::vector<int16_t> ic;
             std::vector<float> fc;
-            cv2_linear_tables(mh, sh, false, ofs, ic, fc);                   // the vertical taps of the resize back (k_upscale_blend)
-            auto clampRow = [&](int y) { return y < 0 ? 0 : (y < mh ? y : mh - 1); };
             int lo = mh, hi = 0;
-            for (int dy = r0; dy < r1; ++dy) {
-                const int a = clampRow(ofs[dy]), b = clampRow(ofs[dy] + 1);
-                lo = a < lo ? a : lo;
-                hi = b + 1 > hi ? b + 1 : hi;
+            if (!det) {
+                // sttn-auto: the strip is blended back where the mask is set -- the model rows the vertical taps of the resize back
+                // (k_upscale_blend) read for those strip rows
+                cv2_linear_tables(mh, sh, false, ofs, ic, fc);
+                auto clampRow = [&](int y) { return y < 0 ? 0 : (y < mh ? y : mh - 1); };
+                for (int dy = r0; dy < r1; ++dy) {
+                    const int a = clampRow(ofs[dy]), b = clampRow(ofs[dy] + 1);
+                    lo = a < lo ? a : lo;
+                    hi = b + 1 > hi ? b + 1 : hi;
+                }
+            } else {
+                // sttn-det: the prediction is taken where the RESIZED mask is non-zero (sttn_det_inpaint.py:132,168), at model
+                // resolution -- the model rows one of whose two source rows (the vertical taps of the resize down) is a mask row
+                cv2_linear_tables(sh, mh, false, ofs, ic, fc);
+                auto clampRow = [&](int y) { return y < 0 ? 0 : (y < sh ? y : sh - 1); };
+                for (int y = 0; y < mh; ++y) {
+                    const int a = clampRow(ofs[y]), b = clampRow(ofs[y] + 1);
+                    if (b >= r0 && a < r1) { lo = y < lo ? y : lo; hi = y + 1 > hi ? y + 1 : hi; }
+                }
             }
-            decLo[k] = lo; decHi[k] = hi;
+            if (hi > lo) { decLo[k] = lo; decHi[k] = hi; }
         }
     }
     PlanDev* pd = nullptr;
@@ -889,14 +902,24 @@ int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_r
     std::vector<int32_t> ofs;
     std::vector<int16_t> ic;
     std::vector<float> fc;
-    cv2_linear_tables(mh, strip_h, false, ofs, ic, fc);
-    auto clampRow = [&](int y) { return y < 0 ? 0 : (y < mh ? y : mh - 1); };
     int lo = mh, hi = 0;
-    for (int dy = mask_row_lo; dy < mask_row_hi; ++dy) {
-        const int a = clampRow(ofs[dy]), b = clampRow(ofs[dy] + 1);
-        lo = a < lo ? a : lo;
-        hi = b + 1 > hi ? b + 1 : hi;
+    if (h->model.g.variant != VSR_VARIANT_STTN_DET) {    // the same two rules as strips_common
+        cv2_linear_tables(mh, strip_h, false, ofs, ic, fc);
+        auto clampRow = [&](int y) { return y < 0 ? 0 : (y < mh ? y : mh - 1); };
+        for (int dy = mask_row_lo; dy < mask_row_hi; ++dy) {
+            const int a = clampRow(ofs[dy]), b = clampRow(ofs[dy] + 1);
+            lo = a < lo ? a : lo;
+            hi = b + 1 > hi ? b + 1 : hi;
+        }
+    } else {
+        cv2_linear_tables(strip_h, mh, false, ofs, ic, fc);
+        auto clampRow = [&](int y) { return y < 0 ? 0 : (y < strip_h ? y : strip_h - 1); };
+        for (int y = 0; y < mh; ++y) {
+            const int a = clampRow(ofs[y]), b = clampRow(ofs[y] + 1);
+            if (b >= mask_row_lo && a < mask_row_hi) { lo = y < lo ? y : lo; hi = y + 1 > hi ? y + 1 : hi; }
+        }
     }
+    if (hi <= lo) { lo = 0; hi = mh; }
     Plan p(h->model, 1, 0, 1, lo, hi);                   // (the widening to whole output-conv blocks)
     *row_lo = p.decLo; *row_hi = p.decHi;
     return 0;
@@ -908,6 +931,14 @@ int vsr_sttn_det_batch(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, 
     RCCHK(need_gpu(h));
     if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
     return strips_common(h, true, frames_dev, L, H, W, mask_dev, n_areas, areas, nullptr, 0, (hipStream_t)stream_);
+}
+
+int vsr_sttn_det_batch_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                            const int32_t* areas, const int32_t* mask_rows, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
+    return strips_common(h, true, frames_dev, L, H, W, mask_dev, n_areas, areas, nullptr, 0, (hipStream_t)stream_, mask_rows);
 }
 
 int vsr_sttn_set_precision(vsr_sttn_t* h, int mode)

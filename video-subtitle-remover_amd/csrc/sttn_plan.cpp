@@ -371,16 +371,17 @@ int PlanBuilder::tColsLinear(int nchunks, int padTo)
 
 // token (t, oy, ox) of scale s inside the plain QKV buffer [T*fh*fw][3C] (auto_sttn.py:182-190:
 // view(b,t,d_k,out_h,height,out_w,width).permute(0,1,3,5,2,4,6) => tokens ordered t, out_h, out_w)
-int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo)
+int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0, int oy1)
 {
+    const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, C3 = 3 * g.channels;
+    if (oy1 < 0) oy1 = oh;
     const std::string key = "RT:" + std::to_string(T) + ":" + std::to_string(s) + ":" + std::to_string(choff) + ":" +
-                            std::to_string(count) + ":" + std::to_string(padTo);
+                            std::to_string(count) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1);
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
-    const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, C3 = 3 * g.channels;
     std::vector<int32_t> v;
     for (int t = 0; t < T; ++t)
-        for (int oy = 0; oy < oh; ++oy)
+        for (int oy = oy0; oy < oy1; ++oy)
             for (int ox = 0; ox < ow; ++ox) {
                 const int64_t o = (((int64_t)t * g.featH + oy * ph) * g.featW + ox * pw) * C3 + choff;
                 checkFits(o);
@@ -409,16 +410,17 @@ int Plan::tColsPatch(int s, int padTo)
     return table(key, std::move(v));
 }
 
-int Plan::tRowsTokensAct(const Act& a, int T, int s, int padTo)
+int Plan::tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0, int oy1)
 {
+    const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, dk = g.channels / g.nscales;
+    if (oy1 < 0) oy1 = oh;
     const std::string key = "RTA:" + std::to_string(a.buf) + ":" + std::to_string(a.halo) + ":" + std::to_string(T) +
-                            ":" + std::to_string(s) + ":" + std::to_string(padTo);
+                            ":" + std::to_string(s) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1);
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
-    const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, dk = g.channels / g.nscales;
     std::vector<int32_t> v;
     for (int t = 0; t < T; ++t)
-        for (int oy = 0; oy < oh; ++oy)
+        for (int oy = oy0; oy < oy1; ++oy)
             for (int ox = 0; ox < ow; ++ox) {
                 const int64_t o = a.pix(t, oy * ph, ox * pw) + (int64_t)dk * s;
                 checkFits(o);
@@ -510,8 +512,11 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
 // would otherwise leave half the chip idle) and combined by a reduce-scatter pass.
 // Tq <= T: the QUERY frames are the first Tq of the T frames (the keys and values are all T): the last block of a window only needs
 // the rows of its neighbour frames (Plan::buildWindow)
-void Plan::addAttention(int Tq, int T, const BlockW&)
+// [attLo, attHi): the feature rows of the attention output that anything reads (the last block of a window that feeds a ranged
+// decoder): the query tokens are the patches that touch those rows
+void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi)
 {
+    if (attHi < 0) attHi = g.featH;
     const Tuning& tu = tu_;
     const int C = g.channels, dk = C / g.nscales;
     const Act att{lb(BUF_ATT), T, g.featH, g.featW, C, 1};
@@ -529,7 +534,8 @@ void Plan::addAttention(int Tq, int T, const BlockW&)
         const int pw = g.patchW[s], ph = g.patchH[s];
         const int Pn = (g.featW / pw) * (g.featH / ph);
         const int Ntok = T * Pn;        // key / value tokens
-        const int Mtok = Tq * Pn;       // query tokens (frame-major: the first Tq frames)
+        const int oy0 = attLo / ph, oy1 = cdiv(attHi, ph);       // patch rows that touch the rows read
+        const int Mtok = Tq * (oy1 - oy0) * (g.featW / pw);      // query tokens: the first Tq frames (frame-major), those patch rows
         const int D = dk * pw * ph;
         const int ldS = (int)rup(Ntok, VSR_GG_KC);
         const int nchunks = D / VSR_GG_KC;
@@ -545,7 +551,7 @@ void Plan::addAttention(int Tq, int T, const BlockW&)
         a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
         a.alpha = 1.f; a.act = VSR_ACT_NONE;
         a.bufA = lb(BUF_QKV); a.offA = 0;
-        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM);
+        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM, oy0, oy1);
         a.tColA = tColsPatch(s, nchunks);
         a.bufB = lb(BUF_QKV); a.offB = 0;
         a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN);
@@ -598,7 +604,7 @@ void Plan::addAttention(int Tq, int T, const BlockW&)
         b.bufB = lb(BUF_QKV); b.offB = 0;
         b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
         b.tColB = tColsPatch(s, b.tilesN * pBN / VSR_GG_KC);
-        const int tRowAtt = tRowsTokensAct(att, Tq, s, pBM);
+        const int tRowAtt = tRowsTokensAct(att, Tq, s, pBM, oy0, oy1);
         const int tColAtt = tColsPatchAct(att, s, b.tilesN * pBN / VSR_GG_KC);
         if (pvSplit == 1) {
             b.bufC = lb(BUF_ATT); b.offC = 0; b.splitStride = 0;
@@ -656,6 +662,25 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     const Act att{lb(BUF_ATT), T, fh, fw, C, 1}, f1{lb(BUF_F1), T, fh, fw, C, 1};
     const std::vector<int> idT = iota(T);
 
+    // Rows of every decoder stage that the output rows [decLo, decHi) depend on (the whole image when no range was given): a 3x3
+    // conv widens by one row, the align_corners x2 upsampling of H source rows reads rows floor(y (H - 1) / (2 H - 1)) and the
+    // next one for output row y -- the kernel's float arithmetic is not repeated here, one row of slack on each side covers its
+    // rounding.  Rows outside a stage's range keep whatever an earlier launch left there; nothing inside the ranges reads them.
+    struct Rng { int lo, hi; };
+    auto widen = [](Rng r, int by, int H) { return Rng{r.lo - by > 0 ? r.lo - by : 0, r.hi + by < H ? r.hi + by : H}; };
+    auto below = [](Rng r, int Hsrc) {          // source rows of the x2 upsampling that produces rows r of 2 * Hsrc
+        const int OH = 2 * Hsrc;
+        int lo = (int)((int64_t)r.lo * (Hsrc - 1) / (OH - 1)) - 1, hi = (int)((int64_t)(r.hi - 1) * (Hsrc - 1) / (OH - 1)) + 3;
+        return Rng{lo > 0 ? lo : 0, hi < Hsrc ? hi : Hsrc};
+    };
+    const bool ranged = decHi > decLo && (decLo > 0 || decHi < mh);
+    const Rng rOut = ranged ? Rng{decLo, decHi} : Rng{0, mh};
+    const Rng rD3 = widen(rOut, 1, mh), rUp2 = widen(rD3, 1, mh);
+    const Rng rD2 = below(rUp2, 2 * fh), rD1 = widen(rD2, 1, 2 * fh), rUp1 = widen(rD1, 1, 2 * fh);
+    const Rng rX1 = below(rUp1, fh);            // rows of the last block's output the decoder reads
+    const int lastLo = rX1.lo, lastHi = rX1.hi;
+    double fullBlockFlops = 0;
+
     Act cur = feats;
     std::vector<int> curIds = ids;
     for (int b = 0; b < g.blocks; ++b) {
@@ -693,17 +718,29 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         // reference and never read.  They are not computed here (Tuning::trimLastBlock): the neighbour rows come out bit for bit as
         // before (same tiles' worth of products in the same order), 3 % of the chunk's FLOPs are not spent.  `refFlops` keeps the
         // reference's count.
-        const int Tq = (tu_.trimLastBlock && b == g.blocks - 1) ? nn : T;
+        // With a decoder row range (Plan::decLo) the same holds for ROWS: the decoder's first upsampling reads feature rows
+        // [lastLo, lastHi) of the last block's output (the chain is walked backwards at the top of this function), its second 3x3
+        // conv needs one more row of the first conv's output on each side, the first (dilation 2) two more of the out-conv's, the
+        // out-conv one more of the attention output, and the attention output rows belong to the patches that touch them.
+        const bool last = tu_.trimLastBlock && b == g.blocks - 1;
+        const int Tq = last ? nn : T;
+        const int r2lo = last ? lastLo : 0, r2hi = last ? lastHi : fh;                       // ffn.2 output = the block's output
+        auto wide = [&](int lo, int hi, int by, int& olo, int& ohi) { olo = lo - by > 0 ? lo - by : 0; ohi = hi + by < fh ? hi + by : fh; };
+        int r1lo, r1hi, r0lo, r0hi, ralo, rahi;
+        wide(r2lo, r2hi, 1, r1lo, r1hi);                                                       // ffn.1 output
+        wide(r2lo, r2hi, 3, r0lo, r0hi);                                                       // out-conv output (and the residual of ffn.2)
+        wide(r2lo, r2hi, 4, ralo, rahi);                                                       // attention output
         const std::vector<int> idQ = iota(Tq);
         const std::vector<int> curIdsQ(curIds.begin(), curIds.begin() + Tq);
         const double before = flops;
-        addAttention(Tq, T, bw);
+        addAttention(Tq, T, bw, ralo, rahi);
         // x = x + LeakyReLU(conv3x3(att))            (auto_sttn.py:162-164,237)
-        addConv("attn.out", att, idQ, x0, Tq, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIdsQ);
+        addConv("attn.out", att, idQ, x0, Tq, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIdsQ, r0lo, r0hi);
         // x = x + LeakyReLU(conv3x3(LeakyReLU(conv3x3 dil2(x))))   (auto_sttn.py:214-218,238)
-        addConv("ffn.1", x0, idQ, f1, Tq, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr);
-        addConv("ffn.2", f1, idQ, x1, Tq, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idQ);
-        trimmedFlops_ += (flops - before) * (double)(T - Tq) / Tq;          // every one of these ops is linear in its query frames
+        addConv("ffn.1", x0, idQ, f1, Tq, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr, r1lo, r1hi);
+        addConv("ffn.2", f1, idQ, x1, Tq, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idQ, r2lo, r2hi);
+        if (last && b > 0) trimmedFlops_ += fullBlockFlops - (flops - before);               // (the blocks of a window are alike in full form)
+        else fullBlockFlops = flops - before;
         cur = x1;
         curIds = idT;
     }
@@ -712,21 +749,6 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     const Act up1{lb(BUF_UP1), nn, 2 * fh, 2 * fw, C, 1}, d1{lb(BUF_D1), nn, 2 * fh, 2 * fw, 128, 1};
     const Act d2{lb(BUF_D2), nn, 2 * fh, 2 * fw, 64, 0}, up2{lb(BUF_UP2), nn, mh, mw, 64, 1}, d3{lb(BUF_D3), nn, mh, mw, 64, 1};
     const std::vector<int> idN = iota(nn);
-    // Rows of every decoder stage that the output rows [decLo, decHi) depend on (the whole image when no range was given): a 3x3
-    // conv widens by one row, the align_corners x2 upsampling of H source rows reads rows floor(y (H - 1) / (2 H - 1)) and the
-    // next one for output row y -- exactly the kernel's float arithmetic is not needed here, one row of slack on each side covers
-    // its rounding.  Rows outside a stage's range keep whatever an earlier launch left there; nothing inside the ranges reads them.
-    struct Rng { int lo, hi; };
-    auto widen = [](Rng r, int by, int H) { return Rng{r.lo - by > 0 ? r.lo - by : 0, r.hi + by < H ? r.hi + by : H}; };
-    auto below = [](Rng r, int Hsrc) {          // source rows of the x2 upsampling that produces rows r of 2 * Hsrc
-        const int OH = 2 * Hsrc;
-        int lo = (int)((int64_t)r.lo * (Hsrc - 1) / (OH - 1)) - 1, hi = (int)((int64_t)(r.hi - 1) * (Hsrc - 1) / (OH - 1)) + 3;
-        return Rng{lo > 0 ? lo : 0, hi < Hsrc ? hi : Hsrc};
-    };
-    const bool ranged = decHi > decLo && (decLo > 0 || decHi < mh);
-    const Rng rOut = ranged ? Rng{decLo, decHi} : Rng{0, mh};
-    const Rng rD3 = widen(rOut, 1, mh), rUp2 = widen(rD3, 1, mh);
-    const Rng rD2 = below(rUp2, 2 * fh), rD1 = widen(rD2, 1, 2 * fh), rUp1 = widen(rD1, 1, 2 * fh);
     {
         Op op;
         op.kind = OP_UPSAMPLE2X; op.tag = "dec.up1";
@@ -837,6 +859,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.kind = OP_DECODE_OUT; op.tag = "dec.out";
         op.bufSrc = lb(BUF_D4); op.bufDst = BUF_COMP; op.ldy = 32; op.pix = mh * mw; op.n = nn;
         op.ipar[1] = rOut.lo; op.ipar[2] = rOut.hi;       // rows of the mw-wide image that are decoded and averaged
+        if (g.variant == 1) { op.ipar[1] = 0; op.ipar[2] = mh; }   // sttn-det: the rows without mask take the input frame here (below), every row is written
         if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) op.W = mw;   // src rows are 2x4 blocks of a mw-wide image
         op.bufMask = g.variant == 1 ? BUF_MASK_U8 : -1;   // sttn-det: model-resolution blend with the input frames
         std::vector<int32_t> fi, fs;

@@ -205,14 +205,15 @@ private:
     int64_t rowmaxElems_ = 0;            // BUF_ROWMAX handed out so far: every fused attention instance of the plan has its own array
     double trimmedFlops_ = 0;            // what the reference spends on last-block rows nobody reads (buildWindow)
     int pickTile(int N) const;
-    int tRowsTokens(int T, int s, int choff, int count, int padTo);
+    // oy0 / oy1: patch rows [oy0, oy1) of every frame only (-1 = all): the query tokens of a last block that feeds a ranged decoder
+    int tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0 = 0, int oy1 = -1);
     int tColsPatch(int s, int padTo);
-    int tRowsTokensAct(const Act& a, int T, int s, int padTo);
+    int tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0 = 0, int oy1 = -1);
     int tColsPatchAct(const Act& a, int s, int padTo);
     void addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut,
                  int ksz, int stride, int dil, const ConvW& w, int act, const Act* res,
                  const std::vector<int>* resIds, int ylo = 0, int yhi = -1);     // [ylo, yhi): output rows computed (stride 1; default all)
-    void addAttention(int Tq, int T, const BlockW& bw);
+    void addAttention(int Tq, int T, const BlockW& bw, int attLo = 0, int attHi = -1);      // [attLo, attHi): feature rows of the output that are read
     void buildWindow(const std::vector<int>& neighbors, const std::vector<int>& refs,
                      std::vector<int32_t>& visits);
 };

@@ -117,18 +117,25 @@ class SttnEngine:
         the promise vsr_sttn_auto_chunk_rows takes.  Read off the device mask once per mask (one row-flag reduction and a
         download of H bytes) and kept while the same tensor object stays unmodified (its version counter)."""
         ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
+
+        def from_flags(flags):
+            rows = np.zeros((ar.shape[0], 2), dtype=np.int32)
+            for k, (ymin, ymax, _, _) in enumerate(ar):
+                nz = np.flatnonzero(flags[int(ymin):int(ymax)])
+                if nz.size:
+                    rows[k] = (int(nz[0]), int(nz[-1]) + 1)
+            return rows
+
+        if isinstance(mask_dev, np.ndarray):             # the caller's host copy of the same mask: no device round trip at all
+            m = mask_dev.reshape(mask_dev.shape[0], mask_dev.shape[1], -1)
+            return from_flags((m != 0).any(axis=(1, 2)))
         ent = getattr(self, "_mask_rows_cache", None)
         if ent is not None and ent[0]() is mask_dev and ent[1] == mask_dev._version and np.array_equal(ent[2], ar):
             return ent[3]
         import weakref
 
         H, W = int(mask_dev.shape[0]), int(mask_dev.shape[1])
-        flags = mask_dev.reshape(H, W).ne(0).any(dim=1).cpu().numpy()
-        rows = np.zeros((ar.shape[0], 2), dtype=np.int32)
-        for k, (ymin, ymax, _, _) in enumerate(ar):
-            nz = np.flatnonzero(flags[int(ymin):int(ymax)])
-            if nz.size:
-                rows[k] = (int(nz[0]), int(nz[-1]) + 1)
+        rows = from_flags(mask_dev.reshape(H, W).ne(0).any(dim=1).cpu().numpy())
         self._mask_rows_cache = (weakref.ref(mask_dev), mask_dev._version, ar.copy(), rows)
         return rows
 
@@ -148,7 +155,7 @@ class SttnEngine:
             total += v
         return total
 
-    def auto_chunk(self, frames_dev, mask_dev, areas, sel=None, decode_rows=True):
+    def auto_chunk(self, frames_dev, mask_dev, areas, sel=None, decode_rows=True, mask_host=None):
         """One chunk of STTNAutoInpaint.__call__, in place on frames_dev uint8 [L,H,W,3] BGR.  The rows of every strip that hold the
         mask go along (mask_rows): the decoder then computes only what the blend reads -- same frames (vsr_sttn_auto_chunk_rows)."""
         assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
@@ -158,7 +165,8 @@ class SttnEngine:
         ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
         sel_arr = None if sel is None else np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
         # decode_rows=False: no promise about the mask, the whole model-resolution image is decoded (tests compare the two)
-        rows = np.ascontiguousarray(self.mask_rows(mask_dev, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
+        # (mask_host: the caller's numpy copy of the mask, when it has one -- the rows are then read off it)
+        rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
         with torch.cuda.device(frames_dev.device):
             check(lib.vsr_sttn_auto_chunk_rows(
                 self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()), ar.shape[0],
@@ -180,15 +188,18 @@ class SttnEngine:
                                            C.c_void_p(comp.data_ptr()), counts.ctypes.data_as(C.c_void_p), _stream_ptr()))
         return comp, counts
 
-    def det_batch(self, frames_dev, mask_dev, areas):
-        """STTNDetInpaint.__call__ on one batch, in place on frames_dev uint8 [L,H,W,3] BGR; mask_dev raw 0/255 [H,W]."""
+    def det_batch(self, frames_dev, mask_dev, areas, decode_rows=True, mask_host=None):
+        """STTNDetInpaint.__call__ on one batch, in place on frames_dev uint8 [L,H,W,3] BGR; mask_dev raw 0/255 [H,W].  The rows of
+        every strip that hold the mask go along (mask_rows): the decoder computes only the model rows the prediction is taken from
+        (vsr_sttn_det_batch_rows) -- same frames; decode_rows=False: no promise."""
         assert frames_dev.dtype == torch.uint8 and frames_dev.is_cuda and frames_dev.is_contiguous()
         assert mask_dev.dtype == torch.uint8 and mask_dev.is_cuda and mask_dev.is_contiguous()
         L, H, W, _ = frames_dev.shape
         ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
+        rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
         with torch.cuda.device(frames_dev.device):
-            check(lib.vsr_sttn_det_batch(self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()),
-                                         ar.shape[0], ar.ctypes.data_as(C.c_void_p), _stream_ptr()))
+            check(lib.vsr_sttn_det_batch_rows(self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()),
+                                              ar.shape[0], ar.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), _stream_ptr()))
         return frames_dev
 
     # ---- measurement ----------------------------------------------------------------------
