@@ -33,13 +33,13 @@ def test_plan_replay_matches_oracle(built_lib):
     assert res["counts"] == [2, 2, 2, 1]
 
 
-@pytest.mark.parametrize("rows", [(76, 118), (0, 7), (41, 80), (113, 120), (59, 61)])
-def test_plan_replay_decoder_rows(built_lib, host_engine, rows):
+def test_plan_replay_decoder_rows(built_lib, host_engine):
     """A plan that was told which rows of the model-resolution output its caller reads (vsr_sttn_auto_chunk_rows: the strip is blended
     back only where the mask is set) runs its decoder on those rows and on what they depend on -- and nothing else: the replay writes
     ONLY the row ranges the ops carry (what lies outside stays zero), so a range that is one row too small anywhere in the chain
     (the last block's convs and patch rows, 3x3 convs, two align_corners upsamplings, the 2-row blocks of the output conv) shows
-    up as rows of garbage.  Inside the range the comps are the full plan's; the FLOPs go down."""
+    up as rows of garbage.  Inside the range the comps are the full plan's; the FLOPs go down.  Three ranges: the bench's subtitle
+    box, the top rows, a sliver in the middle."""
     from vsr_amd import _lib
     from _replay import PlanView, replay
 
@@ -47,23 +47,25 @@ def test_plan_replay_decoder_rows(built_lib, host_engine, rows):
     L = 4
     frames = np.random.default_rng(21).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8)
     full = PlanView(_lib, eng, L)
-    part = PlanView(_lib, eng, L, rows=rows)
-    try:
-        want, counts, _ = replay(full, eng.packed_weights(), frames)
-        got, counts2, _ = replay(part, eng.packed_weights(), frames)
-        lo, hi = rows[0] // 2 * 2, (rows[1] + 1) // 2 * 2            # whole 2-row blocks
-        assert list(counts) == list(counts2)
-        # (the replay's contractions are torch-CPU matmuls, whose blocking -- hence rounding -- depends on how many rows they are
-        # given: a handful of u8 truncation flips, as against the oracle; on the GPU the frames are equal bit for bit,
-        # tests/test_gpu_sttn.py::test_decoder_rows_give_the_same_frames.  A range one row short gives whole rows of garbage.)
-        d = np.abs(got[:, lo:hi] - want[:, lo:hi])
-        assert d.max() <= 1.0 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
-        assert part.flops < full.flops
-        dec = [(i.H, int(i.ipar[1]), int(i.ipar[2])) for i, _ in part.ops if i.kind == 3]      # OP_UPSAMPLE2X
-        assert dec and all(0 <= a < b <= 2 * H for H, a, b in dec) and any(b - a < 2 * H for H, a, b in dec)
-    finally:
-        full.close()
-        part.close()
+    want, counts, _ = replay(full, eng.packed_weights(), frames)
+    full_flops = full.flops
+    full.close()
+    for rows in ((76, 118), (0, 7), (59, 61)):
+        part = PlanView(_lib, eng, L, rows=rows)
+        try:
+            got, counts2, _ = replay(part, eng.packed_weights(), frames)
+            lo, hi = rows[0] // 2 * 2, (rows[1] + 1) // 2 * 2            # whole 2-row blocks
+            assert list(counts) == list(counts2)
+            # (the replay's contractions are torch-CPU matmuls, whose blocking -- hence rounding -- depends on how many rows they are
+            # given: a handful of u8 truncation flips, as against the oracle; on the GPU the frames are equal bit for bit,
+            # tests/test_gpu_sttn.py::test_decoder_rows_give_the_same_frames.  A range one row short gives whole rows of garbage.)
+            d = np.abs(got[:, lo:hi] - want[:, lo:hi])
+            assert d.max() <= 1.0 and (d > 0).mean() < 1e-3, (rows, d.max(), (d > 0).mean())
+            assert part.flops < full_flops
+            dec = [(i.H, int(i.ipar[1]), int(i.ipar[2])) for i, _ in part.ops if i.kind == 3]      # OP_UPSAMPLE2X
+            assert dec and all(0 <= a < b <= 2 * H for H, a, b in dec) and any(b - a < 2 * H for H, a, b in dec)
+        finally:
+            part.close()
 
 
 def test_plan_replay_degenerate_chunks(built_lib):
