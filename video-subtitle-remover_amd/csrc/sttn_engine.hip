@@ -368,6 +368,10 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
     HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 16 * sizeof(unsigned int)));
     *out = pd.get();
+    if (h->plans.size() >= 48) {                   // a long video with ever new mask rows: start over rather than grow without bound
+        HIPCHK(hipDeviceSynchronize());            // (nothing in flight may still read the tables that go)
+        h->plans.clear();
+    }
     h->plans[key] = std::move(pd);
     return 0;
 }
@@ -812,7 +816,9 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
                     if (b >= r0 && a < r1) { lo = y < lo ? y : lo; hi = y + 1 > hi ? y + 1 : hi; }
                 }
             }
-            if (hi > lo) { decLo[k] = lo; decHi[k] = hi; }
+            // whole groups of four rows: every distinct (L, range) is a plan of its own (40-60 MB of offset tables, 30 ms to build),
+            // and the detected boxes of a video differ by a few pixels from interval to interval
+            if (hi > lo) { decLo[k] = lo / 4 * 4; decHi[k] = (hi + 3) / 4 * 4 < mh ? (hi + 3) / 4 * 4 : mh; }
         }
     }
     PlanDev* pd = nullptr;
@@ -920,6 +926,7 @@ int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_r
         }
     }
     if (hi <= lo) { lo = 0; hi = mh; }
+    else { lo = lo / 4 * 4; hi = (hi + 3) / 4 * 4 < mh ? (hi + 3) / 4 * 4 : mh; }      // as strips_common
     Plan p(h->model, 1, 0, 1, lo, hi);                   // (the widening to whole output-conv blocks)
     *row_lo = p.decLo; *row_hi = p.decHi;
     return 0;
