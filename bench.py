@@ -20,6 +20,9 @@ Extra objects in the line:
                   algorithmic FLOPs / HIP-event time on the launch stream against the 157.3 TFLOP/s fp32
                   MFMA peak of MI355X_MICROARCH.md; `every_gemm_launch` beside it is the same ratio over
                   ALL gather-GEMM launches of a chunk (every symbol).
+  full_work    -- `value` is measured on a plan that leaves out what the reference computes and nothing reads (DESIGN
+                  4.3c; the frames are the same bit for bit; `gflop_per_frame` vs `gflop_per_frame_reference`); this is
+                  the same step with all of it, from a child process (the library reads the switches once per process).
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference modules, "port") timed on
                   this box's host cores on ONE full 50-frame chunk of the same clip, end to end (crop,
                   cv2-style resize, network, resize back, blend) with the network-only time beside it.
@@ -237,6 +240,9 @@ def main():
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the check of the gathered chunks against each rank's replica result")
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
+    ap.add_argument("--no-full-work", action="store_true",
+                    help="skip the `full_work` leg: the same step with every row the reference's modules compute (a child process with "
+                         "VSR_TRIM_LAST_BLOCK=0 VSR_DECODE_ROWS=0 -- the library reads these once per process)")
     ap.add_argument("--precision", default=None, choices=["f32", "split", "split-format", "f16"],
                     help="arithmetic of the contractions in the timed region (default: exact fp32; BASELINE.json's config 5 "
                          "is --res 4k --precision f16)")
@@ -435,7 +441,7 @@ def main():
     if replicas is not None:
         out["replicas"] = replicas
     if world > 1:          # the CPU baseline and the informational legs belong to the N = 1 line only
-        args.no_cpu_baseline, args.no_split_half, args.e2e_chunks = True, True, 0
+        args.no_cpu_baseline, args.no_split_half, args.e2e_chunks, args.no_full_work = True, True, 0, True
     if rank == 0:
         # ---- roofline of the dominant kernel from the HIP events of the timed region
         # dominant kernel symbol = the gather-GEMM instantiation with the largest total time; every
@@ -598,6 +604,28 @@ def main():
                     sp["psnr_db_vs_oracle"] = "inf" if mse2 == 0 else round(20 * np.log10(255.0 / np.sqrt(mse2)), 2)
                 out[key] = sp
             eng.set_precision(base_precision)
+        if not args.no_full_work and os.environ.get("VSR_TRIM_LAST_BLOCK", "1") != "0":
+            # `value` is measured on a plan that leaves out what the reference computes and nothing reads (the last block's
+            # reference-frame rows, the decoder rows outside the mask; same frames bit for bit).  The same step with ALL of the
+            # reference's work, for comparison: a child process, because the library reads the two switches once per process.
+            import subprocess
+
+            env = dict(os.environ, VSR_TRIM_LAST_BLOCK="0", VSR_DECODE_ROWS="0")
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--res", args.res,
+                   "--chunk", str(L), "--lanes", str(args.lanes), "--no-cpu-baseline", "--no-split-half", "--e2e-chunks", "0", "--no-full-work"]
+            if args.precision:
+                cmd += ["--precision", args.precision]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                fw = json.loads(line)
+                out["full_work"] = {"value": fw["value"], "unit": "frames/s", "ms_per_step": fw["ms_per_step"],
+                                    "gflop_per_frame": fw["gflop_per_frame"], "model_tflops": fw["model_tflops"],
+                                    "note": "VSR_TRIM_LAST_BLOCK=0 VSR_DECODE_ROWS=0 in a child process: every row of the last block and "
+                                            "of the decoder, i.e. the reference's FLOP count; the frames are the same bit for bit "
+                                            "(tests/test_gpu_sttn.py::test_decoder_rows_give_the_same_frames)"}
+            except Exception as e:                 # noqa: BLE001 -- informational leg, never fatal
+                out["full_work"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
         if world > 1 and replicas is not None and not replicas.get("selftest", {"ok": True})["ok"]:
             print("SELFTEST FAILED: gathered chunks differ from the ranks' replica results", file=sys.stderr, flush=True)
