@@ -95,6 +95,38 @@ def test_mask_islands_without_scipy_equal_scipy_label():
     assert t._islands(noisy) == t._islands_scipy(noisy > 0)
 
 
+def test_mask_rows_promise_from_the_host_mask(built_lib):
+    """SttnEngine.mask_rows on the caller's host copy of the mask (what the plugins pass): per area the strip rows [lo, hi) that hold
+    the mask's set pixels -- the promise vsr_sttn_auto_chunk_rows / vsr_sttn_det_batch_rows take -- and the model rows they turn
+    into (whole groups of four, inside the image)."""
+    import ctypes as C
+
+    from vsr_amd._lib import lib
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+
+    H, W = 1080, 1920
+    mask = t.threshold_mask(t.create_mask((H, W), [(288, 1632, 950, 1070), (300, 1600, 500, 560)]))
+    areas = t.get_inpaint_area_by_mask(W, H, int(W * 3 / 16), mask)
+    eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None)
+    try:
+        rows = eng.mask_rows(mask, areas)
+        assert rows.shape == (len(areas), 2) and len(areas) == 2
+        for (ymin, ymax, _, _), (lo, hi) in zip(areas, rows):
+            strip = mask[ymin:ymax, :, 0]
+            assert 0 <= lo < hi <= ymax - ymin
+            assert strip[lo].any() and strip[hi - 1].any() and not strip[:lo].any() and not strip[hi:].any()
+            a, b = C.c_int32(), C.c_int32()
+            assert lib.vsr_sttn_decode_rows(eng._h, int(ymax - ymin), int(lo), int(hi), C.byref(a), C.byref(b)) == 0
+            assert 0 <= a.value < b.value <= 120 and a.value % 2 == 0 and (b.value % 4 == 0 or b.value == 120)
+            # the model rows the first / last mask row is resized from lie inside the range
+            assert a.value <= (lo + 0.5) * 120 / (ymax - ymin) - 0.5 + 1 and b.value >= (hi - 0.5) * 120 / (ymax - ymin) - 0.5
+            assert lib.vsr_sttn_flops_rows(eng._h, 50, a.value, b.value) < eng.flops(50) < eng.flops(50, reference=True)
+        assert (eng.mask_rows(np.zeros((H, W), np.uint8), areas) == 0).all()          # no set pixel: no promise
+    finally:
+        eng.close()
+
+
 def test_inpaint_area_1080p_value():
     mask = t.create_mask((1080, 1920), [(288, 1632, 950, 1070)])
     assert mask[940, 278] == 255 and mask[939, 278] == 0 and mask[1079, 1642] == 255 and mask[1079, 1643] == 0
