@@ -88,6 +88,12 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
  * A mask that is set outside the promised rows gets undefined pixels there.  VSR_DECODE_ROWS=0 ignores the promise. */
 int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                              int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* sel, int nsel, void* stream);
+/* ... and about its columns: mask_cols host [n_areas][2] = the frame columns [lo, hi) outside which the mask is zero.  The GEMMs of
+ * the decoder and of the last block then take rectangles.  Built and replayed on the CPU in round 4, not yet run on a GPU: the
+ * column promise is honoured only with VSR_DECODE_COLS=1 (otherwise this is vsr_sttn_auto_chunk_rows). */
+int vsr_sttn_auto_chunk_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
+                            int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* mask_cols,
+                            const int32_t* sel, int nsel, void* stream);
 /* model-resolution rows [*row_lo, *row_hi) decoded for a strip of strip_h rows whose mask lives in rows [mask_row_lo, mask_row_hi),
  * and the FLOPs of one L-frame call decoded that way (vsr_sttn_flops = the whole image) */
 int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_row_hi, int32_t* row_lo, int32_t* row_hi);
@@ -523,6 +529,7 @@ typedef struct VsrSoftmaxInfo {
 
 int vsr_plan_create(const vsr_sttn_t* h, int L, vsr_plan_t** out);
 int vsr_plan_create_rows(const vsr_sttn_t* h, int L, int row_lo, int row_hi, vsr_plan_t** out);   /* the decoder on model rows [row_lo, row_hi) only */
+int vsr_plan_create_box(const vsr_sttn_t* h, int L, int row_lo, int row_hi, int col_lo, int col_hi, vsr_plan_t** out);   /* ... and columns */
 int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vsr_plan_t** out);
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);

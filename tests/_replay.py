@@ -16,13 +16,15 @@ BUF_WEIGHTS, BUF_IN_U8 = 0, 1
 
 
 class PlanView:
-    def __init__(self, _lib, engine, L, plan_ptr=None, rows=None):
+    def __init__(self, _lib, engine, L, plan_ptr=None, rows=None, cols=None):
         """STTN: PlanView(_lib, engine, L[, rows=(lo, hi): the decoder on these model rows only]).  Any other plan: pass the
         vsr_plan_t pointer (L = length of the counts array, 0 = none)."""
         self._lib = _lib
         lib = _lib.lib
         self.p = plan_ptr if plan_ptr is not None else C.c_void_p()
-        if plan_ptr is None and rows is not None:
+        if plan_ptr is None and rows is not None and cols is not None:
+            _lib.check(lib.vsr_plan_create_box(engine.handle, L, int(rows[0]), int(rows[1]), int(cols[0]), int(cols[1]), C.byref(self.p)))
+        elif plan_ptr is None and rows is not None:
             _lib.check(lib.vsr_plan_create_rows(engine.handle, L, int(rows[0]), int(rows[1]), C.byref(self.p)))
         elif plan_ptr is None:
             _lib.check(lib.vsr_plan_create(engine.handle, L, C.byref(self.p)))

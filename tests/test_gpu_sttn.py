@@ -1,5 +1,7 @@
 """End-to-end parity of the HIP path (through the C-ABI) against the CPU oracle, plus the
 size-independent properties checked at BASELINE.json's full chunk size."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -393,6 +395,36 @@ def test_decoder_rows_give_the_same_frames(built_lib, gpu_device, sd, mode, H, W
         assert torch.equal(a, b)
         assert not torch.equal(a, frames)
     assert eng.chunk_flops(12, dmask, areas) <= len(areas) * eng.flops(12)
+    eng.close()
+
+
+@pytest.mark.skipif(os.environ.get("VSR_DECODE_COLS", "0") != "1",
+                    reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("H,W,boxes", [
+    (720, 1280, [(620, 700, 400, 900)]),                           # a centred line: columns [400, 900) of 1280
+    (1080, 1920, [(500, 560, 0, 300), (940, 1060, 1500, 1920)]),   # two areas, one box at either edge
+    (480, 852, [(200, 340, 50, 800)]),                             # nearly the whole strip
+])
+def test_decoder_box_gives_the_same_frames(built_lib, gpu_device, sd, mode, H, W, boxes):
+    """vsr_sttn_auto_chunk_box with VSR_DECODE_COLS=1: rows AND columns of the mask promised -- the frames written are those of the
+    call without any promise, bit for bit (tests/test_plan_replay.py::test_plan_replay_decoder_box is the CPU half)."""
+    from vsr_amd.backend.tools.inpaint_tools import create_mask as cm, get_inpaint_area_by_mask as ga, threshold_mask as tm
+
+    eng = _engine(sd, precision=mode)
+    frames = torch.from_numpy(synth.make_clip(12, H, W, boxes[0], seed=9)).to(gpu_device)
+    m01 = tm(cm((H, W), [(b[2], b[3], b[0], b[1]) for b in boxes]))
+    areas = ga(W, H, int(W * 3 / 16), m01)
+    dmask = torch.from_numpy(np.ascontiguousarray(m01[:, :, 0])).to(gpu_device)
+    cols = eng.mask_cols(dmask, areas)
+    assert np.array_equal(cols, eng.mask_cols(m01[:, :, 0], areas)) and all(hi > lo for lo, hi in cols)
+    for sel in (None, [1, 2, 3, 7, 8, 10]):
+        a, b = frames.clone(), frames.clone()
+        eng.auto_chunk(a, dmask, areas, sel=sel, decode_rows=False)
+        eng.auto_chunk(b, dmask, areas, sel=sel)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert not torch.equal(a, frames)
     eng.close()
 
 

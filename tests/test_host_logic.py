@@ -123,6 +123,11 @@ def test_mask_rows_promise_from_the_host_mask(built_lib):
             assert a.value <= (lo + 0.5) * 120 / (ymax - ymin) - 0.5 + 1 and b.value >= (hi - 0.5) * 120 / (ymax - ymin) - 0.5
             assert lib.vsr_sttn_flops_rows(eng._h, 50, a.value, b.value) < eng.flops(50) < eng.flops(50, reference=True)
         assert (eng.mask_rows(np.zeros((H, W), np.uint8), areas) == 0).all()          # no set pixel: no promise
+        cols = eng.mask_cols(mask, areas)              # the column half (vsr_sttn_auto_chunk_box, opt-in)
+        for (ymin, ymax, _, _), (lo, hi) in zip(areas, cols):
+            strip = mask[ymin:ymax, :, 0]
+            assert 0 <= lo < hi <= W and strip[:, lo].any() and strip[:, hi - 1].any() and not strip[:, :lo].any() and not strip[:, hi:].any()
+        assert (eng.mask_cols(np.zeros((H, W), np.uint8), areas) == 0).all()
     finally:
         eng.close()
 

@@ -68,6 +68,37 @@ def test_plan_replay_decoder_rows(built_lib, host_engine):
             part.close()
 
 
+def test_plan_replay_decoder_box(built_lib, host_engine):
+    """... and which columns (vsr_plan_create_box; the engine's VSR_DECODE_COLS=1): the GEMMs of the decoder and of the last block
+    take rectangles of pixels / of patches (the elementwise ops between them keep whole rows).  Inside the rectangle the comps are
+    the full plan's, the FLOPs are below those of the same rows at full width, and a rectangle one column short anywhere in the
+    chain shows up as columns of garbage.  Three rectangles: a centred subtitle line, the left edge, a narrow box touching the right edge."""
+    from vsr_amd import _lib
+    from _replay import PlanView, replay
+
+    sd, eng = host_engine
+    L = 4
+    frames = np.random.default_rng(22).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8)
+    full = PlanView(_lib, eng, L)
+    want, counts, _ = replay(full, eng.packed_weights(), frames)
+    full.close()
+    for rows, cols in (((76, 118), (120, 520)), ((0, 30), (0, 64)), ((40, 90), (600, 640))):
+        strip = PlanView(_lib, eng, L, rows=rows)
+        rows_flops = strip.flops
+        strip.close()
+        part = PlanView(_lib, eng, L, rows=rows, cols=cols)
+        try:
+            got, counts2, _ = replay(part, eng.packed_weights(), frames)
+            lo, hi = rows[0] // 2 * 2, (rows[1] + 1) // 2 * 2            # whole 2x4 blocks
+            c0, c1 = cols[0] // 4 * 4, (cols[1] + 3) // 4 * 4
+            assert list(counts) == list(counts2)
+            d = np.abs(got[:, lo:hi, c0:c1] - want[:, lo:hi, c0:c1])
+            assert d.max() <= 1.0 and (d > 0).mean() < 1e-3, (rows, cols, d.max(), (d > 0).mean())
+            assert part.flops < rows_flops, (rows, cols, part.flops, rows_flops)
+        finally:
+            part.close()
+
+
 def test_plan_replay_degenerate_chunks(built_lib):
     """a 1-frame and a 2-frame chunk with the reference's default stride 5 / references every 10 (the ragged tail of a video,
     sttn_auto_inpaint.py:240-245): one window of T = 1 / T = 2, every frame visited once and returned as uint8"""

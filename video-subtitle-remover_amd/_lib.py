@@ -87,6 +87,7 @@ SIGNATURES = {
     "vsr_sttn_inpaint": (_I, [_P, _P, _I, _P, _P, _P]),
     "vsr_sttn_auto_chunk": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
     "vsr_sttn_auto_chunk_rows": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "vsr_sttn_auto_chunk_box": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "vsr_sttn_decode_rows": (_I, [_P, _I, _I, _I, _P, _P]),
     "vsr_sttn_flops_rows": (_D, [_P, _I, _I, _I]),
     "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "vsr_cv2_linear_tables": (_I, [_I, _I, _I, _P, _P, _P]),
     "vsr_plan_create": (_I, [_P, _I, C.POINTER(_P)]),
     "vsr_plan_create_rows": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "vsr_plan_create_box": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_raft_plan_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_raft_create": (_I, [C.POINTER(_P)]),
     "vsr_raft_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),

@@ -164,9 +164,9 @@ static int gg_wide_queues()
 
 
 // decLo / decHi: the rows of the model-resolution output the caller will read (Plan::decLo; 0, 0 = all)
-static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int decLo = 0, int decHi = 0)
+static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int decLo = 0, int decHi = 0, int decXLo = 0, int decXHi = 0)
 {
-    const int64_t key = ((((int64_t)L * 4 + precision) * 8 + h->lanes) * 4096 + decLo) * 4096 + decHi;
+    const int64_t key = ((((((int64_t)L * 4 + precision) * 8 + h->lanes) * 1024 + decLo) * 1024 + decHi) * 1024 + decXLo) * 1024 + decXHi;
     const bool fmt = precision >= 2;       // split-format tensors: everything a GEMM reads (see gather_gemm_v5.h)
     auto plainF32 = [](int buf) { buf = baseBuf(buf); return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
     if (fmt && !h->weightsSplit) {
@@ -180,7 +180,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
     if (it != h->plans.end()) { *out = it->second.get(); return 0; }
     std::unique_ptr<PlanDev> pd(new PlanDev);
     try {
-        pd->plan.reset(new Plan(h->model, L, precision, h->lanes, decLo, decHi));
+        pd->plan.reset(new Plan(h->model, L, precision, h->lanes, decLo, decHi, decXLo, decXHi));
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
     }
@@ -763,7 +763,8 @@ int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t
 //   back only where the mask is set (vsr_launch_upscale_blend), so only the model-resolution rows those strip rows are resized
 //   from are ever read: the decoder computes them and what they depend on (Plan::decLo), the same values as before.
 static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
-                         const int32_t* areas, const int32_t* sel, int nsel, hipStream_t stream, const int32_t* maskRows = nullptr)
+                         const int32_t* areas, const int32_t* sel, int nsel, hipStream_t stream, const int32_t* maskRows = nullptr,
+                         const int32_t* maskCols = nullptr)
 {
     if (!frames_dev || !mask_dev || L <= 0 || H <= 0 || W <= 0 || n_areas < 0 || (n_areas > 0 && !areas))
         return fail(VSR_ERR_ARG, "bad argument");
@@ -786,7 +787,9 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
     }
     // model-resolution rows every area needs (0, 0 = all)
     static const bool rowsOn = [] { const char* e = getenv("VSR_DECODE_ROWS"); return !(e && atoi(e) == 0); }();
-    std::vector<int> decLo((size_t)n_areas, 0), decHi((size_t)n_areas, 0);
+    // (columns: built, replayed on the CPU, NOT yet run on a GPU -- opt-in, VSR_DECODE_COLS=1)
+    static const bool colsOn = [] { const char* e = getenv("VSR_DECODE_COLS"); return e && atoi(e) == 1; }();
+    std::vector<int> decLo((size_t)n_areas, 0), decHi((size_t)n_areas, 0), decXLo((size_t)n_areas, 0), decXHi((size_t)n_areas, 0);
     if (maskRows && rowsOn) {
         for (int k = 0; k < n_areas; ++k) {
             const int sh = areas[4 * k + 1] - areas[4 * k];
@@ -819,10 +822,24 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
             // whole groups of four rows: every distinct (L, range) is a plan of its own (40-60 MB of offset tables, 30 ms to build),
             // and the detected boxes of a video differ by a few pixels from interval to interval
             if (hi > lo) { decLo[k] = lo / 4 * 4; decHi[k] = (hi + 3) / 4 * 4 < mh ? (hi + 3) / 4 * 4 : mh; }
+            if (hi > lo && !det && maskCols && colsOn) {
+                // the same along x (sttn-auto): the model columns the horizontal taps of the resize back read for the mask's columns
+                const int c0 = maskCols[2 * k], c1 = maskCols[2 * k + 1];
+                if (c0 >= 0 && c1 <= W && c0 < c1) {
+                    cv2_linear_tables(mw, W, true, ofs, ic, fc);
+                    int xl = mw, xh = 0;
+                    for (int dx = c0; dx < c1; ++dx) {
+                        const int a = ofs[dx] < 0 ? 0 : (ofs[dx] < mw ? ofs[dx] : mw - 1), b = a + 1 < mw ? a + 1 : mw - 1;
+                        xl = a < xl ? a : xl;
+                        xh = b + 1 > xh ? b + 1 : xh;
+                    }
+                    if (xh > xl) { decXLo[k] = xl / 8 * 8; decXHi[k] = (xh + 7) / 8 * 8 < mw ? (xh + 7) / 8 * 8 : mw; }
+                }
+            }
         }
     }
     PlanDev* pd = nullptr;
-    RCCHK(build_plan_dev(h, Ls, h->precision, &pd, decLo[0], decHi[0]));
+    RCCHK(build_plan_dev(h, Ls, h->precision, &pd, decLo[0], decHi[0], decXLo[0], decXHi[0]));
     const int64_t compElems = (int64_t)Ls * mh * mw * 3;
     if (n_areas > 1 && h->compAreasCap < compElems * n_areas) {
         if (h->compAreas) HIPCHK(hipFree(h->compAreas));
@@ -847,7 +864,7 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
             if (vsr_launch_resize_u8(mask_dev + (int64_t)ymin * W, 0, W, W, sh, (uint8_t*)h->bufs[BUF_MASK_U8], mw, mh, Ls, 1,
                                      nullptr, st->dxofs, st->dialpha, st->dyofs, st->dibeta, stream) != 0)
                 return fail(VSR_ERR_HIP, "mask resize launch failed");
-        if (k > 0 || attempt > 0) RCCHK(build_plan_dev(h, Ls, attempt ? 0 : h->precision, &pd, decLo[k], decHi[k]));
+        if (k > 0 || attempt > 0) RCCHK(build_plan_dev(h, Ls, attempt ? 0 : h->precision, &pd, decLo[k], decHi[k], decXLo[k], decXHi[k]));
         RCCHK(run_plan(h, pd, stream));
         if (n_areas > 1)
             HIPCHK(hipMemcpyAsync(h->compAreas + compElems * k, h->bufs[BUF_COMP], (size_t)compElems * sizeof(float),
@@ -886,6 +903,14 @@ int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, i
     RCCHK(need_gpu(h));
     if (h->model.g.variant != VSR_VARIANT_STTN_AUTO) return fail(VSR_ERR_STATE, "not an sttn-auto model");
     return strips_common(h, false, frames_dev, L, H, W, mask_dev, n_areas, areas, sel, nsel, (hipStream_t)stream_, mask_rows);
+}
+
+int vsr_sttn_auto_chunk_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                            const int32_t* areas, const int32_t* mask_rows, const int32_t* mask_cols, const int32_t* sel, int nsel, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (h->model.g.variant != VSR_VARIANT_STTN_AUTO) return fail(VSR_ERR_STATE, "not an sttn-auto model");
+    return strips_common(h, false, frames_dev, L, H, W, mask_dev, n_areas, areas, sel, nsel, (hipStream_t)stream_, mask_rows, mask_cols);
 }
 
 double vsr_sttn_flops_rows(vsr_sttn_t* h, int L, int row_lo, int row_hi)
@@ -1192,6 +1217,19 @@ int vsr_plan_create_rows(const vsr_sttn_t* h, int L, int row_lo, int row_hi, vsr
     try {
         std::unique_ptr<vsr_plan> p(new vsr_plan);
         p->plan.reset(new Plan(h->model, L, 0, h->lanes, row_lo, row_hi));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());
+    }
+    return 0;
+}
+int vsr_plan_create_box(const vsr_sttn_t* h, int L, int row_lo, int row_hi, int col_lo, int col_hi, vsr_plan_t** out)
+{
+    if (!h || !out || L <= 0) return fail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return fail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new Plan(h->model, L, 0, h->lanes, row_lo, row_hi, col_lo, col_hi));
         *out = p.release();
     } catch (const std::exception& e) {
         return fail(VSR_ERR_ARG, std::string("plan: ") + e.what());

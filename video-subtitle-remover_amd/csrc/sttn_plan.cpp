@@ -321,6 +321,27 @@ int PlanBuilder::tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int
     return table(key, std::move(v));
 }
 
+int PlanBuilder::tRowsActRect(const Act& a, const std::vector<int>& ids, int ylo, int yhi, int xlo, int xhi, int padTo)
+{
+    const std::string key = "RR:" + std::to_string(a.buf) + ":" + std::to_string(a.halo) + ":" + std::to_string(a.H) + ":" +
+                            std::to_string(a.W) + ":" + std::to_string(a.C) + ":" + std::to_string(ylo) + "-" + std::to_string(yhi) + ":" +
+                            std::to_string(xlo) + "-" + std::to_string(xhi) + ":" + std::to_string(padTo) + ":" + idsKey(ids);
+    auto it = tableKey_.find(key);
+    if (it != tableKey_.end()) return it->second;
+    std::vector<int32_t> v;
+    v.reserve((size_t)rup((int64_t)ids.size() * (yhi - ylo) * (xhi - xlo), padTo));
+    for (size_t ti = 0; ti < ids.size(); ++ti)
+        for (int y = ylo; y < yhi; ++y)
+            for (int x = xlo; x < xhi; ++x) {
+                const int64_t o = a.pix(ids[ti], y, x);
+                checkFits(o);
+                v.push_back((int32_t)o);
+            }
+    const int32_t first = v.empty() ? 0 : v[0];
+    while ((int64_t)v.size() % padTo) v.push_back(first);
+    return table(key, std::move(v));
+}
+
 int PlanBuilder::tColsConvHW(const Act& a, int kh, int kw, int dil, int c0, int cin)
 {
     if (cin < 0) cin = a.C - c0;
@@ -371,18 +392,20 @@ int PlanBuilder::tColsLinear(int nchunks, int padTo)
 
 // token (t, oy, ox) of scale s inside the plain QKV buffer [T*fh*fw][3C] (auto_sttn.py:182-190:
 // view(b,t,d_k,out_h,height,out_w,width).permute(0,1,3,5,2,4,6) => tokens ordered t, out_h, out_w)
-int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0, int oy1)
+int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0, int oy1, int ox0, int ox1)
 {
     const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, C3 = 3 * g.channels;
     if (oy1 < 0) oy1 = oh;
+    if (ox1 < 0) ox1 = ow;
     const std::string key = "RT:" + std::to_string(T) + ":" + std::to_string(s) + ":" + std::to_string(choff) + ":" +
-                            std::to_string(count) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1);
+                            std::to_string(count) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1) +
+                            ":" + std::to_string(ox0) + "-" + std::to_string(ox1);
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
     std::vector<int32_t> v;
     for (int t = 0; t < T; ++t)
         for (int oy = oy0; oy < oy1; ++oy)
-            for (int ox = 0; ox < ow; ++ox) {
+            for (int ox = ox0; ox < ox1; ++ox) {
                 const int64_t o = (((int64_t)t * g.featH + oy * ph) * g.featW + ox * pw) * C3 + choff;
                 checkFits(o);
                 v.push_back((int32_t)o);
@@ -410,18 +433,20 @@ int Plan::tColsPatch(int s, int padTo)
     return table(key, std::move(v));
 }
 
-int Plan::tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0, int oy1)
+int Plan::tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0, int oy1, int ox0, int ox1)
 {
     const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, dk = g.channels / g.nscales;
     if (oy1 < 0) oy1 = oh;
+    if (ox1 < 0) ox1 = ow;
     const std::string key = "RTA:" + std::to_string(a.buf) + ":" + std::to_string(a.halo) + ":" + std::to_string(T) +
-                            ":" + std::to_string(s) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1);
+                            ":" + std::to_string(s) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1) +
+                            ":" + std::to_string(ox0) + "-" + std::to_string(ox1);
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
     std::vector<int32_t> v;
     for (int t = 0; t < T; ++t)
         for (int oy = oy0; oy < oy1; ++oy)
-            for (int ox = 0; ox < ow; ++ox) {
+            for (int ox = ox0; ox < ox1; ++ox) {
                 const int64_t o = a.pix(t, oy * ph, ox * pw) + (int64_t)dk * s;
                 checkFits(o);
                 v.push_back((int32_t)o);
@@ -456,11 +481,15 @@ static std::vector<int> iota(int n)
 // conv (ksz 1 or 3, stride, dilation) + bias + optional LeakyReLU(0.2) + optional residual,
 // as one gather-GEMM: M = nOut*out.H*out.W pixels, N = cout, K = ksz*ksz*cin.
 void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut, int ksz,
-                   int stride, int dil, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds, int ylo, int yhi)
+                   int stride, int dil, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds, int ylo, int yhi,
+                   int xlo, int xhi)
 {
     if (yhi < 0) yhi = out.H;
+    if (xhi < 0) xhi = out.W;
     if (ylo < 0 || yhi > out.H || ylo >= yhi || (stride != 1 && (ylo != 0 || yhi != out.H))) throw std::runtime_error(std::string("conv row range: ") + tag);
-    const int oh = yhi - ylo;           // a row range is a row offset: pix(f, y + ylo, x) = pix(f, y, x) + ylo * Wp * C
+    if (xlo < 0 || xhi > out.W || xlo >= xhi || (stride != 1 && (xlo != 0 || xhi != out.W))) throw std::runtime_error(std::string("conv column range: ") + tag);
+    const bool rect = xlo != 0 || xhi != out.W;   // a column range needs its own table; a row range alone is a row offset of the plain one
+    const int oh = yhi - ylo, ow = xhi - xlo;     // pix(f, y + ylo, x) = pix(f, y, x) + ylo * Wp * C
     if (w.K != ksz * ksz * in.C) throw std::runtime_error(std::string("conv K mismatch: ") + tag);
     if ((int)inIds.size() != nOut) throw std::runtime_error("conv frame list mismatch");
     Op op;
@@ -471,7 +500,7 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
     int BM, BN;
     tileDims(op.tileCfg, BM, BN);
     GemmItem it{};
-    it.M = nOut * oh * out.W;
+    it.M = nOut * oh * ow;
     it.N = w.cout;
     it.K = w.K;
     it.tilesM = cdiv(it.M, BM);
@@ -482,18 +511,18 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
     it.alpha = 1.f;
     it.act = act;
     it.bufA = in.buf; it.offA = 0;
-    it.tRowA = tRowsAct(in, inIds, oh, out.W, stride, BM, (int64_t)ylo * in.Wp() * in.C);
+    it.tRowA = rect ? tRowsActRect(in, inIds, ylo, yhi, xlo, xhi, BM) : tRowsAct(in, inIds, oh, out.W, stride, BM, (int64_t)ylo * in.Wp() * in.C);
     it.tColA = tColsConv(in, ksz, dil);
     it.bufB = BUF_WEIGHTS; it.offB = w.w;
     it.tRowB = tRowsLinear(it.N, it.K, BN);
     it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
     it.bufC = out.buf; it.offC = 0;
-    it.tRowC = tRowsAct(out, iota(nOut), oh, out.W, 1, BM, (int64_t)ylo * out.Wp() * out.C);
+    it.tRowC = rect ? tRowsActRect(out, iota(nOut), ylo, yhi, xlo, xhi, BM) : tRowsAct(out, iota(nOut), oh, out.W, 1, BM, (int64_t)ylo * out.Wp() * out.C);
     it.tColC = tColsLinear(cdiv(it.N, VSR_GG_KC), it.tilesN * BN / VSR_GG_KC);
     it.offBias = w.b;
     if (res) {
         it.bufR = res->buf; it.offR = 0;
-        it.tRowR = tRowsAct(*res, *resIds, oh, out.W, 1, BM, (int64_t)ylo * res->Wp() * res->C);
+        it.tRowR = rect ? tRowsActRect(*res, *resIds, ylo, yhi, xlo, xhi, BM) : tRowsAct(*res, *resIds, oh, out.W, 1, BM, (int64_t)ylo * res->Wp() * res->C);
     } else {
         it.bufR = -1; it.offR = 0; it.tRowR = -1;
     }
@@ -514,9 +543,10 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
 // the rows of its neighbour frames (Plan::buildWindow)
 // [attLo, attHi): the feature rows of the attention output that anything reads (the last block of a window that feeds a ranged
 // decoder): the query tokens are the patches that touch those rows
-void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi)
+void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi, int attXLo, int attXHi)
 {
     if (attHi < 0) attHi = g.featH;
+    if (attXHi < 0) attXHi = g.featW;
     const Tuning& tu = tu_;
     const int C = g.channels, dk = C / g.nscales;
     const Act att{lb(BUF_ATT), T, g.featH, g.featW, C, 1};
@@ -534,8 +564,9 @@ void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi)
         const int pw = g.patchW[s], ph = g.patchH[s];
         const int Pn = (g.featW / pw) * (g.featH / ph);
         const int Ntok = T * Pn;        // key / value tokens
-        const int oy0 = attLo / ph, oy1 = cdiv(attHi, ph);       // patch rows that touch the rows read
-        const int Mtok = Tq * (oy1 - oy0) * (g.featW / pw);      // query tokens: the first Tq frames (frame-major), those patch rows
+        const int oy0 = attLo / ph, oy1 = cdiv(attHi, ph);       // patch rows / columns that touch what is read
+        const int ox0 = attXLo / pw, ox1 = cdiv(attXHi, pw);
+        const int Mtok = Tq * (oy1 - oy0) * (ox1 - ox0);         // query tokens: the first Tq frames (frame-major), those patches
         const int D = dk * pw * ph;
         const int ldS = (int)rup(Ntok, VSR_GG_KC);
         const int nchunks = D / VSR_GG_KC;
@@ -551,7 +582,7 @@ void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi)
         a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
         a.alpha = 1.f; a.act = VSR_ACT_NONE;
         a.bufA = lb(BUF_QKV); a.offA = 0;
-        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM, oy0, oy1);
+        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM, oy0, oy1, ox0, ox1);
         a.tColA = tColsPatch(s, nchunks);
         a.bufB = lb(BUF_QKV); a.offB = 0;
         a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN);
@@ -604,7 +635,7 @@ void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi)
         b.bufB = lb(BUF_QKV); b.offB = 0;
         b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
         b.tColB = tColsPatch(s, b.tilesN * pBN / VSR_GG_KC);
-        const int tRowAtt = tRowsTokensAct(att, Tq, s, pBM, oy0, oy1);
+        const int tRowAtt = tRowsTokensAct(att, Tq, s, pBM, oy0, oy1, ox0, ox1);
         const int tColAtt = tColsPatchAct(att, s, b.tilesN * pBN / VSR_GG_KC);
         if (pvSplit == 1) {
             b.bufC = lb(BUF_ATT); b.offC = 0; b.splitStride = 0;
@@ -679,6 +710,12 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     const Rng rD2 = below(rUp2, 2 * fh), rD1 = widen(rD2, 1, 2 * fh), rUp1 = widen(rD1, 1, 2 * fh);
     const Rng rX1 = below(rUp1, fh);            // rows of the last block's output the decoder reads
     const int lastLo = rX1.lo, lastHi = rX1.hi;
+    // the same chain along x for the GEMMs (the decoder's two elementwise kernels keep whole rows)
+    const bool rangedX = decXHi > decXLo && (decXLo > 0 || decXHi < mw);
+    const Rng cOut = rangedX ? Rng{decXLo, decXHi} : Rng{0, mw};
+    const Rng cD3 = widen(cOut, 1, mw), cUp2 = widen(cD3, 1, mw);
+    const Rng cD2 = below(cUp2, 2 * fw), cD1 = widen(cD2, 1, 2 * fw), cUp1 = widen(cD1, 1, 2 * fw);
+    const Rng cX1 = below(cUp1, fw);
     double fullBlockFlops = 0;
 
     Act cur = feats;
@@ -730,15 +767,16 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         wide(r2lo, r2hi, 1, r1lo, r1hi);                                                       // ffn.1 output
         wide(r2lo, r2hi, 3, r0lo, r0hi);                                                       // out-conv output (and the residual of ffn.2)
         wide(r2lo, r2hi, 4, ralo, rahi);                                                       // attention output
+        const Rng c2 = last ? cX1 : Rng{0, fw}, c1 = widen(c2, 1, fw), c0 = widen(c2, 3, fw), ca = widen(c2, 4, fw);   // the same along x
         const std::vector<int> idQ = iota(Tq);
         const std::vector<int> curIdsQ(curIds.begin(), curIds.begin() + Tq);
         const double before = flops;
-        addAttention(Tq, T, bw, ralo, rahi);
+        addAttention(Tq, T, bw, ralo, rahi, ca.lo, ca.hi);
         // x = x + LeakyReLU(conv3x3(att))            (auto_sttn.py:162-164,237)
-        addConv("attn.out", att, idQ, x0, Tq, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIdsQ, r0lo, r0hi);
+        addConv("attn.out", att, idQ, x0, Tq, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIdsQ, r0lo, r0hi, c0.lo, c0.hi);
         // x = x + LeakyReLU(conv3x3(LeakyReLU(conv3x3 dil2(x))))   (auto_sttn.py:214-218,238)
-        addConv("ffn.1", x0, idQ, f1, Tq, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr, r1lo, r1hi);
-        addConv("ffn.2", f1, idQ, x1, Tq, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idQ, r2lo, r2hi);
+        addConv("ffn.1", x0, idQ, f1, Tq, 3, 1, 2, bw.ffn1, VSR_ACT_LRELU02, nullptr, nullptr, r1lo, r1hi, c1.lo, c1.hi);
+        addConv("ffn.2", f1, idQ, x1, Tq, 3, 1, 1, bw.ffn2, VSR_ACT_LRELU02, &x0, &idQ, r2lo, r2hi, c2.lo, c2.hi);
         if (last && b > 0) trimmedFlops_ += fullBlockFlops - (flops - before);               // (the blocks of a window are alike in full form)
         else fullBlockFlops = flops - before;
         cur = x1;
@@ -759,11 +797,14 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         ops.push_back(std::move(op));
     }
     // (refFlops keeps the reference's count: what a ranged conv leaves out is its flops x (H / rows - 1))
-    auto skipped = [&](Rng r, int H) { trimmedFlops_ += ops.back().flops * (double)(H - (r.hi - r.lo)) / (r.hi - r.lo); };
-    addConv("dec.1", up1, idN, d1, nn, 3, 1, 1, m_.dec[0], VSR_ACT_LRELU02, nullptr, nullptr, rD1.lo, rD1.hi);
-    skipped(rD1, 2 * fh);
-    addConv("dec.2", d1, idN, d2, nn, 3, 1, 1, m_.dec[1], VSR_ACT_LRELU02, nullptr, nullptr, rD2.lo, rD2.hi);
-    skipped(rD2, 2 * fh);
+    auto skipped = [&](Rng r, int H, Rng c, int W) {
+        const double part = (double)(r.hi - r.lo) * (c.hi - c.lo);
+        trimmedFlops_ += ops.back().flops * ((double)H * W - part) / part;
+    };
+    addConv("dec.1", up1, idN, d1, nn, 3, 1, 1, m_.dec[0], VSR_ACT_LRELU02, nullptr, nullptr, rD1.lo, rD1.hi, cD1.lo, cD1.hi);
+    skipped(rD1, 2 * fh, cD1, 2 * fw);
+    addConv("dec.2", d1, idN, d2, nn, 3, 1, 1, m_.dec[1], VSR_ACT_LRELU02, nullptr, nullptr, rD2.lo, rD2.hi, cD2.lo, cD2.hi);
+    skipped(rD2, 2 * fh, cD2, 2 * fw);
     {
         Op op;
         op.kind = OP_UPSAMPLE2X; op.tag = "dec.up2";
@@ -773,8 +814,8 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         need(up2.buf, up2.elems());
         ops.push_back(std::move(op));
     }
-    addConv("dec.3", up2, idN, d3, nn, 3, 1, 1, m_.dec[2], VSR_ACT_LRELU02, nullptr, nullptr, rD3.lo, rD3.hi);
-    skipped(rD3, mh);
+    addConv("dec.3", up2, idN, d3, nn, 3, 1, 1, m_.dec[2], VSR_ACT_LRELU02, nullptr, nullptr, rD3.lo, rD3.hi, cD3.lo, cD3.hi);
+    skipped(rD3, mh, cD3, mw);
     if (tu_.outConvBlocked && mh % Model::kOutBlkH == 0 && mw % Model::kOutBlkW == 0) {
         // 64 -> 3 conv over 2x4 output blocks (Model::pack_conv_blocked): row = block, columns (dy, dx, c) in a [blocks][32] buffer
         const ConvW& w = m_.dec4blk;
@@ -783,8 +824,9 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         op.kind = OP_GEMM; op.tag = "dec.4"; op.tileCfg = VSR_TILE_256x32; op.bmode = VSR_BMODE_NK;
         const int BM = 256, BN = 32;
         GemmItem it{};
-        const int by0 = rOut.lo / bh, by1 = rOut.hi / bh;      // (decLo / decHi are whole blocks: Plan::Plan)
-        it.M = nn * (by1 - by0) * (mw / bw); it.N = w.cout; it.K = w.K;
+        const int by0 = rOut.lo / bh, by1 = rOut.hi / bh;      // (decLo / decHi, decXLo / decXHi are whole blocks: Plan::Plan)
+        const int bx0 = cOut.lo / bw, bx1 = cOut.hi / bw;
+        it.M = nn * (by1 - by0) * (bx1 - bx0); it.N = w.cout; it.K = w.K;
         it.tilesM = cdiv(it.M, BM); it.tilesN = 1;
         it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
         it.bufA = d3.buf; it.offA = 0;
@@ -793,12 +835,12 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
             std::vector<int32_t> rows;
             for (int f = 0; f < nn; ++f)
                 for (int by = by0; by < by1; ++by)
-                    for (int bx = 0; bx < mw / bw; ++bx) {
+                    for (int bx = bx0; bx < bx1; ++bx) {
                         rows.push_back((int32_t)d3.pix(f, by * bh, bx * bw));
                         crows.push_back((int32_t)((((int64_t)f * (mh / bh) + by) * (mw / bw) + bx) * 32));
                     }
             while ((int)rows.size() % BM) { rows.push_back(rows[0]); crows.push_back(crows[0]); }
-            it.tRowA = table("RBLK:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw) + ":" + std::to_string(by0) + "-" + std::to_string(by1), std::move(rows));
+            it.tRowA = table("RBLK:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw) + ":" + std::to_string(by0) + "-" + std::to_string(by1) + ":" + std::to_string(bx0) + "-" + std::to_string(bx1), std::move(rows));
             std::vector<int32_t> cols;
             auto off = [&](int wy, int wx, int c) { return (int32_t)(((int64_t)(wy - 1) * d3.Wp() + (wx - 1)) * d3.C + c); };
             if (tu_.convChannelMajor) {
@@ -816,16 +858,16 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         it.tRowB = tRowsLinear(it.N, it.K, BN);
         it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
         it.bufC = lb(BUF_D4); it.offC = 0;
-        it.tRowC = table("CBLKROW:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw) + ":" + std::to_string(by0) + "-" + std::to_string(by1), std::move(crows));
+        it.tRowC = table("CBLKROW:" + std::to_string(nn) + ":" + std::to_string(mh) + "x" + std::to_string(mw) + ":" + std::to_string(by0) + "-" + std::to_string(by1) + ":" + std::to_string(bx0) + "-" + std::to_string(bx1), std::move(crows));
         it.tColC = tColsLinear(1, 1);
         it.offBias = w.b;
         it.bufR = -1; it.tRowR = -1;
-        op.flops = 2.0 * (double)nn * (rOut.hi - rOut.lo) * mw * 3.0 * (9.0 * d3.C);     // the algorithmic work of the 3x3 conv, not the padded window's
+        op.flops = 2.0 * (double)nn * (rOut.hi - rOut.lo) * (cOut.hi - cOut.lo) * 3.0 * (9.0 * d3.C);     // the algorithmic work of the 3x3 conv, not the padded window's
         flops += op.flops;
         op.gemm.push_back(it);
         need(lb(BUF_D4), (int64_t)cdiv(nn * (mh / bh) * (mw / bw), BM) * BM * 32);
         ops.push_back(std::move(op));
-        skipped(rOut, mh);
+        skipped(rOut, mh, cOut, mw);
     } else
     {   // 64 -> 3 conv into a plain [M][32] buffer (columns 0..2 valid)
         const ConvW& w = m_.dec[3];
@@ -881,7 +923,7 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     ++nwindows;
 }
 
-Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, int decHi_)
+Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, int decHi_, int decXLo_, int decXHi_)
     : L(L_), precision(precision_), lanes(lanes_ < 1 ? 1 : (lanes_ > kMaxLanes ? kMaxLanes : lanes_)), g(model.g), m_(model), tu_(Tuning::get(precision_))
 {
     if (decHi_ > decLo_ && tu_.outConvBlocked && g.modelH % Model::kOutBlkH == 0 && g.modelW % Model::kOutBlkW == 0) {
@@ -890,6 +932,12 @@ Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, i
         decHi = (decHi_ > g.modelH ? g.modelH : decHi_);
         decHi = (decHi + Model::kOutBlkH - 1) / Model::kOutBlkH * Model::kOutBlkH;
         if (decHi > g.modelH) decHi = g.modelH;
+        if (decXHi_ > decXLo_) {         // columns only together with rows; whole 4-column blocks
+            decXLo = (decXLo_ < 0 ? 0 : decXLo_) / Model::kOutBlkW * Model::kOutBlkW;
+            decXHi = (decXHi_ > g.modelW ? g.modelW : decXHi_);
+            decXHi = (decXHi + Model::kOutBlkW - 1) / Model::kOutBlkW * Model::kOutBlkW;
+            if (decXHi > g.modelW) decXHi = g.modelW;
+        }
     }
     if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
     if (L <= 0) throw std::runtime_error("empty frame list");

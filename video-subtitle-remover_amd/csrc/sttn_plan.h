@@ -176,6 +176,8 @@ protected:
     int table(const std::string& key, std::vector<int32_t>&& v);
     // element offset of pixel (ids[i], y*stride, x*stride) of `a` (+ add) for every output pixel, padded to padTo rows
     int tRowsAct(const Act& a, const std::vector<int>& ids, int oh, int ow, int stride, int padTo, int64_t add);
+    // pixels (y, x) of a rectangle [ylo, yhi) x [xlo, xhi) of every listed frame, row-major, padded to padTo rows
+    int tRowsActRect(const Act& a, const std::vector<int>& ids, int ylo, int yhi, int xlo, int xhi, int padTo);
     // 32-channel chunk offsets of a kh x kw window (dilation dil) over channels [c0, c0+cin) of `a`; K order mirrors pack
     int tColsConvHW(const Act& a, int kh, int kw, int dil, int c0 = 0, int cin = -1);
     int tColsConv(const Act& a, int ksz, int dil) { return tColsConvHW(a, ksz, ksz, dil); }
@@ -189,8 +191,10 @@ public:
     // decLo / decHi: rows [decLo, decHi) of the model-resolution output are all the caller will read (sttn-auto blends the strip back
     // only where the mask is set: vsr_sttn_auto_chunk) -- the decoder computes those rows and what they depend on, nothing else
     // (buildWindow); decHi <= decLo = the whole image
-    Plan(const Model& model, int L, int precision = 0, int lanes = 1, int decLo = 0, int decHi = 0);
+    // decXLo / decXHi: the same for columns (the GEMMs take rectangles; the two elementwise kernels of the decoder keep whole rows)
+    Plan(const Model& model, int L, int precision = 0, int lanes = 1, int decLo = 0, int decHi = 0, int decXLo = 0, int decXHi = 0);
     int decLo = 0, decHi = 0;            // as given, clipped to the image and widened to whole 2-row blocks of the output conv
+    int decXLo = 0, decXHi = 0;          // ... to whole 4-column blocks
     int L;
     int precision;
     int lanes;                           // 1 .. kMaxLanes: window w runs on lane w % lanes
@@ -206,14 +210,16 @@ private:
     double trimmedFlops_ = 0;            // what the reference spends on last-block rows nobody reads (buildWindow)
     int pickTile(int N) const;
     // oy0 / oy1: patch rows [oy0, oy1) of every frame only (-1 = all): the query tokens of a last block that feeds a ranged decoder
-    int tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0 = 0, int oy1 = -1);
+    int tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0 = 0, int oy1 = -1, int ox0 = 0, int ox1 = -1);
     int tColsPatch(int s, int padTo);
-    int tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0 = 0, int oy1 = -1);
+    int tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0 = 0, int oy1 = -1, int ox0 = 0, int ox1 = -1);
     int tColsPatchAct(const Act& a, int s, int padTo);
     void addConv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, int nOut,
                  int ksz, int stride, int dil, const ConvW& w, int act, const Act* res,
-                 const std::vector<int>* resIds, int ylo = 0, int yhi = -1);     // [ylo, yhi): output rows computed (stride 1; default all)
-    void addAttention(int Tq, int T, const BlockW& bw, int attLo = 0, int attHi = -1);      // [attLo, attHi): feature rows of the output that are read
+                 const std::vector<int>* resIds, int ylo = 0, int yhi = -1,      // [ylo, yhi): output rows computed (stride 1; default all)
+                 int xlo = 0, int xhi = -1);                                       // [xlo, xhi): output columns computed (default all)
+    // [attLo, attHi) x [attXLo, attXHi): feature rows / columns of the output that are read
+    void addAttention(int Tq, int T, const BlockW& bw, int attLo = 0, int attHi = -1, int attXLo = 0, int attXHi = -1);
     void buildWindow(const std::vector<int>& neighbors, const std::vector<int>& refs,
                      std::vector<int32_t>& visits);
 };

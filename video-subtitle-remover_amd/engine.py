@@ -139,6 +139,21 @@ class SttnEngine:
         self._mask_rows_cache = (weakref.ref(mask_dev), mask_dev._version, ar.copy(), rows)
         return rows
 
+    def mask_cols(self, mask, areas):
+        """int32 [n_areas, 2]: the frame columns [lo, hi) that hold the set pixels of every area's strip (0, 0: none) -- the second
+        half of the promise vsr_sttn_auto_chunk_box takes (honoured with VSR_DECODE_COLS=1 only; built in round 4, not yet measured)."""
+        ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
+        cols = np.zeros((ar.shape[0], 2), dtype=np.int32)
+        for k, (ymin, ymax, _, _) in enumerate(ar):
+            if isinstance(mask, np.ndarray):
+                flags = (mask[int(ymin):int(ymax)].reshape(int(ymax - ymin), mask.shape[1], -1) != 0).any(axis=(0, 2))
+            else:
+                flags = mask[int(ymin):int(ymax)].reshape(int(ymax - ymin), int(mask.shape[1]), -1).ne(0).any(dim=2).any(dim=0).cpu().numpy()
+            nz = np.flatnonzero(flags)
+            if nz.size:
+                cols[k] = (int(nz[0]), int(nz[-1]) + 1)
+        return cols
+
     def chunk_flops(self, L, mask_dev, areas):
         """FLOPs of one auto_chunk call on this mask: every area's plan decodes only the rows its mask rows are resized from"""
         ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
@@ -167,6 +182,15 @@ class SttnEngine:
         # decode_rows=False: no promise about the mask, the whole model-resolution image is decoded (tests compare the two)
         # (mask_host: the caller's numpy copy of the mask, when it has one -- the rows are then read off it)
         rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
+        if decode_rows and os.environ.get("VSR_DECODE_COLS", "0") == "1":
+            cols = np.ascontiguousarray(self.mask_cols(mask_dev if mask_host is None else mask_host, ar))
+            with torch.cuda.device(frames_dev.device):
+                check(lib.vsr_sttn_auto_chunk_box(
+                    self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()), ar.shape[0],
+                    ar.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), cols.ctypes.data_as(C.c_void_p),
+                    None if sel_arr is None else sel_arr.ctypes.data_as(C.c_void_p),
+                    0 if sel_arr is None else int(sel_arr.size), _stream_ptr()))
+            return frames_dev
         with torch.cuda.device(frames_dev.device):
             check(lib.vsr_sttn_auto_chunk_rows(
                 self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()), ar.shape[0],
