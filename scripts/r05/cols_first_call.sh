@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round 5, first GPU call: the column ranges of DESIGN 4.3c were built and replayed on the CPU in round 4 but never ran on a GPU.
+#   1. bit equality of the frames with the promise-free call (tests/test_gpu_sttn.py::test_decoder_box_gives_the_same_frames)
+#   2. the default bench with the columns on / off, interleaved on one box (fps, GFLOP per frame, dominant-kernel rate)
+# If 1 is green and 2 follows the FLOPs: make VSR_DECODE_COLS default 1 (sttn_engine.hip colsOn, engine.py auto_chunk / chunk_flops).
+OUT=gpurun_out/r05_cols; mkdir -p $OUT
+(VSR_DECODE_COLS=1 timeout 900 python -m pytest tests/test_gpu_sttn.py -q -x -k "decoder_box or decoder_rows" 2>&1 | tail -5) > $OUT/pytest.log; tail -2 $OUT/pytest.log
+B="python bench.py --no-cpu-baseline --no-split-half --no-full-work --e2e-chunks 0 --steps 8 --warmup 2"
+for i in 1 2; do
+  for v in 1 0; do
+    VSR_DECODE_COLS=$v timeout 600 $B > $OUT/bench_cols${v}_$i.log 2>&1
+    grep '"metric"' $OUT/bench_cols${v}_$i.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+r=d['roofline']
+print('COLS=$v run $i:', d['value'], 'fps', d['ms_per_step'], 'ms; single lane', d['single_lane']['value'], '; GFLOP/frame', d['gflop_per_frame'], '|', d.get('gflop_per_frame_reference'), '; model TF', d['model_tflops'], '; roofline', r['achieved'], r['frac'])"
+  done
+done

@@ -95,7 +95,7 @@ def test_mask_islands_without_scipy_equal_scipy_label():
     assert t._islands(noisy) == t._islands_scipy(noisy > 0)
 
 
-def test_mask_rows_promise_from_the_host_mask(built_lib):
+def test_mask_rows_promise_from_the_host_mask(built_lib, monkeypatch):
     """SttnEngine.mask_rows on the caller's host copy of the mask (what the plugins pass): per area the strip rows [lo, hi) that hold
     the mask's set pixels -- the promise vsr_sttn_auto_chunk_rows / vsr_sttn_det_batch_rows take -- and the model rows they turn
     into (whole groups of four, inside the image)."""
@@ -128,6 +128,17 @@ def test_mask_rows_promise_from_the_host_mask(built_lib):
             strip = mask[ymin:ymax, :, 0]
             assert 0 <= lo < hi <= W and strip[:, lo].any() and strip[:, hi - 1].any() and not strip[:, :lo].any() and not strip[:, hi:].any()
         assert (eng.mask_cols(np.zeros((H, W), np.uint8), areas) == 0).all()
+        for (lo, hi) in cols:                          # ... and the model columns they turn into: whole groups of eight around the taps
+            a, b = C.c_int32(), C.c_int32()
+            assert lib.vsr_sttn_decode_cols(eng._h, W, int(lo), int(hi), C.byref(a), C.byref(b)) == 0
+            assert 0 <= a.value < b.value <= 640 and a.value % 8 == 0 and (b.value % 8 == 0 or b.value == 640)
+            assert a.value <= (lo + 0.5) * 640 / W - 0.5 and b.value >= (hi - 0.5) * 640 / W - 0.5 + 1 or b.value == 640
+            assert lib.vsr_sttn_flops_box(eng._h, 50, 76, 120, a.value, b.value) < lib.vsr_sttn_flops_rows(eng._h, 50, 76, 120)
+        assert lib.vsr_sttn_decode_cols(eng._h, W, 5, 5, C.byref(a), C.byref(b)) != 0             # an empty promise is an error
+        monkeypatch.setenv("VSR_DECODE_COLS", "1")     # chunk_flops prices what the engine would run with the switch on
+        with_cols = eng.chunk_flops(50, mask[:, :, 0], areas)
+        monkeypatch.delenv("VSR_DECODE_COLS")
+        assert with_cols < eng.chunk_flops(50, mask[:, :, 0], areas)
     finally:
         eng.close()
 

@@ -89,6 +89,8 @@ SIGNATURES = {
     "vsr_sttn_auto_chunk_rows": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "vsr_sttn_auto_chunk_box": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "vsr_sttn_decode_rows": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vsr_sttn_decode_cols": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vsr_sttn_flops_box": (_D, [_P, _I, _I, _I, _I, _I]),
     "vsr_sttn_flops_rows": (_D, [_P, _I, _I, _I]),
     "vsr_sttn_det_inpaint": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vsr_sttn_det_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),

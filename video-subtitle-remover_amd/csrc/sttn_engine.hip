@@ -762,6 +762,25 @@ int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t
 //   maskRows (sttn-auto, nullable): per area, the strip rows [lo, hi) outside which the caller's mask is zero.  The strip is blended
 //   back only where the mask is set (vsr_launch_upscale_blend), so only the model-resolution rows those strip rows are resized
 //   from are ever read: the decoder computes them and what they depend on (Plan::decLo), the same values as before.
+// The model columns [*lo, *hi) (whole groups of eight) that the horizontal taps of the resize back to W columns read for the frame
+// columns [c0, c1); 0, 0 = no restriction (an empty or out-of-range promise).
+static void model_cols_of_mask(int mw, int W, int c0, int c1, int* lo, int* hi)
+{
+    *lo = *hi = 0;
+    if (c0 < 0 || c1 > W || c0 >= c1) return;
+    std::vector<int32_t> ofs;
+    std::vector<int16_t> ic;
+    std::vector<float> fc;
+    cv2_linear_tables(mw, W, true, ofs, ic, fc);
+    int xl = mw, xh = 0;
+    for (int dx = c0; dx < c1; ++dx) {
+        const int a = ofs[dx] < 0 ? 0 : (ofs[dx] < mw ? ofs[dx] : mw - 1), b = a + 1 < mw ? a + 1 : mw - 1;
+        xl = a < xl ? a : xl;
+        xh = b + 1 > xh ? b + 1 : xh;
+    }
+    if (xh > xl) { *lo = xl / 8 * 8; *hi = (xh + 7) / 8 * 8 < mw ? (xh + 7) / 8 * 8 : mw; }
+}
+
 static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
                          const int32_t* areas, const int32_t* sel, int nsel, hipStream_t stream, const int32_t* maskRows = nullptr,
                          const int32_t* maskCols = nullptr)
@@ -824,17 +843,7 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
             if (hi > lo) { decLo[k] = lo / 4 * 4; decHi[k] = (hi + 3) / 4 * 4 < mh ? (hi + 3) / 4 * 4 : mh; }
             if (hi > lo && !det && maskCols && colsOn) {
                 // the same along x (sttn-auto): the model columns the horizontal taps of the resize back read for the mask's columns
-                const int c0 = maskCols[2 * k], c1 = maskCols[2 * k + 1];
-                if (c0 >= 0 && c1 <= W && c0 < c1) {
-                    cv2_linear_tables(mw, W, true, ofs, ic, fc);
-                    int xl = mw, xh = 0;
-                    for (int dx = c0; dx < c1; ++dx) {
-                        const int a = ofs[dx] < 0 ? 0 : (ofs[dx] < mw ? ofs[dx] : mw - 1), b = a + 1 < mw ? a + 1 : mw - 1;
-                        xl = a < xl ? a : xl;
-                        xh = b + 1 > xh ? b + 1 : xh;
-                    }
-                    if (xh > xl) { decXLo[k] = xl / 8 * 8; decXHi[k] = (xh + 7) / 8 * 8 < mw ? (xh + 7) / 8 * 8 : mw; }
-                }
+                model_cols_of_mask(mw, W, maskCols[2 * k], maskCols[2 * k + 1], &decXLo[k], &decXHi[k]);
             }
         }
     }
@@ -923,6 +932,29 @@ double vsr_sttn_flops_rows(vsr_sttn_t* h, int L, int row_lo, int row_hi)
         fail(VSR_ERR_ARG, e.what());
         return -1.0;
     }
+}
+
+double vsr_sttn_flops_box(vsr_sttn_t* h, int L, int row_lo, int row_hi, int col_lo, int col_hi)
+{
+    if (!h || !h->model.packed_ready() || L <= 0) { fail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        Plan p(h->model, L, 0, 1, row_lo, row_hi, col_lo, col_hi);
+        return p.flops;
+    } catch (const std::exception& e) {
+        fail(VSR_ERR_ARG, e.what());
+        return -1.0;
+    }
+}
+
+int vsr_sttn_decode_cols(vsr_sttn_t* h, int frame_w, int mask_col_lo, int mask_col_hi, int32_t* col_lo, int32_t* col_hi)
+{
+    if (!h || !col_lo || !col_hi || frame_w <= 0 || mask_col_lo < 0 || mask_col_hi > frame_w || mask_col_lo >= mask_col_hi)
+        return fail(VSR_ERR_ARG, "bad argument");
+    if (h->model.g.variant == VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "column ranges: sttn-auto only");
+    int lo = 0, hi = 0;
+    model_cols_of_mask(h->model.g.modelW, frame_w, mask_col_lo, mask_col_hi, &lo, &hi);
+    *col_lo = lo; *col_hi = hi;
+    return 0;
 }
 
 int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_row_hi, int32_t* row_lo, int32_t* row_hi)

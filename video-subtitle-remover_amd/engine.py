@@ -158,11 +158,18 @@ class SttnEngine:
         """FLOPs of one auto_chunk call on this mask: every area's plan decodes only the rows its mask rows are resized from"""
         ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
         total = 0.0
-        for (ymin, ymax, _, _), (lo, hi) in zip(ar, self.mask_rows(mask_dev, ar)):
+        with_cols = self.variant == "auto" and os.environ.get("VSR_DECODE_COLS", "0") == "1"
+        cols = self.mask_cols(mask_dev, ar) if with_cols else np.zeros((ar.shape[0], 2), dtype=np.int32)
+        for (ymin, ymax, _, _), (lo, hi), (c0, c1) in zip(ar, self.mask_rows(mask_dev, ar), cols):
             if hi > lo and os.environ.get("VSR_DECODE_ROWS", "1") != "0":
                 a, b = C.c_int32(), C.c_int32()
                 check(lib.vsr_sttn_decode_rows(self._h, int(ymax - ymin), int(lo), int(hi), C.byref(a), C.byref(b)))
-                v = lib.vsr_sttn_flops_rows(self._h, int(L), a.value, b.value)
+                if c1 > c0:
+                    ca, cb = C.c_int32(), C.c_int32()
+                    check(lib.vsr_sttn_decode_cols(self._h, int(mask_dev.shape[1]), int(c0), int(c1), C.byref(ca), C.byref(cb)))
+                    v = lib.vsr_sttn_flops_box(self._h, int(L), a.value, b.value, ca.value, cb.value)
+                else:
+                    v = lib.vsr_sttn_flops_rows(self._h, int(L), a.value, b.value)
             else:
                 v = lib.vsr_sttn_flops(self._h, int(L))
             if v < 0:
