@@ -366,6 +366,17 @@ int vsr_pp_window_flags(const uint8_t* masks_host, int lt, int H, int W, uint8_t
 int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev,
                    const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t, int lt, int H, int W,
                    const uint8_t* window_flags, int nflags, float* out_dev, void* stream);
+/* The same with a promise of the caller: of the output it reads rows [row_lo, row_hi) and columns [col_lo, col_hi) only (the
+ * plugin blends a window's prediction into its frames under the dilated mask, propainter_inpaint.py:350-357); lo = hi = 0: the
+ * whole axis.  The soft composition's embedding and the decoder's convs then run on what that box depends on; inside it the
+ * output is the one of vsr_pp_forward, outside it is undefined.  (Built and replayed on the CPU in round 4; the plugin passes the
+ * promise only with VSR_PP_DECODE_BOX=1 until it has run on a GPU.) */
+int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev,
+                       const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t, int lt, int H, int W,
+                       const uint8_t* window_flags, int nflags, int row_lo, int row_hi, int col_lo, int col_hi, float* out_dev, void* stream);
+/* FLOPs of that call; *reference (may be NULL) = what the reference spends on the same window */
+double vsr_pp_flops_box(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi,
+                        int col_lo, int col_hi, double* reference);
 /* The plugin's own array work (PropainterInpaint.inpaint, propainter_inpaint.py:190-361) on frames that stay in HBM as the uint8
  * BGR crops [n][h][w][3]; mask: the dilated mask uint8 [h][w] (non-zero = hole), the same for every frame (:195-197).
  *   prepare : masked_frames fp32 [n][3][h][w] = (to_tensors(RGB) * 2 - 1) * (1 - mask)                                  (:193-213,298)
@@ -539,6 +550,8 @@ int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vs
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_gen_plan_create(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, vsr_plan_t** out);
+int vsr_pp_gen_plan_create_box(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi,
+                               int col_lo, int col_hi, vsr_plan_t** out);
 int vsr_lama_plan_create(const vsr_lama_t* h, int B, int H, int W, vsr_plan_t** out);
 int64_t vsr_plan_consts(const vsr_plan_t* p, float* out, int64_t capacity);   /* fp32 plan constants (buffer id -2), returns the count */
 void vsr_plan_destroy(vsr_plan_t* p);

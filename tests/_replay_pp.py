@@ -114,10 +114,15 @@ def replay_imgprop(view, masked_frames, flows_f, flows_b, masks_u8):
 PG_OUT = 47
 
 
-def gen_plan_view(_lib, engine, t, lt, H, W, flags):
+def gen_plan_view(_lib, engine, t, lt, H, W, flags, box=None):
+    """box = (row_lo, row_hi, col_lo, col_hi): the plan of vsr_pp_forward_box"""
     p = C.c_void_p()
     f = np.ascontiguousarray(flags, dtype=np.uint8)
-    _lib.check(_lib.lib.vsr_pp_gen_plan_create(engine.handle, t, lt, H, W, f.ctypes.data_as(C.c_void_p), f.size, C.byref(p)))
+    if box is not None:
+        _lib.check(_lib.lib.vsr_pp_gen_plan_create_box(engine.handle, t, lt, H, W, f.ctypes.data_as(C.c_void_p), f.size, *[int(b) for b in box],
+                                                       C.byref(p)))
+    else:
+        _lib.check(_lib.lib.vsr_pp_gen_plan_create(engine.handle, t, lt, H, W, f.ctypes.data_as(C.c_void_p), f.size, C.byref(p)))
     return _replay.PlanView(_lib, None, 0, plan_ptr=p)
 
 

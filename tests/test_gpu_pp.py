@@ -1,4 +1,6 @@
 """ProPainter generator stages on the MI355X through the C-ABI against oracle/propainter.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -85,6 +87,26 @@ def test_generator_strip_size_smoke(gen_engine, gpu_device):
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and a.abs().max() <= 1.0
     assert torch.equal(a, b)
+
+
+@pytest.mark.skipif(os.environ.get("VSR_PP_DECODE_BOX", "0") != "1",
+                    reason="the generator's decoder box is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_PP_DECODE_BOX=1 pytest -k decoder_box")
+@pytest.mark.parametrize("box", [(224, 360, 0, 0), (224, 360, 280, 1640), (0, 64, 0, 512), (120, 200, 1400, 1920)])
+def test_generator_decoder_box(gen_engine, gpu_device, box):
+    """vsr_pp_forward_box at the 1080p strip size: inside the promised box the output is the one of the call without a promise bit
+    for bit (the same products in the same order per output element), also after the stale rows of an earlier, different box."""
+    t, lt, H, W = 15, 11, 360, 1920
+    frames, masks, ff, fb = propainter_inputs(93, t, lt, H, W)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+    m8 = masks[:, 0].astype(np.uint8)
+    args = (d(frames * (1 - masks)), d(ff), d(fb), d(m8), d(m8), lt)
+    want = gen_engine.forward(*args).clone()
+    gen_engine.forward(*args, box=(8, 40, 8, 200))                       # leaves other rows stale
+    got = gen_engine.forward(*args, box=box)
+    torch.cuda.synchronize()
+    y0, y1, x0, x1 = box[0], box[1], box[2], (box[3] if box[3] > box[2] else W)
+    assert torch.equal(got[:, :, y0:y1, x0:x1], want[:, :, y0:y1, x0:x1])
+    assert torch.isfinite(got).all()
 
 
 def test_propainter_plugin_matches_oracle(built_lib, gpu_device, pp_sd):

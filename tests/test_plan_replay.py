@@ -44,7 +44,7 @@ def test_plan_replay_decoder_rows(built_lib, host_engine):
     from _replay import PlanView, replay
 
     sd, eng = host_engine
-    L = 4
+    L = 2                # one window of two neighbour frames: the row / column logic does not depend on the window's length
     frames = np.random.default_rng(21).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8)
     full = PlanView(_lib, eng, L)
     want, counts, _ = replay(full, eng.packed_weights(), frames)
@@ -77,7 +77,7 @@ def test_plan_replay_decoder_box(built_lib, host_engine):
     from _replay import PlanView, replay
 
     sd, eng = host_engine
-    L = 4
+    L = 2                # one window of two neighbour frames: the row / column logic does not depend on the window's length
     frames = np.random.default_rng(22).integers(0, 256, size=(L, 120, 640, 3), dtype=np.uint8)
     full = PlanView(_lib, eng, L)
     want, counts, _ = replay(full, eng.packed_weights(), frames)

@@ -68,6 +68,39 @@ def test_generator_replay_matches_oracle(pp_host_engine, pp_sd, t, lt, H, W, exp
     view.close()
 
 
+@pytest.mark.parametrize("box", [(40, 60, 0, 0), (0, 9, 100, 192), (100, 128, 0, 30), (50, 70, 60, 130)])
+def test_generator_replay_box(pp_host_engine, pp_sd, box):
+    """vsr_pp_forward_box: with the promise that only a box of the output is read (the plugin blends a prediction in under the dilated
+    mask), the soft composition's embedding and the decoder's convs run on the tokens / pixels that box depends on.  The replay starts
+    from zeroed buffers and the elementwise ops keep whole images, so a range one row or column short anywhere in the chain (3x3
+    convs, two align_corners upsamplings, the 7x7 / stride-3 fold) shows inside the box; inside it the output is the full plan's
+    (up to torch-CPU's M-dependent matmul blocking), outside it differs, the FLOPs go down and the reference count stays."""
+    import ctypes as C
+
+    t, lt, H, W = 5, 3, 128, 192
+    sel, ff, fb, m_in, m_upd, ref = _generator_case(75, t, lt, H, W, pp_sd)
+    flags = pp_host_engine.window_flags(m_in[:lt])
+    full = rp.gen_plan_view(_lib, pp_host_engine, t, lt, H, W, flags)
+    want, _ = rp.replay_gen(full, pp_host_engine.packed_weights(), sel, ff, fb, m_in, m_upd, lt)
+    full_flops = full.flops
+    full.close()
+    part = rp.gen_plan_view(_lib, pp_host_engine, t, lt, H, W, flags, box=box)
+    try:
+        got, _ = rp.replay_gen(part, pp_host_engine.packed_weights(), sel, ff, fb, m_in, m_upd, lt)
+        y0, y1, x0, x1 = box[0], box[1], box[2], (box[3] if box[3] > box[2] else W)
+        d = np.abs(got - want)
+        assert d[:, :, y0:y1, x0:x1].max() <= 2e-5, d[:, :, y0:y1, x0:x1].max()
+        assert np.abs(want[:, :, y0:y1, x0:x1] - ref[:, :, y0:y1, x0:x1]).max() <= 5e-4
+        assert d.max() > 1e-2                               # ... and the ranges are ranges: far from the box nothing was computed
+        assert part.flops < full_flops
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        r = C.c_double()
+        x = _lib.lib.vsr_pp_flops_box(pp_host_engine.handle, t, lt, H, W, f.ctypes.data_as(C.c_void_p), f.size, *box, C.byref(r))
+        assert x == part.flops and abs(r.value - full_flops) <= 1e-6 * full_flops
+    finally:
+        part.close()
+
+
 def test_generator_strict_state_dict(pp_sd, built_lib):
     from vsr_amd.engine import PpEngine
 

@@ -160,6 +160,14 @@ class PropainterInpaint:
             stride = self.neighbor_length // 2
             ref_num = svl // self.ref_stride if n > svl else -1
             flags_cache = {}
+            # The window's prediction is blended in under the dilated mask only (vsr_pp_blend_window below, :350-357): with the promise
+            # about those rows / columns the generator's decoder runs on what they depend on (vsr_pp_forward_box; whole groups of
+            # eight, so that the boxes of a video that differ by a few pixels share their plans).  Built and replayed on the CPU in
+            # round 4, not yet run on a GPU: opt-in.
+            box = None
+            if os.environ.get("VSR_PP_DECODE_BOX", "0") == "1" and md.any():
+                ys, xs = np.flatnonzero(md.any(axis=1)), np.flatnonzero(md.any(axis=0))
+                box = (int(ys[0]) // 8 * 8, min(h, (int(ys[-1]) + 8) // 8 * 8), int(xs[0]) // 8 * 8, min(w, (int(xs[-1]) + 8) // 8 * 8))
             for f in range(0, n, stride):
                 nb = [i for i in range(max(0, f - stride), min(n, f + stride + 1))]
                 ref = get_ref_index(f, nb, n, self.ref_stride, ref_num)
@@ -168,7 +176,7 @@ class PropainterInpaint:
                 if l_t not in flags_cache:                                                  # the same mask on every frame
                     flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
                 pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
-                                          md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t])
+                                          md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t], box=box)
                 idx = torch.tensor(nb, dtype=torch.int32).to(dev, non_blocking=True)
                 first = torch.tensor([0 if visited[i] else 1 for i in nb], dtype=torch.int32).to(dev, non_blocking=True)
                 check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), stream()))

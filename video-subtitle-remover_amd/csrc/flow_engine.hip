@@ -962,13 +962,22 @@ int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_de
                    const uint8_t* masks_updated_dev, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, float* out_dev,
                    void* stream_)
 {
+    return vsr_pp_forward_box(h, frames_dev, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t, lt, H, W, window_flags, nflags, 0, 0, 0, 0,
+                              out_dev, stream_);
+}
+
+int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_in_dev,
+                       const uint8_t* masks_updated_dev, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo,
+                       int row_hi, int col_lo, int col_hi, float* out_dev, void* stream_)
+{
     if (!h || !frames_dev || !masks_in_dev || !masks_updated_dev || !window_flags || !out_dev || (lt > 1 && (!flows_f_dev || !flows_b_dev)))
         return rfail(VSR_ERR_ARG, "bad argument");
     if (!h->finalized || h->device < 0)
         return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device; there is no CPU fallback");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t stream = (hipStream_t)stream_;
-    std::string key = std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W) + ":";
+    std::string key = std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W) + ":" +
+                      std::to_string(row_lo) + "-" + std::to_string(row_hi) + ":" + std::to_string(col_lo) + "-" + std::to_string(col_hi) + ":";
     key.append((const char*)window_flags, (size_t)nflags);
     FlowPlanDev* pd = nullptr;
     auto it = h->genPlans.find(key);
@@ -977,7 +986,7 @@ int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_de
     } else {
         std::unique_ptr<PlanIR> plan;
         try {
-            plan.reset(new PpGenPlan(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags)));
+            plan.reset(new PpGenPlan(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags), row_lo, row_hi, col_lo, col_hi));
         } catch (const std::exception& e) {
             return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
         }
@@ -1006,8 +1015,8 @@ int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_de
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {
         h->ws.precision = 0;
-        const int rc = vsr_pp_forward(h, frames_dev, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t, lt, H, W, window_flags, nflags,
-                                      out_dev, stream_);
+        const int rc = vsr_pp_forward_box(h, frames_dev, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t, lt, H, W, window_flags, nflags,
+                                          row_lo, row_hi, col_lo, col_hi, out_dev, stream_);
         h->ws.precision = 1;
         return rc;
     }
@@ -1034,6 +1043,35 @@ double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* win
         rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
         return -1.0;
     }
+}
+
+double vsr_pp_flops_box(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi, int col_lo,
+                        int col_hi, double* reference)
+{
+    if (!h || !h->model.packed_ready() || !window_flags) { rfail(VSR_ERR_ARG, "bad argument"); return -1.0; }
+    try {
+        PpGenPlan p(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags), row_lo, row_hi, col_lo, col_hi);
+        if (reference) *reference = p.refFlops;
+        return p.flops;
+    } catch (const std::exception& e) {
+        rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+        return -1.0;
+    }
+}
+
+int vsr_pp_gen_plan_create_box(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi,
+                               int col_lo, int col_hi, vsr_plan_t** out)
+{
+    if (!h || !out || !window_flags) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return rfail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new PpGenPlan(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags), row_lo, row_hi, col_lo, col_hi));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+    }
+    return 0;
 }
 
 int vsr_pp_gen_plan_create(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, vsr_plan_t** out)

@@ -336,6 +336,22 @@ void PpGenPlan::conv(const char* tag, const Act& in, const std::vector<int>& inI
          res ? tRowsAct(*res, *resIds, out.H, out.W, 1, BM, 0) : -1, tile, appendTo);
 }
 
+void PpGenPlan::convRect(const char* tag, const Act& in, const std::vector<int>& ids, const std::vector<int>& chunkCh, const Act& out,
+                         const ConvW& w, int act, const Act* res, int ylo, int yhi, int xlo, int xhi)
+{
+    if (in.H != out.H || in.W != out.W || ylo < 0 || yhi > out.H || xlo < 0 || xhi > out.W || ylo >= yhi || xlo >= xhi)
+        throw std::runtime_error(std::string("propainter conv rectangle: ") + tag);
+    const int tile = pickTile(w.cout);
+    int BM, BN;
+    tileDims(tile, BM, BN);
+    const int M = (int)ids.size() * (yhi - ylo) * (xhi - xlo);
+    trimmedFlops_ += 2.0 * ((double)ids.size() * out.H * out.W - M) * w.cout * (9.0 * 32 * chunkCh.size());
+    need(out.buf, out.elems());
+    gemm(tag, in.buf, 0, tRowsActRect(in, ids, ylo, yhi, xlo, xhi, BM), tColsChunks(in, 3, 3, 1, chunkCh), 9 * 32 * (int)chunkCh.size(), M, out.buf,
+         0, tRowsActRect(out, ids, ylo, yhi, xlo, xhi, BM), -1, w, act, res ? res->buf : -1, 0,
+         res ? tRowsActRect(*res, ids, ylo, yhi, xlo, xhi, BM) : -1, tile, nullptr);
+}
+
 void PpGenPlan::upsample(const Act& in, const Act& out)
 {
     Op op;
@@ -465,9 +481,19 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
     ops.push_back(std::move(pv));
 }
 
-PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, const std::vector<uint8_t>& windowMasked)
+PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, const std::vector<uint8_t>& windowMasked, int decLo_, int decHi_,
+                     int decXLo_, int decXHi_)
     : t(t_), lt(lt_), H(H_), W(W_), h(H_ / 4), w(W_ / 4), m_(model)
 {
+    decLo = 0; decHi = H; decXLo = 0; decXHi = W;
+    if (decHi_ > decLo_) {
+        if (decLo_ < 0 || decHi_ > H) throw std::runtime_error("bad output row range");
+        decLo = decLo_; decHi = decHi_;
+    }
+    if (decXHi_ > decXLo_) {
+        if (decXLo_ < 0 || decXHi_ > W) throw std::runtime_error("bad output column range");
+        decXLo = decXLo_; decXHi = decXHi_;
+    }
     if (!model.packed_ready()) throw std::runtime_error("ProPainter model is not packed");
     if (lt < 1 || lt > t) throw std::runtime_error("bad number of local frames");
     if (H % 4 || W % 4 || h < 7 || w < 7) throw std::runtime_error("frame size must be a multiple of 4 and at least 28");
@@ -699,10 +725,53 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
     }
 
     // ---- soft composition (:34-64) of the local frames + enc_feat, decoder (:270-277,371-376)
+    // Only the local frames' output is produced, and PropainterInpaint reads it under the dilated mask only.  With a promise about
+    // those rows / columns (decLo ...) the chain is walked backwards: a 3x3 conv widens a range by one, the align_corners x2
+    // upsampling of n source rows reads rows floor(y (n - 1) / (2 n - 1)) and the next one for output row y (one more of slack on
+    // each side for the kernel's float arithmetic), a token of the soft composition covers feature rows 3 ty - 3 .. 3 ty + 3.
+    // The elementwise ops between the GEMMs (fold, the two upsamplings, tanh) keep whole images: what they compute outside the
+    // ranges comes from rows no GEMM wrote in this pass, and nothing inside the ranges reads it.
+    struct Rng { int lo, hi; };
+    auto widen = [](Rng r, int by, int n) { return Rng{r.lo - by > 0 ? r.lo - by : 0, r.hi + by < n ? r.hi + by : n}; };
+    auto below = [](Rng r, int nsrc) {
+        const int on = 2 * nsrc;
+        int lo = (int)((int64_t)r.lo * (nsrc - 1) / (on - 1)) - 1, hi = (int)((int64_t)(r.hi - 1) * (nsrc - 1) / (on - 1)) + 3;
+        return Rng{lo > 0 ? lo : 0, hi < nsrc ? hi : nsrc};
+    };
+    auto tokens = [](Rng r, int ntok) {           // tokens whose 7x7 / stride 3 / padding 3 patch touches feature rows r
+        int lo = r.lo - 3 <= 0 ? 0 : (r.lo - 3 + 2) / 3, hi = (r.hi + 2) / 3 + 1;
+        return Rng{lo, hi < ntok ? hi : ntok};
+    };
+    const bool ranged = decLo > 0 || decHi < H || decXLo > 0 || decXHi < W;
+    const Rng rD3{decLo, decHi}, rD2 = widen(rD3, 1, H), rUp1 = widen(rD2, 1, H);
+    const Rng rD1 = below(rUp1, 2 * h), rD0 = widen(rD1, 1, 2 * h), rUp0 = widen(rD0, 1, 2 * h);
+    const Rng rDin = below(rUp0, h), rScf = widen(rDin, 1, h), rTok = tokens(rScf, fh);
+    const Rng cD3{decXLo, decXHi}, cD2 = widen(cD3, 1, W), cUp1 = widen(cD2, 1, W);
+    const Rng cD1 = below(cUp1, 2 * w), cD0 = widen(cD1, 1, 2 * w), cUp0 = widen(cD0, 1, 2 * w);
+    const Rng cDin = below(cUp0, w), cScf = widen(cDin, 1, w), cTok = tokens(cScf, fw);
     const int ntokL = lt * fh * fw;
     need(PG_SC, (int64_t)ntokL * 6272);
-    gemm("sc.embed", PG_X, 0, tRowsLinear(ntokL, 512, BM), tColsLinear(16, 16), 512, ntokL, PG_SC, 0, tRowsLinear(ntokL, 6272, BM), -1, m_.sc,
-         VSR_ACT_NONE, -1, 0, -1, VSR_TILE_128x64);
+    if (!ranged) {
+        gemm("sc.embed", PG_X, 0, tRowsLinear(ntokL, 512, BM), tColsLinear(16, 16), 512, ntokL, PG_SC, 0, tRowsLinear(ntokL, 6272, BM), -1, m_.sc,
+             VSR_ACT_NONE, -1, 0, -1, VSR_TILE_128x64);
+    } else {
+        std::vector<int32_t> ra, rc;
+        for (int f = 0; f < lt; ++f)
+            for (int ty = rTok.lo; ty < rTok.hi; ++ty)
+                for (int tx = cTok.lo; tx < cTok.hi; ++tx) {
+                    const int64_t tok = ((int64_t)f * fh + ty) * fw + tx;
+                    if (tok * 6272 > 2147483647LL) throw std::runtime_error("offset table entry exceeds int32");
+                    ra.push_back((int32_t)(tok * 512));
+                    rc.push_back((int32_t)(tok * 6272));
+                }
+        const int M = (int)ra.size();
+        trimmedFlops_ += 2.0 * (ntokL - M) * 6272.0 * 512;
+        while (ra.size() % BM) { ra.push_back(ra[0]); rc.push_back(rc[0]); }
+        const std::string key = std::to_string(lt) + ":" + std::to_string(rTok.lo) + "-" + std::to_string(rTok.hi) + ":" + std::to_string(cTok.lo) +
+                                "-" + std::to_string(cTok.hi);
+        gemm("sc.embed", PG_X, 0, table("SCTOKA:" + key, std::move(ra)), tColsLinear(16, 16), 512, M, PG_SC, 0, table("SCTOKC:" + key, std::move(rc)),
+             -1, m_.sc, VSR_ACT_NONE, -1, 0, -1, VSR_TILE_128x64);
+    }
     const Act scf{PG_SCF, lt, h, w, 128, 1}, din{PG_DIN, lt, h, w, 128, 0};
     {
         Op& op = ew(EW_PP_FOLD, "sc.fold");
@@ -710,21 +779,33 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
         op.ipar[0] = 6272; op.ipar[1] = lt; op.ipar[2] = fh; op.ipar[3] = fw; op.ipar[4] = h; op.ipar[5] = w; op.ipar[6] = 128; op.ipar[7] = 1; op.ipar[8] = 0;
         need(PG_SCF, scf.elems());
     }
-    conv("sc.conv", scf, idsL, chunks(0, 4), 3, 3, 1, 1, din, idsL, 0, m_.scConv, VSR_ACT_NONE, &feat, &idsL);
+    if (ranged) convRect("sc.conv", scf, idsL, chunks(0, 4), din, m_.scConv, VSR_ACT_NONE, &feat, rDin.lo, rDin.hi, cDin.lo, cDin.hi);
+    else conv("sc.conv", scf, idsL, chunks(0, 4), 3, 3, 1, 1, din, idsL, 0, m_.scConv, VSR_ACT_NONE, &feat, &idsL);
     const Act up0{PG_UP0, lt, 2 * h, 2 * w, 128, 1}, d0{PG_D0, lt, 2 * h, 2 * w, 128, 1}, d1{PG_D1, lt, 2 * h, 2 * w, 64, 0};
     const Act up1{PG_UP1, lt, H, W, 64, 1}, d2{PG_D2, lt, H, W, 64, 1}, d3{PG_D3, lt, H, W, 32, 0};
     upsample(din, up0);
-    conv("dec.0", up0, idsL, chunks(0, 4), 3, 3, 1, 1, d0, idsL, 0, m_.dec0, L, nullptr, nullptr);
-    conv("dec.2", d0, idsL, chunks(0, 4), 3, 3, 1, 1, d1, idsL, 0, m_.dec2, L, nullptr, nullptr);
+    if (ranged) {
+        convRect("dec.0", up0, idsL, chunks(0, 4), d0, m_.dec0, L, nullptr, rD0.lo, rD0.hi, cD0.lo, cD0.hi);
+        convRect("dec.2", d0, idsL, chunks(0, 4), d1, m_.dec2, L, nullptr, rD1.lo, rD1.hi, cD1.lo, cD1.hi);
+    } else {
+        conv("dec.0", up0, idsL, chunks(0, 4), 3, 3, 1, 1, d0, idsL, 0, m_.dec0, L, nullptr, nullptr);
+        conv("dec.2", d0, idsL, chunks(0, 4), 3, 3, 1, 1, d1, idsL, 0, m_.dec2, L, nullptr, nullptr);
+    }
     upsample(d1, up1);
-    conv("dec.4", up1, idsL, chunks(0, 2), 3, 3, 1, 1, d2, idsL, 0, m_.dec4, L, nullptr, nullptr);
-    conv("dec.6", d2, idsL, chunks(0, 2), 3, 3, 1, 1, d3, idsL, 0, m_.dec6, VSR_ACT_NONE, nullptr, nullptr);
+    if (ranged) {
+        convRect("dec.4", up1, idsL, chunks(0, 2), d2, m_.dec4, L, nullptr, rD2.lo, rD2.hi, cD2.lo, cD2.hi);
+        convRect("dec.6", d2, idsL, chunks(0, 2), d3, m_.dec6, VSR_ACT_NONE, nullptr, rD3.lo, rD3.hi, cD3.lo, cD3.hi);
+    } else {
+        conv("dec.4", up1, idsL, chunks(0, 2), 3, 3, 1, 1, d2, idsL, 0, m_.dec4, L, nullptr, nullptr);
+        conv("dec.6", d2, idsL, chunks(0, 2), 3, 3, 1, 1, d3, idsL, 0, m_.dec6, VSR_ACT_NONE, nullptr, nullptr);
+    }
     {
         Op& op = ew(EW_PP_TANH_OUT, "dec.tanh");
         op.ibuf[0] = PG_D3; op.ibuf[1] = PG_OUT;
         op.ipar[0] = 32; op.ipar[1] = lt; op.ipar[2] = H; op.ipar[3] = W;
         need(PG_OUT, (int64_t)lt * 3 * HW);
     }
+    refFlops = flops + trimmedFlops_;
 }
 
 } // namespace vsr

@@ -76,8 +76,14 @@ private:
 // "mask.sum > 0" test (:229-236), computed by the caller from the masks (host side, see flow_engine.hip).
 class PpGenPlan : public PlanBuilder {
 public:
-    PpGenPlan(const PpModel& model, int t, int lt, int H, int W, const std::vector<uint8_t>& windowMasked);
+    // decLo .. decXHi: a promise of the caller that it reads rows [decLo, decHi) and columns [decXLo, decXHi) of the output only
+    // (PropainterInpaint blends a window's prediction into its frames where the dilated mask is set, propainter_inpaint.py:350-357):
+    // the soft composition's embedding and the decoder's convs then run on the tokens / pixels those depend on.  0, 0 = everything.
+    PpGenPlan(const PpModel& model, int t, int lt, int H, int W, const std::vector<uint8_t>& windowMasked, int decLo = 0, int decHi = 0,
+              int decXLo = 0, int decXHi = 0);
     int t, lt, H, W;
+    int decLo = 0, decHi = 0, decXLo = 0, decXHi = 0;        // as taken (whole image: 0, H / 0, W)
+    double refFlops = 0;                                      // the reference's count (flops = what this plan executes)
     int h, w;            // H/4, W/4
     int fh, fw;          // token grid (soft split 7/3/3)
     int gh, gw;          // token grid padded to whole 5x9 windows
@@ -85,6 +91,7 @@ public:
     static void token_grid(int H, int W, int& fh, int& fw, int& gh, int& gw);
 private:
     const PpModel& m_;
+    double trimmedFlops_ = 0;
     int pickTile(int N) const;
     int tColsChunks(const Act& a, int kh, int kw, int dil, const std::vector<int>& chunkCh);
     void gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tColA, int K, int M, int bufC, int64_t offC, int tRowC, int tColC,
@@ -92,6 +99,9 @@ private:
     void conv(const char* tag, const Act& in, const std::vector<int>& inIds, const std::vector<int>& chunkCh, int kh, int kw, int stride, int dil,
               const Act& out, const std::vector<int>& outIds, int c0out, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds,
               Op* appendTo = nullptr);
+    // the same for a stride-1 conv on the output pixels of rows [ylo, yhi) x columns [xlo, xhi) only (row tables over the rectangle)
+    void convRect(const char* tag, const Act& in, const std::vector<int>& ids, const std::vector<int>& chunkCh, const Act& out, const ConvW& w,
+                  int act, const Act* res, int ylo, int yhi, int xlo, int xhi);
     void upsample(const Act& in, const Act& out);
     Op& ew(int kind, const char* tag);
     void attention(int blk, const std::vector<uint8_t>& windowMasked);

@@ -448,9 +448,10 @@ class PpEngine:
         check(lib.vsr_pp_read_buffer(self._h, buf, offset, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def forward(self, frames, flows_f, flows_b, masks_in, masks_updated, lt, flags=None):
+    def forward(self, frames, flows_f, flows_b, masks_in, masks_updated, lt, flags=None, box=None):
         """InpaintGenerator.forward in eval mode: frames fp32 [t,3,H,W], flows fp32 [lt-1,2,H,W], masks uint8 [t,H,W] on the GPU
-        -> tanh output fp32 [lt,3,H,W]."""
+        -> tanh output fp32 [lt,3,H,W].  box = (row_lo, row_hi, col_lo, col_hi): a promise that only that box of the output is read
+        (vsr_pp_forward_box: the decoder runs on what the box depends on; outside it the output is undefined)."""
         assert frames.dtype == torch.float32 and frames.is_cuda and frames.is_contiguous()
         assert masks_in.dtype == torch.uint8 and masks_in.is_contiguous() and masks_updated.is_contiguous()
         t, _, H, W = frames.shape
@@ -458,9 +459,10 @@ class PpEngine:
             flags = self.window_flags(masks_in[:lt].cpu().numpy())
         out = torch.empty((lt, 3, H, W), dtype=torch.float32, device=frames.device)
         with torch.cuda.device(frames.device):
-            check(lib.vsr_pp_forward(self._h, C.c_void_p(frames.data_ptr()), C.c_void_p(flows_f.data_ptr()), C.c_void_p(flows_b.data_ptr()),
-                                     C.c_void_p(masks_in.data_ptr()), C.c_void_p(masks_updated.data_ptr()), t, lt, H, W,
-                                     flags.ctypes.data_as(C.c_void_p), flags.size, C.c_void_p(out.data_ptr()), _stream_ptr()))
+            check(lib.vsr_pp_forward_box(self._h, C.c_void_p(frames.data_ptr()), C.c_void_p(flows_f.data_ptr()), C.c_void_p(flows_b.data_ptr()),
+                                         C.c_void_p(masks_in.data_ptr()), C.c_void_p(masks_updated.data_ptr()), t, lt, H, W,
+                                         flags.ctypes.data_as(C.c_void_p), flags.size, *[int(b) for b in (box or (0, 0, 0, 0))],
+                                         C.c_void_p(out.data_ptr()), _stream_ptr()))
         return out
 
     def close(self):
