@@ -94,11 +94,13 @@ int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, i
 int vsr_sttn_auto_chunk_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                             int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* mask_cols,
                             const int32_t* sel, int nsel, void* stream);
-/* the column half of the same two questions (sttn-auto; what VSR_DECODE_COLS=1 makes vsr_sttn_auto_chunk_box do): the model columns
+/* the column half of the same two questions (what VSR_DECODE_COLS=1 makes vsr_sttn_auto_chunk_box / vsr_sttn_det_batch_box do): the model columns
  * [*col_lo, *col_hi) decoded for a mask in frame columns [mask_col_lo, mask_col_hi) of a frame_w-wide frame (0, 0: all), and the
  * FLOPs of a plan restricted to a box of model rows and columns */
 int vsr_sttn_decode_cols(vsr_sttn_t* h, int frame_w, int mask_col_lo, int mask_col_hi, int32_t* col_lo, int32_t* col_hi);
 double vsr_sttn_flops_box(vsr_sttn_t* h, int L, int row_lo, int row_hi, int col_lo, int col_hi);
+int vsr_sttn_det_batch_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                           const int32_t* areas, const int32_t* mask_rows, const int32_t* mask_cols, void* stream);   /* the same for sttn-det */
 /* model-resolution rows [*row_lo, *row_hi) decoded for a strip of strip_h rows whose mask lives in rows [mask_row_lo, mask_row_hi),
  * and the FLOPs of one L-frame call decoded that way (vsr_sttn_flops = the whole image) */
 int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_row_hi, int32_t* row_lo, int32_t* row_hi);

@@ -5,6 +5,7 @@
 # If 1 is green and 2 follows the FLOPs: make VSR_DECODE_COLS default 1 (sttn_engine.hip colsOn, engine.py auto_chunk / chunk_flops).
 OUT=gpurun_out/r05_cols; mkdir -p $OUT
 (VSR_DECODE_COLS=1 timeout 900 python -m pytest tests/test_gpu_sttn.py -q -x -k "decoder_box or decoder_rows" 2>&1 | tail -5) > $OUT/pytest.log; tail -2 $OUT/pytest.log
+# config 3's inpainting with the columns off / on: scripts/r04/rows_det.sh with VSR_DECODE_COLS=0 / 1 is the det-side A/B
 B="python bench.py --no-cpu-baseline --no-split-half --no-full-work --e2e-chunks 0 --steps 8 --warmup 2"
 for i in 1 2; do
   for v in 1 0; do

@@ -44,6 +44,46 @@ def run_det(L=2, ns=1, rl=2, seed=5):
     return {"counts": counts.tolist(), "psnr": calculate_psnr(comp, refa), "max_abs": float(d.max()), "flops": flops}
 
 
+def run_det_box(L=2, seed=6):
+    """sttn-det with the promise about the mask's rows and columns (vsr_sttn_det_batch_box): the prediction is taken where the resized
+    mask is non-zero, everything else is the input frame -- so with a box around the non-zero mask the WHOLE composite is the full
+    plan's (the replay starts from zeroed buffers: a range one row / column short shows as zeros under the mask)."""
+    import vsr_amd  # noqa: F401
+    from vsr_amd import _lib
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+    from oracle import cv2_restate as cv2r
+    from _replay import PlanView, replay
+
+    eng = SttnEngine(make_state_dict(1, "det"), "det", device=None, neighbor_stride=1, ref_length=2)
+    frames = np.random.default_rng(seed).integers(0, 256, size=(L, 240, 432, 3), dtype=np.uint8)
+    res = []
+    for L, (r0, r1, c0, c1) in ((L, (150, 330, 300, 1500)), (1, (400, 533, 0, 420)), (1, (20, 60, 1700, 1920))):
+        frames = frames[:L]
+        big = np.zeros((533, 1920, 1), np.uint8)
+        big[r0:r1, c0:c1] = 255
+        small = cv2r.resize_linear(big, (432, 240))[:, :, 0]
+        masks = np.stack([small] * L)
+        ys, xs = np.flatnonzero(small.any(axis=1)), np.flatnonzero(small.any(axis=0))
+        rows, cols = (int(ys[0]), int(ys[-1]) + 1), (int(xs[0]), int(xs[-1]) + 1)
+        full = PlanView(_lib, eng, L)
+        want, counts, _ = replay(full, eng.packed_weights(), frames, masks)
+        full.close()
+        strip = PlanView(_lib, eng, L, rows=rows)
+        rows_flops = strip.flops
+        strip.close()
+        part = PlanView(_lib, eng, L, rows=rows, cols=cols)
+        got, counts2, _ = replay(part, eng.packed_weights(), frames, masks)
+        d = np.abs(got - want)
+        assert list(counts) == list(counts2)
+        assert d.max() <= 1.0 and (d > 0).mean() < 1e-3, (rows, cols, d.max(), (d > 0).mean())
+        assert part.flops < rows_flops
+        res.append((rows, cols, part.flops / rows_flops))
+        part.close()
+    eng.close()
+    return res
+
+
 def run(L=4, ns=2, rl=3, seed=11):
     import vsr_amd  # noqa: F401
     from vsr_amd import _lib

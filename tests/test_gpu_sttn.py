@@ -452,6 +452,29 @@ def test_decoder_rows_give_the_same_frames_det(built_lib, gpu_device, sd_det, H,
     eng.close()
 
 
+@pytest.mark.skipif(os.environ.get("VSR_DECODE_COLS", "0") != "1",
+                    reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
+@pytest.mark.parametrize("H,W,box", [(720, 1280, (620, 700, 400, 900)), (1080, 1920, (40, 160, 1500, 1900)), (480, 852, (150, 400, 0, 200))])
+def test_decoder_box_gives_the_same_frames_det(built_lib, gpu_device, sd_det, H, W, box):
+    """vsr_sttn_det_batch_box with VSR_DECODE_COLS=1: the frames are those of the call without a promise, bit for bit"""
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.backend.tools.inpaint_tools import create_mask as cm, get_inpaint_area_by_mask as ga
+
+    eng = SttnEngine(sd_det, "det", device=0)
+    frames = torch.from_numpy(synth.make_clip(9, H, W, box, seed=12)).to(gpu_device)
+    mask = cm((H, W), [(box[2], box[3], box[0], box[1])])
+    areas = ga(W, H, int(W * 5 / 18), mask[:, :, None])
+    dmask = torch.from_numpy(np.ascontiguousarray(mask)).to(gpu_device)
+    assert np.array_equal(eng.mask_cols(dmask, areas), eng.mask_cols(mask, areas))
+    a, b = frames.clone(), frames.clone()
+    eng.det_batch(a, dmask, areas, decode_rows=False)
+    eng.det_batch(b, dmask, areas, mask_host=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, frames)
+    eng.close()
+
+
 def test_two_lanes_equal_one_lane_det(built_lib, gpu_device, sd_det):
     from vsr_amd.engine import SttnEngine
 

@@ -116,6 +116,14 @@ def test_plan_replay_sttn_det(built_lib):
     assert res["counts"] == [2, 2]
 
 
+def test_plan_replay_sttn_det_box(built_lib):
+    """sttn-det with the decoder / last block on the box of the resized mask (rows and columns): the whole composite is the full plan's"""
+    import _replay_check
+
+    res = _replay_check.run_det_box()
+    assert len(res) == 3 and all(r[2] < 1.0 for r in res), res
+
+
 def test_plan_flops_det_matches_survey(built_lib):
     """733.8 GFLOP per frame for a 50-frame sttn-det batch."""
     from vsr_amd.engine import SttnEngine

@@ -88,6 +88,7 @@ SIGNATURES = {
     "vsr_sttn_auto_chunk": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _P]),
     "vsr_sttn_auto_chunk_rows": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "vsr_sttn_auto_chunk_box": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "vsr_sttn_det_batch_box": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "vsr_sttn_decode_rows": (_I, [_P, _I, _I, _I, _P, _P]),
     "vsr_sttn_decode_cols": (_I, [_P, _I, _I, _I, _P, _P]),
     "vsr_sttn_flops_box": (_D, [_P, _I, _I, _I, _I, _I]),

@@ -764,19 +764,27 @@ int vsr_sttn_det_inpaint(vsr_sttn_t* h, const uint8_t* frames_dev, const uint8_t
 //   from are ever read: the decoder computes them and what they depend on (Plan::decLo), the same values as before.
 // The model columns [*lo, *hi) (whole groups of eight) that the horizontal taps of the resize back to W columns read for the frame
 // columns [c0, c1); 0, 0 = no restriction (an empty or out-of-range promise).
-static void model_cols_of_mask(int mw, int W, int c0, int c1, int* lo, int* hi)
+static void model_cols_of_mask(bool det, int mw, int W, int c0, int c1, int* lo, int* hi)
 {
     *lo = *hi = 0;
     if (c0 < 0 || c1 > W || c0 >= c1) return;
     std::vector<int32_t> ofs;
     std::vector<int16_t> ic;
     std::vector<float> fc;
-    cv2_linear_tables(mw, W, true, ofs, ic, fc);
     int xl = mw, xh = 0;
-    for (int dx = c0; dx < c1; ++dx) {
-        const int a = ofs[dx] < 0 ? 0 : (ofs[dx] < mw ? ofs[dx] : mw - 1), b = a + 1 < mw ? a + 1 : mw - 1;
-        xl = a < xl ? a : xl;
-        xh = b + 1 > xh ? b + 1 : xh;
+    if (!det) {
+        cv2_linear_tables(mw, W, true, ofs, ic, fc);
+        for (int dx = c0; dx < c1; ++dx) {
+            const int a = ofs[dx] < 0 ? 0 : (ofs[dx] < mw ? ofs[dx] : mw - 1), b = a + 1 < mw ? a + 1 : mw - 1;
+            xl = a < xl ? a : xl;
+            xh = b + 1 > xh ? b + 1 : xh;
+        }
+    } else {
+        cv2_linear_tables(W, mw, true, ofs, ic, fc);
+        for (int x = 0; x < mw; ++x) {
+            const int a = ofs[x] < 0 ? 0 : (ofs[x] < W ? ofs[x] : W - 1), b = a + 1 < W ? a + 1 : W - 1;
+            if (b >= c0 && a < c1) { xl = x < xl ? x : xl; xh = x + 1 > xh ? x + 1 : xh; }
+        }
     }
     if (xh > xl) { *lo = xl / 8 * 8; *hi = (xh + 7) / 8 * 8 < mw ? (xh + 7) / 8 * 8 : mw; }
 }
@@ -841,9 +849,10 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
             // whole groups of four rows: every distinct (L, range) is a plan of its own (40-60 MB of offset tables, 30 ms to build),
             // and the detected boxes of a video differ by a few pixels from interval to interval
             if (hi > lo) { decLo[k] = lo / 4 * 4; decHi[k] = (hi + 3) / 4 * 4 < mh ? (hi + 3) / 4 * 4 : mh; }
-            if (hi > lo && !det && maskCols && colsOn) {
-                // the same along x (sttn-auto): the model columns the horizontal taps of the resize back read for the mask's columns
-                model_cols_of_mask(mw, W, maskCols[2 * k], maskCols[2 * k + 1], &decXLo[k], &decXHi[k]);
+            if (hi > lo && maskCols && colsOn) {
+                // the same along x: sttn-auto, the model columns the horizontal taps of the resize back read for the mask's columns;
+                // sttn-det, the model columns one of whose two source columns (the taps of the resize down) is a mask column
+                model_cols_of_mask(det, mw, W, maskCols[2 * k], maskCols[2 * k + 1], &decXLo[k], &decXHi[k]);
             }
         }
     }
@@ -950,9 +959,8 @@ int vsr_sttn_decode_cols(vsr_sttn_t* h, int frame_w, int mask_col_lo, int mask_c
 {
     if (!h || !col_lo || !col_hi || frame_w <= 0 || mask_col_lo < 0 || mask_col_hi > frame_w || mask_col_lo >= mask_col_hi)
         return fail(VSR_ERR_ARG, "bad argument");
-    if (h->model.g.variant == VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "column ranges: sttn-auto only");
     int lo = 0, hi = 0;
-    model_cols_of_mask(h->model.g.modelW, frame_w, mask_col_lo, mask_col_hi, &lo, &hi);
+    model_cols_of_mask(h->model.g.variant == VSR_VARIANT_STTN_DET, h->model.g.modelW, frame_w, mask_col_lo, mask_col_hi, &lo, &hi);
     *col_lo = lo; *col_hi = hi;
     return 0;
 }
@@ -1003,6 +1011,14 @@ int vsr_sttn_det_batch_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, in
     RCCHK(need_gpu(h));
     if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
     return strips_common(h, true, frames_dev, L, H, W, mask_dev, n_areas, areas, nullptr, 0, (hipStream_t)stream_, mask_rows);
+}
+
+int vsr_sttn_det_batch_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev, int n_areas,
+                           const int32_t* areas, const int32_t* mask_rows, const int32_t* mask_cols, void* stream_)
+{
+    RCCHK(need_gpu(h));
+    if (h->model.g.variant != VSR_VARIANT_STTN_DET) return fail(VSR_ERR_STATE, "not an sttn-det model");
+    return strips_common(h, true, frames_dev, L, H, W, mask_dev, n_areas, areas, nullptr, 0, (hipStream_t)stream_, mask_rows, mask_cols);
 }
 
 int vsr_sttn_set_precision(vsr_sttn_t* h, int mode)

@@ -158,7 +158,7 @@ class SttnEngine:
         """FLOPs of one auto_chunk call on this mask: every area's plan decodes only the rows its mask rows are resized from"""
         ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
         total = 0.0
-        with_cols = self.variant == "auto" and os.environ.get("VSR_DECODE_COLS", "0") == "1"
+        with_cols = os.environ.get("VSR_DECODE_COLS", "0") == "1"
         cols = self.mask_cols(mask_dev, ar) if with_cols else np.zeros((ar.shape[0], 2), dtype=np.int32)
         for (ymin, ymax, _, _), (lo, hi), (c0, c1) in zip(ar, self.mask_rows(mask_dev, ar), cols):
             if hi > lo and os.environ.get("VSR_DECODE_ROWS", "1") != "0":
@@ -228,6 +228,13 @@ class SttnEngine:
         L, H, W, _ = frames_dev.shape
         ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
         rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
+        if decode_rows and os.environ.get("VSR_DECODE_COLS", "0") == "1":
+            cols = np.ascontiguousarray(self.mask_cols(mask_dev if mask_host is None else mask_host, ar))
+            with torch.cuda.device(frames_dev.device):
+                check(lib.vsr_sttn_det_batch_box(self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()),
+                                                 ar.shape[0], ar.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p),
+                                                 cols.ctypes.data_as(C.c_void_p), _stream_ptr()))
+            return frames_dev
         with torch.cuda.device(frames_dev.device):
             check(lib.vsr_sttn_det_batch_rows(self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()),
                                               ar.shape[0], ar.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), _stream_ptr()))
