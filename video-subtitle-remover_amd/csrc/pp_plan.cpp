@@ -377,8 +377,11 @@ static std::vector<int> cat(std::vector<int> a, const std::vector<int>& b)
 // row softmax, P.V -- one problem per (window, head).  Keys of a masked window: its own tokens, the rolled-window tokens
 // outside it (valid_ind_rolled) and all pooled tokens, on the frames of this block's temporal stride; an unmasked window
 // attends to its own tokens on all frames.  Key order is irrelevant to softmax(QK^T)V, only the set matters.
-void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
+void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked, int tq, int ty0, int ty1, int tx0, int tx1)
 {
+    const bool allQ = tq == t && ty0 <= 0 && ty1 >= fh && tx0 <= 0 && tx1 >= fw;
+    const std::string qSfx = allQ ? std::string() : ":q" + std::to_string(tq);      // (a window is taken whole or not at all)
+    double fullFlops = 0;
     const int nwh = gh / 5, nww = gw / 9, C = 512, CH = 128, Q3 = 3 * C;
     const int parity = blk % 2;                                   // T_ind = arange(parity, t, 2)  (:330-334, t_dilation = 2)
     Op qk, sm, pv;
@@ -431,15 +434,19 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
             pv.gemm.push_back(b);
             const double fl = 2.0 * M * (double)nk * CH;
             qk.flops += fl; pv.flops += fl;
+            fullFlops -= 2 * fl;
             sOff += rup((int64_t)M * ldS, 32);
         }
     };
     for (int win = 0; win < nwh * nww; ++win) {
         const int wy = win / nww, wx = win % nww;
         const std::string wkey = std::to_string(win);
+        const bool unread = !allQ && (wy * 5 >= ty1 || wy * 5 + 5 <= ty0 || wx * 9 >= tx1 || wx * 9 + 9 <= tx0);      // none of its tokens is read
         if (!windowMasked[win]) {
+            fullFlops += 4 * 2 * 2.0 * (45.0 * t) * 45 * CH;           // what the reference spends on it: 4 heads, QK^T and P.V
+            if (unread) continue;
             // unmasked window (:253-262): every frame's 45 queries attend to the same frame's 45 window tokens (t is a batch dimension)
-            for (int f = 0; f < t; ++f) {
+            for (int f = 0; f < tq; ++f) {
                 std::vector<int64_t> tok;
                 for (int i = 0; i < 5; ++i)
                     for (int j = 0; j < 9; ++j) tok.push_back(tokRow(f, wy * 5 + i, wx * 9 + j));
@@ -451,7 +458,7 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
         // masked window (:238-251): all frames' queries; keys on the frames of this block's temporal stride: the window tokens,
         // the rolled-window tokens outside the window, all pooled tokens
         std::vector<int64_t> qTok, kTok;
-        for (int f = 0; f < t; ++f)
+        for (int f = 0; f < tq; ++f)
             for (int i = 0; i < 5; ++i)
                 for (int j = 0; j < 9; ++j) qTok.push_back(tokRow(f, wy * 5 + i, wx * 9 + j));
         for (int f = parity; f < t; f += 2) {
@@ -471,11 +478,14 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked)
                     }
             for (int p = 0; p < ph * pw; ++p) kTok.push_back(pooledBase + (int64_t)f * ph * pw + p);
         }
-        addProblem(wkey, qTok, wkey + ":m" + std::to_string(parity), kTok);
+        fullFlops += 4 * 2 * 2.0 * (45.0 * t) * (double)kTok.size() * CH;
+        if (unread) continue;
+        addProblem(wkey + qSfx, qTok, wkey + ":m" + std::to_string(parity), kTok);
     }
     need(PG_S, sOff);
     need(PG_P, sOff);
     flops += qk.flops + pv.flops;
+    if (!allQ && fullFlops > 0) trimmedFlops_ += fullFlops;
     ops.push_back(std::move(qk));
     ops.push_back(std::move(sm));
     ops.push_back(std::move(pv));
@@ -669,6 +679,50 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
     const Act xTok{PG_X, t, fh, fw, 512, 0};
     conv("ss", feat, idsT, chunks(0, 4), 7, 7, 3, 1, xTok, idsT, 0, m_.ss, VSR_ACT_NONE, nullptr, nullptr);
 
+    // Only the local frames' output is produced, and PropainterInpaint reads it under the dilated mask only.  With a promise about
+    // those rows / columns (decLo ...) the chain is walked backwards: a 3x3 conv widens a range by one, the align_corners x2
+    // upsampling of n source rows reads rows floor(y (n - 1) / (2 n - 1)) and the next one for output row y (one more of slack on
+    // each side for the kernel's float arithmetic), a token of the soft composition covers feature rows 3 ty - 3 .. 3 ty + 3.
+    // The elementwise ops between the GEMMs (fold, the two upsamplings, tanh) keep whole images: what they compute outside the
+    // ranges comes from rows no GEMM wrote in this pass, and nothing inside the ranges reads it.
+    struct Rng { int lo, hi; };
+    auto widen = [](Rng r, int by, int n) { return Rng{r.lo - by > 0 ? r.lo - by : 0, r.hi + by < n ? r.hi + by : n}; };
+    auto below = [](Rng r, int nsrc) {
+        const int on = 2 * nsrc;
+        int lo = (int)((int64_t)r.lo * (nsrc - 1) / (on - 1)) - 1, hi = (int)((int64_t)(r.hi - 1) * (nsrc - 1) / (on - 1)) + 3;
+        return Rng{lo > 0 ? lo : 0, hi < nsrc ? hi : nsrc};
+    };
+    auto tokens = [](Rng r, int ntok) {           // tokens whose 7x7 / stride 3 / padding 3 patch touches feature rows r
+        int lo = r.lo - 3 <= 0 ? 0 : (r.lo - 3 + 2) / 3, hi = (r.hi + 2) / 3 + 1;
+        return Rng{lo, hi < ntok ? hi : ntok};
+    };
+    const bool ranged = decLo > 0 || decHi < H || decXLo > 0 || decXHi < W;
+    const Rng rD3{decLo, decHi}, rD2 = widen(rD3, 1, H), rUp1 = widen(rD2, 1, H);
+    const Rng rD1 = below(rUp1, 2 * h), rD0 = widen(rD1, 1, 2 * h), rUp0 = widen(rD0, 1, 2 * h);
+    const Rng rDin = below(rUp0, h), rScf = widen(rDin, 1, h), rTok = tokens(rScf, fh);
+    const Rng cD3{decXLo, decXHi}, cD2 = widen(cD3, 1, W), cUp1 = widen(cD2, 1, W);
+    const Rng cD1 = below(cUp1, 2 * w), cD0 = widen(cD1, 1, 2 * w), cUp0 = widen(cD0, 1, 2 * w);
+    const Rng cDin = below(cUp0, w), cScf = widen(cDin, 1, w), cTok = tokens(cScf, fw);
+    // The LAST transformer block is read by the soft composition alone.  Under a box promise its output is needed on tokens rTok x cTok
+    // of the local frames; fc2 is per token, the fold / unfold pair in front of it reads the fc1 output of every token whose patch
+    // touches the feature rows those tokens cover (rF1 x cF1), and so do norm2, the projection and the attention queries.  The keys
+    // and values (all frames, all tokens) are never restricted; the elementwise ops keep whole token grids.
+    auto patchRows = [](Rng r, int n) { return Rng{3 * r.lo - 3 > 0 ? 3 * r.lo - 3 : 0, 3 * r.hi + 1 < n ? 3 * r.hi + 1 : n}; };
+    const Rng rF1 = tokens(patchRows(rTok, h), fh), cF1 = tokens(patchRows(cTok, w), fw);
+    auto tokTable = [&](const char* name, Rng ry, Rng rx, int64_t ld, bool padded) {
+        std::vector<int32_t> v;
+        for (int f = 0; f < lt; ++f)
+            for (int ty = ry.lo; ty < ry.hi; ++ty)
+                for (int tx = rx.lo; tx < rx.hi; ++tx) {
+                    const int64_t o = (padded ? ((int64_t)f * gh + ty) * gw + tx : ((int64_t)f * fh + ty) * fw + tx) * ld;
+                    if (o > 2147483647LL) throw std::runtime_error("offset table entry exceeds int32");
+                    v.push_back((int32_t)o);
+                }
+        while (v.size() % BM) v.push_back(v[0]);
+        return table(std::string(name) + ":" + std::to_string(lt) + ":" + std::to_string(ry.lo) + "-" + std::to_string(ry.hi) + ":" +
+                         std::to_string(rx.lo) + "-" + std::to_string(rx.hi) + ":" + std::to_string(ld) + (padded ? "p" : ""),
+                     std::move(v));
+    };
     // ---- 8 TemporalSparseTransformer blocks (:273-344)
     const int64_t gridRows = (int64_t)t * gh * gw, poolRows = (int64_t)t * ph * pw, qRows = gridRows + poolRows;
     need(PG_YQ, qRows * 512);
@@ -699,8 +753,17 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
         }
         gemm("tr.qkv", PG_YQ, 0, tRowsLinear((int)qRows, 512, BM), tColsLinear(16, 16), 512, (int)qRows, PG_QKV, 0, tRowsLinear((int)qRows, 1536, BM),
              -1, bw.qkv, VSR_ACT_NONE, -1, 0, -1, VSR_TILE_128x64);
-        attention(i, windowMasked);
+        const bool boxed = ranged && i == 7;
+        const int mF1 = lt * (rF1.hi - rF1.lo) * (cF1.hi - cF1.lo), mTok = lt * (rTok.hi - rTok.lo) * (cTok.hi - cTok.lo);
+        if (boxed) attention(i, windowMasked, lt, rF1.lo, rF1.hi, cF1.lo, cF1.hi);
+        else attention(i, windowMasked, t, 0, fh, 0, fw);
         // x = shortcut + proj(att) on the un-padded tokens (:263-269,288-291)
+        if (boxed) {
+            const int tx512 = tokTable("TOKBOX", rF1, cF1, 512, false);
+            gemm("tr.proj", PG_ATT, 0, tokTable("TOKBOX", rF1, cF1, 512, true), tColsLinear(16, 16), 512, mF1, PG_X, 0, tx512, -1, bw.proj, VSR_ACT_NONE,
+                 PG_X, 0, tx512, VSR_TILE_128x64);
+            trimmedFlops_ += 2.0 * (ntok - mF1) * 512.0 * 512;
+        } else
         gemm("tr.proj", PG_ATT, 0, tValid, tColsLinear(16, 16), 512, ntok, PG_X, 0, tRowX, -1, bw.proj, VSR_ACT_NONE, PG_X, 0, tRowX, VSR_TILE_128x64);
         {
             Op& op = ew(EW_PP_LAYERNORM, "tr.norm2");
@@ -708,6 +771,11 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
             op.ipar[0] = t; op.ipar[1] = fh; op.ipar[2] = fw; op.ipar[3] = 512; op.ipar[4] = fh; op.ipar[5] = fw;
         }
         // FusionFeedForward (:67-104): fc1, fold / normalise / unfold, GELU, fc2
+        if (boxed) {
+            gemm("tr.fc1", PG_Y2, 0, tokTable("TOKBOX", rF1, cF1, 512, false), tColsLinear(16, 16), 512, mF1, PG_F1, 0,
+                 tokTable("TOKBOX", rF1, cF1, 1984, false), -1, bw.fc1, VSR_ACT_NONE, -1, 0, -1, VSR_TILE_128x64);
+            trimmedFlops_ += 2.0 * (ntok - mF1) * (double)bw.fc1.cout * 512;
+        } else
         gemm("tr.fc1", PG_Y2, 0, tRowX, tColsLinear(16, 16), 512, ntok, PG_F1, 0, tRowsLinear(ntok, 1984, BM), -1, bw.fc1, VSR_ACT_NONE, -1, 0, -1,
              VSR_TILE_128x64);
         {
@@ -720,35 +788,17 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
             op.ibuf[0] = PG_FMAP; op.ibuf[1] = PG_F2;
             op.ipar[0] = t; op.ipar[1] = fh; op.ipar[2] = fw; op.ipar[3] = h; op.ipar[4] = w; op.ipar[5] = 40; op.ipar[6] = 1984;
         }
+        if (boxed) {
+            const int tx512 = tokTable("TOKBOX", rTok, cTok, 512, false);
+            gemm("tr.fc2", PG_F2, 0, tokTable("TOKBOX", rTok, cTok, 1984, false), tColsLinear(62, 62), 1984, mTok, PG_X, 0, tx512, -1, bw.fc2,
+                 VSR_ACT_NONE, PG_X, 0, tx512, VSR_TILE_128x64);
+            trimmedFlops_ += 2.0 * (ntok - mTok) * 512.0 * 1984;
+        } else
         gemm("tr.fc2", PG_F2, 0, tRowsLinear(ntok, 1984, BM), tColsLinear(62, 62), 1984, ntok, PG_X, 0, tRowX, -1, bw.fc2, VSR_ACT_NONE, PG_X, 0, tRowX,
              VSR_TILE_128x64);
     }
 
     // ---- soft composition (:34-64) of the local frames + enc_feat, decoder (:270-277,371-376)
-    // Only the local frames' output is produced, and PropainterInpaint reads it under the dilated mask only.  With a promise about
-    // those rows / columns (decLo ...) the chain is walked backwards: a 3x3 conv widens a range by one, the align_corners x2
-    // upsampling of n source rows reads rows floor(y (n - 1) / (2 n - 1)) and the next one for output row y (one more of slack on
-    // each side for the kernel's float arithmetic), a token of the soft composition covers feature rows 3 ty - 3 .. 3 ty + 3.
-    // The elementwise ops between the GEMMs (fold, the two upsamplings, tanh) keep whole images: what they compute outside the
-    // ranges comes from rows no GEMM wrote in this pass, and nothing inside the ranges reads it.
-    struct Rng { int lo, hi; };
-    auto widen = [](Rng r, int by, int n) { return Rng{r.lo - by > 0 ? r.lo - by : 0, r.hi + by < n ? r.hi + by : n}; };
-    auto below = [](Rng r, int nsrc) {
-        const int on = 2 * nsrc;
-        int lo = (int)((int64_t)r.lo * (nsrc - 1) / (on - 1)) - 1, hi = (int)((int64_t)(r.hi - 1) * (nsrc - 1) / (on - 1)) + 3;
-        return Rng{lo > 0 ? lo : 0, hi < nsrc ? hi : nsrc};
-    };
-    auto tokens = [](Rng r, int ntok) {           // tokens whose 7x7 / stride 3 / padding 3 patch touches feature rows r
-        int lo = r.lo - 3 <= 0 ? 0 : (r.lo - 3 + 2) / 3, hi = (r.hi + 2) / 3 + 1;
-        return Rng{lo, hi < ntok ? hi : ntok};
-    };
-    const bool ranged = decLo > 0 || decHi < H || decXLo > 0 || decXHi < W;
-    const Rng rD3{decLo, decHi}, rD2 = widen(rD3, 1, H), rUp1 = widen(rD2, 1, H);
-    const Rng rD1 = below(rUp1, 2 * h), rD0 = widen(rD1, 1, 2 * h), rUp0 = widen(rD0, 1, 2 * h);
-    const Rng rDin = below(rUp0, h), rScf = widen(rDin, 1, h), rTok = tokens(rScf, fh);
-    const Rng cD3{decXLo, decXHi}, cD2 = widen(cD3, 1, W), cUp1 = widen(cD2, 1, W);
-    const Rng cD1 = below(cUp1, 2 * w), cD0 = widen(cD1, 1, 2 * w), cUp0 = widen(cD0, 1, 2 * w);
-    const Rng cDin = below(cUp0, w), cScf = widen(cDin, 1, w), cTok = tokens(cScf, fw);
     const int ntokL = lt * fh * fw;
     need(PG_SC, (int64_t)ntokL * 6272);
     if (!ranged) {

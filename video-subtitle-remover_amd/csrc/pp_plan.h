@@ -104,7 +104,9 @@ private:
                   int act, const Act* res, int ylo, int yhi, int xlo, int xhi);
     void upsample(const Act& in, const Act& out);
     Op& ew(int kind, const char* tag);
-    void attention(int blk, const std::vector<uint8_t>& windowMasked);
+    // tq, ty0 .. tx1: queries of the first tq frames and of the windows that hold a token of rows [ty0, ty1) x columns [tx0, tx1) only
+    // (the last block under a box promise); the keys are never restricted
+    void attention(int blk, const std::vector<uint8_t>& windowMasked, int tq, int ty0, int ty1, int tx0, int tx1);
 };
 
 } // namespace vsr
