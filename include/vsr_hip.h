@@ -379,6 +379,24 @@ int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_
 /* FLOPs of that call; *reference (may be NULL) = what the reference spends on the same window */
 double vsr_pp_flops_box(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi,
                         int col_lo, int col_hi, double* reference);
+/* The encoder and the soft split ONCE PER FRAME.  Both are per-frame functions of a frame's own inputs (propainter.py:333-335: the
+ * frames are a batch dimension of the encoder; sparse_transformer.py:7-31), and the plugin's windows overlap -- a frame is a local
+ * frame of two or three windows and, if it is one of the every-tenth reference candidates, a reference frame of most others
+ * (propainter_inpaint.py:317-341) -- so InpaintGenerator.forward encodes every frame of a 70-frame batch 3.2 times over.
+ *   vsr_pp_encode         n frames (fp32 [n][3][H][W], masks uint8 [n][H][W]) -> features fp32 [n][H/4][W/4][128]; for the first
+ *                         ntok_frames of them also the soft-split tokens fp32 [ntok_frames][tokens][512] (what a REFERENCE frame
+ *                         contributes; a local frame's tokens are taken after the feature propagation and are not cacheable)
+ *   vsr_pp_forward_cached vsr_pp_forward_box without the encoder: cache_idx (host, t entries) names for each of the lt local frames
+ *                         its entry of the feature cache and for each reference frame its entry of the token cache.
+ * Same GEMM rows in the same K order as in vsr_pp_forward: the output is the same.  Built and replayed on the CPU in round 4
+ * (tests/test_pp_replay.py::test_generator_replay_encoder_cache), not yet run on a GPU: the plugin uses it with VSR_PP_ENC_CACHE=1. */
+int vsr_pp_encode(vsr_pp_t* h, const float* frames_dev, const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int n, int ntok_frames,
+                  int H, int W, float* feat_out_dev, float* tok_out_dev, void* stream);
+int vsr_pp_forward_cached(vsr_pp_t* h, const float* feat_cache_dev, const float* tok_cache_dev, const int32_t* cache_idx,
+                          const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev,
+                          int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi, int col_lo, int col_hi,
+                          float* out_dev, void* stream);
+int vsr_pp_token_count(int H, int W);                    /* soft-split tokens per frame */
 /* The plugin's own array work (PropainterInpaint.inpaint, propainter_inpaint.py:190-361) on frames that stay in HBM as the uint8
  * BGR crops [n][h][w][3]; mask: the dilated mask uint8 [h][w] (non-zero = hole), the same for every frame (:195-197).
  *   prepare : masked_frames fp32 [n][3][h][w] = (to_tensors(RGB) * 2 - 1) * (1 - mask)                                  (:193-213,298)
@@ -552,6 +570,10 @@ int vsr_raft_plan_create(const vsr_raft_t* h, int t, int H, int W, int iters, vs
 int vsr_rfc_plan_create(const vsr_rfc_t* h, int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_imgprop_plan_create(int t, int H, int W, vsr_plan_t** out);
 int vsr_pp_gen_plan_create(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, vsr_plan_t** out);
+/* mode: 0 the whole generator, 1 encoder + soft split of t frames only (vsr_pp_encode), 2 the generator on cached encoder features / tokens
+ * (vsr_pp_forward_cached); see csrc/pp_plan.h PpPlanMode */
+int vsr_pp_gen_plan_create_mode(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi,
+                                int col_lo, int col_hi, int mode, vsr_plan_t** out);
 int vsr_pp_gen_plan_create_box(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi,
                                int col_lo, int col_hi, vsr_plan_t** out);
 int vsr_lama_plan_create(const vsr_lama_t* h, int B, int H, int W, vsr_plan_t** out);

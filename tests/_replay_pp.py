@@ -114,11 +114,14 @@ def replay_imgprop(view, masked_frames, flows_f, flows_b, masks_u8):
 PG_OUT = 47
 
 
-def gen_plan_view(_lib, engine, t, lt, H, W, flags, box=None):
-    """box = (row_lo, row_hi, col_lo, col_hi): the plan of vsr_pp_forward_box"""
+def gen_plan_view(_lib, engine, t, lt, H, W, flags, box=None, mode=0):
+    """box = (row_lo, row_hi, col_lo, col_hi): the plan of vsr_pp_forward_box; mode 1 / 2: vsr_pp_encode / vsr_pp_forward_cached"""
     p = C.c_void_p()
-    f = np.ascontiguousarray(flags, dtype=np.uint8)
-    if box is not None:
+    f = np.ascontiguousarray(flags if flags is not None else np.zeros(0), dtype=np.uint8)
+    if mode:
+        _lib.check(_lib.lib.vsr_pp_gen_plan_create_mode(engine.handle, t, lt, H, W, f.ctypes.data_as(C.c_void_p) if f.size else None, f.size,
+                                                        *[int(b) for b in (box or (0, 0, 0, 0))], mode, C.byref(p)))
+    elif box is not None:
         _lib.check(_lib.lib.vsr_pp_gen_plan_create_box(engine.handle, t, lt, H, W, f.ctypes.data_as(C.c_void_p), f.size, *[int(b) for b in box],
                                                        C.byref(p)))
     else:
@@ -257,11 +260,35 @@ def gen_ew_reference(info, bufs):
         raise AssertionError(f"unknown generator op {k}")
 
 
-def replay_gen(view, packed_weights, frames, flows_f, flows_b, masks_in_u8, masks_upd_u8, lt):
-    """frames [t,3,H,W] fp32, flows [lt-1,2,H,W], masks u8 [t,H,W] -> (tanh output [lt,3,H,W], buffers)"""
+PG_FEAT, PG_PROP, PG_X, PG_TOKOUT = 17, 20, 28, 48         # csrc/pp_plan.h PpBuf
+
+
+def replay_encode(view, packed_weights, frames, masks_in_u8, masks_upd_u8):
+    """PP_PLAN_ENCODE: -> (features [n,h,w,128], tokens [n, fh*fw, 512]) as vsr_pp_encode returns them"""
+    n, _, H, W = frames.shape
+    h, w = H // 4, W // 4
+    out, bufs = replay_gen(view, packed_weights, frames, None, None, masks_in_u8, masks_upd_u8, 1, want_out=False)
+    feat = bufs[PG_FEAT][: n * (h + 6) * (w + 6) * 128].reshape(n, h + 6, w + 6, 128)[:, 3:3 + h, 3:3 + w, :].copy()
+    return feat, bufs[PG_TOKOUT].reshape(-1, (((h - 1) // 3) + 1) * (((w - 1) // 3) + 1), 512).copy()       # tokens of the first lt frames
+
+
+def replay_gen(view, packed_weights, frames, flows_f, flows_b, masks_in_u8, masks_upd_u8, lt, want_out=True, cached=None):
+    """frames [t,3,H,W] fp32, flows [lt-1,2,H,W], masks u8 [t,H,W] -> (tanh output [lt,3,H,W], buffers).
+    cached = (features [t,h,w,128], tokens [t,ntok,512]) of the window's frames (PP_PLAN_CACHED): what vsr_pp_forward_cached copies in --
+    the local frames' features into the propagation buffer's input slots, the reference frames' tokens into the token buffer."""
     t, _, H, W = frames.shape
     bufs = _make_bufs(view, packed_weights)
-    bufs[PB_IN_FRAMES][: frames.size] = frames.reshape(-1)
+    if cached is not None:
+        feats, toks = cached
+        h, w = H // 4, W // 4
+        slots = bufs[PG_PROP].reshape(-1, h + 2, w + 2, 128)
+        slots[:lt, 1:1 + h, 1:1 + w, :] = feats[:lt]
+        ntok = toks.shape[1]
+        bufs[PG_X][lt * ntok * 512: t * ntok * 512] = toks[lt:].reshape(-1)
+    else:
+        bufs[PB_IN_FRAMES][: frames.size] = frames.reshape(-1)
+    if not want_out:
+        lt = 0
     bufs[PB_IN_MASK_U8][: masks_in_u8.size] = masks_in_u8.reshape(-1)
     bufs[PB_IN_MASK_UPD_U8][: masks_upd_u8.size] = masks_upd_u8.reshape(-1)
     if lt > 1:
@@ -281,4 +308,6 @@ def replay_gen(view, packed_weights, frames, flows_f, flows_b, masks_in_u8, mask
                 gen_ew_reference(info, bufs)
             else:
                 raise AssertionError(f"unexpected op kind {info.kind}")
+    if not want_out:
+        return None, bufs
     return bufs[PG_OUT][: lt * 3 * H * W].reshape(lt, 3, H, W).copy(), bufs

@@ -109,6 +109,32 @@ def test_generator_decoder_box(gen_engine, gpu_device, box):
     assert torch.isfinite(got).all()
 
 
+@pytest.mark.skipif(os.environ.get("VSR_PP_ENC_CACHE", "0") != "1",
+                    reason="the per-frame encoder cache is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_PP_ENC_CACHE=1 pytest -k encoder_cache")
+@pytest.mark.parametrize("t,lt,H,W", [(5, 3, 128, 192), (15, 11, 360, 1920)])
+def test_generator_encoder_cache(gen_engine, gpu_device, t, lt, H, W):
+    """vsr_pp_encode + vsr_pp_forward_cached: the frames encoded once, in two calls and in another order than the window's, give the
+    output of vsr_pp_forward bit for bit (same GEMM rows, same K order) -- alone and with a box promise."""
+    frames, masks, ff, fb = propainter_inputs(95, t, lt, H, W)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+    m8 = masks[:, 0].astype(np.uint8)
+    sel = d(frames * (1 - masks))
+    dm = d(m8)
+    want = gen_engine.forward(sel, d(ff), d(fb), dm, dm, lt).clone()
+    refs, local = list(range(t - 1, lt - 1, -1)), list(range(lt))
+    f1, k1 = gen_engine.encode(sel[refs].contiguous(), dm[refs].contiguous(), dm[refs].contiguous(), len(refs))
+    f2, _ = gen_engine.encode(sel[local].contiguous(), dm[local].contiguous(), dm[local].contiguous(), 0)
+    feat = torch.cat([f1, f2])
+    idx = [len(refs) + k for k in range(lt)] + [refs.index(k) for k in range(lt, t)]
+    flags = gen_engine.window_flags(m8[:lt])
+    got = gen_engine.forward_cached(feat, k1, idx, d(ff), d(fb), dm, dm, lt, H, W, flags)
+    box = (H // 2 // 8 * 8, H, W // 4 // 8 * 8, W // 4 * 3 // 8 * 8)
+    got_box = gen_engine.forward_cached(feat, k1, idx, d(ff), d(fb), dm, dm, lt, H, W, flags, box=box)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(got_box[:, :, box[0]:box[1], box[2]:box[3]], want[:, :, box[0]:box[1], box[2]:box[3]])
+
+
 def test_propainter_plugin_matches_oracle(built_lib, gpu_device, pp_sd):
     """PropainterInpaint.__call__ (row a13) end to end -- crop, mask dilation, RAFT, flow completion, image propagation,
     sliding neighbour / reference windows of the generator, u8 overlap blending -- against the restated reference wrapper

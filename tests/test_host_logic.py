@@ -260,3 +260,28 @@ def test_propainter_mode_driver_with_stub_detector_and_plugin():
     assert (out[touched, 0, 0, 0] == clip[touched, 0, 0, 0] + 1).all()
     rest = sorted(set(range(n)) - set(touched))
     assert np.array_equal(out[rest], clip[rest])
+
+
+def test_propainter_encoder_cache_plan():
+    """encoder_cache_plan (the host side of vsr_pp_encode / vsr_pp_forward_cached): every frame gets one feature entry, every frame that is
+    a reference frame of some window one token entry, the entries follow the order of the encode calls (tokens for the leading frames
+    of a call), and a batch's windows ask for 3.2 times as many frame encodings as there are frames."""
+    from vsr_amd.backend.inpaint.propainter_inpaint import encoder_cache_plan, get_ref_index
+
+    for n, ref_num in ((70, -1), (23, -1), (7, -1), (100, 8)):
+        windows = []
+        for f in range(0, n, 5):
+            nb = list(range(max(0, f - 5), min(n, f + 6)))
+            windows.append((nb, get_ref_index(f, nb, n, 10, ref_num)))
+        calls, feat_slot, tok_slot = encoder_cache_plan(windows, chunk=16)
+        assert sorted(feat_slot) == list(range(n)) and sorted(feat_slot.values()) == list(range(n))
+        refs = sorted({i for _, r in windows for i in r})
+        assert sorted(tok_slot) == refs and sorted(tok_slot.values()) == list(range(len(refs)))
+        fpos = tpos = 0
+        for ids, ntok in calls:
+            assert 1 <= len(ids) <= 16 and 0 <= ntok <= len(ids)
+            assert [feat_slot[i] for i in ids] == list(range(fpos, fpos + len(ids)))
+            assert [tok_slot[i] for i in ids[:ntok]] == list(range(tpos, tpos + ntok)) and not any(i in tok_slot for i in ids[ntok:])
+            fpos, tpos = fpos + len(ids), tpos + ntok
+        if n == 70:
+            assert sum(len(nb) + len(r) for nb, r in windows) == 226 and refs == [0, 10, 20, 30, 40, 50, 60]

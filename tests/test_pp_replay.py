@@ -101,6 +101,44 @@ def test_generator_replay_box(pp_host_engine, pp_sd, box):
         part.close()
 
 
+def test_generator_replay_encoder_cache(pp_host_engine, pp_sd):
+    """vsr_pp_encode + vsr_pp_forward_cached: the encoder and the soft split are per-frame functions of a frame's inputs, and the
+    plugin's windows overlap (a frame is a local frame of 2-3 windows and a reference frame of several more), so they run once per
+    frame (PP_PLAN_ENCODE, in chunks of any size) and the generator (PP_PLAN_CACHED) starts from the cached features of its local
+    frames and the cached tokens of its reference frames.  Same output as the full plan -- alone and together with a box promise --
+    and the FLOPs of the two plans add up to the full plan's (nothing else changed)."""
+    t, lt, H, W = 5, 3, 128, 192
+    sel, ff, fb, m_in, m_upd, ref = _generator_case(75, t, lt, H, W, pp_sd)
+    flags = pp_host_engine.window_flags(m_in[:lt])
+    wts = pp_host_engine.packed_weights()
+    full = rp.gen_plan_view(_lib, pp_host_engine, t, lt, H, W, flags)
+    want, _ = rp.replay_gen(full, wts, sel, ff, fb, m_in, m_upd, lt)
+    full_flops = full.flops
+    full.close()
+    # the frames are encoded in two calls, in an order that is not the window's: the reference frames with their tokens (only those
+    # are read), the local ones without
+    feats, toks = np.zeros((t, H // 4, W // 4, 128), np.float32), None
+    enc_flops = 0.0
+    for part, ntokf in (([4, 3], 2), ([1, 0, 2], 0)):
+        ev = rp.gen_plan_view(_lib, pp_host_engine, len(part), ntokf, H, W, None, mode=1)
+        f, k = rp.replay_encode(ev, wts, sel[part], m_in[part], m_upd[part])
+        enc_flops += ev.flops
+        ev.close()
+        if toks is None:
+            toks = np.zeros((t,) + k.shape[1:], np.float32)
+        feats[part] = f
+        toks[part[:ntokf]] = k[:ntokf]
+    for box in (None, (50, 70, 60, 130)):
+        cv = rp.gen_plan_view(_lib, pp_host_engine, t, lt, H, W, flags, box=box, mode=2)
+        got, _ = rp.replay_gen(cv, wts, sel, ff, fb, m_in, m_upd, lt, cached=(feats, toks))
+        y0, y1, x0, x1 = box if box else (0, H, 0, W)
+        assert np.abs(got[:, :, y0:y1, x0:x1] - want[:, :, y0:y1, x0:x1]).max() <= 2e-5
+        if box is None:
+            assert abs(cv.flops + enc_flops - full_flops) <= 1e-9 * full_flops, (cv.flops, enc_flops, full_flops)
+            assert not any(i.tag.decode().startswith("enc.") for i, _ in cv.ops)
+        cv.close()
+
+
 def test_generator_strict_state_dict(pp_sd, built_lib):
     from vsr_amd.engine import PpEngine
 

@@ -180,8 +180,12 @@ SIGNATURES = {
     "vsr_pp_fallbacks": (_L, [_P]),
     "vsr_pp_flops": (_D, [_P, _I, _I, _I, _I, _P, _I]),
     "vsr_pp_forward_box": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "vsr_pp_encode": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "vsr_pp_forward_cached": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "vsr_pp_token_count": (_I, [_I, _I]),
     "vsr_pp_flops_box": (_D, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "vsr_pp_gen_plan_create": (_I, [_P, _I, _I, _I, _I, _P, _I, C.POINTER(_P)]),
+    "vsr_pp_gen_plan_create_mode": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_pp_gen_plan_create_box": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_lama_create": (_I, [C.POINTER(_P)]),
     "vsr_lama_set_param": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),

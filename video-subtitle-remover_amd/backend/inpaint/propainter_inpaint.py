@@ -39,6 +39,24 @@ def read_mask(mask, length, flow_mask_dilates=8, mask_dilates=5):
     return dil(flow_mask_dilates), dil(mask_dilates)
 
 
+def encoder_cache_plan(windows, chunk=16):
+    """windows: [(neighbour ids, reference ids)] of one inpaint() call.  The generator's encoder (and, for frames that are a reference
+    frame of some window, its soft split) is a per-frame function: -> (calls, feat_slot, tok_slot) where calls = [(frame ids, how many
+    of the first of them need tokens)] of at most `chunk` frames each and feat_slot / tok_slot map a frame to its cache entry (the
+    entries are filled in call order)."""
+    refs = sorted({i for _, ref in windows for i in ref})
+    local = sorted({i for nb, _ in windows for i in nb} - set(refs))
+    calls = [(refs[i:i + chunk], len(refs[i:i + chunk])) for i in range(0, len(refs), chunk)]
+    calls += [(local[i:i + chunk], 0) for i in range(0, len(local), chunk)]
+    feat_slot, tok_slot = {}, {}
+    for ids, ntok in calls:
+        for k, i in enumerate(ids):
+            feat_slot[i] = len(feat_slot)
+            if k < ntok:
+                tok_slot[i] = len(tok_slot)
+    return calls, feat_slot, tok_slot
+
+
 def get_ref_index(mid_neighbor_id, neighbor_ids, length, ref_stride=10, ref_num=-1):
     ref_index = []
     if ref_num == -1:
@@ -168,15 +186,34 @@ class PropainterInpaint:
             if os.environ.get("VSR_PP_DECODE_BOX", "0") == "1" and md.any():
                 ys, xs = np.flatnonzero(md.any(axis=1)), np.flatnonzero(md.any(axis=0))
                 box = (int(ys[0]) // 8 * 8, min(h, (int(ys[-1]) + 8) // 8 * 8), int(xs[0]) // 8 * 8, min(w, (int(xs[-1]) + 8) // 8 * 8))
+            windows = []
             for f in range(0, n, stride):
                 nb = [i for i in range(max(0, f - stride), min(n, f + stride + 1))]
-                ref = get_ref_index(f, nb, n, self.ref_stride, ref_num)
+                windows.append((nb, get_ref_index(f, nb, n, self.ref_stride, ref_num)))
+            # The encoder (and a reference frame's soft split) is a per-frame function and the windows overlap: with the switch on every
+            # frame is encoded once per call instead of once per window it appears in (vsr_pp_encode / vsr_pp_forward_cached).  Built and
+            # replayed on the CPU in round 4, not yet run on a GPU: opt-in.
+            enc_cache = None
+            if os.environ.get("VSR_PP_ENC_CACHE", "0") == "1":
+                calls, feat_slot, tok_slot = encoder_cache_plan(windows)
+                fc, tc = [], []
+                for cids, ntok in calls:
+                    a, b = self.model.encode(updated_frames[cids].contiguous(), md_dev[cids].contiguous(), updated_masks[cids].contiguous(), ntok)
+                    fc.append(a)
+                    tc.append(b)
+                enc_cache = (torch.cat(fc), torch.cat(tc) if tok_slot else None)
+            for nb, ref in windows:
                 ids = nb + ref
                 l_t = len(nb)
                 if l_t not in flags_cache:                                                  # the same mask on every frame
                     flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
-                pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
-                                          md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t], box=box)
+                if enc_cache is not None:
+                    pred = self.model.forward_cached(enc_cache[0], enc_cache[1], [feat_slot[i] for i in nb] + [tok_slot[i] for i in ref],
+                                                     pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(), md_dev[ids].contiguous(),
+                                                     updated_masks[ids].contiguous(), l_t, h, w, flags_cache[l_t], box=box)
+                else:
+                    pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
+                                              md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t], box=box)
                 idx = torch.tensor(nb, dtype=torch.int32).to(dev, non_blocking=True)
                 first = torch.tensor([0 if visited[i] else 1 for i in nb], dtype=torch.int32).to(dev, non_blocking=True)
                 check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), stream()))

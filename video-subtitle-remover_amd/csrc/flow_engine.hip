@@ -1024,6 +1024,142 @@ int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_
     return 0;
 }
 
+// ---- the encoder and the soft split once per frame (csrc/pp_plan.h PpPlanMode) ----------------------------------------------
+static int pp_plan_for(vsr_pp_t* h, const std::string& key, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo,
+                       int row_hi, int col_lo, int col_hi, int mode, FlowPlanDev** out)
+{
+    auto it = h->genPlans.find(key);
+    if (it != h->genPlans.end()) { *out = it->second.get(); return 0; }
+    std::unique_ptr<PlanIR> plan;
+    try {
+        plan.reset(new PpGenPlan(h->model, t, lt, H, W,
+                                 window_flags ? std::vector<uint8_t>(window_flags, window_flags + nflags) : std::vector<uint8_t>(), row_lo, row_hi,
+                                 col_lo, col_hi, mode));
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+    }
+    if (h->ws.needs_growth(*plan)) { h->genPlans.clear(); h->imgPlans.clear(); }
+    std::unique_ptr<FlowPlanDev> npd;
+    RCCHK(materialize(h->ws, std::move(plan), &npd));
+    *out = npd.get();
+    h->genPlans[key] = std::move(npd);
+    return 0;
+}
+
+int vsr_pp_encode(vsr_pp_t* h, const float* frames_dev, const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int n, int ntok_frames,
+                  int H, int W, float* feat_out_dev, float* tok_out_dev, void* stream_)
+{
+    if (!h || !frames_dev || !masks_in_dev || !masks_updated_dev || !feat_out_dev || n < 1 || ntok_frames < 0 || ntok_frames > n ||
+        (ntok_frames > 0 && !tok_out_dev))
+        return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->finalized || h->device < 0)
+        return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device; there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const std::string geom = "enc:" + std::to_string(n) + ":" + std::to_string(ntok_frames) + ":" + std::to_string(H) + ":" + std::to_string(W);
+    FlowPlanDev* pd = nullptr;
+    RCCHK(pp_plan_for(h, geom, n, ntok_frames, H, W, nullptr, 0, 0, 0, 0, 0, PP_PLAN_ENCODE, &pd));
+    if (h->geom != geom) {
+        RCCHK(clear_workspace(h->ws, stream));
+        h->geom = geom;
+    }
+    const size_t hw = (size_t)H * W;
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FRAMES], frames_dev, (size_t)n * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_in_dev, (size_t)n * hw, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_UPD_U8], masks_updated_dev, (size_t)n * hw, hipMemcpyDeviceToDevice, stream));
+    RCCHK(range_guard_arm(h->ws, stream));
+    RCCHK(run_plan(h->ws, pd, 0, stream));
+    bool fired = false;
+    RCCHK(range_guard_fired(h->ws, stream, &fired));
+    if (fired) {
+        h->ws.precision = 0;
+        const int rc = vsr_pp_encode(h, frames_dev, masks_in_dev, masks_updated_dev, n, ntok_frames, H, W, feat_out_dev, tok_out_dev, stream_);
+        h->ws.precision = 1;
+        return rc;
+    }
+    // the features leave PG_FEAT's halo (3) behind: [n][h][w][128] dense
+    const PpGenPlan& gp = static_cast<const PpGenPlan&>(*pd->plan);
+    const int fh_ = gp.h, fw_ = gp.w, halo = gp.featHalo;
+    const size_t rowB = (size_t)fw_ * 128 * sizeof(float), pitchB = (size_t)(fw_ + 2 * halo) * 128 * sizeof(float);
+    const size_t frameElems = (size_t)(fh_ + 2 * halo) * (fw_ + 2 * halo) * 128;
+    for (int f = 0; f < n; ++f) {
+        const float* src = (const float*)h->ws.bufs[PG_FEAT] + f * frameElems + ((size_t)halo * (fw_ + 2 * halo) + halo) * 128;
+        HIPCHK(hipMemcpy2DAsync(feat_out_dev + (size_t)f * fh_ * fw_ * 128, rowB, src, pitchB, rowB, (size_t)fh_, hipMemcpyDeviceToDevice, stream));
+    }
+    if (ntok_frames > 0)
+        HIPCHK(hipMemcpyAsync(tok_out_dev, h->ws.bufs[PG_TOKOUT], (size_t)ntok_frames * gp.fh * gp.fw * 512 * sizeof(float), hipMemcpyDeviceToDevice,
+                              stream));
+    return 0;
+}
+
+int vsr_pp_forward_cached(vsr_pp_t* h, const float* feat_cache_dev, const float* tok_cache_dev, const int32_t* cache_idx,
+                          const float* flows_f_dev, const float* flows_b_dev, const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t,
+                          int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo, int row_hi, int col_lo, int col_hi,
+                          float* out_dev, void* stream_)
+{
+    if (!h || !feat_cache_dev || !cache_idx || !masks_in_dev || !masks_updated_dev || !window_flags || !out_dev || t < 1 || lt < 1 || lt > t ||
+        (t > lt && !tok_cache_dev) || (lt > 1 && (!flows_f_dev || !flows_b_dev)))
+        return rfail(VSR_ERR_ARG, "bad argument");
+    for (int k = 0; k < t; ++k)
+        if (cache_idx[k] < 0) return rfail(VSR_ERR_ARG, "negative cache index");
+    if (!h->finalized || h->device < 0)
+        return rfail(VSR_ERR_NOGPU, "model is not finalized on a HIP device; there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const std::string geom = "genc:" + std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W);
+    std::string key = geom + ":" + std::to_string(row_lo) + "-" + std::to_string(row_hi) + ":" + std::to_string(col_lo) + "-" + std::to_string(col_hi) + ":";
+    key.append((const char*)window_flags, (size_t)nflags);
+    FlowPlanDev* pd = nullptr;
+    RCCHK(pp_plan_for(h, key, t, lt, H, W, window_flags, nflags, row_lo, row_hi, col_lo, col_hi, PP_PLAN_CACHED, &pd));
+    if (h->geom != geom) {
+        RCCHK(clear_workspace(h->ws, stream));
+        h->geom = geom;
+    }
+    const PpGenPlan& gp = static_cast<const PpGenPlan&>(*pd->plan);
+    const size_t hw = (size_t)H * W;
+    {   // the local frames' features into the propagation buffer's input slots (interiors; the halos stay zero), the reference frames' tokens
+        const int fh_ = gp.h, fw_ = gp.w, halo = gp.propHalo;
+        const size_t rowB = (size_t)fw_ * 128 * sizeof(float), pitchB = (size_t)(fw_ + 2 * halo) * 128 * sizeof(float);
+        const size_t slotElems = (size_t)(fh_ + 2 * halo) * (fw_ + 2 * halo) * 128;
+        for (int k = 0; k < lt; ++k) {
+            float* dst = (float*)h->ws.bufs[PG_PROP] + k * slotElems + ((size_t)halo * (fw_ + 2 * halo) + halo) * 128;
+            HIPCHK(hipMemcpy2DAsync(dst, pitchB, feat_cache_dev + (size_t)cache_idx[k] * fh_ * fw_ * 128, rowB, rowB, (size_t)fh_,
+                                    hipMemcpyDeviceToDevice, stream));
+        }
+        const size_t tokElems = (size_t)gp.fh * gp.fw * 512;
+        for (int k = lt; k < t; ++k)
+            HIPCHK(hipMemcpyAsync((float*)h->ws.bufs[PG_X] + k * tokElems, tok_cache_dev + (size_t)cache_idx[k] * tokElems, tokElems * sizeof(float),
+                                  hipMemcpyDeviceToDevice, stream));
+    }
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_in_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_UPD_U8], masks_updated_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));
+    if (lt > 1) {
+        HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_F], flows_f_dev, (size_t)(lt - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FLOW_B], flows_b_dev, (size_t)(lt - 1) * 2 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    RCCHK(range_guard_arm(h->ws, stream));
+    RCCHK(run_plan(h->ws, pd, 0, stream));
+    bool fired = false;
+    RCCHK(range_guard_fired(h->ws, stream, &fired));
+    if (fired) {
+        h->ws.precision = 0;
+        const int rc = vsr_pp_forward_cached(h, feat_cache_dev, tok_cache_dev, cache_idx, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t,
+                                             lt, H, W, window_flags, nflags, row_lo, row_hi, col_lo, col_hi, out_dev, stream_);
+        h->ws.precision = 1;
+        return rc;
+    }
+    HIPCHK(hipMemcpyAsync(out_dev, h->ws.bufs[PG_OUT], (size_t)lt * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int vsr_pp_token_count(int H, int W)
+{
+    if (H < 28 || W < 28 || H % 4 || W % 4) return rfail(VSR_ERR_ARG, "bad argument");
+    int fh, fw, gh, gw;
+    PpGenPlan::token_grid(H, W, fh, fw, gh, gw);
+    return fh * fw;
+}
+
 int vsr_pp_set_precision(vsr_pp_t* h, int mode) { return h ? set_precision(h->ws, mode) : rfail(VSR_ERR_ARG, "null handle"); }
 int64_t vsr_pp_fallbacks(const vsr_pp_t* h) { return h ? h->ws.fallbacks : -1; }
 
@@ -1067,6 +1203,23 @@ int vsr_pp_gen_plan_create_box(const vsr_pp_t* h, int t, int lt, int H, int W, c
     try {
         std::unique_ptr<vsr_plan> p(new vsr_plan);
         p->plan.reset(new PpGenPlan(h->model, t, lt, H, W, std::vector<uint8_t>(window_flags, window_flags + nflags), row_lo, row_hi, col_lo, col_hi));
+        *out = p.release();
+    } catch (const std::exception& e) {
+        return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());
+    }
+    return 0;
+}
+
+int vsr_pp_gen_plan_create_mode(const vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags, int row_lo,
+                                int row_hi, int col_lo, int col_hi, int mode, vsr_plan_t** out)
+{
+    if (!h || !out || (!window_flags && mode != PP_PLAN_ENCODE)) return rfail(VSR_ERR_ARG, "bad argument");
+    if (!h->model.packed_ready()) return rfail(VSR_ERR_STATE, "model not finalized");
+    try {
+        std::unique_ptr<vsr_plan> p(new vsr_plan);
+        p->plan.reset(new PpGenPlan(h->model, t, lt, H, W,
+                                    window_flags ? std::vector<uint8_t>(window_flags, window_flags + nflags) : std::vector<uint8_t>(), row_lo,
+                                    row_hi, col_lo, col_hi, mode));
         *out = p.release();
     } catch (const std::exception& e) {
         return rfail(VSR_ERR_ARG, std::string("generator plan: ") + e.what());

@@ -492,9 +492,16 @@ void PpGenPlan::attention(int blk, const std::vector<uint8_t>& windowMasked, int
 }
 
 PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, const std::vector<uint8_t>& windowMasked, int decLo_, int decHi_,
-                     int decXLo_, int decXHi_)
-    : t(t_), lt(lt_), H(H_), W(W_), h(H_ / 4), w(W_ / 4), m_(model)
+                     int decXLo_, int decXHi_, int mode_)
+    : t(t_), lt(lt_), H(H_), W(W_), mode(mode_), h(H_ / 4), w(W_ / 4), m_(model)
 {
+    if (mode < PP_PLAN_FULL || mode > PP_PLAN_CACHED) throw std::runtime_error("bad plan mode");
+    const bool encodeOnly = mode == PP_PLAN_ENCODE, cached = mode == PP_PLAN_CACHED;
+    const int encTok = encodeOnly ? lt_ : 0;       // PP_PLAN_ENCODE: soft-split tokens for the first lt_ frames only (the ones that can be reference frames)
+    if (encodeOnly) {
+        if (encTok < 0 || encTok > t) throw std::runtime_error("bad number of token frames");
+        lt = t;
+    }
     decLo = 0; decHi = H; decXLo = 0; decXHi = W;
     if (decHi_ > decLo_) {
         if (decLo_ < 0 || decHi_ > H) throw std::runtime_error("bad output row range");
@@ -510,19 +517,30 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
     if (!Tuning::get().convChannelMajor) throw std::runtime_error("the ProPainter plan needs the channel-major K order");
     token_grid(H, W, fh, fw, gh, gw);
     ph = (gh - 4) / 4 + 1; pw = (gw - 4) / 4 + 1;
-    if ((int)windowMasked.size() != (gh / 5) * (gw / 9)) throw std::runtime_error("window mask flags do not match the token grid");
+    if (!encodeOnly && (int)windowMasked.size() != (gh / 5) * (gw / 9)) throw std::runtime_error("window mask flags do not match the token grid");
     bufElems.assign(PB_COUNT, 0);
     bufElems[PB_WEIGHTS] = (int64_t)model.packed.size();
     const int H2 = H / 2, W2 = W / 2;
     const int64_t HW = (int64_t)H * W;
     const std::vector<int> idsT = iota(t), idsL = iota(lt), idsR = iota(t - lt, lt);
-    need(PB_IN_FRAMES, t * 3 * HW);
+    if (!cached) need(PB_IN_FRAMES, t * 3 * HW);
     need(PB_IN_MASK_U8, t * HW);
     need(PB_IN_MASK_UPD_U8, t * HW);
-    need(PB_IN_FLOW_F, (int64_t)(lt > 1 ? lt - 1 : 1) * 2 * HW);
-    need(PB_IN_FLOW_B, (int64_t)(lt > 1 ? lt - 1 : 1) * 2 * HW);
+    if (!encodeOnly) {
+        need(PB_IN_FLOW_F, (int64_t)(lt > 1 ? lt - 1 : 1) * 2 * HW);
+        need(PB_IN_FLOW_B, (int64_t)(lt > 1 ? lt - 1 : 1) * 2 * HW);
+    }
+    const int L = VSR_ACT_LRELU02;
+    // propagation buffer: slots of one frame [h+2][w+2][128]: input[lt] | backward[lt] | forward[lt] | masks[lt] | warped | misc | aligned
+    const int sIN = 0, sBK = lt, sFW = 2 * lt, sMK = 3 * lt, sWARP = 4 * lt, sMISC = 4 * lt + 1, sALN = 4 * lt + 2;
+    const Act prop{PG_PROP, 4 * lt + 3, h, w, 128, 1};
+    const Act feat{PG_FEAT, t, h, w, 128, 3};
+    propHalo = prop.halo; featHalo = feat.halo;
+    const int ntok = t * fh * fw;
+    const Act xTok{PG_X, t, fh, fw, 512, 0};
 
     // ---- encoder (:196-224)
+    if (!cached) {
     {
         Op& op = ew(EW_PP_IM2COL3, "enc.im2col");
         op.ibuf[0] = PB_IN_FRAMES; op.ibuf[1] = PB_IN_MASK_U8; op.ibuf[2] = PB_IN_MASK_UPD_U8; op.ibuf[3] = PG_IM2COL;
@@ -534,7 +552,6 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
     // re-injected x0 slices and the previous layer's slices (view(bt, g, -1, h, w) + cat, :218-222) through chunk lists
     const int cX0 = 0, cL8 = 256, cL10 = 640, cL12 = 1152, cL14 = 1664;
     const Act enc{PG_ENC, t, h, w, 1920, 1};
-    const int L = VSR_ACT_LRELU02;
     conv("enc.0", cols, idsT, chunks(0, 2), 1, 1, 1, 1, e0, idsT, 0, m_.enc0, L, nullptr, nullptr);
     conv("enc.2", e0, idsT, chunks(0, 2), 3, 3, 1, 1, e1, idsT, 0, m_.enc2, L, nullptr, nullptr);
     conv("enc.4", e1, idsT, chunks(0, 2), 3, 3, 2, 1, e2, idsT, 0, m_.enc4, L, nullptr, nullptr);
@@ -564,10 +581,21 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
                  nullptr, nullptr, &g);
         ops.push_back(std::move(g));
     }
-    // propagation buffer: slots of one frame [h+2][w+2][128]: input[lt] | backward[lt] | forward[lt] | masks[lt] | warped | misc | aligned
-    const int sIN = 0, sBK = lt, sFW = 2 * lt, sMK = 3 * lt, sWARP = 4 * lt, sMISC = 4 * lt + 1, sALN = 4 * lt + 2;
-    const Act prop{PG_PROP, 4 * lt + 3, h, w, 128, 1};
-    const Act feat{PG_FEAT, t, h, w, 128, 3};
+    if (encodeOnly) {
+        // every frame's features as a reference frame gets them (PG_FEAT, halo 3: the engine copies the interiors out for the windows
+        // in which the frame is a local one), then its soft-split tokens.  Same GEMM rows and K order as in the full plan: same bits.
+        need(PG_FEAT, feat.elems());
+        Op g;
+        g.kind = OP_GEMM; g.tag = "enc.16"; g.bmode = VSR_BMODE_NK; g.tileCfg = VSR_TILE_128x64;
+        const std::vector<int> ch16 = cat(chunks(cX0, 8), chunks(cL14, 8));
+        conv("enc.16", enc, idsT, ch16, 3, 3, 1, 1, feat, idsT, 0, m_.enc16, L, nullptr, nullptr, &g);
+        ops.push_back(std::move(g));
+        const Act tokOut{PG_TOKOUT, encTok > 0 ? encTok : 1, fh, fw, 512, 0};
+        need(PG_TOKOUT, tokOut.elems());
+        if (encTok > 0) conv("ss", feat, iota(encTok), chunks(0, 4), 7, 7, 3, 1, tokOut, iota(encTok), 0, m_.ss, VSR_ACT_NONE, nullptr, nullptr);
+        refFlops = flops;
+        return;
+    }
     need(PG_PROP, prop.elems());
     need(PG_FEAT, feat.elems());
     {   // layer 16 over cat[x0, layer 14]: local frames go to the propagation input slots, reference frames straight to enc_feat
@@ -577,6 +605,10 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
         conv("enc.16", enc, idsL, ch16, 3, 3, 1, 1, prop, iota(lt, sIN), 0, m_.enc16, L, nullptr, nullptr, &g);
         if (t > lt) conv("enc.16", enc, idsR, ch16, 3, 3, 1, 1, feat, idsR, 0, m_.enc16, L, nullptr, nullptr, &g);
         ops.push_back(std::move(g));
+    }
+    } else {        // PP_PLAN_CACHED: the engine has put the local frames' features into slots sIN .. and the reference frames' tokens into PG_X
+        need(PG_PROP, prop.elems());
+        need(PG_FEAT, feat.elems());
     }
 
     // ---- flows and masks at 1/4 resolution (:341-350)
@@ -675,8 +707,10 @@ PpGenPlan::PpGenPlan(const PpModel& model, int t_, int lt_, int H_, int W_, cons
     }
 
     // ---- soft split (sparse_transformer.py:7-31): unfold 7x7 / stride 3 / pad 3 + Linear = a strided 7x7 conv
-    const int ntok = t * fh * fw;
-    const Act xTok{PG_X, t, fh, fw, 512, 0};
+    if (cached) {
+        need(PG_X, xTok.elems());
+        conv("ss", feat, idsL, chunks(0, 4), 7, 7, 3, 1, xTok, idsL, 0, m_.ss, VSR_ACT_NONE, nullptr, nullptr);
+    } else
     conv("ss", feat, idsT, chunks(0, 4), 7, 7, 3, 1, xTok, idsT, 0, m_.ss, VSR_ACT_NONE, nullptr, nullptr);
 
     // Only the local frames' output is produced, and PropainterInpaint reads it under the dilated mask only.  With a promise about

@@ -30,8 +30,17 @@ enum PpBuf {
     PG_IM2COL, PG_E0, PG_E1, PG_E2, PG_ENC, PG_FEAT, PG_DSF_F, PG_DSF_B, PG_PROP, PG_T1, PG_T2, PG_T3, PG_OFF, PG_COLS, PG_BB, PG_FU,
     PG_X, PG_YQ, PG_QKV, PG_S, PG_P, PG_ATT, PG_Y2, PG_F1, PG_FMAP, PG_F2, PG_SC, PG_SCF, PG_DIN, PG_UP0, PG_D0, PG_D1, PG_UP1, PG_D2, PG_D3,
     PG_OUT,
+    PG_TOKOUT,                // PP_PLAN_ENCODE: soft-split tokens [n][fh * fw][512] of every frame (the features are PG_FEAT's interiors)
     PB_COUNT
 };
+
+// What a PpGenPlan covers.  The encoder and the soft split of a REFERENCE frame are per-frame functions of that frame's inputs
+// (propainter.py:333-335 -- the frames are a batch dimension -- and sparse_transformer.py:7-31), and PropainterInpaint's windows
+// overlap: a frame is a local frame of two or three windows and a reference frame of up to n / 10 more (propainter_inpaint.py:
+// 317-341), so the reference encodes every frame of a 70-frame batch 3.2 times.  PP_PLAN_ENCODE runs the encoder + soft split once
+// per frame, PP_PLAN_CACHED is the generator without them: the engine puts the cached features of the local frames into the
+// propagation buffer's input slots and the cached tokens of the reference frames into the token buffer (flow_engine.hip).
+enum PpPlanMode { PP_PLAN_FULL = 0, PP_PLAN_ENCODE = 1, PP_PLAN_CACHED = 2 };
 
 // InpaintGenerator.img_propagation(masked_frames, (flows_f, flows_b), masks, 'nearest'): t frames of H x W.
 // Outputs: PB_FW (propagated frames, planar fp32 [t][3][H][W]) and PB_FWM (updated masks, fp32 [t][H][W]).
@@ -80,8 +89,13 @@ public:
     // (PropainterInpaint blends a window's prediction into its frames where the dilated mask is set, propainter_inpaint.py:350-357):
     // the soft composition's embedding and the decoder's convs then run on the tokens / pixels those depend on.  0, 0 = everything.
     PpGenPlan(const PpModel& model, int t, int lt, int H, int W, const std::vector<uint8_t>& windowMasked, int decLo = 0, int decHi = 0,
-              int decXLo = 0, int decXHi = 0);
+              int decXLo = 0, int decXHi = 0, int mode = PP_PLAN_FULL);
     int t, lt, H, W;
+    int mode = PP_PLAN_FULL;
+    // PP_PLAN_CACHED: local frame k's cached features go to slot k of PG_PROP ([h + 2 propHalo][w + 2 propHalo][128] each, interior),
+    // reference frame j's cached tokens to rows [j fh fw, (j + 1) fh fw) of PG_X; PP_PLAN_ENCODE leaves the features in PG_FEAT
+    // ([h + 2 featHalo][w + 2 featHalo][128] per frame) and the tokens in PG_TOKOUT
+    int propHalo = 1, featHalo = 3;
     int decLo = 0, decHi = 0, decXLo = 0, decXHi = 0;        // as taken (whole image: 0, H / 0, W)
     double refFlops = 0;                                      // the reference's count (flops = what this plan executes)
     int h, w;            // H/4, W/4

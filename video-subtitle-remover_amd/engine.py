@@ -472,6 +472,40 @@ class PpEngine:
                                          C.c_void_p(out.data_ptr()), _stream_ptr()))
         return out
 
+    def encode(self, frames, masks_in, masks_updated, ntok_frames=0):
+        """The generator's encoder (and, for the first ntok_frames frames, the soft split) once per frame: frames fp32 [n,3,H,W], masks
+        uint8 [n,H,W] on the GPU -> (features fp32 [n,H/4,W/4,128], tokens fp32 [ntok_frames,tokens,512]) for forward_cached."""
+        assert frames.dtype == torch.float32 and frames.is_cuda and frames.is_contiguous()
+        assert masks_in.dtype == torch.uint8 and masks_in.is_contiguous() and masks_updated.is_contiguous()
+        n, _, H, W = frames.shape
+        feats = torch.empty((n, H // 4, W // 4, 128), dtype=torch.float32, device=frames.device)
+        toks = torch.empty((ntok_frames, int(lib.vsr_pp_token_count(H, W)), 512), dtype=torch.float32, device=frames.device)
+        with torch.cuda.device(frames.device):
+            check(lib.vsr_pp_encode(self._h, C.c_void_p(frames.data_ptr()), C.c_void_p(masks_in.data_ptr()), C.c_void_p(masks_updated.data_ptr()),
+                                    n, int(ntok_frames), H, W, C.c_void_p(feats.data_ptr()),
+                                    C.c_void_p(toks.data_ptr()) if ntok_frames else None, _stream_ptr()))
+        return feats, toks
+
+    def forward_cached(self, feat_cache, tok_cache, cache_idx, flows_f, flows_b, masks_in, masks_updated, lt, H, W, flags, box=None):
+        """forward() from cached per-frame encoder output: cache_idx[k] = entry of feat_cache for the local frame k < lt, entry of
+        tok_cache for the reference frame k >= lt; masks uint8 [t,H,W] of the window's frames."""
+        assert feat_cache.dtype == torch.float32 and feat_cache.is_cuda and feat_cache.is_contiguous()
+        assert tok_cache is None or (tok_cache.dtype == torch.float32 and tok_cache.is_contiguous())
+        assert masks_in.dtype == torch.uint8 and masks_in.is_contiguous() and masks_updated.is_contiguous()
+        idx = np.ascontiguousarray(np.asarray(cache_idx, dtype=np.int32))
+        t = int(idx.size)
+        assert tuple(masks_in.shape) == (t, H, W) and 1 <= lt <= t
+        assert int(idx[:lt].max()) < feat_cache.shape[0] and (t == lt or int(idx[lt:].max()) < tok_cache.shape[0])
+        out = torch.empty((lt, 3, H, W), dtype=torch.float32, device=feat_cache.device)
+        with torch.cuda.device(feat_cache.device):
+            check(lib.vsr_pp_forward_cached(self._h, C.c_void_p(feat_cache.data_ptr()),
+                                            C.c_void_p(tok_cache.data_ptr()) if tok_cache is not None and tok_cache.numel() else None,
+                                            idx.ctypes.data_as(C.c_void_p), C.c_void_p(flows_f.data_ptr()), C.c_void_p(flows_b.data_ptr()),
+                                            C.c_void_p(masks_in.data_ptr()), C.c_void_p(masks_updated.data_ptr()), t, lt, H, W,
+                                            flags.ctypes.data_as(C.c_void_p), flags.size, *[int(b) for b in (box or (0, 0, 0, 0))],
+                                            C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             lib.vsr_pp_destroy(self._h)
