@@ -285,3 +285,47 @@ def test_propainter_encoder_cache_plan():
             fpos, tpos = fpos + len(ids), tpos + ntok
         if n == 70:
             assert sum(len(nb) + len(r) for nb, r in windows) == 226 and refs == [0, 10, 20, 30, 40, 50, 60]
+
+
+def test_decode_rows_and_cols_cover_what_the_resize_back_reads(built_lib):
+    """vsr_sttn_decode_rows / _cols against the oracle's cv2.resize: a model-resolution image that is changed OUTSIDE the rows and columns
+    the engine would decode gives the same strip pixels under the mask after the resize back (sttn_auto_inpaint.py:60-67) -- for the
+    strip heights and widths of 480p ... 4K frames and masks at the edges, in the middle and one pixel wide.  (sttn-det goes the
+    other way -- the mask is resized DOWN and the blend happens at model resolution: the rows / columns returned contain every
+    non-zero pixel of the resized mask.)"""
+    import ctypes as C
+
+    from oracle import cv2_restate as cv2r
+    from vsr_amd._lib import lib
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+
+    rng = np.random.default_rng(5)
+    eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None)
+    det = SttnEngine(make_state_dict(0, "det"), "det", device=None)
+    try:
+        for W, sh in ((852, 159), (1280, 240), (1920, 360), (3840, 720), (1000, 187)):
+            for _ in range(4):
+                r0 = int(rng.integers(0, sh - 1)); r1 = int(rng.integers(r0 + 1, min(sh, r0 + 1 + sh // 2) + 1))
+                c0 = int(rng.integers(0, W - 1)); c1 = int(rng.integers(c0 + 1, min(W, c0 + 1 + W // 2) + 1))
+                if _ == 0:
+                    r0, r1, c0, c1 = 0, 1, W - 1, W
+                a, b, ca, cb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+                assert lib.vsr_sttn_decode_rows(eng._h, sh, r0, r1, C.byref(a), C.byref(b)) == 0
+                assert lib.vsr_sttn_decode_cols(eng._h, W, c0, c1, C.byref(ca), C.byref(cb)) == 0
+                x = rng.integers(0, 256, size=(120, 640, 3), dtype=np.uint8)
+                y = rng.integers(0, 256, size=(120, 640, 3), dtype=np.uint8)
+                y[a.value:b.value, ca.value:cb.value] = x[a.value:b.value, ca.value:cb.value]
+                assert np.array_equal(cv2r.resize_linear(x, (W, sh))[r0:r1, c0:c1], cv2r.resize_linear(y, (W, sh))[r0:r1, c0:c1]), (W, sh, r0, r1, c0, c1)
+                # sttn-det: mask resized down to 432 x 240
+                assert lib.vsr_sttn_decode_rows(det._h, sh, r0, r1, C.byref(a), C.byref(b)) == 0
+                assert lib.vsr_sttn_decode_cols(det._h, W, c0, c1, C.byref(ca), C.byref(cb)) == 0
+                m = np.zeros((sh, W, 1), np.uint8)
+                m[r0:r1, c0:c1] = 255
+                small = cv2r.resize_linear(m, (432, 240))[:, :, 0]
+                ys, xs = np.flatnonzero(small.any(axis=1)), np.flatnonzero(small.any(axis=0))
+                if ys.size:
+                    assert a.value <= ys[0] and ys[-1] < b.value and ca.value <= xs[0] and xs[-1] < cb.value, (W, sh, r0, r1, c0, c1)
+    finally:
+        eng.close()
+        det.close()
