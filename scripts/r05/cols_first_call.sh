@@ -17,3 +17,10 @@ r=d['roofline']
 print('COLS=$v run $i:', d['value'], 'fps', d['ms_per_step'], 'ms; single lane', d['single_lane']['value'], '; GFLOP/frame', d['gflop_per_frame'], '|', d.get('gflop_per_frame_reference'), '; model TF', d['model_tflops'], '; roofline', r['achieved'], r['frac'])"
   done
 done
+# window lanes after the dead-work elimination made the last block's launches shorter: 2 (default) vs 3
+for l in 2 3 2 3; do
+  timeout 600 $B --lanes $l > $OUT/bench_lanes${l}.log 2>&1
+  grep '"metric"' $OUT/bench_lanes${l}.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('lanes $l:', d['value'], 'fps', d['ms_per_step'], 'ms')"
+done
