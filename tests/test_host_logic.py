@@ -128,6 +128,11 @@ def test_mask_rows_promise_from_the_host_mask(built_lib, monkeypatch):
             strip = mask[ymin:ymax, :, 0]
             assert 0 <= lo < hi <= W and strip[:, lo].any() and strip[:, hi - 1].any() and not strip[:, :lo].any() and not strip[:, hi:].any()
         assert (eng.mask_cols(np.zeros((H, W), np.uint8), areas) == 0).all()
+        import torch                                   # the tensor route (what a caller without a host copy of the mask takes)
+        mt = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0]))
+        assert np.array_equal(eng.mask_cols(mt, areas), cols) and np.array_equal(eng.mask_rows(mt, areas), rows)
+        mt[0, 0] = 1                                   # an in-place change is seen (the rows are cached per tensor version)
+        assert eng.mask_rows(mt, [(0, 100, 0, W)])[0].tolist() == [0, 1]
         for (lo, hi) in cols:                          # ... and the model columns they turn into: whole groups of eight around the taps
             a, b = C.c_int32(), C.c_int32()
             assert lib.vsr_sttn_decode_cols(eng._h, W, int(lo), int(hi), C.byref(a), C.byref(b)) == 0
