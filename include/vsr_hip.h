@@ -89,8 +89,9 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
 int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                              int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* sel, int nsel, void* stream);
 /* ... and about its columns: mask_cols host [n_areas][2] = the frame columns [lo, hi) outside which the mask is zero.  The GEMMs of
- * the decoder and of the last block then take rectangles.  Built and replayed on the CPU in round 4, not yet run on a GPU: the
- * column promise is honoured only with VSR_DECODE_COLS=1 (otherwise this is vsr_sttn_auto_chunk_rows). */
+ * the decoder and of the last block then take rectangles.  Built and replayed on the CPU in round 4, not yet run on a GPU: calling
+ * this entry point is the opt-in (the Python side does so with its VSR_DECODE_COLS switch); VSR_DECODE_COLS=0 in the environment makes
+ * it ignore mask_cols (= vsr_sttn_auto_chunk_rows). */
 int vsr_sttn_auto_chunk_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                             int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* mask_cols,
                             const int32_t* sel, int nsel, void* stream);

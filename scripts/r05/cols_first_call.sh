@@ -2,7 +2,7 @@
 # Round 5, first GPU call: the column ranges of DESIGN 4.3c were built and replayed on the CPU in round 4 but never ran on a GPU.
 #   1. bit equality of the frames with the promise-free call (tests/test_gpu_sttn.py::test_decoder_box_gives_the_same_frames)
 #   2. the default bench with the columns on / off, interleaved on one box (fps, GFLOP per frame, dominant-kernel rate)
-# If 1 is green and 2 follows the FLOPs: make VSR_DECODE_COLS default 1 (sttn_engine.hip colsOn, engine.py auto_chunk / chunk_flops).
+# If 1 is green and 2 follows the FLOPs: make VSR_DECODE_COLS default 1 (vsr_amd/switches.py).
 OUT=gpurun_out/r05_cols; mkdir -p $OUT
 (VSR_DECODE_COLS=1 timeout 900 python -m pytest tests/test_gpu_sttn.py -q -x -k "decoder_box or decoder_rows" 2>&1 | tail -5) > $OUT/pytest.log; tail -2 $OUT/pytest.log
 # config 3's inpainting with the columns off / on: scripts/r04/rows_det.sh with VSR_DECODE_COLS=0 / 1 is the det-side A/B

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from vsr_amd import switches
 from oracle.make_golden import propainter_inputs
 from oracle.propainter import ProPainterOracle
 from vsr_amd.engine import PpEngine
@@ -89,7 +90,7 @@ def test_generator_strip_size_smoke(gen_engine, gpu_device):
     assert torch.equal(a, b)
 
 
-@pytest.mark.skipif(os.environ.get("VSR_PP_DECODE_BOX", "0") != "1",
+@pytest.mark.skipif(not switches.on("VSR_PP_DECODE_BOX"),
                     reason="the generator's decoder box is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_PP_DECODE_BOX=1 pytest -k decoder_box")
 @pytest.mark.parametrize("box", [(224, 360, 0, 0), (224, 360, 280, 1640), (0, 64, 0, 512), (120, 200, 1400, 1920)])
 def test_generator_decoder_box(gen_engine, gpu_device, box):
@@ -109,7 +110,7 @@ def test_generator_decoder_box(gen_engine, gpu_device, box):
     assert torch.isfinite(got).all()
 
 
-@pytest.mark.skipif(os.environ.get("VSR_PP_ENC_CACHE", "0") != "1",
+@pytest.mark.skipif(not switches.on("VSR_PP_ENC_CACHE"),
                     reason="the per-frame encoder cache is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_PP_ENC_CACHE=1 pytest -k encoder_cache")
 @pytest.mark.parametrize("t,lt,H,W", [(5, 3, 128, 192), (15, 11, 360, 1920)])
 def test_generator_encoder_cache(gen_engine, gpu_device, t, lt, H, W):

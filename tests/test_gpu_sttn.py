@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from vsr_amd import switches
 from vsr_amd import synth
 from oracle.sttn_auto import (STTNInpaintOracle, calculate_psnr, create_mask, get_inpaint_area_by_mask)
 from oracle import cv2_restate as cv2r
@@ -398,7 +399,7 @@ def test_decoder_rows_give_the_same_frames(built_lib, gpu_device, sd, mode, H, W
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("VSR_DECODE_COLS", "0") != "1",
+@pytest.mark.skipif(not switches.on("VSR_DECODE_COLS"),
                     reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
 @pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("H,W,boxes", [
@@ -452,7 +453,7 @@ def test_decoder_rows_give_the_same_frames_det(built_lib, gpu_device, sd_det, H,
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("VSR_DECODE_COLS", "0") != "1",
+@pytest.mark.skipif(not switches.on("VSR_DECODE_COLS"),
                     reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
 @pytest.mark.parametrize("H,W,box", [(720, 1280, (620, 700, 400, 900)), (1080, 1920, (40, 160, 1500, 1900)), (480, 852, (150, 400, 0, 200))])
 def test_decoder_box_gives_the_same_frames_det(built_lib, gpu_device, sd_det, H, W, box):

@@ -19,6 +19,7 @@ import scipy.ndimage
 import torch
 
 from ..tools.inpaint_tools import get_inpaint_area_by_mask
+from ... import switches
 from ..._lib import check, lib
 from ...engine import PpEngine, RaftEngine, RfcEngine
 from .sttn_auto_inpaint import _device_index
@@ -183,7 +184,7 @@ class PropainterInpaint:
             # eight, so that the boxes of a video that differ by a few pixels share their plans).  Built and replayed on the CPU in
             # round 4, not yet run on a GPU: opt-in.
             box = None
-            if os.environ.get("VSR_PP_DECODE_BOX", "0") == "1" and md.any():
+            if switches.on("VSR_PP_DECODE_BOX") and md.any():
                 ys, xs = np.flatnonzero(md.any(axis=1)), np.flatnonzero(md.any(axis=0))
                 box = (int(ys[0]) // 8 * 8, min(h, (int(ys[-1]) + 8) // 8 * 8), int(xs[0]) // 8 * 8, min(w, (int(xs[-1]) + 8) // 8 * 8))
             windows = []
@@ -194,7 +195,7 @@ class PropainterInpaint:
             # frame is encoded once per call instead of once per window it appears in (vsr_pp_encode / vsr_pp_forward_cached).  Built and
             # replayed on the CPU in round 4, not yet run on a GPU: opt-in.
             enc_cache = None
-            if os.environ.get("VSR_PP_ENC_CACHE", "0") == "1":
+            if switches.on("VSR_PP_ENC_CACHE"):
                 calls, feat_slot, tok_slot = encoder_cache_plan(windows)
                 fc, tc = [], []
                 for cids, ntok in calls:

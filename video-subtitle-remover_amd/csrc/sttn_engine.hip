@@ -814,8 +814,9 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
     }
     // model-resolution rows every area needs (0, 0 = all)
     static const bool rowsOn = [] { const char* e = getenv("VSR_DECODE_ROWS"); return !(e && atoi(e) == 0); }();
-    // (columns: built, replayed on the CPU, NOT yet run on a GPU -- opt-in, VSR_DECODE_COLS=1)
-    static const bool colsOn = [] { const char* e = getenv("VSR_DECODE_COLS"); return e && atoi(e) == 1; }();
+    // (columns: built, replayed on the CPU, NOT yet run on a GPU -- a caller opts in by handing over mask_cols (the _box entry points; the
+    // Python side does so with its VSR_DECODE_COLS switch, switches.py); VSR_DECODE_COLS=0 makes this side ignore them)
+    static const bool colsOn = [] { const char* e = getenv("VSR_DECODE_COLS"); return !(e && atoi(e) == 0); }();
     std::vector<int> decLo((size_t)n_areas, 0), decHi((size_t)n_areas, 0), decXLo((size_t)n_areas, 0), decXHi((size_t)n_areas, 0);
     if (maskRows && rowsOn) {
         for (int k = 0; k < n_areas; ++k) {

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, switches
 from ._lib import check, lib
 
 
@@ -158,7 +158,7 @@ class SttnEngine:
         """FLOPs of one auto_chunk call on this mask: every area's plan decodes only the rows its mask rows are resized from"""
         ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
         total = 0.0
-        with_cols = os.environ.get("VSR_DECODE_COLS", "0") == "1"
+        with_cols = switches.on("VSR_DECODE_COLS")
         cols = self.mask_cols(mask_dev, ar) if with_cols else np.zeros((ar.shape[0], 2), dtype=np.int32)
         for (ymin, ymax, _, _), (lo, hi), (c0, c1) in zip(ar, self.mask_rows(mask_dev, ar), cols):
             if hi > lo and os.environ.get("VSR_DECODE_ROWS", "1") != "0":
@@ -189,7 +189,7 @@ class SttnEngine:
         # decode_rows=False: no promise about the mask, the whole model-resolution image is decoded (tests compare the two)
         # (mask_host: the caller's numpy copy of the mask, when it has one -- the rows are then read off it)
         rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
-        if decode_rows and os.environ.get("VSR_DECODE_COLS", "0") == "1":
+        if decode_rows and switches.on("VSR_DECODE_COLS"):
             cols = np.ascontiguousarray(self.mask_cols(mask_dev if mask_host is None else mask_host, ar))
             with torch.cuda.device(frames_dev.device):
                 check(lib.vsr_sttn_auto_chunk_box(
@@ -228,7 +228,7 @@ class SttnEngine:
         L, H, W, _ = frames_dev.shape
         ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
         rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
-        if decode_rows and os.environ.get("VSR_DECODE_COLS", "0") == "1":
+        if decode_rows and switches.on("VSR_DECODE_COLS"):
             cols = np.ascontiguousarray(self.mask_cols(mask_dev if mask_host is None else mask_host, ar))
             with torch.cuda.device(frames_dev.device):
                 check(lib.vsr_sttn_det_batch_box(self._h, C.c_void_p(frames_dev.data_ptr()), L, H, W, C.c_void_p(mask_dev.data_ptr()),
