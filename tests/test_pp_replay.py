@@ -150,3 +150,25 @@ def test_generator_strict_state_dict(pp_sd, built_lib):
     bad["encoder.layers.14.weight"] = np.zeros((256, 96, 3, 3), np.float32)
     with pytest.raises(_lib.VsrError, match="shape mismatch"):
         PpEngine(device=-1, state_dict=bad)
+
+
+def test_generator_entry_points_have_no_cpu_path(pp_host_engine):
+    """a handle that was packed without a device: every generator entry point -- the round-4 ones too -- fails with VSR_ERR_NOGPU"""
+    import ctypes as C
+
+    lib = _lib.lib
+    f = np.zeros(64, np.float32)
+    u = np.zeros(64, np.uint8)
+    idx = np.zeros(2, np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    h = pp_host_engine.handle
+    calls = [
+        lambda: lib.vsr_pp_forward(h, P(f), P(f), P(f), P(u), P(u), 2, 2, 64, 96, P(u), 4, P(f), None),
+        lambda: lib.vsr_pp_forward_box(h, P(f), P(f), P(f), P(u), P(u), 2, 2, 64, 96, P(u), 4, 8, 16, 8, 16, P(f), None),
+        lambda: lib.vsr_pp_encode(h, P(f), P(u), P(u), 2, 1, 64, 96, P(f), P(f), None),
+        lambda: lib.vsr_pp_forward_cached(h, P(f), P(f), P(idx), P(f), P(f), P(u), P(u), 2, 2, 64, 96, P(u), 4, 0, 0, 0, 0, P(f), None),
+    ]
+    for call in calls:
+        assert call() == _lib.VSR_ERR_NOGPU and "no CPU fallback" in _lib.last_error()
+    assert lib.vsr_pp_encode(h, P(f), P(u), P(u), 2, 3, 64, 96, P(f), P(f), None) == _lib.VSR_ERR_ARG          # more token frames than frames
+    assert lib.vsr_pp_token_count(64, 96) == 6 * 8 and lib.vsr_pp_token_count(360, 1920) == 30 * 160
