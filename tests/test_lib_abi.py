@@ -42,6 +42,12 @@ def test_no_cpu_fallback(built_lib):
     assert "no CPU fallback" in built_lib.last_error()
     prob = built_lib.GGProblem()
     assert lib.vsr_run_gather_gemm(C.byref(prob), 1, 0, 0, None) == built_lib.VSR_ERR_NOGPU
+    # the chunk entry points with the promises about the mask (rows, rows + columns) are no different
+    ar = np.array([[0, 8, 0, 16]], np.int32)
+    rc2 = np.array([[0, 8]], np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.vsr_sttn_auto_chunk_rows(eng.handle, P(buf), 1, 8, 16, P(buf), 1, P(ar), P(rc2), None, 0, None) == built_lib.VSR_ERR_NOGPU
+    assert lib.vsr_sttn_auto_chunk_box(eng.handle, P(buf), 1, 8, 16, P(buf), 1, P(ar), P(rc2), P(rc2), None, 0, None) == built_lib.VSR_ERR_NOGPU
     eng.close()
 
 
