@@ -17,6 +17,16 @@ r=d['roofline']
 print('COLS=$v run $i:', d['value'], 'fps', d['ms_per_step'], 'ms; single lane', d['single_lane']['value'], '; GFLOP/frame', d['gflop_per_frame'], '|', d.get('gflop_per_frame_reference'), '; model TF', d['model_tflops'], '; roofline', r['achieved'], r['frac'])"
   done
 done
+# the first block's q/k/v once per frame of the chunk instead of once per window (VSR_QKV0_SHARED, -0.6 % of a chunk's FLOPs): same bits?
+(VSR_QKV0_SHARED=1 timeout 900 python -m pytest tests/test_gpu_sttn.py -q -x -k "shared_first" 2>&1 | tail -3) >> $OUT/pytest.log; tail -1 $OUT/pytest.log
+for i in 1 2; do
+  for v in 1 0; do
+    VSR_QKV0_SHARED=$v timeout 600 $B > $OUT/bench_qkv0_${v}_$i.log 2>&1
+    grep '"metric"' $OUT/bench_qkv0_${v}_$i.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('QKV0_SHARED=$v run $i:', d['value'], 'fps', d['ms_per_step'], 'ms; GFLOP/frame', d['gflop_per_frame'])"
+  done
+done
 # window lanes after the dead-work elimination made the last block's launches shorter: 2 (default) vs 3
 for l in 2 3 2 3; do
   timeout 600 $B --lanes $l > $OUT/bench_lanes${l}.log 2>&1

@@ -98,6 +98,8 @@ def run(L=4, ns=2, rl=3, seed=11):
     view = PlanView(_lib, eng, L)
     kinds = [info.kind for info, _ in view.ops]
     nsplit_pv = max([it.splitK for info, items in view.ops if info.kind == 1 and info.bmode == 1 for it in items] + [1])
+    n_qkv = sum(1 for info, _ in view.ops if info.tag.decode() == "attn.qkv")
+    flops, ref_flops = view.flops, eng.flops(L, reference=True)
     comp, counts, _ = replay(view, eng.packed_weights(), frames)
     view.close()
     eng.close()
@@ -112,10 +114,13 @@ def run(L=4, ns=2, rl=3, seed=11):
     assert calculate_psnr(comp, refa) > 70.0
     assert 20.0 < comp.std() < 120.0, "synthetic weights should give a full-range image"
     return {"counts": counts.tolist(), "pv_split": int(nsplit_pv), "has_reduce": 5 in kinds,
-            "psnr": calculate_psnr(comp, refa), "max_abs": float(d.max())}
+            "psnr": calculate_psnr(comp, refa), "max_abs": float(d.max()), "n_qkv": n_qkv, "flops": flops, "ref_flops": ref_flops}
 
 
 if __name__ == "__main__":
     import json
 
-    print(json.dumps(run_det() if "--det" in sys.argv else run()))
+    if "--long" in sys.argv:            # more windows than lanes, reference frames that are neighbours elsewhere
+        print(json.dumps(run(L=5, ns=2, rl=4, seed=12)))
+    else:
+        print(json.dumps(run_det() if "--det" in sys.argv else run()))

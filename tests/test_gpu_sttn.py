@@ -476,6 +476,26 @@ def test_decoder_box_gives_the_same_frames_det(built_lib, gpu_device, sd_det, H,
     eng.close()
 
 
+@pytest.mark.skipif(not switches.on("VSR_QKV0_SHARED"),
+                    reason="the shared first-block q/k/v is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_QKV0_SHARED=1 pytest -k shared_first")
+@pytest.mark.parametrize("L,H,W,lanes", [(50, 1080, 1920, 2), (23, 720, 1280, 1), (7, 480, 852, 3)])
+def test_shared_first_block_qkv_gives_the_same_frames(built_lib, gpu_device, L, H, W, lanes):
+    """VSR_QKV0_SHARED (read once per process, hence two children): the first block's q/k/v once per frame of the chunk instead of once
+    per window -- the written frames are the same bits, the FLOPs fewer."""
+    import subprocess
+    import sys
+
+    res = {}
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_qkv0_child.py"), str(L), str(H), str(W), str(lanes), "0"],
+                           env=dict(os.environ, VSR_QKV0_SHARED=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1].split()
+        res[v] = (line[1], float(line[2]))
+    assert res["0"][0] == res["1"][0]
+    assert res["1"][1] < res["0"][1]
+
+
 def test_two_lanes_equal_one_lane_det(built_lib, gpu_device, sd_det):
     from vsr_amd.engine import SttnEngine
 

@@ -138,6 +138,31 @@ def test_plan_flops_det_matches_survey(built_lib):
     assert 0.95 * f50 < x50 < 0.985 * f50          # the last block of a window runs on its neighbour frames only
 
 
+def test_plan_replay_shared_first_block_qkv(built_lib):
+    """VSR_QKV0_SHARED=1 in a fresh process (the library reads its tuning once): the first block's q/k/v run once per frame of the chunk
+    (one GEMM in front of the windows) and every window's first attention reads its frames' rows there -- the oracle's composites,
+    one q/k/v GEMM fewer per window, fewer FLOPs than the default plan, the reference's count unchanged.  Three windows on two
+    kinds of frames: reference frames that are neighbours elsewhere."""
+    from vsr_amd import _lib
+    from vsr_amd.engine import SttnEngine
+    from vsr_amd.synth import make_state_dict
+    from _replay import PlanView
+
+    env = dict(os.environ, VSR_QKV0_SHARED="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_replay_check.py"), "--long"], env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(r.stdout.strip().splitlines()[-1])
+    eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None, neighbor_stride=2, ref_length=4)     # this process: the default plan
+    view = PlanView(_lib, eng, 5)
+    n_qkv = sum(1 for info, _ in view.ops if info.tag.decode() == "attn.qkv")
+    nwin = 3
+    assert n_qkv == 8 * nwin and b["n_qkv"] == 7 * nwin + 1
+    assert b["flops"] < view.flops and abs(eng.flops(5, reference=True) - b["ref_flops"]) <= 1e-9 * b["ref_flops"]
+    assert b["counts"] == view.counts.tolist()
+    view.close()
+    eng.close()
+
+
 def test_plan_replay_split_pv_and_square_tiles():
     """Non-default tuning in a fresh process: PV split-K + reduce-scatter, 128x128 conv tiles,
     tap-major K order (the library reads its tuning env once per process)."""

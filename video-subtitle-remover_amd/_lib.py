@@ -226,6 +226,9 @@ if not os.path.exists(LIB_PATH):
 # before anything had imported torch (profiles/r02_cli_e2e.log).
 import torch  # noqa: E402,F401
 
+from . import switches  # noqa: E402
+
+switches.export_defaults()             # the library reads some switches itself, once per process (switches.py)
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = library does not match the header

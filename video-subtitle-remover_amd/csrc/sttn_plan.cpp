@@ -32,6 +32,7 @@ const Tuning& Tuning::get(int precision)
             x.fuseSoftmax = envInt("VSR_FUSE_SOFTMAX", 1) && envInt("VSR_GG_VARIANT", 3) == 3 && envInt("VSR_PV_VARIANT", 1) == 1;
             x.outConvBlocked = envInt("VSR_OUT_CONV_BLOCKED", 1);
             x.trimLastBlock = envInt("VSR_TRIM_LAST_BLOCK", 1);
+            x.shareQkv0 = envInt("VSR_QKV0_SHARED", 0);
             return x;
         }(),
         [] {
@@ -45,6 +46,7 @@ const Tuning& Tuning::get(int precision)
             x.fuseSoftmax = 0;      // split-format tensors: the probabilities are a GEMM operand in that format, k_softmax_rows writes it
             x.outConvBlocked = envInt("VSR_OUT_CONV_BLOCKED", 1);
             x.trimLastBlock = envInt("VSR_TRIM_LAST_BLOCK", 1);
+            x.shareQkv0 = envInt("VSR_QKV0_SHARED", 0);
             return x;
         }()};
     return t[precision ? 1 : 0];
@@ -392,22 +394,24 @@ int PlanBuilder::tColsLinear(int nchunks, int padTo)
 
 // token (t, oy, ox) of scale s inside the plain QKV buffer [T*fh*fw][3C] (auto_sttn.py:182-190:
 // view(b,t,d_k,out_h,height,out_w,width).permute(0,1,3,5,2,4,6) => tokens ordered t, out_h, out_w)
-int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0, int oy1, int ox0, int ox1)
+int Plan::tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0, int oy1, int ox0, int ox1, const std::vector<int>* fids)
 {
     const int pw = g.patchW[s], ph = g.patchH[s], ow = g.featW / pw, oh = g.featH / ph, C3 = 3 * g.channels;
     if (oy1 < 0) oy1 = oh;
     if (ox1 < 0) ox1 = ow;
-    const std::string key = "RT:" + std::to_string(T) + ":" + std::to_string(s) + ":" + std::to_string(choff) + ":" +
-                            std::to_string(count) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1) +
-                            ":" + std::to_string(ox0) + "-" + std::to_string(ox1);
+    std::string key = "RT:" + std::to_string(T) + ":" + std::to_string(s) + ":" + std::to_string(choff) + ":" +
+                      std::to_string(count) + ":" + std::to_string(padTo) + ":" + std::to_string(oy0) + "-" + std::to_string(oy1) +
+                      ":" + std::to_string(ox0) + "-" + std::to_string(ox1);
+    if (fids) key += ":f" + idsKey(std::vector<int>(fids->begin(), fids->begin() + T));
     auto it = tableKey_.find(key);
     if (it != tableKey_.end()) return it->second;
     std::vector<int32_t> v;
     for (int t = 0; t < T; ++t)
         for (int oy = oy0; oy < oy1; ++oy)
             for (int ox = ox0; ox < ox1; ++ox) {
-                const int64_t o = (((int64_t)t * g.featH + oy * ph) * g.featW + ox * pw) * C3 + choff;
+                const int64_t o = (((int64_t)(fids ? (*fids)[t] : t) * g.featH + oy * ph) * g.featW + ox * pw) * C3 + choff;
                 checkFits(o);
+                if (o * 4 > 4294967295LL) throw std::runtime_error("q/k/v row offset exceeds the kernels' 32-bit byte offsets");
                 v.push_back((int32_t)o);
             }
     assert((int)v.size() == count);
@@ -543,8 +547,9 @@ void Plan::addConv(const char* tag, const Act& in, const std::vector<int>& inIds
 // the rows of its neighbour frames (Plan::buildWindow)
 // [attLo, attHi): the feature rows of the attention output that anything reads (the last block of a window that feeds a ranged
 // decoder): the query tokens are the patches that touch those rows
-void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi, int attXLo, int attXHi)
+void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi, int attXLo, int attXHi, int qkvBuf, const std::vector<int>* fids)
 {
+    if (qkvBuf < 0) qkvBuf = lb(BUF_QKV);
     if (attHi < 0) attHi = g.featH;
     if (attXHi < 0) attXHi = g.featW;
     const Tuning& tu = tu_;
@@ -581,11 +586,11 @@ void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi, int 
         a.tilesM = cdiv(Mtok, qBM); a.tilesN = cdiv(Ntok, qBN);
         a.splitK = splitK; a.chunksPerSplit = cps; a.splitStride = plane;
         a.alpha = 1.f; a.act = VSR_ACT_NONE;
-        a.bufA = lb(BUF_QKV); a.offA = 0;
-        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM, oy0, oy1, ox0, ox1);
+        a.bufA = qkvBuf; a.offA = 0;
+        a.tRowA = tRowsTokens(Tq, s, dk * s, Mtok, qBM, oy0, oy1, ox0, ox1, fids);
         a.tColA = tColsPatch(s, nchunks);
-        a.bufB = lb(BUF_QKV); a.offB = 0;
-        a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN);
+        a.bufB = qkvBuf; a.offB = 0;
+        a.tRowB = tRowsTokens(T, s, C + dk * s, Ntok, qBN, 0, -1, 0, -1, fids);
         a.tColB = a.tColA;
         a.bufC = lb(BUF_S); a.offC = sOff;
         a.tRowC = tRowsLinear(Mtok, ldS, qBM);
@@ -632,8 +637,8 @@ void Plan::addAttention(int Tq, int T, const BlockW&, int attLo, int attHi, int 
         b.bufA = fused ? lb(BUF_S) : lb(BUF_P); b.offA = fused ? sOff : pOff;
         b.tRowA = tRowsLinear(Mtok, ldS, pBM);
         b.tColA = tColsLinear(kchunks, kchunks);
-        b.bufB = lb(BUF_QKV); b.offB = 0;
-        b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS); // K rows, padded with token 0 (P pad cols are 0)
+        b.bufB = qkvBuf; b.offB = 0;
+        b.tRowB = tRowsTokens(T, s, 2 * C + dk * s, Ntok, ldS, 0, -1, 0, -1, fids); // K rows, padded with token 0 (P pad cols are 0)
         b.tColB = tColsPatch(s, b.tilesN * pBN / VSR_GG_KC);
         const int tRowAtt = tRowsTokensAct(att, Tq, s, pBM, oy0, oy1, ox0, ox1);
         const int tColAtt = tColsPatchAct(att, s, b.tilesN * pBN / VSR_GG_KC);
@@ -722,7 +727,9 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     std::vector<int> curIds = ids;
     for (int b = 0; b < g.blocks; ++b) {
         const BlockW& bw = m_.blk[b];
-        {   // fused Q/K/V 1x1 (auto_sttn.py:172-174) -> plain [T*fh*fw][3C]
+        const bool shared0 = b == 0 && qkv0_;     // this block's q/k/v of every frame of the chunk are in BUF_QKV0 (Plan::Plan)
+        if (shared0) trimmedFlops_ += 2.0 * T * fh * fw * (3.0 * C) * C;
+        if (!shared0) {   // fused Q/K/V 1x1 (auto_sttn.py:172-174) -> plain [T*fh*fw][3C]
             Op op;
             op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = tu_.qkvTile; op.bmode = VSR_BMODE_NK;
             int BM, BN;
@@ -771,7 +778,8 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
         const std::vector<int> idQ = iota(Tq);
         const std::vector<int> curIdsQ(curIds.begin(), curIds.begin() + Tq);
         const double before = flops;
-        addAttention(Tq, T, bw, ralo, rahi, ca.lo, ca.hi);
+        if (shared0) addAttention(Tq, T, bw, ralo, rahi, ca.lo, ca.hi, BUF_QKV0, &ids);
+        else addAttention(Tq, T, bw, ralo, rahi, ca.lo, ca.hi);
         // x = x + LeakyReLU(conv3x3(att))            (auto_sttn.py:162-164,237)
         addConv("attn.out", att, idQ, x0, Tq, 3, 1, 1, bw.out, VSR_ACT_LRELU02, &cur, &curIdsQ, r0lo, r0hi, c0.lo, c0.hi);
         // x = x + LeakyReLU(conv3x3(LeakyReLU(conv3x3 dil2(x))))   (auto_sttn.py:214-218,238)
@@ -989,6 +997,42 @@ Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, i
     addConv("enc.2", e1, idL, e2, L, 3, 1, 1, model.enc[1], VSR_ACT_LRELU02, nullptr, nullptr);
     addConv("enc.3", e2, idL, e3, L, 3, 2, 1, model.enc[2], VSR_ACT_LRELU02, nullptr, nullptr);
     addConv("enc.4", e3, idL, feats, L, 3, 1, 1, model.enc[3], VSR_ACT_LRELU02, nullptr, nullptr);
+
+    // The first transformer block of EVERY window reads the encoder features, and its q/k/v projection is a 1x1 conv: the same rows of
+    // the same GEMM for a frame whichever window it is in.  With Tuning::shareQkv0 it runs here, once per frame of the chunk, and the
+    // first block's attention of a window addresses its frames' rows in BUF_QKV0 (row tables by chunk frame id; read-only, so the
+    // lanes share it).  Same products in the same order per output element: the same bits.  (Exact fp32 only, and only while the
+    // buffer stays inside the kernels' 32-bit byte offsets.)
+    qkv0_ = tu_.shareQkv0 && precision == 0 && g.blocks > 1 && (int64_t)L * g.featH * g.featW * 3 * g.channels * 4 < 4294967296LL;
+    if (qkv0_) {
+        const int fh = g.featH, fw = g.featW, C = g.channels;
+        const BlockW& bw = model.blk[0];
+        Op op;
+        op.kind = OP_GEMM; op.tag = "attn.qkv"; op.tileCfg = tu_.qkvTile; op.bmode = VSR_BMODE_NK;
+        int BM, BN;
+        tileDims(op.tileCfg, BM, BN);
+        GemmItem it{};
+        it.M = L * fh * fw; it.N = 3 * C; it.K = C;
+        it.tilesM = cdiv(it.M, BM); it.tilesN = cdiv(it.N, BN);
+        it.splitK = 1; it.chunksPerSplit = it.K / VSR_GG_KC; it.alpha = 1.f; it.act = VSR_ACT_NONE;
+        it.bufA = feats.buf; it.offA = 0;
+        it.tRowA = tRowsAct(feats, idL, fh, fw, 1, BM, 0);
+        it.tColA = tColsConv(feats, 1, 1);
+        it.bufB = BUF_WEIGHTS; it.offB = bw.qkv.w;
+        it.tRowB = tRowsLinear(it.N, it.K, BN);
+        it.tColB = tColsLinear(it.K / VSR_GG_KC, it.K / VSR_GG_KC);
+        it.bufC = BUF_QKV0; it.offC = 0;
+        it.tRowC = tRowsLinear(it.M, 3 * C, BM);
+        it.tColC = tColsLinear(it.N / VSR_GG_KC, it.tilesN * BN / VSR_GG_KC);
+        it.offBias = bw.qkv.b;
+        it.bufR = -1; it.tRowR = -1;
+        op.flops = 2.0 * it.M * (double)it.N * it.K;
+        flops += op.flops;
+        trimmedFlops_ -= op.flops;              // (buildWindow adds what every window would have spent)
+        op.gemm.push_back(it);
+        need(BUF_QKV0, (int64_t)it.M * 3 * C);
+        ops.push_back(std::move(op));
+    }
 
     std::vector<int32_t> visits(L, 0);
     const int ns = g.neighborStride;

@@ -36,6 +36,8 @@ struct Tuning {
                          //   chunks when it has at least twice as many (0 = never split)
     int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
     int outConvBlocked;  // VSR_OUT_CONV_BLOCKED: 1 = the 64 -> 3 output conv runs over 2x4 output blocks (Model::pack_conv_blocked)
+    int shareQkv0;       // VSR_QKV0_SHARED: 1 = the first block's q/k/v once per frame of the chunk (BUF_QKV0) instead of once per window;
+                         // built and replayed on the CPU in round 4, not yet run on a GPU: default 0
     int trimLastBlock;   // VSR_TRIM_LAST_BLOCK: 1 = the last transformer block of a window computes its attention output, out-conv and
                          //   FFN for the NEIGHBOUR frames only -- the decoder reads nothing else (Plan::buildWindow); same bits
     int fuseSoftmax;     // VSR_FUSE_SOFTMAX: 1 = exact-fp32 mode keeps no probability matrix for the scales whose scores are not
@@ -82,7 +84,12 @@ enum BufId {
     // further instances of every buffer a sliding window works in: the windows of a chunk are independent until their decoded
     // frames are averaged into BUF_COMP, so window w runs on stream ("lane") w % lanes in lane-owned instances (Plan::lanes, laneBuf())
     BUF_LANE_FIRST,
-    BUF_COUNT = BUF_LANE_FIRST + 15 * 3      // kLaneBufs * (kMaxLanes - 1)
+    BUF_LANE_END = BUF_LANE_FIRST + 15 * 3,  // kLaneBufs * (kMaxLanes - 1)
+    // Tuning::shareQkv0: the FIRST transformer block's q/k/v of every frame of the chunk [L * featH * featW][3C].  That block reads the
+    // encoder features, which the windows share, and its q/k/v projection is a 1x1 conv -- a per-frame function -- so the reference
+    // computes it once per window a frame appears in (about three times per frame); here once, read by every window and lane
+    BUF_QKV0 = BUF_LANE_END,
+    BUF_COUNT
 };
 constexpr int kLaneBufs = 15, kMaxLanes = 4;
 // the window-scoped buffers, in the order of their lane instances
@@ -96,7 +103,7 @@ inline int laneBuf(int buf, int lane)
         if (kLaneBufList[i] == buf) return BUF_LANE_FIRST + (lane - 1) * kLaneBufs + i;
     return buf;
 }
-inline int baseBuf(int buf) { return buf >= BUF_LANE_FIRST ? kLaneBufList[(buf - BUF_LANE_FIRST) % kLaneBufs] : buf; }   // the lane-0 buffer an instance mirrors
+inline int baseBuf(int buf) { return buf >= BUF_LANE_FIRST && buf < BUF_LANE_END ? kLaneBufList[(buf - BUF_LANE_FIRST) % kLaneBufs] : buf; }   // the lane-0 buffer an instance mirrors
 
 enum OpKind { OP_NORM_IM2COL = 0, OP_GEMM = 1, OP_SOFTMAX = 2, OP_UPSAMPLE2X = 3, OP_DECODE_OUT = 4, OP_REDUCE_SCATTER = 5,
               OP_EW = 6 /* RAFT's elementwise / gather kernels, sub-kind in Op::ew (raft_plan.h) */ };
@@ -205,12 +212,15 @@ private:
     const Model& m_;
     const Tuning& tu_;
     int lane_ = 0;                       // lane of the window being built
+    bool qkv0_ = false;                  // the first block's q/k/v live in BUF_QKV0 (Tuning::shareQkv0)
     int lb(int buf) const { return laneBuf(buf, lane_); }
     int64_t rowmaxElems_ = 0;            // BUF_ROWMAX handed out so far: every fused attention instance of the plan has its own array
     double trimmedFlops_ = 0;            // what the reference spends on last-block rows nobody reads (buildWindow)
     int pickTile(int N) const;
     // oy0 / oy1: patch rows [oy0, oy1) of every frame only (-1 = all): the query tokens of a last block that feeds a ranged decoder
-    int tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0 = 0, int oy1 = -1, int ox0 = 0, int ox1 = -1);
+    // fids: the frame of the q/k/v buffer that token frame t lives in (BUF_QKV0: the window's chunk frame ids); nullptr: t itself
+    int tRowsTokens(int T, int s, int choff, int count, int padTo, int oy0 = 0, int oy1 = -1, int ox0 = 0, int ox1 = -1,
+                    const std::vector<int>* fids = nullptr);
     int tColsPatch(int s, int padTo);
     int tRowsTokensAct(const Act& a, int T, int s, int padTo, int oy0 = 0, int oy1 = -1, int ox0 = 0, int ox1 = -1);
     int tColsPatchAct(const Act& a, int s, int padTo);
@@ -219,7 +229,8 @@ private:
                  const std::vector<int>* resIds, int ylo = 0, int yhi = -1,      // [ylo, yhi): output rows computed (stride 1; default all)
                  int xlo = 0, int xhi = -1);                                       // [xlo, xhi): output columns computed (default all)
     // [attLo, attHi) x [attXLo, attXHi): feature rows / columns of the output that are read
-    void addAttention(int Tq, int T, const BlockW& bw, int attLo = 0, int attHi = -1, int attXLo = 0, int attXHi = -1);
+    void addAttention(int Tq, int T, const BlockW& bw, int attLo = 0, int attHi = -1, int attXLo = 0, int attXHi = -1, int qkvBuf = -1,
+                      const std::vector<int>* fids = nullptr);
     void buildWindow(const std::vector<int>& neighbors, const std::vector<int>& refs,
                      std::vector<int32_t>& visits);
 };
