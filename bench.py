@@ -16,16 +16,23 @@ chunk, nothing exchanged) is reported beside it as `replicas`.  Rank 0 prints ON
 
 Extra objects in the line:
   roofline     -- the dominant kernel symbol (the gather-GEMM instantiation with the largest total time:
-                  since round 4 gather_gemm_f32_v8<9>, the 3x3 256->256 convs = 59 % of the model FLOPs),
-                  algorithmic FLOPs / HIP-event time on the launch stream against the 157.3 TFLOP/s fp32
-                  MFMA peak of MI355X_MICROARCH.md; `every_gemm_launch` beside it is the same ratio over
+                  gather_gemm_f32_v3<128, 64, 2, 2, 0>, the 3x3 / 1x1 convs and QK^T as implicit GEMMs, 83 % of
+                  the GPU time), algorithmic FLOPs / HIP-event time on the launch stream against the 157.3 TFLOP/s
+                  fp32 MFMA peak of MI355X_MICROARCH.md; `every_gemm_launch` beside it is the same ratio over
                   ALL gather-GEMM launches of a chunk (every symbol).
+  configs      -- BASELINE.json's other configurations on this GPU, each with its own `roofline` (scripts/bench_configs.py:
+                  2 = 720p sttn-auto, 3 = 1080p sttn-det 47-frame batches + the text detector's forward, 4 = 1080p
+                  propainter 68-frame batches in exact fp32 and in the reference's GPU arithmetic, 5 = 4K sttn-auto on
+                  fp16 operands); measured after the timed region, N = 1 only.
   full_work    -- `value` is measured on a plan that leaves out what the reference computes and nothing reads (DESIGN
                   4.3c; the frames are the same bit for bit; `gflop_per_frame` vs `gflop_per_frame_reference`); this is
                   the same step with all of it, from a child process (the library reads the switches once per process).
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference modules, "port") timed on
                   this box's host cores on ONE full 50-frame chunk of the same clip, end to end (crop,
                   cv2-style resize, network, resize back, blend) with the network-only time beside it.
+                  kind is "port", not "reference": /root/reference does not exist on the GPU box and its
+                  wrappers need cv2; the port's network was checked identical (max |d| = 0.0) to the reference's
+                  own module on the build container (tests/golden/sttn_auto_net.npz, oracle/make_golden.py).
 """
 import argparse
 import json
@@ -240,6 +247,8 @@ def main():
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the check of the gathered chunks against each rank's replica result")
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2-5, scripts/bench_configs.py)")
+    ap.add_argument("--configs", default=None, help="comma-separated legs of scripts/bench_configs.py (default: 2,3,3d,4,4h,5)")
     ap.add_argument("--no-full-work", action="store_true",
                     help="skip the `full_work` leg: the same step with every row the reference's modules compute (a child process with "
                          "VSR_TRIM_LAST_BLOCK=0 VSR_DECODE_ROWS=0 -- the library reads these once per process)")
@@ -251,9 +260,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one
+        # process per GPU; rank 0 still prints the ONE JSON line).  HSA_ENABLE_IPC_MODE_LEGACY=0 is already in the environment (above).
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
     # VSR_BENCH_DRYRUN_1GPU=1: exercise the N > 1 code path on a single-GPU box (every rank on cuda:0, gloo)
@@ -441,7 +461,7 @@ def main():
     if replicas is not None:
         out["replicas"] = replicas
     if world > 1:          # the CPU baseline and the informational legs belong to the N = 1 line only
-        args.no_cpu_baseline, args.no_split_half, args.e2e_chunks, args.no_full_work = True, True, 0, True
+        args.no_cpu_baseline, args.no_split_half, args.e2e_chunks, args.no_full_work, args.no_configs = True, True, 0, True, True
     if rank == 0:
         # ---- roofline of the dominant kernel from the HIP events of the timed region
         # dominant kernel symbol = the gather-GEMM instantiation with the largest total time; every
@@ -533,6 +553,8 @@ def main():
             psnr = float("inf") if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
             out["cpu_baseline"] = {
                 "value": round(L / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+                "kind_note": "torch-CPU restatement of the reference modules (identical to them: tests/golden/sttn_auto_net.npz); /root/reference "
+                             "is not on the GPU box and its wrappers need cv2, so the reference itself cannot be timed here",
                 "model_only": {"value": round(L / dt_net, 4), "unit": "frames/s", "tflops": round(flops_chunk_ref / dt_net / 1e12, 3)},
                 "host": {"cpu_count": os.cpu_count(), "limits": effective_cpus()[1], "cpu_model": cpu_model_name(), "torch_threads": threads,
                          "probe_seconds_by_threads": tried},
@@ -612,7 +634,7 @@ def main():
 
             env = dict(os.environ, VSR_TRIM_LAST_BLOCK="0", VSR_DECODE_ROWS="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--res", args.res,
-                   "--chunk", str(L), "--lanes", str(args.lanes), "--no-cpu-baseline", "--no-split-half", "--e2e-chunks", "0", "--no-full-work"]
+                   "--chunk", str(L), "--lanes", str(args.lanes), "--no-cpu-baseline", "--no-split-half", "--e2e-chunks", "0", "--no-full-work", "--no-configs"]
             if args.precision:
                 cmd += ["--precision", args.precision]
             try:
@@ -626,6 +648,15 @@ def main():
                                             "(tests/test_gpu_sttn.py::test_decoder_rows_give_the_same_frames)"}
             except Exception as e:                 # noqa: BLE001 -- informational leg, never fatal
                 out["full_work"] = {"error": repr(e)[:200]}
+        if not args.no_configs:
+            # BASELINE.json's other configurations, each with its own roofline: outside the timed region, informational beside `value`
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import bench_configs
+
+                out["configs"] = bench_configs.run_all(args.configs.split(",") if args.configs else None)
+            except Exception as e:                 # noqa: BLE001 -- never fatal for the headline line
+                out["configs"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
         if world > 1 and replicas is not None and not replicas.get("selftest", {"ok": True})["ok"]:
             print("SELFTEST FAILED: gathered chunks differ from the ranks' replica results", file=sys.stderr, flush=True)

@@ -311,7 +311,9 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
  * after a device synchronisation -- stage-by-stage parity against the CPU replay of the plan */
 /* arithmetic of the contractions: 0 (default) exact fp32 MFMA; 1 split-half fp16 operands (22 significand bits) with fp32 accumulation,
  * range-guarded: a call whose operands leave the fp16 range is redone in fp32 and counted by *_fallbacks.  The reference runs RAFT in
- * fp32 and the other two networks in fp16 on a GPU (propainter_inpaint.py:140-146,230,249-251); mode 1 is closer to fp32 than either. */
+ * fp32 and the other two networks in fp16 on a GPU (propainter_inpaint.py:140-146,230,249-251); mode 1 is closer to fp32 than either.
+ * 2: fp16 operands (fp32 tensors rounded on their way into the matrix cores), fp32 accumulation, bias / activation / residual in fp32,
+ * same range guard -- the arithmetic class of the reference's `.half()` flow-completion and generator modules. */
 int vsr_raft_set_precision(vsr_raft_t* h, int mode);
 int64_t vsr_raft_fallbacks(const vsr_raft_t* h);
 int vsr_raft_read_buffer(vsr_raft_t* h, int buf, int64_t offset, int64_t count, float* out_host);
@@ -413,6 +415,15 @@ int vsr_pp_set_precision(vsr_pp_t* h, int mode);          /* see vsr_raft_set_pr
 int64_t vsr_pp_fallbacks(const vsr_pp_t* h);
 int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host);   /* test hook */
 double vsr_pp_flops(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t* window_flags, int nflags);
+
+/* Launch timing of the flow engines (RAFT, flow completion, ProPainter generator, LaMa), bench / profile use: with enable != 0 every op
+ * a replayed plan launches is bracketed by HIP events on the launch stream; vsr_flow_timing_get sums time (ms), launches and algorithmic
+ * FLOPs of the records whose key starts with `prefix`.  Keys: "<raft|rfc|pp|lama>:gg:<tile cfg>:<bmode>:v<kernel variant>:<op tag>" for
+ * gather-GEMM launches, "<engine>:op:<op tag>" for everything else.  Process-wide state, not thread-safe. */
+int vsr_flow_timing(int enable);
+int vsr_flow_timing_reset(void);
+int vsr_flow_timing_get(const char* prefix, double* total_ms, int64_t* launches, double* flops);
+int64_t vsr_flow_timing_keys(char* buf, int64_t capacity);   /* '\n'-separated keys; returns the bytes needed */
 
 /* ---------------------------------------------------------------------------------------
  * LaMa.  Replaces `self.model = torch.jit.load(model_path)` and `self.model(image, mask)` of

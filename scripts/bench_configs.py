@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""Throughput of the other BASELINE.json configurations on ONE GPU (chunks resident in HBM, same timing rules as
-bench.py, which keeps the headline config).  One JSON line per configuration; fills BASELINE.md section 4.
+"""Throughput of the other BASELINE.json configurations on ONE GPU (units resident in HBM, same timing rules as bench.py, which keeps
+the headline config).  bench.py calls `run_all()` after its timed region and puts the result into the driver's JSON line as `configs`;
+run on its own this prints one JSON line per configuration.
 
   config 2: 720p  sttn-auto, 50-frame chunks, fp32
-  config 3: 1080p sttn-det, batch_generator sizes of a 1200-frame interval (25 x 47 + 25), fp32
+  config 3: 1080p sttn-det, batch_generator sizes of a 1200-frame interval (25 x 47 + 25), fp32; the detector forward beside it
+  config 4: 1080p propainter, the 68-frame batches batch_generator(1200, 70) makes (strip 1920x360, 20 RAFT iterations): exact fp32 and
+            the reference's GPU arithmetic (RAFT fp32; flow completion + generator on fp16 operands, fp32 accumulation)
   config 5: 4K    sttn-auto, 50-frame chunks, fp16 operands (per GPU; the 8-GPU run is the driver's)
+
+Every entry carries a `roofline` of its dominant gather-GEMM kernel symbol: algorithmic FLOPs / HIP-event time on the launch stream
+(vsr_sttn_timing / vsr_flow_timing), against the dense MFMA peak of the arithmetic it runs in (MI355X_MICROARCH.md).
 """
 import json
 import os
@@ -14,12 +20,29 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 import vsr_amd  # noqa: E402,F401
-from bench import RES, make_chunk_on_device  # noqa: E402
 from vsr_amd.backend.tools.inpaint_tools import batch_generator, create_mask, get_inpaint_area_by_mask, threshold_mask  # noqa: E402
 from vsr_amd.engine import SttnEngine  # noqa: E402
 from vsr_amd.synth import make_state_dict  # noqa: E402
+
+PEAK_FP32 = 157.3          # TFLOP/s, v_mfma_f32_32x32x2_f32 dense (MI355X_MICROARCH.md)
+PEAK_F16 = 2500.0          # TFLOP/s, dense f16 MFMA
+RES = {"720p": (720, 1280, (620, 700, 192, 1088)), "1080p": (1080, 1920, (950, 1070, 288, 1632)),
+       "4k": (2160, 3840, (1900, 2140, 576, 3264))}
+TILE_DIMS = {0: (128, 128, 2, 2), 1: (256, 32, 4, 1), 2: (256, 64, 4, 1), 3: (128, 64, 2, 2)}
+
+
+def make_chunk_on_device(L, H, W, box, seed, device):
+    """Seeded synthetic clip (vsr_amd.synth) -- 10 generated frames, extended to L by rolling (bench.py's)."""
+    from vsr_amd import synth
+
+    base = synth.make_clip(min(L, 10), H, W, box, seed=seed)
+    d = torch.from_numpy(base).to(device)
+    reps = [torch.roll(d, shifts=(3 * k, 5 * k), dims=(1, 2)) for k in range((L + base.shape[0] - 1) // base.shape[0])]
+    return torch.cat(reps, 0)[:L].contiguous()
 
 
 def timed(fn, steps, warmup):
@@ -31,6 +54,63 @@ def timed(fn, steps, warmup):
         fn()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
+
+
+def sttn_kernels_timed(eng, precision="f32"):
+    """{kernel symbol: (ms, launches, flops)} from the engine's HIP-event records (vsr_sttn_timing_get)"""
+    per_kernel = {}
+    for cfg, (bm, bn, wm, wn) in TILE_DIMS.items():
+        for bmode in (0, 1):
+            for var, sym in ((1, "gather_gemm_f32"), (2, "gather_gemm_f32_v2"), (3, "gather_gemm_f32_v3"),
+                             (4, "gather_gemm_f32_v4"), (5, "gather_gemm_f32_v5"), (6, "gather_gemm_f32_v5")):
+                a, b, c = eng.timing_get(f"kernel:gg:{cfg}:{bmode}:v{var}")
+                if var == 1 and bmode == 1:        # timing_get matches by prefix: "...:v1" also counts "...:v1x" (below)
+                    ax, bx, cx = eng.timing_get(f"kernel:gg:{cfg}:1:v1x")
+                    a, b, c = a - ax, b - bx, c - cx
+                if b:
+                    per_kernel[f"{sym}<{bm}, {bn}, {wm}, {wn}, {bmode}>"] = (a, b, c)
+            a, b, c = eng.timing_get(f"kernel:gg:{cfg}:1:v1x")          # P.V of the fused attention (gather_gemm_pvx.h)
+            if b:
+                per_kernel[f"gather_gemm_f32_aexp<{bm}, {bn}, {wm}, {wn}>"] = (a, b, c)
+    a, b, c = eng.timing_get("kernel:gg:6:0:v8")                    # the 288 x 256 tile of the long-K convolutions (gather_gemm_v8.h)
+    if b:
+        per_kernel["gather_gemm_f32_v8<9>"] = (a, b, c)
+    a, b, c = eng.timing_get("kernel:gg:5:0:v7")                    # split-format modes: the 256 x 256 tile (gather_gemm_v7.h)
+    if b:
+        per_kernel["gather_gemm_f16_v7<%d>" % (0 if precision == "f16" else 1)] = (a, b, c)
+    return per_kernel
+
+
+def roofline_of(per_kernel, peak, what):
+    """the `roofline` object of the kernel symbol with the largest total time, plus the rate over every gather-GEMM launch"""
+    if not per_kernel:
+        return None
+    dom = max(per_kernel, key=lambda k: per_kernel[k][0])
+    ms, n, fl = per_kernel[dom]
+    ach = fl / ms / 1e9 if ms > 0 else 0.0
+    tms, tfl = sum(v[0] for v in per_kernel.values()), sum(v[2] for v in per_kernel.values())
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "launches": int(n), "avg_launch_ms": round(ms / n, 4) if n else None, "flops_per_launch": round(fl / n) if n else None,
+            "share_of_gemm_time": round(ms / tms, 3) if tms > 0 else None,
+            "every_gemm_launch": {"achieved": round(tfl / tms / 1e9, 2) if tms > 0 else None, "frac": round(tfl / tms / 1e9 / peak, 4) if tms > 0 else None},
+            "measured_on": what}
+
+
+def sttn_roofline(eng, step, precision, steps=2):
+    """single-lane pass with HIP events around every launch (outside any timed region)"""
+    eng.set_lanes(1)
+    step()
+    torch.cuda.synchronize()
+    eng.timing_reset()
+    eng.timing(1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    eng.timing(False)
+    r = roofline_of(sttn_kernels_timed(eng, precision), PEAK_FP32 if precision == "f32" else PEAK_F16,
+                    f"{steps} single-lane units, HIP events around every launch, after the timed passes")
+    eng.set_lanes(2)
+    return r
 
 
 def run_auto(name, res, precision, steps=4, warmup=1, L=50):
@@ -48,14 +128,17 @@ def run_auto(name, res, precision, steps=4, warmup=1, L=50):
 
     dt = timed(step, steps, warmup)
     fps = steps * L / dt
-    out = {"config": name, "mode": "sttn-auto", "res": res, "precision": precision, "chunk_frames": L, "fps": round(fps, 2),
-           "ms_per_chunk": round(dt / steps * 1e3, 2), "model_tflops": round(eng.chunk_flops(L, dmask, areas) / L * fps / 1e12, 2),
-           "fp32_fallback_chunks": eng.fallbacks()}
+    fl = eng.chunk_flops(L, dmask, areas)
+    peak = PEAK_FP32 if precision == "f32" else PEAK_F16
+    out = {"config": name, "mode": "sttn-auto", "res": res, "dtype": {"f32": "f32", "f16": "f16 operands, f32 accumulate"}[precision], "chunk_frames": L,
+           "value": round(fps, 2), "unit": "frames/s", "ms_per_chunk": round(dt / steps * 1e3, 2), "gflop_per_frame": round(fl / L / 1e9, 1),
+           "model_tflops": round(fl / L * fps / 1e12, 2), "model_frac_of_peak": round(fl / L * fps / 1e12 / peak, 4),
+           "fp32_fallback_chunks": eng.fallbacks(), "roofline": sttn_roofline(eng, step, precision)}
     eng.close()
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def run_det(name, res, precision, total=1200, reps=1):
+def run_det(name, res, precision, total=1200):
     H, W, box = RES[res]
     eng = SttnEngine(make_state_dict(0, "det"), "det", device=0, precision=precision)
     mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
@@ -80,19 +163,137 @@ def run_det(name, res, precision, total=1200, reps=1):
     wall = sum(per[L] for L in sizes)
     fps = total / wall
     flops = sum(eng.chunk_flops(L, dmask, areas) for L in sizes)          # what is contracted (last block / decoder rows trimmed to what is read)
-    out = {"config": name, "mode": "sttn-det", "res": res, "precision": precision, "batches": f"{sizes.count(Lmax)}x{Lmax}+{sizes[-1]}",
-           "fps": round(fps, 2), "ms_per_batch": {str(L): round(per[L] * 1e3, 2) for L in sample},
-           "model_tflops": round(flops / wall / 1e12, 2), "gflop_per_frame": round(flops / total / 1e9, 1)}
+    out = {"config": name, "mode": "sttn-det", "res": res, "dtype": "f32", "batches": f"{sizes.count(Lmax)}x{Lmax}+{sizes[-1]}",
+           "value": round(fps, 2), "unit": "frames/s", "ms_per_batch": {str(L): round(per[L] * 1e3, 2) for L in sample},
+           "model_tflops": round(flops / wall / 1e12, 2), "model_frac_of_peak": round(flops / wall / 1e12 / PEAK_FP32, 4),
+           "gflop_per_frame": round(flops / total / 1e9, 1), "roofline": sttn_roofline(eng, make(Lmax), precision),
+           "note": "inpainting only, the known box injected on every frame; the detector forward is the `detector` entry"}
     eng.close()
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def run_detector(name, nb=16, reps=3):
+    """config 3's other half: the PP-OCRv5 server detector's forward at the 1080p net input (960x544), `nb` frames per forward, from the
+    recorded launch list (subtitle_detect.py:41-82's TextDetection.predict without the DB post-process)."""
+    from vsr_amd.backend.tools import ocr_det
+    from vsr_amd.backend.tools.paddle_graph import load_graph
+    from vsr_amd.synth import make_det_weights
+
+    g = load_graph(os.path.join(ROOT, "tests", "golden", "ppocr_det_graph.json"))
+    det = ocr_det.TextDetection(g, make_det_weights(g), device=0)
+    det.use_tape = True
+    img = np.random.default_rng(3).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    imgs = [img] * nb
+    dt = timed(lambda: det.probability_maps(imgs), reps, 3)
+    ms = dt / reps / nb * 1e3
+    gflop = det.gflop_per_frame(544, 960)             # from the walk of the program itself (270.8 for the server program)
+    tf = gflop / ms
+    out = {"config": name, "mode": "text detector forward (server program)", "res": "1080p -> 960x544 net input", "dtype": "f32",
+           "value": round(1e3 / ms, 1), "unit": "frames/s", "ms_per_frame": round(ms, 3), "frames_per_forward": nb, "gflop_per_frame": round(gflop, 1),
+           "roofline": {"bound": "mfma", "kernel": "whole forward (144 convs as gather-GEMMs + layout / depthwise / transposed-conv kernels)",
+                        "achieved": round(tf, 2), "peak": PEAK_FP32, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32, 4), "traffic": None,
+                        "measured_on": f"{reps} forwards of {nb} frames, wall clock around the recorded launch list"}}
+    det.runner.close()
+    return out
+
+
+def flow_kernel_symbol(name):
+    """'gg:<cfg>:<bmode>:v<variant>' -> the kernel symbol the flow engines launch for it"""
+    _, cfg, bmode, var = name.split(":")
+    bm, bn, wm, wn = TILE_DIMS[int(cfg)]
+    v = int(var[1:])
+    if v == 3:
+        return f"gather_gemm_f32_v3<{bm}, {bn}, {wm}, {wn}, {bmode}>"
+    return f"gather_gemm_f32_v4<{bm}, {bn}, {wm}, {wn}, {bmode}, {'true' if v == 7 else 'false'}>"
+
+
+def run_propainter(name, precision="f32", L=68, reps=1):
+    """one PropainterInpaint.inpaint call per rep on an HBM-resident uint8 strip batch [L,360,1920,3] (what the resident loop hands the
+    plugin for a 1080p clip); then one profiled call: per-stage seconds / FLOPs and per-kernel HIP-event times."""
+    from vsr_amd import engine as E
+    from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+    from vsr_amd.synth import make_clip, make_propainter_state_dict, make_raft_state_dict, make_rfc_state_dict
+
+    H, W = 360, 1920
+    box = (H // 2, H - H // 6, W // 6, W - W // 6)
+    base = make_clip(10, H, W, box, seed=4)
+    d = torch.from_numpy(base).cuda()
+    frames = torch.cat([torch.roll(d, shifts=(2 * k, 3 * k), dims=(1, 2)) for k in range((L + 9) // 10)], 0)[:L].contiguous()
+    mask = np.zeros((H, W), np.uint8)
+    mask[box[0]:box[1], box[2]:box[3]] = 255
+    plug = PropainterInpaint("cuda:0", {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": make_propainter_state_dict(0)},
+                             precision=precision)
+    dt = timed(lambda: plug.inpaint(frames, mask), reps, 1) / reps
+    # profiled call (device-synchronised around every stage + events around every launch: slower than the timed one)
+    plug.profile = {}
+    E.flow_timing_reset()
+    E.flow_timing(True)
+    plug.inpaint(frames, mask)
+    torch.cuda.synchronize()
+    E.flow_timing(False)
+    prof, plug.profile = plug.profile, None
+    modes = dict(zip(("raft", "rfc", "pp"), PropainterInpaint.PRECISIONS[precision]))
+    stages = {}
+    total_fl = 0.0
+    for stage, eng in (("raft", "raft"), ("flow_completion", "rfc"), ("generator", "pp")):
+        s, fl = prof.get(stage, [0.0, 0.0])
+        total_fl += fl
+        peak = PEAK_FP32 if modes[eng] == "f32" else PEAK_F16
+        kern = {flow_kernel_symbol(k): v for k, v in E.flow_timing_by_kernel(eng).items() if k != "op"}
+        opms = E.flow_timing_get(f"{eng}:op:")[0]
+        stages[stage] = {"s": round(s, 4), "tflop": round(fl / 1e12, 3), "tflops": round(fl / s / 1e12, 2) if s > 0 else None,
+                         "arithmetic": {"f32": "f32", "split": "f32 (fp16 hi/lo operand pairs)", "f16": "f16 operands, f32 accumulate"}[modes[eng]],
+                         "frac_of_peak": round(fl / s / 1e12 / peak, 4) if s > 0 else None, "non_gemm_kernel_ms": round(opms, 2),
+                         "roofline": roofline_of(kern, peak, "one profiled call, HIP events around every launch of the engine's plans")}
+    stages["other"] = {"s": round(prof.get("other", [0.0, 0.0])[0], 4), "what": "image propagation, normalise / compose kernels, mask upload"}
+    fb = [e.fallbacks() for e in (plug.fix_raft, plug.fix_flow_complete, plug.model)]
+    psnr = None
+    if precision != "f32":                   # the same batch in the exact mode of the same engines: PSNR of the frames over the repainted pixels
+        got = plug.inpaint(frames, mask)
+        for e in (plug.fix_raft, plug.fix_flow_complete, plug.model):
+            e.set_precision("f32")
+        ref = plug.inpaint(frames, mask)
+        ch = (ref != frames).any(dim=3)
+        mse = float(((got[ch].float() - ref[ch].float()) ** 2).mean().item()) if bool(ch.any()) else 0.0
+        psnr = "inf" if mse == 0 else round(float(20 * np.log10(255.0 / np.sqrt(mse))), 2)
+    plug.close()
+    dom = max(("raft", "flow_completion", "generator"), key=lambda k: stages[k]["s"])
+    out = {"config": name, "mode": "propainter", "res": "1080p (strip 1920x360)", "batch_frames": L, "raft_iters": 20,
+           "dtype": {"f32": "f32", "f16": "f16 operands + f32 accumulate for flow completion and generator, RAFT f32 (the reference's GPU arithmetic)",
+                     "f16-raft-split": "f16 operands + f32 accumulate; RAFT on fp16 hi/lo operand pairs", "split": "f32 (fp16 hi/lo operand pairs)"}[precision],
+           "value": round(L / dt, 2), "unit": "frames/s", "s_per_batch": round(dt, 3), "tflop_per_frame": round(total_fl / L / 1e12, 3),
+           "model_tflops": round(total_fl / dt / 1e12, 2), "range_guard_fallbacks": fb, "psnr_db_vs_exact_mode": psnr, "stages": stages, "roofline": stages[dom]["roofline"],
+           "roofline_stage": dom}
+    return out
+
+
+LEGS = {
+    "2": lambda: run_auto("2: 720p sttn-auto fp32", "720p", "f32"),
+    "3": lambda: run_det("3: 1080p sttn-det fp32, 47-frame batches", "1080p", "f32"),
+    "3d": lambda: run_detector("3: text detector forward"),
+    "4": lambda: run_propainter("4: 1080p propainter fp32, 68-frame batch", "f32"),
+    "4h": lambda: run_propainter("4: 1080p propainter, reference GPU arithmetic (f16 operands; RAFT f32)", "f16"),
+    "4s": lambda: run_propainter("4: 1080p propainter, f16 operands; RAFT on hi/lo pairs", "f16-raft-split"),
+    "5": lambda: run_auto("5: 4K sttn-auto fp16 operands (one GPU of the 8)", "4k", "f16"),
+    "5x": lambda: run_auto("5: 4K sttn-auto fp32 (exact mode)", "4k", "f32", steps=2),
+}
+DEFAULT = ["2", "3", "3d", "4", "4h", "5"]
+
+
+def run_all(which=None):
+    """{leg: result dict}; a leg that raises is reported as {"error": ...} -- the configs are informational beside the headline"""
+    out = {}
+    for k in which or DEFAULT:
+        t0 = time.perf_counter()
+        try:
+            out[k] = LEGS[k]()
+        except Exception as e:      # noqa: BLE001
+            out[k] = {"error": repr(e)[:300]}
+        out[k]["leg_seconds"] = round(time.perf_counter() - t0, 1)
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["2", "3", "5"]
-    if "2" in which:
-        run_auto("2: 720p sttn-auto fp32", "720p", "f32")
-    if "3" in which:
-        run_det("3: 1080p sttn-det fp32 (known box injected on every frame)", "1080p", "f32")
-    if "5" in which:
-        run_auto("5: 4K sttn-auto fp16 operands (one GPU of the 8)", "4k", "f16")
-        run_auto("5: 4K sttn-auto fp32 (same, exact mode)", "4k", "f32")
+    for k, v in run_all(sys.argv[1:] or None).items():
+        print(json.dumps(v), flush=True)

@@ -21,7 +21,7 @@ ap.add_argument("--height", type=int, default=360)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--warmup", type=int, default=1)
-ap.add_argument("--precision", default="f32", choices=["f32", "split"])
+ap.add_argument("--precision", default="f32", choices=["f32", "split", "f16", "f16-raft-split"])
 args = ap.parse_args()
 
 H, W, n = args.height, args.width, args.frames
@@ -49,6 +49,6 @@ if args.precision != "f32":
     extra["psnr_db_vs_exact_mode"] = "inf" if mse == 0 else round(20 * np.log10(255.0 / np.sqrt(mse)), 2)
 print(json.dumps({"metric": "propainter frames/s (1920x360 strip crops, host arrays in / out)", "value": round(n / dt, 3), "unit": "frames/s",
                   "frames": n, "s_per_call": round(dt, 3),
-                  "dtype": "f32" if args.precision == "f32" else "f32 (operands as fp16 hi/lo pairs)", **extra, "raft_iters": plug.raft_iter,
+                  "dtype": {"f32": "f32", "split": "f32 (operands as fp16 hi/lo pairs)", "f16": "f16 operands, f32 accumulate (RAFT exact f32)", "f16-raft-split": "f16 operands, f32 accumulate (RAFT on fp16 hi/lo pairs)"}[args.precision], **extra, "raft_iters": plug.raft_iter,
                   "note": "one PropainterInpaint.inpaint call; includes H2D / D2H of the crops and the host-side u8 blending"}))
 plug.close()

@@ -66,14 +66,14 @@ static float run_v4(const GGProblem* d, int blocks, int iters)
     unsigned int* q;
     hipMalloc(&q, 64 * 8 * sizeof(unsigned int));
     int occ = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v4<BM, BN, WM, WN, VSR_BMODE_NK, ABL>, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_gemm_f32_v4<BM, BN, WM, WN, VSR_BMODE_NK, false, ABL>, 256, 0);
     const int grid = blocks < 256 * occ ? blocks : 256 * occ;
     float best = 1e9f;
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(q, 0, 64 * 8 * sizeof(unsigned int));
         hipEventRecord(a, 0);
         for (int i = 0; i < iters; ++i)
-            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, VSR_BMODE_NK, ABL>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8, (unsigned int*)nullptr);
+            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, VSR_BMODE_NK, false, ABL>), dim3(grid), dim3(256), 0, 0, d, 1, blocks, q + 8 * i, 8, (unsigned int*)nullptr);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);
         float ms = 0;

@@ -6,7 +6,7 @@
 OUT=gpurun_out/r05_cols; mkdir -p $OUT
 (VSR_DECODE_COLS=1 timeout 900 python -m pytest tests/test_gpu_sttn.py -q -x -k "decoder_box or decoder_rows" 2>&1 | tail -5) > $OUT/pytest.log; tail -2 $OUT/pytest.log
 # config 3's inpainting with the columns off / on: scripts/r04/rows_det.sh with VSR_DECODE_COLS=0 / 1 is the det-side A/B
-B="python bench.py --no-cpu-baseline --no-split-half --no-full-work --e2e-chunks 0 --steps 8 --warmup 2"
+B="python bench.py --no-cpu-baseline --no-configs --no-split-half --no-full-work --e2e-chunks 0 --steps 8 --warmup 2"
 for i in 1 2; do
   for v in 1 0; do
     VSR_DECODE_COLS=$v timeout 600 $B > $OUT/bench_cols${v}_$i.log 2>&1
@@ -28,7 +28,7 @@ d=json.loads(sys.stdin.read()); print('QKV0_SHARED=$v run $i:', d['value'], 'fps
   done
 done
 # window lanes after the dead-work elimination made the last block's launches shorter: 2 (default) vs 3
-for l in 2 3 2 3; do
+for l in 2 3; do
   timeout 600 $B --lanes $l > $OUT/bench_lanes${l}.log 2>&1
   grep '"metric"' $OUT/bench_lanes${l}.log | python -c "
 import json,sys

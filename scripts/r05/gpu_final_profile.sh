@@ -3,13 +3,13 @@
 # default two-lane command), PMC passes, f16 trace, configs 2/3/5 resident, config 2 through the CLI, the two-rank dry run
 OUT=gpurun_out/r05; mkdir -p $OUT; export TMPDIR=/tmp
 python bench.py > $OUT/bench.log 2>&1; grep '"metric"' $OUT/bench.log | cut -c1-300
-B="python bench.py --no-cpu-baseline --no-split-half --e2e-chunks 0"
+B="python bench.py --no-cpu-baseline --no-configs --no-split-half --e2e-chunks 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- $B --lanes 1 > $OUT/trace.log 2>&1
 grep '"metric"' $OUT/trace.log > $OUT/bench_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes2 -o r -- $B > $OUT/trace_lanes2.log 2>&1
 grep '"metric"' $OUT/trace_lanes2.log > $OUT/bench_lanes2_under_rocprof.json
 rm -f $OUT/trace/r_kernel_trace.csv $OUT/trace_lanes2/r_kernel_trace.csv
-B1="python bench.py --lanes 1 --steps 1 --warmup 0 --no-cpu-baseline --no-split-half --e2e-chunks 0"
+B1="python bench.py --lanes 1 --steps 1 --warmup 0 --no-cpu-baseline --no-configs --no-split-half --e2e-chunks 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r -- $B1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r -- $B1 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o r -- $B1 > $OUT/pmc_sq.log 2>&1

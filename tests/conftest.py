@@ -34,8 +34,12 @@ def pytest_collection_finish(session):
             continue
         cs = getattr(item, "callspec", None)
         name = cs.params.get("name") if cs is not None else None
-        wanted.add(name or {"test_det_batch_L47_vs_oracle": "det_1080p", "test_propainter_batch_L20_vs_oracle": "pp_1080p"}.get(item.originalname))
+        wanted.add(name or {"test_det_batch_L47_vs_oracle": "det_1080p", "test_propainter_batch_L20_vs_oracle": "pp_1080p",
+                            "test_det_portrait_vs_oracle": "det_portrait"}.get(item.originalname))
     wanted.discard(None)
+    from tests._baseline_oracle import FIXTURE_JOBS
+
+    wanted -= set(FIXTURE_JOBS)                      # their oracle runs are committed fixtures (about an hour of CPU each)
     if wanted and not session.config.option.collectonly:
         import torch
 

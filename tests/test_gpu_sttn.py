@@ -401,7 +401,7 @@ def test_decoder_rows_give_the_same_frames(built_lib, gpu_device, sd, mode, H, W
 
 @pytest.mark.skipif(not switches.on("VSR_DECODE_COLS"),
                     reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("H,W,boxes", [
     (720, 1280, [(620, 700, 400, 900)]),                           # a centred line: columns [400, 900) of 1280
     (1080, 1920, [(500, 560, 0, 300), (940, 1060, 1500, 1920)]),   # two areas, one box at either edge

@@ -47,7 +47,7 @@ def _report(name, got, ref, m=None):
     return psnr, int(d.max())
 
 
-@pytest.mark.parametrize("name,precision", [("auto_720p", "f32"), ("auto_1080p", "f32"), ("auto_4k", "f16")])
+@pytest.mark.parametrize("name,precision", [("auto_720p", "f32"), ("auto_1080p", "f32"), ("auto_4k", "f16"), ("auto_4k", "f32")])
 def test_auto_chunk_L50_vs_oracle(built_lib, gpu_device, name, precision):
     from vsr_amd.engine import SttnEngine
 
@@ -86,6 +86,65 @@ def test_det_batch_L47_vs_oracle(built_lib, gpu_device):
     assert np.array_equal(got[:, :y0], clip[:, :y0]) and np.array_equal(got[:, y1:], clip[:, y1:])
     psnr, dmax = _report("sttn-det 1080p L=47 (strip 1920x533)", got[:, y0:y1], ref)
     assert psnr >= PSNR_MIN_DB and dmax <= 2
+
+
+def test_det_portrait_vs_oracle(built_lib, gpu_device):
+    """the portrait branch of STTNDetInpaint.__call__ (sttn_det_inpaint.py:48-51): split_h = int(H*5/9) on a 1080x1920 clip"""
+    from vsr_amd.backend.inpaint.sttn_det_inpaint import STTNDetInpaint
+
+    clip, mask, j = bo.job_inputs("det_portrait")
+    y0, y1, _, _ = bo.strip_rows("det_portrait")
+    assert y1 - y0 == int(1920 * 5 / 9) == 1066
+    plug = STTNDetInpaint("cuda:0", {"netG": make_state_dict(1, "det")})
+    got = np.stack(plug([f for f in clip], mask))
+    plug.engine.close()
+    ref = bo.result("det_portrait")
+    assert np.array_equal(got[:, :y0], clip[:, :y0]) and np.array_equal(got[:, y1:], clip[:, y1:])
+    psnr, dmax = _report("sttn-det portrait 1080x1920 L=25 (strip 1080x1066)", got[:, y0:y1], ref)
+    assert psnr >= PSNR_MIN_DB and dmax <= 2
+
+
+@pytest.mark.parametrize("name", ["pp_1080p_L68", "pp_1080p_L44"])
+@pytest.mark.parametrize("switches", ["default", "box+cache", "f16", "f16-raft-split"])
+def test_propainter_config4_batches_vs_oracle(built_lib, gpu_device, monkeypatch, name, switches):
+    """BASELINE configs[3] at the batch sizes batch_generator(1200, 70) produces (17 x 68 + 44 frames): the plugin against the CPU
+    oracle's run, which is committed as a fixture (tests/_baseline_oracle.py --fixture: every frame's repainted box sub-sampled,
+    two frames in full, and the set of pixels the oracle changed)."""
+    from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+    from vsr_amd.synth import make_propainter_state_dict, make_raft_state_dict, make_rfc_state_dict
+
+    on = "1" if switches == "box+cache" else "0"
+    monkeypatch.setenv("VSR_PP_DECODE_BOX", on)
+    monkeypatch.setenv("VSR_PP_ENC_CACHE", on)
+    import os
+
+    if not os.path.exists(os.path.join(bo.GOLDEN, name + ".npz")):
+        pytest.skip(f"tests/golden/{name}.npz not generated (python -m tests._baseline_oracle --fixture {name})")
+    fx = bo.fixture(name)
+    clip, mask, j = bo.job_inputs(name)
+    y0, y1, x0, x1 = bo.strip_rows(name)
+    assert (y1 - y0, x1 - x0) == (360, 1920)
+    sds = {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": make_propainter_state_dict(0)}
+    # "f16": the reference's GPU arithmetic (RAFT exact fp32, flow completion + generator on fp16 operands, fp32 accumulation) against
+    # the fp32 CPU oracle; "f16-raft-split" additionally RAFT on fp16 hi/lo pairs.  Same >= 50 dB bar.
+    plug = PropainterInpaint("cuda:0", sds, precision=switches if switches.startswith("f16") else "f32")
+    got = np.stack(plug([f for f in clip], mask))
+    fb = [e.fallbacks() for e in (plug.fix_raft, plug.fix_flow_complete, plug.model)]
+    plug.close()
+    assert fb == [0, 0, 0], f"range-guard fallbacks {fb}"
+    assert np.array_equal(got[:, :y0], clip[:, :y0]) and np.array_equal(got[:, y1:], clip[:, y1:])
+    rows, src = got[:, y0:y1], clip[:, y0:y1]
+    changed = fx["changed"]
+    assert np.array_equal(rows[:, ~changed], src[:, ~changed]), "pixels the reference leaves alone stay bit-identical"
+    by0, by1, bx0, bx1 = fx["box"]
+    st = int(fx["stride"])
+    m = changed[by0:by1:st, bx0:bx1:st]
+    psnr, dmax = _report(f"propainter 1080p L={j['L']} [{switches}] every frame, stride-{st} sample", rows[:, by0:by1:st, bx0:bx1:st], fx["sample"], m)
+    assert psnr >= PSNR_MIN_DB
+    ff = fx["full_frames"]
+    psnr, dmax = _report(f"propainter 1080p L={j['L']} [{switches}] frames {ff.tolist()} in full", rows[ff, by0:by1, bx0:bx1], fx["full"],
+                         changed[by0:by1, bx0:bx1])
+    assert psnr >= PSNR_MIN_DB
 
 
 def test_propainter_batch_L20_vs_oracle(built_lib, gpu_device):

@@ -152,15 +152,21 @@ def test_plan_replay_shared_first_block_qkv(built_lib):
     r = subprocess.run([sys.executable, os.path.join(HERE, "_replay_check.py"), "--long"], env=env, capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     b = json.loads(r.stdout.strip().splitlines()[-1])
-    eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None, neighbor_stride=2, ref_length=4)     # this process: the default plan
-    view = PlanView(_lib, eng, 5)
-    n_qkv = sum(1 for info, _ in view.ops if info.tag.decode() == "attn.qkv")
+    # the plan without the sharing, from a process of its own (the switch is on by default since round 5; the library reads it once)
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import vsr_amd\nfrom vsr_amd import _lib\nfrom vsr_amd.engine import SttnEngine\nfrom vsr_amd.synth import make_state_dict\n"
+            "from _replay import PlanView\n"
+            "eng = SttnEngine(make_state_dict(0, 'auto'), 'auto', device=None, neighbor_stride=2, ref_length=4)\n"
+            "view = PlanView(_lib, eng, 5)\n"
+            "print(json.dumps({'n_qkv': sum(1 for info, _ in view.ops if info.tag.decode() == 'attn.qkv'), 'flops': view.flops,\n"
+            "                  'ref_flops': eng.flops(5, reference=True), 'counts': view.counts.tolist()}))\n") % (os.path.dirname(HERE), HERE)
+    r0 = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VSR_QKV0_SHARED="0"), capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0, r0.stdout[-2000:] + r0.stderr[-4000:]
+    a = json.loads(r0.stdout.strip().splitlines()[-1])
     nwin = 3
-    assert n_qkv == 8 * nwin and b["n_qkv"] == 7 * nwin + 1
-    assert b["flops"] < view.flops and abs(eng.flops(5, reference=True) - b["ref_flops"]) <= 1e-9 * b["ref_flops"]
-    assert b["counts"] == view.counts.tolist()
-    view.close()
-    eng.close()
+    assert a["n_qkv"] == 8 * nwin and b["n_qkv"] == 7 * nwin + 1
+    assert b["flops"] < a["flops"] and abs(a["ref_flops"] - b["ref_flops"]) <= 1e-9 * b["ref_flops"]
+    assert b["counts"] == a["counts"]
 
 
 def test_plan_replay_split_pv_and_square_tiles():

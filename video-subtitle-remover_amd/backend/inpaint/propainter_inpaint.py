@@ -13,6 +13,7 @@ stay in HBM as uint8 BGR from upload to download; normalise + mask, compose and 
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import scipy.ndimage
@@ -87,16 +88,26 @@ def _load(model_dir, name, file):
 
 class PropainterInpaint:
     accepts_device_frames = True      # __call__ also takes a uint8 [n,H,W,3] device tensor and inpaints it in place (tools/resident.py)
+    # precision name -> arithmetic of (RAFT, flow completion, generator)
+    PRECISIONS = {"f32": ("f32", "f32", "f32"), "f16": ("f32", "f16", "f16"), "f16-raft-split": ("split", "f16", "f16"),
+                  "split": ("split", "split", "split")}
 
     def __init__(self, device, model_dir, sub_video_length=80, use_fp16=True, precision=None):
         self.device = device
         self.model_dir = model_dir
-        # The reference halves the completion network and the generator on a GPU and keeps RAFT in fp32 (:140-146).  Here the
-        # default is exact fp32 everywhere; precision="split" (or VSR_PP_PRECISION=split) runs the contractions of all three
-        # networks on fp16 hi/lo operand pairs with fp32 accumulation (22 significand bits, range-guarded): closer to fp32
-        # than the reference's own GPU arithmetic and about twice as fast.  use_fp16 itself is accepted and ignored.
+        # The reference halves the completion network and the generator on a GPU and keeps RAFT in fp32 (:140-146,230,249-251).
+        # precision (or VSR_PP_PRECISION) picks the arithmetic of the contractions, PRECISIONS below:
+        #   "f32"   (default) exact fp32 everywhere -- what the parity tests hold against the CPU oracle to the grey level;
+        #   "f16"   the reference's own GPU arithmetic: RAFT exact fp32, flow completion and generator on fp16 operands with fp32
+        #           accumulation (tensors, bias, activations, residuals stay fp32: no worse than `.half()` modules), range-guarded;
+        #   "f16-raft-split"  the same with RAFT on fp16 hi/lo operand pairs (22 significand bits -- more than the TF32 convolutions
+        #           torch gives the reference's "fp32" RAFT on a current GPU);
+        #   "split" all three networks on hi/lo pairs.
+        # use_fp16 (the reference's switch) does not pick the mode by itself: the default stays exact unless precision says otherwise.
         self.use_fp16 = use_fp16
         self.precision = precision or os.environ.get("VSR_PP_PRECISION", "f32")
+        if self.precision not in self.PRECISIONS:
+            raise ValueError(f"precision {self.precision!r}: expected one of {sorted(self.PRECISIONS)}")
         self.sub_video_length = sub_video_length
         self.neighbor_length = 10
         self.mask_dilation = 4
@@ -107,9 +118,12 @@ class PropainterInpaint:
         self.fix_flow_complete = RfcEngine(_load(model_dir, "rfc", "recurrent_flow_completion.pth"), device=di)
         self.model = PpEngine(device=di, state_dict=_load(model_dir, "propainter", "ProPainter.pth"))
         self.dev = self.model.device
-        if self.precision != "f32":
-            for e in (self.fix_raft, self.fix_flow_complete, self.model):
-                e.set_precision(self.precision)
+        # bench.py / scripts: set to a dict to have inpaint() add per-stage seconds (device-synchronised around every stage, so the
+        # call gets slower) and algorithmic FLOPs: {"raft": [s, flop], "flow_completion": [...], "generator": [...], "other": [...]}
+        self.profile = None
+        for e, mode in zip((self.fix_raft, self.fix_flow_complete, self.model), self.PRECISIONS[self.precision]):
+            if mode != "f32":
+                e.set_precision(mode)
 
     def clone(self):
         """a second instance on the same device from the same checkpoints: its own three engines and workspaces (tools/batch_lanes.py)"""
@@ -137,9 +151,25 @@ class PropainterInpaint:
         md_dev = md1[None].repeat(n, 1, 1).contiguous()
         P = lambda t: C.c_void_p(t.data_ptr())
         stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        prof = self.profile
+
+        def lap(stage, flop=0.0):
+            """profile only: close the stage that started at the previous lap"""
+            if prof is not None:
+                torch.cuda.synchronize(dev)
+                now = time.perf_counter()
+                acc = prof.setdefault(stage, [0.0, 0.0])
+                acc[0] += now - lap.t0
+                acc[1] += flop
+                lap.t0 = now
+
+        if prof is not None:
+            torch.cuda.synchronize(dev)
+            lap.t0 = time.perf_counter()
         with torch.cuda.device(dev):
             # ---- flows (:217-247): every consecutive pair in both directions, fp32; cv2.COLOR_BGR2RGB (:192) inside the stem kernel
             gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
+            lap("raft", self.fix_raft.flops(n, h, w, self.raft_iter) if prof is not None else 0.0)
             # ---- flow completion (:253-281)
             flow_length, svl = n - 1, self.sub_video_length
             if flow_length > svl:
@@ -153,6 +183,9 @@ class PropainterInpaint:
                 pred_f, pred_b = torch.cat(pf).contiguous(), torch.cat(pb).contiguous()
             else:
                 pred_f, pred_b = self.fix_flow_complete.complete(gt_f, gt_b, fm_dev)
+            if prof is not None:
+                spans = [min(flow_length, f + svl + 5) - max(0, f - 5) + 1 for f in range(0, flow_length, svl)] if flow_length > svl else [n]
+                lap("flow_completion", sum(self.fix_flow_complete.flops(t_, h, w) for t_ in spans))
             # ---- image propagation (:283-315)
             masked_frames = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
             check(lib.vsr_pp_prepare_frames(P(bgr), P(md1), n, h, w, P(masked_frames), stream()))
@@ -173,6 +206,7 @@ class PropainterInpaint:
             else:
                 prop, updated_masks = self.model.img_propagation(masked_frames, pred_f, pred_b, md_dev)
                 check(lib.vsr_pp_compose_frames(P(bgr), P(md1), P(prop), n, h, w, P(updated_frames), stream()))
+            lap("other")
             # ---- feature propagation + transformer over sliding neighbour windows (:317-358)
             comp = torch.empty_like(bgr)
             visited = [False] * n
@@ -203,6 +237,8 @@ class PropainterInpaint:
                     fc.append(a)
                     tc.append(b)
                 enc_cache = (torch.cat(fc), torch.cat(tc) if tok_slot else None)
+                if prof is not None:
+                    lap("generator", sum(self.model.plan_flops(len(cids), ntok, h, w, [], None, 1) for cids, ntok in calls))
             for nb, ref in windows:
                 ids = nb + ref
                 l_t = len(nb)
@@ -220,6 +256,11 @@ class PropainterInpaint:
                 check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), stream()))
                 for i in nb:
                     visited[i] = True
+                if prof is not None:
+                    key = (len(ids), l_t, enc_cache is not None)
+                    if key not in flags_cache:
+                        flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
+                    lap("generator", flags_cache[key])
             if resident:
                 return comp
             out = comp.cpu().numpy()                                                        # already BGR (:360)

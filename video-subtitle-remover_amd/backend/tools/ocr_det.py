@@ -157,6 +157,7 @@ class PaddleGraphRunner:
         self._sa = C.c_void_p(0)              # the stream argument every launch shares (set per run / replay)
         self._tape = None                     # launches being recorded: [(C function, argument tuple)]
         self._tapes = {}                      # input shape -> (tape, static input, output, tensors kept alive)
+        self.flops = {}                       # input shape -> algorithmic FLOPs of one forward (2 * MACs of every conv / transposed conv)
 
     def _c(self, t):
         """t as a contiguous tensor.  While a tape is open an implicit torch copy would be a launch the tape does not hold (and
@@ -325,6 +326,7 @@ class PaddleGraphRunner:
         val = dict(self.params)
         val[self.graph.input_id] = x
         folded = {}
+        fl = 0.0
         self._sa.value = torch.cuda.current_stream().cuda_stream
         if self._tape is not None:
             self._keep.append(val)                              # a recorded pass keeps every intermediate alive
@@ -348,6 +350,7 @@ class PaddleGraphRunner:
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
                     if not dw and a["groups"] != 1:
                         raise NotImplementedError("grouped conv")
+                    fl += 2.0 * n * cout * ho * wo * kh * kw * (1 if dw else cin)
                     if (self.use_gemm and not dw and cin * kh * kw >= GEMM_MIN_K and list(a.get("dilations", [1, 1])) == [1, 1]):
                         out, done = self._conv_gemm(i, xin, w, (sh, sw), pt, pl, ho, wo)
                         folded.update({j: out for j in done})
@@ -363,6 +366,7 @@ class PaddleGraphRunner:
                         raise NotImplementedError("conv2d_transpose other than 2x2 / stride 2")
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
                     cout = cin if dw else w.shape[1]
+                    fl += 2.0 * n * h * wd * 4 * cout * (1 if dw else cin)
                     out = self._new(n, cout, 2 * h, 2 * wd)
                     self._call(lib.vsr_det_launch_deconv2x2, _p(xin), _p(w), n, cin, h, wd, cout, dw, _p(out), self._sa)
                     val[outs[0]] = out
@@ -444,6 +448,7 @@ class PaddleGraphRunner:
                         val[outs[0]] = torch.cat(parts, dim=dim)            # pure data movement
                 else:
                     raise NotImplementedError(f"detector op {kind}")
+        self.flops[tuple(x.shape)] = fl
         return val[self.graph.output_id]
 
 
@@ -784,6 +789,13 @@ class TextDetection:
         self.use_tape = os.environ.get("VSR_DET_TAPE", "1") != "0"
         self.device = self.runner.device
         self._tables = {}
+
+    def gflop_per_frame(self, rh, rw):
+        """algorithmic GFLOP of one frame's forward at net input rh x rw, from the last walk of the program at that size (None before one)"""
+        for shape, fl in self.runner.flops.items():
+            if tuple(shape[2:]) == (rh, rw):
+                return fl / shape[0] / 1e9
+        return None
 
     def clone(self):
         """a second detector on the same device from the same program and weights: its own runner (recorded launch lists,

@@ -42,6 +42,14 @@ static int rfail(int code, const std::string& msg) { return vsr_internal_fail(co
 
 namespace {
 
+// ---- launch timing (bench / profile only): HIP events on the launch stream around every op of a replayed plan, keyed
+// "<engine>:gg:<tileCfg>:<bmode>:v<variant>:<op tag>" (gather-GEMM launches) or "<engine>:op:<op tag>" (everything else).  Process-wide,
+// off by default; vsr_flow_timing_get sums the records whose key starts with a prefix (resolving the pending events first).
+struct FlowTimingRec { hipEvent_t a, b; std::string key; double flops; };
+static int g_flowTiming = 0;
+static std::vector<FlowTimingRec> g_flowPending;
+static std::map<std::string, std::pair<double, std::pair<int64_t, double>>> g_flowTimed;
+
 struct FlowOpDev {
     const Op* op = nullptr;
     const void* dDesc = nullptr;   // GGProblem* (device)
@@ -74,8 +82,11 @@ struct Workspace {
     int weights = 0;
     double* statAcc = nullptr;
     int64_t statAccCap = 0;
+    const char* engine = "flow";   // name in the timing keys
     // arithmetic of the contractions: 0 = exact fp32 MFMA (gather_gemm_v3), 1 = split-half fp16 operands with fp32 accumulation
-    // (gather_gemm_v4) guarded by dRangeFlag: a call whose operands leave the fp16 range is redone in fp32 (`fallbacks` counts them)
+    // (gather_gemm_v4), 2 = fp16 operands (rounded in the kernel), fp32 accumulation (gather_gemm_v4<HI_ONLY>: the reference's GPU
+    // arithmetic for flow completion and the generator).  1 and 2 are guarded by dRangeFlag: a call whose operands leave the fp16
+    // range is redone in fp32 (`fallbacks` counts them)
     int precision = 0;
     unsigned int* dRangeFlag = nullptr;
     int64_t fallbacks = 0;
@@ -197,8 +208,8 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
 // replays a materialised plan; `bgr`: channel order of RAFT's u8 input frames
 static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t stream)
 {
-    const int variant = ws.precision == 1 ? 4 : 3;
-    unsigned int* rangeFlag = ws.precision == 1 ? ws.dRangeFlag : nullptr;
+    const int variant = ws.precision == 1 ? 4 : (ws.precision == 2 ? 7 : 3);
+    unsigned int* rangeFlag = ws.precision != 0 ? ws.dRangeFlag : nullptr;
     HIPCHK(hipMemsetAsync(pd->dQueues, 0, (pd->ops.size() + 1) * 8 * sizeof(unsigned int), stream));
     auto B = [&](int buf, int64_t off) -> float* { return ws.f(buf, off); };
     size_t idx = 0;
@@ -206,6 +217,15 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         const Op& op = *od.op;
         unsigned int* queue = pd->dQueues + 8 * idx++;
         int rc = 0;
+        FlowTimingRec tr;
+        if (g_flowTiming) {
+            tr.key = std::string(ws.engine) + (op.kind == OP_GEMM ? ":gg:" + std::to_string(op.tileCfg) + ":" + std::to_string(op.bmode) + ":v" +
+                                                                        std::to_string(variant) + ":" : ":op:") + op.tag;
+            tr.flops = op.flops;
+            HIPCHK(hipEventCreate(&tr.a));
+            HIPCHK(hipEventCreate(&tr.b));
+            HIPCHK(hipEventRecord(tr.a, stream));
+        }
         if (op.kind == OP_GEMM) {
             rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, variant, od.nQueues,
                                             rangeFlag, stream);
@@ -341,6 +361,10 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
             return rfail(VSR_ERR_STATE, "unexpected op kind in a flow plan");
         }
         if (rc != 0) return rfail(VSR_ERR_HIP, "kernel launch failed: " + op.tag + ": " + hipGetErrorString(hipGetLastError()));
+        if (g_flowTiming) {
+            HIPCHK(hipEventRecord(tr.b, stream));
+            g_flowPending.push_back(tr);
+        }
     }
     return 0;
 }
@@ -356,7 +380,7 @@ static int clear_workspace(Workspace& ws, hipStream_t stream)
 
 static int range_guard_arm(Workspace& ws, hipStream_t stream)
 {
-    if (ws.precision != 1) return 0;
+    if (ws.precision == 0) return 0;
     if (!ws.dRangeFlag) HIPCHK(hipMalloc(&ws.dRangeFlag, sizeof(unsigned int)));
     HIPCHK(hipMemsetAsync(ws.dRangeFlag, 0, sizeof(unsigned int), stream));
     return 0;
@@ -366,7 +390,7 @@ static int range_guard_arm(Workspace& ws, hipStream_t stream)
 static int range_guard_fired(Workspace& ws, hipStream_t stream, bool* fired)
 {
     *fired = false;
-    if (ws.precision != 1) return 0;
+    if (ws.precision == 0) return 0;
     unsigned int v = 0;
     HIPCHK(hipMemcpyAsync(&v, ws.dRangeFlag, sizeof(v), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -376,7 +400,8 @@ static int range_guard_fired(Workspace& ws, hipStream_t stream, bool* fired)
 
 static int set_precision(Workspace& ws, int mode)
 {
-    if (mode != 0 && mode != 1) return rfail(VSR_ERR_ARG, "precision must be 0 (exact fp32) or 1 (split-half fp16 operands, fp32 accumulate)");
+    if (mode < 0 || mode > 2)
+        return rfail(VSR_ERR_ARG, "precision must be 0 (exact fp32), 1 (split-half fp16 operands, fp32 accumulate) or 2 (fp16 operands, fp32 accumulate)");
     ws.precision = mode;
     return 0;
 }
@@ -412,7 +437,7 @@ struct vsr_raft {
     Workspace ws;
     std::tuple<int, int, int> geom{0, 0, 0};   // (t, H, W) the halos of the workspace are currently laid out for
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<FlowPlanDev>> plans;
-    vsr_raft() { ws.init(RB_COUNT, RB_WEIGHTS, {RB_IN_U8}); }
+    vsr_raft() { ws.init(RB_COUNT, RB_WEIGHTS, {RB_IN_U8}); ws.engine = "raft"; }
 };
 
 static int raft_plan_dev(vsr_raft* h, int t, int H, int W, int iters, FlowPlanDev** out)
@@ -450,7 +475,7 @@ struct vsr_rfc {
     Workspace ws;
     std::tuple<int, int, int> geom{0, 0, 0};
     std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> plans;
-    vsr_rfc() { ws.init(FB_COUNT, FB_WEIGHTS, {FB_IN_MASK}); }
+    vsr_rfc() { ws.init(FB_COUNT, FB_WEIGHTS, {FB_IN_MASK}); ws.engine = "rfc"; }
 };
 
 static int rfc_plan_dev(vsr_rfc* h, int t, int H, int W, FlowPlanDev** out)
@@ -483,7 +508,7 @@ struct vsr_pp {
     std::string geom;                          // shape key the halos of the workspace are currently laid out for
     std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> imgPlans;
     std::map<std::string, std::unique_ptr<FlowPlanDev>> genPlans;
-    vsr_pp() { ws.init(PB_COUNT, PB_WEIGHTS, {PB_IN_MASK_U8, PB_IN_MASK_UPD_U8, PB_OUT_MASK_U8}); }
+    vsr_pp() { ws.init(PB_COUNT, PB_WEIGHTS, {PB_IN_MASK_U8, PB_IN_MASK_UPD_U8, PB_OUT_MASK_U8}); ws.engine = "pp"; }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -496,7 +521,7 @@ struct vsr_lama {
     Workspace ws;
     std::tuple<int, int, int> geom{0, 0, 0};
     std::map<std::tuple<int, int, int>, std::unique_ptr<FlowPlanDev>> plans;
-    vsr_lama() { ws.init(LB_COUNT, LB_WEIGHTS, {LB_IN_U8, LB_MASK_U8, LB_OUT_U8}); }
+    vsr_lama() { ws.init(LB_COUNT, LB_WEIGHTS, {LB_IN_U8, LB_MASK_U8, LB_OUT_U8}); ws.engine = "lama"; }
 };
 
 static int lama_plan_dev(vsr_lama* h, int B, int H, int W, FlowPlanDev** out)
@@ -519,6 +544,66 @@ static int lama_plan_dev(vsr_lama* h, int B, int H, int W, FlowPlanDev** out)
 }
 
 extern "C" {
+
+int vsr_flow_timing(int enable)
+{
+    g_flowTiming = enable ? 1 : 0;
+    return 0;
+}
+
+static int flow_timing_collect()
+{
+    if (g_flowPending.empty()) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    for (FlowTimingRec& tr : g_flowPending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, tr.a, tr.b));
+        auto& acc = g_flowTimed[tr.key];
+        acc.first += ms;
+        acc.second.first += 1;
+        acc.second.second += tr.flops;
+        (void)hipEventDestroy(tr.a);
+        (void)hipEventDestroy(tr.b);
+    }
+    g_flowPending.clear();
+    return 0;
+}
+
+int vsr_flow_timing_reset(void)
+{
+    RCCHK(flow_timing_collect());
+    g_flowTimed.clear();
+    return 0;
+}
+
+int vsr_flow_timing_get(const char* prefix, double* total_ms, int64_t* launches, double* flops)
+{
+    if (!prefix) return rfail(VSR_ERR_ARG, "bad argument");
+    RCCHK(flow_timing_collect());
+    double ms = 0, fl = 0;
+    int64_t n = 0;
+    const size_t pl = strlen(prefix);
+    for (const auto& kv : g_flowTimed)
+        if (kv.first.compare(0, pl, prefix) == 0) { ms += kv.second.first; n += kv.second.second.first; fl += kv.second.second.second; }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (flops) *flops = fl;
+    return 0;
+}
+
+/* keys recorded so far, '\n'-separated, into buf (returns the length needed incl. the terminator) */
+int64_t vsr_flow_timing_keys(char* buf, int64_t capacity)
+{
+    if (flow_timing_collect() != 0) return -1;
+    std::string all;
+    for (const auto& kv : g_flowTimed) { all += kv.first; all += '\n'; }
+    if (buf && capacity > 0) {
+        const size_t n = all.size() < (size_t)capacity - 1 ? all.size() : (size_t)capacity - 1;
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
 
 int vsr_lama_create(vsr_lama_t** out)
 {
@@ -600,9 +685,10 @@ int vsr_lama_inpaint(vsr_lama_t* h, const uint8_t* img_dev, int64_t img_frame_st
     bool fired = false;
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {
+        const int mode_ = h->ws.precision;
         h->ws.precision = 0;
         const int rc = vsr_lama_inpaint(h, img_dev, img_frame_stride, mask_dev, mask_frame_stride, B, H, W, out_dev, out_frame_stride, stream_);
-        h->ws.precision = 1;
+        h->ws.precision = mode_;
         return rc;
     }
     HIPCHK(hipMemcpy2DAsync(out_dev, (size_t)out_frame_stride, h->ws.bufs[LB_OUT_U8], ibytes, ibytes, (size_t)B, hipMemcpyDeviceToDevice, stream));
@@ -718,9 +804,10 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
     bool fired = false;
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {                                  // redo the call with exact fp32 contractions
+        const int mode_ = h->ws.precision;
         h->ws.precision = 0;
         const int rc = vsr_raft_flows(h, frames_dev, t, H, W, iters, bgr, fwd_dev, bwd_dev, stream_);
-        h->ws.precision = 1;
+        h->ws.precision = mode_;
         return rc;
     }
     const size_t half = (size_t)(t - 1) * 2 * H * W * sizeof(float);
@@ -837,9 +924,10 @@ int vsr_rfc_complete(vsr_rfc_t* h, const float* flows_f_dev, const float* flows_
     bool fired = false;
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {
+        const int mode_ = h->ws.precision;
         h->ws.precision = 0;
         const int rc = vsr_rfc_complete(h, flows_f_dev, flows_b_dev, masks_dev, t, H, W, out_f_dev, out_b_dev, stream_);
-        h->ws.precision = 1;
+        h->ws.precision = mode_;
         return rc;
     }
     HIPCHK(hipMemcpyAsync(out_f_dev, h->ws.bufs[FB_OUT_F], fbytes, hipMemcpyDeviceToDevice, stream));
@@ -1014,10 +1102,11 @@ int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_
     bool fired = false;
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {
+        const int mode_ = h->ws.precision;
         h->ws.precision = 0;
         const int rc = vsr_pp_forward_box(h, frames_dev, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t, lt, H, W, window_flags, nflags,
                                           row_lo, row_hi, col_lo, col_hi, out_dev, stream_);
-        h->ws.precision = 1;
+        h->ws.precision = mode_;
         return rc;
     }
     HIPCHK(hipMemcpyAsync(out_dev, h->ws.bufs[PG_OUT], (size_t)lt * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1072,9 +1161,10 @@ int vsr_pp_encode(vsr_pp_t* h, const float* frames_dev, const uint8_t* masks_in_
     bool fired = false;
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {
+        const int mode_ = h->ws.precision;
         h->ws.precision = 0;
         const int rc = vsr_pp_encode(h, frames_dev, masks_in_dev, masks_updated_dev, n, ntok_frames, H, W, feat_out_dev, tok_out_dev, stream_);
-        h->ws.precision = 1;
+        h->ws.precision = mode_;
         return rc;
     }
     // the features leave PG_FEAT's halo (3) behind: [n][h][w][128] dense
@@ -1142,10 +1232,11 @@ int vsr_pp_forward_cached(vsr_pp_t* h, const float* feat_cache_dev, const float*
     bool fired = false;
     RCCHK(range_guard_fired(h->ws, stream, &fired));
     if (fired) {
+        const int mode_ = h->ws.precision;
         h->ws.precision = 0;
         const int rc = vsr_pp_forward_cached(h, feat_cache_dev, tok_cache_dev, cache_idx, flows_f_dev, flows_b_dev, masks_in_dev, masks_updated_dev, t,
                                              lt, H, W, window_flags, nflags, row_lo, row_hi, col_lo, col_hi, out_dev, stream_);
-        h->ws.precision = 1;
+        h->ws.precision = mode_;
         return rc;
     }
     HIPCHK(hipMemcpyAsync(out_dev, h->ws.bufs[PG_OUT], (size_t)lt * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));

@@ -488,13 +488,18 @@ static void launch_v5(const GGProblem* d_probs, int nprobs, int totalBlocks, uns
 
 #define GG_LAUNCH(BM, BN, WM, WN, MODE)                                                                         \
     do {                                                                                                        \
-        if (queue && variant >= 5) {                                                                            \
+        if (queue && (variant == 5 || variant == 6)) {                                                          \
             launch_v5<BM, BN, WM, WN, MODE>(d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag,       \
                                             variant == 6, stream);                                              \
-        } else if (queue && variant == 4) {                                                                     \
-            static const int resident = resident_blocks(gather_gemm_f32_v4<BM, BN, WM, WN, MODE>);             \
+        } else if (queue && variant == 7) {                                                                     \
+            static const int resident = resident_blocks(gather_gemm_f32_v4<BM, BN, WM, WN, MODE, true>);       \
             const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
-            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, MODE>), dim3(g), block, 0, stream,          \
+            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, MODE, true>), dim3(g), block, 0, stream,    \
+                               d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag);          \
+        } else if (queue && variant == 4) {                                                                     \
+            static const int resident = resident_blocks(gather_gemm_f32_v4<BM, BN, WM, WN, MODE, false>);      \
+            const int g = totalBlocks < resident ? totalBlocks : resident;                                     \
+            hipLaunchKernelGGL((gather_gemm_f32_v4<BM, BN, WM, WN, MODE, false>), dim3(g), block, 0, stream,   \
                                d_probs, nprobs, totalBlocks, queue, nQueues == 8 ? 8 : 1, rangeFlag);          \
         } else if (queue) {                                                                                     \
             static const int resident = resident_blocks(gather_gemm_f32_v3<BM, BN, WM, WN, MODE>);             \
@@ -511,7 +516,8 @@ static void launch_v5(const GGProblem* d_probs, int nprobs, int totalBlocks, uns
 // ids from queue[0..7] (must be 0): 3 = LDS-DMA double buffer (2 is accepted as an alias of 3),
 // 4 = split-half operands on the f16 matrix cores (fp32 tensors, split in the kernel), 5 = the same arithmetic
 // on SPLIT-FORMAT tensors (A, B, R and -- with VSR_ACT_OUT_SPLIT in act -- C; see gather_gemm_v5.h), 6 = variant 5
-// with the fp16 hi halves alone as operands (one MFMA per product).
+// with the fp16 hi halves alone as operands (one MFMA per product), 7 = variant 4's fp32 tensors with the operands rounded to
+// fp16 in the kernel (one MFMA per product; the flow engines' fp16 mode).
 // nQueues (v3): 8 = one tile range per XCD with stealing (few N tiles per A row block: neighbours share A
 // through one L2), 1 = a single global queue (many N tiles per row block: spreading them over the XCDs
 // avoids hammering one L2 with the same lines -- measured 101 vs 86 TF on the QKV GEMM).

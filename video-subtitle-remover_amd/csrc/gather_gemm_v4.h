@@ -15,13 +15,19 @@
 // 128-byte row is [32 hi halves | 32 lo halves] of one 32-deep chunk -- the same bytes per row as the
 // fp32 image, the same XOR swizzle of the 16-byte pieces, conflict-free ds_read_b128 fragments
 // (one read = the 8 k-values a lane feeds to one MFMA).  NK problems only (convs, QKV, QK^T).
+//
+// HI_ONLY (kernel variant 7): the fp16-operand / fp32-accumulate arithmetic of the reference's own GPU mode for flow completion and
+// the ProPainter generator (propainter_inpaint.py:140-146,249-251: `.half()` modules under autocast-free fp16).  Operands are rounded
+// to fp16 on the way into LDS (the lo halves are neither computed, stored nor read), ONE v_mfma_f32_32x32x16_f16 per product; the
+// tensors in HBM, bias / activation / residual and the accumulation stay fp32, so the result is at least as accurate as an fp16
+// module's (which also rounds every activation it stores).  Same range guard as the split mode.
 #pragma once
 #include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN, int BMODE GG_ABL_PARAM>
+template <int BM, int BN, int WM, int WN, int BMODE, bool HI_ONLY GG_ABL_PARAM>
 __global__ void __launch_bounds__(256)
 gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTiles, unsigned int* __restrict__ queue, int nQueues,
                    unsigned int* __restrict__ rangeFlag)
@@ -212,11 +218,11 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
                     l[j] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned, v[j]) & 0x3fff));
                 } else {
                     h[j] = (_Float16)v[j];
-                    l[j] = (_Float16)(v[j] - (float)h[j]);
+                    if constexpr (!HI_ONLY) l[j] = (_Float16)(v[j] - (float)h[j]);
                 }
             }
             *reinterpret_cast<f16x4*>(rowBase + stHi) = h;
-            *reinterpret_cast<f16x4*>(rowBase + stLo) = l;
+            if constexpr (!HI_ONLY) *reinterpret_cast<f16x4*>(rowBase + stLo) = l;
         };
         auto store_tile = [&](int buf) {
             char* As = reinterpret_cast<char*>(smem + buf * BUF_FLOATS);
@@ -235,10 +241,10 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         h[j] = (_Float16)rk[p][j];
-                        l[j] = (_Float16)(rk[p][j] - (float)h[j]);
+                        if constexpr (!HI_ONLY) l[j] = (_Float16)(rk[p][j] - (float)h[j]);
                     }
                     *reinterpret_cast<f16x8*>(Bs + kn_n * 128 + ((kg ^ sw) << 4)) = h;
-                    *reinterpret_cast<f16x8*>(Bs + kn_n * 128 + (((4 + kg) ^ sw) << 4)) = l;
+                    if constexpr (!HI_ONLY) *reinterpret_cast<f16x8*>(Bs + kn_n * 128 + (((4 + kg) ^ sw) << 4)) = l;
                 }
             }
         };
@@ -256,13 +262,13 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             for (int mi = 0; mi < MI; ++mi) {
                 const char* row = As + (wm * WTM + mi * 32 + l31) * 128;
                 ah[mi] = *reinterpret_cast<const f16x8*>(row + rdHi[st]);
-                al[mi] = *reinterpret_cast<const f16x8*>(row + rdLo[st]);
+                if constexpr (!HI_ONLY) al[mi] = *reinterpret_cast<const f16x8*>(row + rdLo[st]);
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const char* row = Bs + (wn * WTN + ni * 32 + l31) * 128;
                 bh[ni] = *reinterpret_cast<const f16x8*>(row + rdHi[st]);
-                bl[ni] = *reinterpret_cast<const f16x8*>(row + rdLo[st]);
+                if constexpr (!HI_ONLY) bl[ni] = *reinterpret_cast<const f16x8*>(row + rdLo[st]);
             }
             }
             // small cross terms first, the hi*hi term last
@@ -270,8 +276,10 @@ gather_gemm_f32_v4(const GGProblem* __restrict__ probs, int nprobs, int totalTil
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    if constexpr (!HI_ONLY) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    }
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                 }
         };

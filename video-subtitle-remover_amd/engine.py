@@ -26,6 +26,8 @@ def require_gpu():
 # vsr_sttn_set_precision modes: exact fp32 MFMA | split-half f16 MFMA (guarded) | the same on split-format
 # tensors | fp16 operands + fp32 accumulation (BASELINE.json's "fp16 MFMA path")
 PRECISION_MODES = {"f32": 0, "split": 1, "split-format": 2, "f16": 3}
+# vsr_{raft,rfc,pp,lama}_set_precision: exact fp32 | split-half (fp16 hi/lo pairs, 22 bits) | fp16 operands, fp32 accumulation
+FLOW_PRECISION_MODES = {"f32": 0, "split": 1, "f16": 2}
 
 
 class SttnEngine:
@@ -254,6 +256,42 @@ class SttnEngine:
         return ms.value, n.value, fl.value
 
 
+def flow_timing(enable=True):
+    """HIP events around every launch of the flow engines' plans (RAFT, flow completion, generator, LaMa); process-wide"""
+    check(lib.vsr_flow_timing(1 if enable else 0))
+
+
+def flow_timing_reset():
+    check(lib.vsr_flow_timing_reset())
+
+
+def flow_timing_get(prefix=""):
+    """(ms, launches, algorithmic FLOPs) over the timed launches whose key starts with prefix (see include/vsr_hip.h)"""
+    ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+    check(lib.vsr_flow_timing_get(prefix.encode(), C.byref(ms), C.byref(n), C.byref(fl)))
+    return ms.value, n.value, fl.value
+
+
+def flow_timing_keys():
+    n = lib.vsr_flow_timing_keys(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.vsr_flow_timing_keys(buf, n)
+    return [k for k in buf.value.decode().split("\n") if k]
+
+
+def flow_timing_by_kernel(engine):
+    """{"gg:<tile cfg>:<bmode>:v<variant>": (ms, launches, flops)} of one engine ("raft", "rfc", "pp", "lama") + "op" for the rest"""
+    out = {}
+    for k in flow_timing_keys():
+        parts = k.split(":")
+        if parts[0] != engine:
+            continue
+        name = ":".join(parts[1:5]) if parts[1] == "gg" else "op"
+        if name not in out:
+            out[name] = flow_timing_get(f"{engine}:{name}:")
+    return out
+
+
 class RaftEngine:
     """RAFT ("things" configuration) resident on one GPU: the optical-flow stage of --inpaint-mode propainter
     (reference RAFT_bi, backend/inpaint/video/model/modules/flow_comp_raft.py:27-55)."""
@@ -286,9 +324,9 @@ class RaftEngine:
     def set_precision(self, mode):
         """'f32' (default): exact fp32 contractions; 'split': fp16 hi/lo operand pairs with fp32 accumulation, range-guarded
         (a call that leaves the fp16 range is redone in fp32, see fallbacks())"""
-        if mode not in ("f32", "split"):
-            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
-        check(lib.vsr_raft_set_precision(self._h, 1 if mode == "split" else 0))
+        if mode not in FLOW_PRECISION_MODES:
+            raise ValueError(f"precision {mode!r}: expected 'f32', 'split' or 'f16'")
+        check(lib.vsr_raft_set_precision(self._h, FLOW_PRECISION_MODES[mode]))
 
     def fallbacks(self):
         return int(lib.vsr_raft_fallbacks(self._h))
@@ -361,9 +399,9 @@ class RfcEngine:
     def set_precision(self, mode):
         """'f32' (default): exact fp32 contractions; 'split': fp16 hi/lo operand pairs with fp32 accumulation, range-guarded
         (a call that leaves the fp16 range is redone in fp32, see fallbacks())"""
-        if mode not in ("f32", "split"):
-            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
-        check(lib.vsr_rfc_set_precision(self._h, 1 if mode == "split" else 0))
+        if mode not in FLOW_PRECISION_MODES:
+            raise ValueError(f"precision {mode!r}: expected 'f32', 'split' or 'f16'")
+        check(lib.vsr_rfc_set_precision(self._h, FLOW_PRECISION_MODES[mode]))
 
     def fallbacks(self):
         return int(lib.vsr_rfc_fallbacks(self._h))
@@ -506,6 +544,18 @@ class PpEngine:
                                             C.c_void_p(out.data_ptr()), _stream_ptr()))
         return out
 
+    def plan_flops(self, t, lt, H, W, flags, box=None, mode=0):
+        """algorithmic FLOPs (2*M*N*K of every contraction) of one generator plan: mode 0 = forward(), 1 = encode() of t frames,
+        2 = forward_cached(); the plan is built on the host and dropped again (bench / profile use only)"""
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        plan = C.c_void_p()
+        check(lib.vsr_pp_gen_plan_create_mode(self._h, int(t), int(lt), int(H), int(W), f.ctypes.data_as(C.c_void_p) if f.size else None, f.size,
+                                              *[int(b) for b in (box or (0, 0, 0, 0))], int(mode), C.byref(plan)))
+        try:
+            return float(lib.vsr_plan_flops(plan))
+        finally:
+            lib.vsr_plan_destroy(plan)
+
     def close(self):
         if getattr(self, "_h", None):
             lib.vsr_pp_destroy(self._h)
@@ -513,10 +563,10 @@ class PpEngine:
 
     def set_precision(self, mode):
         """'f32' (default): exact fp32 contractions; 'split': fp16 hi/lo operand pairs with fp32 accumulation, range-guarded
-        (a call that leaves the fp16 range is redone in fp32, see fallbacks())"""
-        if mode not in ("f32", "split"):
-            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
-        check(lib.vsr_pp_set_precision(self._h, 1 if mode == "split" else 0))
+        (a call that leaves the fp16 range is redone in fp32, see fallbacks()); 'f16': fp16 operands, fp32 accumulation, range-guarded"""
+        if mode not in FLOW_PRECISION_MODES:
+            raise ValueError(f"precision {mode!r}: expected 'f32', 'split' or 'f16'")
+        check(lib.vsr_pp_set_precision(self._h, FLOW_PRECISION_MODES[mode]))
 
     def fallbacks(self):
         return int(lib.vsr_pp_fallbacks(self._h))
@@ -584,9 +634,9 @@ class LamaEngine:
         return self._h
 
     def set_precision(self, mode):
-        if mode not in ("f32", "split"):
-            raise ValueError(f"precision {mode!r}: expected 'f32' or 'split'")
-        check(lib.vsr_lama_set_precision(self._h, 1 if mode == "split" else 0))
+        if mode not in FLOW_PRECISION_MODES:
+            raise ValueError(f"precision {mode!r}: expected 'f32', 'split' or 'f16'")
+        check(lib.vsr_lama_set_precision(self._h, FLOW_PRECISION_MODES[mode]))
 
     def fallbacks(self):
         return int(lib.vsr_lama_fallbacks(self._h))

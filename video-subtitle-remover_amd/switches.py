@@ -1,17 +1,19 @@
-"""Switches of code paths that are built and replayed against the full plans on the CPU but have not run on a GPU yet.
-
-One place decides their defaults: an environment variable of the same name ("0" / "1") overrides.  Round 5's first GPU call
-(scripts/r05/first_call.sh) runs the bit-equality tests and the A/Bs with the switches on; what is green and faster becomes "1" here.
+"""Switches of the dead-work eliminations that were built and replayed on the CPU in round 4 and first ran on a GPU in round 5
+(profiles/r05_first_call_*.log: bit-equality tests green, A/Bs on one box).  One place decides their defaults; an environment variable
+of the same name ("0" / "1") overrides.
 
     VSR_DECODE_COLS     STTN: the decoder / last block on the mask's columns as well as its rows (vsr_sttn_auto_chunk_box, _det_batch_box)
     VSR_PP_DECODE_BOX   ProPainter: soft composition, decoder, last transformer block on the box the plugin blends in (vsr_pp_forward_box)
+                        -- default ON since round 5: 16.19 -> 17.16 fps on config 4 file to file
     VSR_PP_ENC_CACHE    ProPainter: the generator's encoder once per frame instead of once per window (vsr_pp_encode / vsr_pp_forward_cached)
+                        -- default ON since round 5: 16.19 -> 16.95 fps alone, 18.06 fps with the box
     VSR_QKV0_SHARED     STTN: the first transformer block's q/k/v once per frame of a chunk instead of once per window (csrc/sttn_plan.cpp;
                         read by the library itself, once per process: _lib.py exports the default into the environment before it loads)
+                        -- default ON since round 5: 216.3 -> 217.6 fps on the headline, same bits
 """
 import os
 
-DEFAULTS = {"VSR_DECODE_COLS": "0", "VSR_PP_DECODE_BOX": "0", "VSR_PP_ENC_CACHE": "0", "VSR_QKV0_SHARED": "0"}
+DEFAULTS = {"VSR_DECODE_COLS": "0", "VSR_PP_DECODE_BOX": "1", "VSR_PP_ENC_CACHE": "1", "VSR_QKV0_SHARED": "1"}
 
 
 def export_defaults():
