@@ -140,6 +140,9 @@ int vsr_sttn_det_batch_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, in
  * lo halves left out of the contractions -- one v_mfma_f32_32x32x16_f16 per product, 11-bit operands; bias,
  * activation, residual adds, softmax and the decoder output stay fp32-accurate.  Same guard and fallback.
  * Environment default: VSR_PRECISION=split (mode 1) / VSR_PRECISION=2 / VSR_PRECISION=3. */
+/* how THIS library instance reads one of its process-wide switches (read once, at first use): "VSR_DECODE_ROWS", "VSR_DECODE_COLS",
+ * "VSR_QKV0_SHARED", "VSR_TRIM_LAST_BLOCK" -> 0 / 1, anything else -> -1.  The Python side (vsr_amd/switches.py) asserts that both agree. */
+int vsr_switch_state(const char* name);
 int vsr_sttn_set_precision(vsr_sttn_t* h, int mode);
 int64_t vsr_sttn_fallbacks(const vsr_sttn_t* h);
 /* Streams a chunk's sliding windows are issued on (1 .. 4; default 2, environment VSR_STTN_LANES).  The windows of

@@ -124,11 +124,14 @@ def test_resident_chunk_loop_writes_the_same_file(built_lib, gpu_device, tmp_pat
         from vsr_amd.backend.tools.pinned import PinnedPool
 
         # (the "-late-pins" passes hold the page-locking thread back, so that the first transfers of the loop take the pageable path)
+        # ("by-offset": the per-rank file access of tools/rank_io.py, forced for this single process: pread / pwrite of the records)
         for mode, color, resident in (("host", "host", "0"), ("device-frames", "device", "0"), ("resident", "device", "1"),
-                                      ("device-frames-late-pins", "device", "0"), ("resident-late-pins", "device", "1")):
+                                      ("device-frames-late-pins", "device", "0"), ("resident-late-pins", "device", "1"),
+                                      ("by-offset", "device", "1"), ("by-offset-late-pins", "device", "1")):
             monkeypatch.setattr(PinnedPool, "test_delay", 0.25 if mode.endswith("late-pins") else 0.0)
             monkeypatch.setenv("VSR_IO_COLOR", color)
             monkeypatch.setenv("VSR_IO_RESIDENT", resident)
+            monkeypatch.setenv("VSR_IO_PER_RANK", "1" if mode.startswith("by-offset") else "0")
             sr = SubtitleRemover(src, model_path={"netG": synth.make_state_dict(0, "auto")})
             sr.sub_areas = [box]
             if ab:
@@ -145,6 +148,7 @@ def test_resident_chunk_loop_writes_the_same_file(built_lib, gpu_device, tmp_pat
             getattr(config, k).value = v
         config.inpaintMode.value = old_mode
     assert outs["host"] == outs["device-frames"] == outs["resident"] == outs["device-frames-late-pins"] == outs["resident-late-pins"]
+    assert outs["by-offset"] == outs["host"] and outs["by-offset-late-pins"] == outs["host"]
     monkeypatch.setenv("VSR_IO_COLOR", "host")
     got, want = _read_all(str(tmp_path / "out_resident.y4m")), _read_all(src)
     assert got.shape == want.shape

@@ -213,6 +213,7 @@ SIGNATURES = {
     "vsr_plan_op_softmax": (_I, [_P, _I, _I, C.POINTER(VsrSoftmaxInfo)]),
     "vsr_plan_counts": (_I, [_P, _P]),
     "vsr_plan_flops": (_D, [_P]),
+    "vsr_switch_state": (_I, [C.c_char_p]),
     "vsr_flow_timing": (_I, [_I]),
     "vsr_flow_timing_reset": (_I, []),
     "vsr_flow_timing_get": (_I, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -153,15 +153,16 @@ class PropainterInpaint:
         stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
         prof = self.profile
 
-        def lap(stage, flop=0.0):
-            """profile only: close the stage that started at the previous lap"""
+        def lap(stage, flop=None):
+            """profile only: close the stage that started at the previous lap.  flop: a callable, evaluated AFTER the clock was read and
+            outside every stage (the FLOP counters build whole plans on the host: 0.3-0.7 s for a 68-frame batch)"""
             if prof is not None:
                 torch.cuda.synchronize(dev)
-                now = time.perf_counter()
                 acc = prof.setdefault(stage, [0.0, 0.0])
-                acc[0] += now - lap.t0
-                acc[1] += flop
-                lap.t0 = now
+                acc[0] += time.perf_counter() - lap.t0
+                if flop is not None:
+                    acc[1] += flop()
+                lap.t0 = time.perf_counter()
 
         if prof is not None:
             torch.cuda.synchronize(dev)
@@ -169,7 +170,7 @@ class PropainterInpaint:
         with torch.cuda.device(dev):
             # ---- flows (:217-247): every consecutive pair in both directions, fp32; cv2.COLOR_BGR2RGB (:192) inside the stem kernel
             gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
-            lap("raft", self.fix_raft.flops(n, h, w, self.raft_iter) if prof is not None else 0.0)
+            lap("raft", lambda: self.fix_raft.flops(n, h, w, self.raft_iter))
             # ---- flow completion (:253-281)
             flow_length, svl = n - 1, self.sub_video_length
             if flow_length > svl:
@@ -185,7 +186,7 @@ class PropainterInpaint:
                 pred_f, pred_b = self.fix_flow_complete.complete(gt_f, gt_b, fm_dev)
             if prof is not None:
                 spans = [min(flow_length, f + svl + 5) - max(0, f - 5) + 1 for f in range(0, flow_length, svl)] if flow_length > svl else [n]
-                lap("flow_completion", sum(self.fix_flow_complete.flops(t_, h, w) for t_ in spans))
+                lap("flow_completion", lambda: sum(self.fix_flow_complete.flops(t_, h, w) for t_ in spans))
             # ---- image propagation (:283-315)
             masked_frames = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
             check(lib.vsr_pp_prepare_frames(P(bgr), P(md1), n, h, w, P(masked_frames), stream()))
@@ -238,7 +239,7 @@ class PropainterInpaint:
                     tc.append(b)
                 enc_cache = (torch.cat(fc), torch.cat(tc) if tok_slot else None)
                 if prof is not None:
-                    lap("generator", sum(self.model.plan_flops(len(cids), ntok, h, w, [], None, 1) for cids, ntok in calls))
+                    lap("generator", lambda: sum(self.model.plan_flops(len(cids), ntok, h, w, [], None, 1) for cids, ntok in calls))
             for nb, ref in windows:
                 ids = nb + ref
                 l_t = len(nb)
@@ -258,9 +259,13 @@ class PropainterInpaint:
                     visited[i] = True
                 if prof is not None:
                     key = (len(ids), l_t, enc_cache is not None)
-                    if key not in flags_cache:
-                        flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
-                    lap("generator", flags_cache[key])
+
+                    def window_flops(key=key, ids=ids, l_t=l_t):
+                        if key not in flags_cache:
+                            flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
+                        return flags_cache[key]
+
+                    lap("generator", window_flops)
             if resident:
                 return comp
             out = comp.cpu().numpy()                                                        # already BGR (:360)

@@ -189,6 +189,16 @@ class STTNAutoInpaint:
                 writer.write(frame)
                 tick(original, frame)
 
+        local = self._rank_local_io(dist, rank, reader, writer, gui, inpaint_area, frame_info["len"])
+        if local is not None:
+            # every rank reads and writes its own chunks by offset (tools/rank_io.py): no rank-0 funnel, no collective on the data path
+            try:
+                self._run_rank_local(local, dist, rank, engine, ranges, mask, inpaint_area, (H_ori, W_ori), ab_sections, tick, frame_info["len"])
+            finally:
+                reader.release()
+                if writer:
+                    writer.release()
+            return
         resident = self._resident_io(rank, reader, writer, gui, inpaint_area)
         if resident is not None:
             load, store = self._resident_load_store(resident, engine, reader, writer, ranges, kept, (H_ori, W_ori), (y_lo, y_hi), tick)
@@ -212,6 +222,98 @@ class STTNAutoInpaint:
             reader.release()
             if writer:
                 writer.release()
+
+    @staticmethod
+    def _rank_local_io(dist, rank, reader, writer, gui, inpaint_area, total):
+        """(source layout, sink layout, source plane format, sink plane format) when every rank can read and write its own chunks by
+        offset: more than one rank (VSR_IO_PER_RANK=1 forces it for a single process too, =0 keeps the rank-0 funnel), a *.y4m source
+        with fixed-size records and a *.y4m sink on rank 0, colour conversion on the GPU, no preview consumer.  Rank 0 decides and
+        tells the others (the sink is its object); the sink is grown to its final size before anybody writes."""
+        want = os.environ.get("VSR_IO_PER_RANK", "1" if dist is not None else "0")
+        if want != "1" or gui or not inpaint_area:
+            return None
+        rl = getattr(reader, "record_layout", None)
+        pf = getattr(reader, "planes_format", None)
+        src = rl() if rl is not None else None
+        rf = pf() if pf is not None else None
+        decision = [None]
+        if rank == 0:
+            wl = getattr(writer, "record_layout", None)
+            wpf = getattr(writer, "planes_format", None)
+            wf = wpf() if wpf is not None else None
+            if src is not None and rf is not None and wl is not None and wf is not None and src["count"] == total:
+                dst = wl(total)
+                if dst is not None:
+                    decision = [(dst, wf)]
+        if dist is not None:
+            dist.broadcast_object_list(decision, src=0)         # also orders "the sink has its final size" before every rank's first write
+        if decision[0] is None or src is None or rf is None:
+            return None
+        return src, decision[0][0], rf, decision[0][1]
+
+    def _run_rank_local(self, local, dist, rank, engine, ranges, mask, inpaint_area, size, ab_sections, tick, total):
+        """the chunk loop of _run with per-rank file access: chunk i's stored planes -> pinned -> HBM -> BGR (vsr_io_yuv_to_bgr) ->
+        vsr_sttn_auto_chunk in place on the whole frames -> planes (vsr_io_bgr_to_yuv) -> pinned -> the sink, at the records' offsets"""
+        import ctypes as C
+
+        from ..._lib import check, lib
+        from ..tools import rank_io
+        from ..tools.pinned import PinnedPool
+
+        src, dst, rf, wf = local
+        (H, W), dev = size, engine.device
+        maxn = max((e - s for s, e in ranges), default=0)
+        u8 = torch.uint8
+        d_in = torch.empty((maxn, rf["frame_bytes"]), dtype=u8, device=dev)
+        d_out = torch.empty((maxn, wf["frame_bytes"]), dtype=u8, device=dev)
+        full = torch.empty((maxn, H, W, 3), dtype=u8, device=dev)
+        dmask = torch.from_numpy(np.ascontiguousarray(mask[:, :, 0])).to(dev)
+        mask_host = mask[:, :, 0]
+        # staging is page-locked by a helper thread in the order of first use (tools/pinned.py); asked for with wait=True: the first
+        # chunk waits for ITS buffer only
+        order = [("in", 0), ("out", 0), ("in", 1), ("out", 1)]
+        pool = PinnedPool([(maxn, rf["frame_bytes"] if k == "in" else wf["frame_bytes"]) for k, _ in order], device=dev)
+        tensors = {}
+
+        def alloc(kind, b, shape):
+            t = pool.get(order.index((kind, b)), wait=True)
+            if t is None:                                    # page-locking failed: ordinary memory
+                t = torch.empty(shape, dtype=u8)
+            tensors[t.numpy().ctypes.data] = t
+            return t.numpy()
+
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        cur = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+        def work(i, inp, out):
+            s, _ = ranges[i]
+            k = inp.shape[0]
+            ti, to = tensors[inp.ctypes.data][:k], tensors[out.ctypes.data][:k]
+            with torch.cuda.device(dev):
+                d_in[:k].copy_(ti, non_blocking=True)
+                check(lib.vsr_io_yuv_to_bgr(ptr(d_in), rf["frame_bytes"], H, W, rf["cw"], rf["ch"], int(rf["full_range"]), ptr(full), k, cur()))
+                sel = [j - s for j in range(s, s + k) if is_frame_number_in_ab_sections(j, ab_sections)]
+                if sel:
+                    engine.auto_chunk(full[:k], dmask, inpaint_area, sel=None if len(sel) == k else sel, mask_host=mask_host)
+                check(lib.vsr_io_bgr_to_yuv(ptr(full), H, W, int(wf["subsample_420"]), int(wf["full_range"]), ptr(d_out), wf["frame_bytes"], k, cur()))
+                to.copy_(d_out[:k], non_blocking=True)
+                torch.cuda.current_stream(dev).synchronize()
+
+        done = {"n": 0}
+
+        def ticks(n):
+            done["n"] += n
+            if rank == 0:
+                for _ in range(n):
+                    tick(None, None)
+
+        try:
+            rank_io.run_rank_local(ranges, src, dst, work, dist=dist, alloc=alloc, tick=ticks)
+        finally:
+            pool.close()
+        if rank == 0:
+            for _ in range(total - done["n"]):               # the other ranks' frames: the progress bar ends at 100 %
+                tick(None, None)
 
     @staticmethod
     def _resident_io(rank, reader, writer, gui, inpaint_area):

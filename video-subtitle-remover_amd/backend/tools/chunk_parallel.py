@@ -169,6 +169,7 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
             failure.append(e)
 
     owners = range(world) if rank == 0 else [rank]
+    pool = None
     dbuf = {(q, k): torch.empty((maxn, h, W, C), dtype=torch.uint8, device=dev) for q in range(RING) for k in owners}
     if rank == 0 and host_io and st.gpu:
         # pinned staging, page-locked by a helper thread in the order of first use (tools/pinned.py): rounds 0 and 1 in, the results
@@ -265,30 +266,33 @@ def run_chunk_parallel(ranges, row_shape, load, process, store, dist=None, devic
         if rank != 0 and r_recv is not None and chunk_of(r_recv, rank) is not None:
             staged[r_recv] = st.event("io")    # the peer's chunk of round r_recv has arrived
 
-    if rank == 0:
-        stage(0)
-        stage(1)
-    finish(post(0), 0)
-    for r in range(n_rounds + 2):
-        compute(r)
-        works = post(r + 1)
+    try:
         if rank == 0:
-            drain(r - 2)
-            stage(r + 2)
-        finish(works, r + 1)
-        ev = computed.get(r)
-        if ev is not None:
-            ev.synchronize()                   # paces the host: at most one round of launches ahead of the GPU
-        staged.pop(r - RING, None)
-        computed.pop(r - RING, None)
-    if st.gpu:
-        try:
-            torch.cuda.synchronize(dev)
-        except BaseException as e:            # noqa: BLE001 -- an asynchronous kernel error surfaces here
-            if not failure:
-                failure.append(e)
-        if rank == 0 and host_io:
-            pool.close()                       # (a short run ends before the page-locking thread does)
+            stage(0)
+            stage(1)
+        finish(post(0), 0)
+        for r in range(n_rounds + 2):
+            compute(r)
+            works = post(r + 1)
+            if rank == 0:
+                drain(r - 2)
+                stage(r + 2)
+            finish(works, r + 1)
+            ev = computed.get(r)
+            if ev is not None:
+                ev.synchronize()                   # paces the host: at most one round of launches ahead of the GPU
+            staged.pop(r - RING, None)
+            computed.pop(r - RING, None)
+        if st.gpu:
+            try:
+                torch.cuda.synchronize(dev)
+            except BaseException as e:            # noqa: BLE001 -- an asynchronous kernel error surfaces here
+                if not failure:
+                    failure.append(e)
+    finally:
+        if pool is not None:
+            pool.close()                           # also when an exchange raised: no page-locking thread outlives the loop
+                                                   # (and a short run ends before that thread does)
     if dist is not None:
         # agree on the outcome: the lowest failed rank + 1, 0 = everybody fine (all-reduce MAX of -(rank + 1) would do too; MIN
         # over a large sentinel keeps it one collective).  Also the closing barrier.

@@ -124,25 +124,27 @@ class StreamingStore:
     def _run(self):
         dev = self.clip.frames.device
         lo = 0
-        try:
-            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
-                while True:
-                    item = self._q.get()
-                    if item is None:
-                        return
+        with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
+            while True:
+                item = self._q.get()
+                if item is None:
+                    return
+                if self._error is not None:       # after a failed write: drain the queue until the sentinel, write nothing more
+                    continue
+                try:
                     hi, event = item
-                    if self._error is not None:
-                        continue
                     if event is not None:
                         event.synchronize()
                     hi = min(int(hi), len(self.clip))
                     if hi > lo:
                         self.clip.store(self.writer, self.wf, lo, hi, self.tick)
                         lo = hi
-        except BaseException as e:                # noqa: BLE001 -- re-raised by finish() in the caller's thread
-            self._error = e
+                except BaseException as e:        # noqa: BLE001 -- re-raised by ready() / finish() in the caller's thread
+                    self._error = e
 
     def ready(self, hi, event=None):
+        if self._error is not None:               # fail fast: do not inpaint the rest of the clip for a file that cannot be written
+            raise self._error
         self._q.put((hi, event))
 
     def abort(self):

@@ -374,6 +374,15 @@ class Y4mVideo:
             raise RuntimeError("read() and read_planes_into() cannot be mixed on one reader")
         return {"frame_bytes": self._fsize, "cw": self.cw, "ch": self.ch, "full_range": self.full_range}
 
+    def record_layout(self):
+        """{path, data_offset, prefix, frame_bytes, count} when every frame of the file is one fixed-size record (no per-frame parameters):
+        what tools/rank_io.py needs to read a chunk by offset; None otherwise"""
+        total = os.path.getsize(self.path) - self._data0
+        rec = 6 + self._fsize
+        if total % rec != 0:
+            return None
+        return {"path": os.path.abspath(self.path), "data_offset": self._data0, "prefix": b"FRAME\n", "frame_bytes": self._fsize, "count": total // rec}
+
     def read_planes_into(self, out):
         """fill out[k] (uint8 [n][frame_bytes], e.g. pinned memory) with the next frames as stored; returns how many were read"""
         k = 0
@@ -398,6 +407,7 @@ class Y4mWriter:
         self._f = open(path, "wb", buffering=1 << 22)
         tag = "444" if chroma == "444" else "420mpeg2"
         self._f.write(f"YUV4MPEG2 W{self.w} H{self.h} F{num}:{den} Ip A1:1 C{tag} XCOLORRANGE=LIMITED\n".encode())
+        self._header_bytes = self._f.tell()
         cw, ch = (self.w, self.h) if chroma == "444" else ((self.w + 1) // 2, (self.h + 1) // 2)
         self._dc_args = (self.h, self.w, self.w * self.h + 2 * cw * ch) if _device_color_enabled() else None
         self._dc_obj = None
@@ -448,6 +458,16 @@ class Y4mWriter:
         for rec in recs:
             self._f.write(b"FRAME\n")
             self._f.write(rec)
+
+    def record_layout(self, count):
+        """For tools/rank_io.py: the header goes to disk, the file is grown to its final size of `count` frames, and the layout of its
+        records comes back ({path, data_offset, prefix, frame_bytes}); the ranks then write their records by offset and this object
+        writes nothing more.  None when frames were already written through it, or without the device colour conversion."""
+        if self._dc_args is None or self._pending or self._f.tell() != self._header_bytes:
+            return None
+        self._f.flush()
+        os.truncate(self._f.name, self._header_bytes + (6 + self._dc_args[2]) * int(count))
+        return {"path": os.path.abspath(self._f.name), "data_offset": self._header_bytes, "prefix": b"FRAME\n", "frame_bytes": self._dc_args[2]}
 
     def release(self):
         if self._dc_obj is not None:
@@ -735,6 +755,13 @@ class AsyncWriter:
     def planes_format(self):
         fmt = getattr(self.sink, "planes_format", None)
         return fmt() if fmt is not None else None
+
+    def record_layout(self, count):
+        """see Y4mWriter.record_layout (None for sinks without offsets: pipes, image files)"""
+        fn = getattr(self.sink, "record_layout", None)
+        if fn is None or self._err is not None or not self._q.empty():
+            return None
+        return fn(count)
 
     def write_planes(self, recs):
         """a batch of frames converted on the device (see Y4mWriter.write_planes); keeps its place in the frame order"""

@@ -1,5 +1,7 @@
 // Weight packer + plan builder for the recurrent flow completion network (see rfc_plan.h).
 #include "rfc_plan.h"
+#include <algorithm>
+#include <stdlib.h>
 #include "gather_gemm.h"
 #include <stdexcept>
 
@@ -144,14 +146,19 @@ std::vector<int> RfcPlan::seqIds(bool temporalHalo) const
 }
 
 void RfcPlan::gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tColA, int K, int M, int bufC, int64_t offC, int tRowC,
-                   const ConvW& w, int act, int bufR, int64_t offR, int tRowR, int tile)
+                   const ConvW& w, int act, int bufR, int64_t offR, int tRowR, int tile, bool append)
 {
     if (w.K != K) throw std::runtime_error(std::string("rfc gemm K mismatch: ") + tag);
-    Op op;
-    op.kind = OP_GEMM;
-    op.tag = tag;
-    op.bmode = VSR_BMODE_NK;
-    op.tileCfg = tile;
+    if (append) {                                  // one more problem of the previous op's launch (conv() cutting a large batch into frame groups)
+        if (ops.empty() || ops.back().kind != OP_GEMM || ops.back().tileCfg != tile) throw std::runtime_error("rfc gemm: nothing to append to");
+    } else {
+        ops.emplace_back();
+        ops.back().kind = OP_GEMM;
+        ops.back().tag = tag;
+        ops.back().bmode = VSR_BMODE_NK;
+        ops.back().tileCfg = tile;
+    }
+    Op& op = ops.back();
     int BM, BN;
     tileDims(tile, BM, BN);
     GemmItem it{};
@@ -166,10 +173,10 @@ void RfcPlan::gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tColA
     it.tColC = tColsLinear(cdiv(it.N, VSR_GG_KC), it.tilesN * BN / VSR_GG_KC);
     it.offBias = w.b;
     it.bufR = bufR; it.offR = offR; it.tRowR = tRowR;
-    op.flops = 2.0 * M * (double)it.N * K;
-    flops += op.flops;
+    const double fl = 2.0 * M * (double)it.N * K;
+    op.flops += fl;
+    flops += fl;
     op.gemm.push_back(it);
-    ops.push_back(std::move(op));
 }
 
 void RfcPlan::conv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, const std::vector<int>& outIds, int kh,
@@ -178,11 +185,35 @@ void RfcPlan::conv(const char* tag, const Act& in, const std::vector<int>& inIds
     const int tile = pickTile(w.cout);
     int BM, BN;
     tileDims(tile, BM, BN);
-    const int M = (int)outIds.size() * out.H * out.W;
+    const int nf = (int)outIds.size();
     need(out.buf, out.elems());
-    gemm(tag, in.buf, 0, tRowsAct(in, inIds, out.H, out.W, stride, BM, 0), tColsConvHW(in, kh, kw, dil), kh * kw * in.C, M, out.buf, 0,
-         tRowsAct(out, outIds, out.H, out.W, 1, BM, 0), w, act, res ? res->buf : -1, 0,
-         res ? tRowsAct(*res, *resIds, out.H, out.W, 1, BM, 0) : -1, tile);
+    // Offset tables hold 32-bit element offsets from the problem's base pointer.  A 70-frame batch of 1080p strips (what
+    // batch_generator(1200, 70) hands the plugin: 138 flow fields of 1920 x 360) has operands beyond 2^31 elements -- the stem's im2col
+    // (2.3e9) and the full-resolution 32-channel map in front of the last conv (3.1e9).  Such a conv becomes several problems of ONE
+    // launch: groups of consecutive frames, each with its own 64-bit base (GemmItem::offA / offC / offR) and tables relative to the
+    // group's first frame (equal groups share their tables).  Same rows, same K order, same arithmetic per output element.
+    auto span = [](const Act& a, const std::vector<int>& v) { return ((int64_t)*std::max_element(v.begin(), v.end()) + 1) * a.frameElems(); };
+    // (VSR_RFC_SPAN_LIMIT: test hook -- a small limit makes small plans take the grouped form, tests/test_rfc_replay.py)
+    static const int64_t kMaxSpan = [] { const char* e = getenv("VSR_RFC_SPAN_LIMIT"); const long long x = e ? atoll(e) : 0;
+                                         return x > 0 ? (int64_t)x : (int64_t)(2147483647LL - 8 * 1024 * 1024); }();   // room for the column offsets added to a row offset
+    const bool fits = span(in, inIds) < kMaxSpan && span(out, outIds) < kMaxSpan && (!res || span(*res, *resIds) < kMaxSpan);
+    int per = nf;
+    if (!fits) {
+        const int64_t fe = std::max(std::max(in.frameElems(), out.frameElems()), res ? res->frameElems() : (int64_t)0);
+        per = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)1 << 30, kMaxSpan / 2) / fe);
+        for (size_t j = 1; j < inIds.size(); ++j)
+            if (inIds[j] < inIds[j - 1] || outIds[j] < outIds[j - 1] || (res && (*resIds)[j] < (*resIds)[j - 1]))
+                throw std::runtime_error(std::string("rfc conv: frame ids of an operand beyond 2^31 elements must ascend: ") + tag);
+    }
+    for (int j0 = 0; j0 < nf; j0 += per) {
+        const int j1 = std::min(nf, j0 + per);
+        auto rel = [&](const std::vector<int>& v) { std::vector<int> r(v.begin() + j0, v.begin() + j1); for (int& x : r) x -= v[j0]; return r; };
+        const std::vector<int> ri = rel(inIds), ro = rel(outIds);
+        gemm(tag, in.buf, (int64_t)inIds[j0] * in.frameElems(), tRowsAct(in, ri, out.H, out.W, stride, BM, 0), tColsConvHW(in, kh, kw, dil),
+             kh * kw * in.C, (j1 - j0) * out.H * out.W, out.buf, (int64_t)outIds[j0] * out.frameElems(), tRowsAct(out, ro, out.H, out.W, 1, BM, 0), w, act,
+             res ? res->buf : -1, res ? (int64_t)(*resIds)[j0] * res->frameElems() : 0,
+             res ? tRowsAct(*res, rel(*resIds), out.H, out.W, 1, BM, 0) : -1, tile, j0 > 0);
+    }
 }
 
 // Conv3d kernel (3,1,1), dilation (2,1,1), padding (2,0,0) (P3DBlock.conv2, :160-163): K = 3*C gathered from steps i-2, i, i+2

@@ -55,7 +55,7 @@ private:
     std::vector<int> seqIds(bool temporalHalo) const;   // frame ids (i-major, sequence-minor) inside a [S][T(+4)] buffer
     // generic gather-GEMM: A rows/cols and C rows given as tables built by the caller
     void gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tColA, int K, int M, int bufC, int64_t offC, int tRowC, const ConvW& w,
-              int act, int bufR, int64_t offR, int tRowR, int tile);
+              int act, int bufR, int64_t offR, int tRowR, int tile, bool append = false);
     void conv(const char* tag, const Act& in, const std::vector<int>& inIds, const Act& out, const std::vector<int>& outIds, int kh, int kw,
               int stride, int dil, const ConvW& w, int act, const Act* res, const std::vector<int>* resIds);
     void tconv(const char* tag, const Act& in, const std::vector<int>& ids, const Act& out, const ConvW& w, int act);   // (3,1,1) dilation 2

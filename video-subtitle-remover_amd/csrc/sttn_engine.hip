@@ -6,6 +6,7 @@
 // descriptor arrays once per chunk length L, and replays it on the caller's stream: ~16
 // launches per transformer block, no host synchronisation, no allocation in steady state.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -78,6 +79,7 @@ struct OpDev {
 
 struct PlanDev {
     std::unique_ptr<Plan> plan;
+    uint64_t lastUse = 0;              // vsr_sttn::useClock at the last lookup (least-recently-used eviction of the plan cache)
     int32_t* dTables = nullptr;
     void* dDescs = nullptr;
     int32_t* dIsFloat = nullptr;
@@ -118,6 +120,7 @@ struct vsr_sttn {
     void* bufs[BUF_COUNT] = {};
     int64_t cap[BUF_COUNT] = {};
     std::map<int64_t, std::unique_ptr<PlanDev>> plans;
+    uint64_t useClock = 0;
     std::map<std::pair<int, int>, StripTables> strips;
     float* compAreas = nullptr;
     int64_t compAreasCap = 0;
@@ -166,6 +169,9 @@ static int gg_wide_queues()
 // decLo / decHi: the rows of the model-resolution output the caller will read (Plan::decLo; 0, 0 = all)
 static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int decLo = 0, int decHi = 0, int decXLo = 0, int decXHi = 0)
 {
+    // the key packs the four decoder bounds into 10 bits each
+    if (h->model.g.modelH >= 1024 || h->model.g.modelW >= 1024 || decLo < 0 || decHi >= 1024 || decXLo < 0 || decXHi >= 1024)
+        return fail(VSR_ERR_ARG, "plan key: model resolution / decoder bounds beyond 1023");
     const int64_t key = ((((((int64_t)L * 4 + precision) * 8 + h->lanes) * 1024 + decLo) * 1024 + decHi) * 1024 + decXLo) * 1024 + decXHi;
     const bool fmt = precision >= 2;       // split-format tensors: everything a GEMM reads (see gather_gemm_v5.h)
     auto plainF32 = [](int buf) { buf = baseBuf(buf); return buf == BUF_S || buf == BUF_PVPART || buf == BUF_D4 || buf == BUF_COMP; };
@@ -177,8 +183,9 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
         HIPCHK(hipDeviceSynchronize());
     }
     auto it = h->plans.find(key);
-    if (it != h->plans.end()) { *out = it->second.get(); return 0; }
+    if (it != h->plans.end()) { it->second->lastUse = ++h->useClock; *out = it->second.get(); return 0; }
     std::unique_ptr<PlanDev> pd(new PlanDev);
+    pd->lastUse = ++h->useClock;
     try {
         pd->plan.reset(new Plan(h->model, L, precision, h->lanes, decLo, decHi, decXLo, decXHi));
     } catch (const std::exception& e) {
@@ -368,9 +375,16 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
     HIPCHK(hipMemcpy(pd->dIsFloat, isf.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 16 * sizeof(unsigned int)));
     *out = pd.get();
-    if (h->plans.size() >= 48) {                   // a long video with ever new mask rows: start over rather than grow without bound
+    if (h->plans.size() >= 48) {
+        // a long video with ever new mask rows: drop the 16 least recently used plans -- never a promise-free one (decoder bounds all
+        // 0: the hot default of its L) and never the one a multi-area call is in the middle of (they are the most recent ones)
         HIPCHK(hipDeviceSynchronize());            // (nothing in flight may still read the tables that go)
-        h->plans.clear();
+        std::vector<std::pair<uint64_t, int64_t>> byUse;
+        for (const auto& kv : h->plans)
+            if (kv.first % ((int64_t)1 << 40) != 0) byUse.push_back({kv.second->lastUse, kv.first});
+        std::sort(byUse.begin(), byUse.end());
+        for (size_t i = 0; i < byUse.size() && i < 16; ++i) h->plans.erase(byUse[i].second);
+        if (h->plans.size() >= 48) h->plans.clear();      // only promise-free plans of 48 different lengths: start over
     }
     h->plans[key] = std::move(pd);
     return 0;
@@ -513,6 +527,10 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         }
     return 0;
 }
+
+// process-wide switches of this file, read once (vsr_switch_state reports them; vsr_amd/switches.py holds the same defaults)
+static bool switch_rows_on() { static const bool v = [] { const char* e = getenv("VSR_DECODE_ROWS"); return !(e && atoi(e) == 0); }(); return v; }
+static bool switch_cols_on() { static const bool v = [] { const char* e = getenv("VSR_DECODE_COLS"); return e && atoi(e) == 1; }(); return v; }
 
 static int collect_timing(vsr_sttn* h, hipStream_t stream)
 {
@@ -813,10 +831,10 @@ static int strips_common(vsr_sttn* h, bool det, uint8_t* frames_dev, int L, int 
         dSel = h->dSel;
     }
     // model-resolution rows every area needs (0, 0 = all)
-    static const bool rowsOn = [] { const char* e = getenv("VSR_DECODE_ROWS"); return !(e && atoi(e) == 0); }();
-    // (columns: built, replayed on the CPU, NOT yet run on a GPU -- a caller opts in by handing over mask_cols (the _box entry points; the
-    // Python side does so with its VSR_DECODE_COLS switch, switches.py); VSR_DECODE_COLS=0 makes this side ignore them)
-    static const bool colsOn = [] { const char* e = getenv("VSR_DECODE_COLS"); return !(e && atoi(e) == 0); }();
+    const bool rowsOn = switch_rows_on();
+    // (columns: a caller opts in by handing over mask_cols (the _box entry points) AND this side must have been started with
+    // VSR_DECODE_COLS=1 -- the same rule as vsr_amd/switches.py, so that a direct C caller gets the same default as the Python one)
+    const bool colsOn = switch_cols_on();
     std::vector<int> decLo((size_t)n_areas, 0), decHi((size_t)n_areas, 0), decXLo((size_t)n_areas, 0), decXHi((size_t)n_areas, 0);
     if (maskRows && rowsOn) {
         for (int k = 0; k < n_areas; ++k) {
@@ -993,8 +1011,9 @@ int vsr_sttn_decode_rows(vsr_sttn_t* h, int strip_h, int mask_row_lo, int mask_r
     }
     if (hi <= lo) { lo = 0; hi = mh; }
     else { lo = lo / 4 * 4; hi = (hi + 3) / 4 * 4 < mh ? (hi + 3) / 4 * 4 : mh; }      // as strips_common
-    Plan p(h->model, 1, 0, 1, lo, hi);                   // (the widening to whole output-conv blocks)
-    *row_lo = p.decLo; *row_hi = p.decHi;
+    int wlo = 0, whi = 0, wxlo = 0, wxhi = 0;               // (the widening to whole output-conv blocks, as Plan::Plan does it)
+    Plan::decoder_bounds(h->model.g, 0, lo, hi, 0, 0, &wlo, &whi, &wxlo, &wxhi);
+    *row_lo = wlo; *row_hi = whi;
     return 0;
 }
 
@@ -1061,6 +1080,17 @@ double vsr_sttn_flops_reference(vsr_sttn_t* h, int L)
         fail(VSR_ERR_ARG, e.what());
         return -1.0;
     }
+}
+
+int vsr_switch_state(const char* name)
+{
+    if (!name) return -1;
+    const std::string n(name);
+    if (n == "VSR_DECODE_ROWS") return switch_rows_on() ? 1 : 0;
+    if (n == "VSR_DECODE_COLS") return switch_cols_on() ? 1 : 0;
+    if (n == "VSR_QKV0_SHARED") return Tuning::get(0).shareQkv0 ? 1 : 0;
+    if (n == "VSR_TRIM_LAST_BLOCK") return Tuning::get(0).trimLastBlock ? 1 : 0;
+    return -1;
 }
 
 int vsr_sttn_timing(vsr_sttn_t* h, int enable)

@@ -931,10 +931,10 @@ void Plan::buildWindow(const std::vector<int>& neighbors, const std::vector<int>
     ++nwindows;
 }
 
-Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, int decHi_, int decXLo_, int decXHi_)
-    : L(L_), precision(precision_), lanes(lanes_ < 1 ? 1 : (lanes_ > kMaxLanes ? kMaxLanes : lanes_)), g(model.g), m_(model), tu_(Tuning::get(precision_))
+void Plan::decoder_bounds(const Geometry& g, int precision, int decLo_, int decHi_, int decXLo_, int decXHi_, int* lo, int* hi, int* xlo, int* xhi)
 {
-    if (decHi_ > decLo_ && tu_.outConvBlocked && g.modelH % Model::kOutBlkH == 0 && g.modelW % Model::kOutBlkW == 0) {
+    int decLo = 0, decHi = 0, decXLo = 0, decXHi = 0;
+    if (decHi_ > decLo_ && Tuning::get(precision).outConvBlocked && g.modelH % Model::kOutBlkH == 0 && g.modelW % Model::kOutBlkW == 0) {
         // whole 2-row blocks of the output conv, inside the image (the per-pixel form of that conv keeps the whole image)
         decLo = (decLo_ < 0 ? 0 : decLo_) / Model::kOutBlkH * Model::kOutBlkH;
         decHi = (decHi_ > g.modelH ? g.modelH : decHi_);
@@ -947,6 +947,13 @@ Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, i
             if (decXHi > g.modelW) decXHi = g.modelW;
         }
     }
+    *lo = decLo; *hi = decHi; *xlo = decXLo; *xhi = decXHi;
+}
+
+Plan::Plan(const Model& model, int L_, int precision_, int lanes_, int decLo_, int decHi_, int decXLo_, int decXHi_)
+    : L(L_), precision(precision_), lanes(lanes_ < 1 ? 1 : (lanes_ > kMaxLanes ? kMaxLanes : lanes_)), g(model.g), m_(model), tu_(Tuning::get(precision_))
+{
+    decoder_bounds(g, precision_, decLo_, decHi_, decXLo_, decXHi_, &decLo, &decHi, &decXLo, &decXHi);
     if (!model.packed_ready()) throw std::runtime_error("model weights are not packed");
     if (L <= 0) throw std::runtime_error("empty frame list");
     bufElems.assign(BUF_COUNT, 0);

@@ -200,6 +200,9 @@ public:
     // (buildWindow); decHi <= decLo = the whole image
     // decXLo / decXHi: the same for columns (the GEMMs take rectangles; the two elementwise kernels of the decoder keep whole rows)
     Plan(const Model& model, int L, int precision = 0, int lanes = 1, int decLo = 0, int decHi = 0, int decXLo = 0, int decXHi = 0);
+    // the bounds a plan with these arguments decodes: clipped to the image and widened to whole blocks of the output conv (all 0 = the
+    // whole image: no promise, or the per-pixel form of the output conv).  Needs no plan: vsr_sttn_decode_rows asks once per area.
+    static void decoder_bounds(const Geometry& g, int precision, int decLo, int decHi, int decXLo, int decXHi, int* lo, int* hi, int* xlo, int* xhi);
     int decLo = 0, decHi = 0;            // as given, clipped to the image and widened to whole 2-row blocks of the output conv
     int decXLo = 0, decXHi = 0;          // ... to whole 4-column blocks
     int L;

@@ -143,8 +143,12 @@ class SttnEngine:
 
     def mask_cols(self, mask, areas):
         """int32 [n_areas, 2]: the frame columns [lo, hi) that hold the set pixels of every area's strip (0, 0: none) -- the second
-        half of the promise vsr_sttn_auto_chunk_box takes (honoured with VSR_DECODE_COLS=1 only; built in round 4, not yet measured)."""
+        half of the promise vsr_sttn_auto_chunk_box takes (honoured with VSR_DECODE_COLS=1, the default since round 5)."""
         ar = np.asarray(areas, dtype=np.int32).reshape(-1, 4)
+        if not isinstance(mask, np.ndarray):             # device mask: one download per (mask object, version, areas), like mask_rows
+            ent = getattr(self, "_mask_cols_cache", None)
+            if ent is not None and ent[0]() is mask and ent[1] == mask._version and np.array_equal(ent[2], ar):
+                return ent[3]
         cols = np.zeros((ar.shape[0], 2), dtype=np.int32)
         for k, (ymin, ymax, _, _) in enumerate(ar):
             if isinstance(mask, np.ndarray):
@@ -154,7 +158,25 @@ class SttnEngine:
             nz = np.flatnonzero(flags)
             if nz.size:
                 cols[k] = (int(nz[0]), int(nz[-1]) + 1)
+        if not isinstance(mask, np.ndarray):
+            import weakref
+
+            self._mask_cols_cache = (weakref.ref(mask), mask._version, ar.copy(), cols)
         return cols
+
+    @staticmethod
+    def _check_mask_host(mask_host, mask_dev):
+        """the promise about the mask's rows / columns is read off the caller's host copy: it must be THE mask (a stale or differently
+        cropped copy would make the decoder skip rows the blend still reads).  Shape always; content with VSR_DEBUG_MASK_HOST=1."""
+        if mask_host is None:
+            return
+        if tuple(mask_host.shape[:2]) != tuple(mask_dev.shape[:2]):
+            raise ValueError(f"mask_host {tuple(mask_host.shape[:2])} is not the device mask's shape {tuple(mask_dev.shape[:2])}")
+        if os.environ.get("VSR_DEBUG_MASK_HOST") == "1":
+            h = np.asarray(mask_host).reshape(mask_host.shape[0], mask_host.shape[1], -1)[:, :, 0] != 0
+            d = mask_dev.reshape(int(mask_dev.shape[0]), int(mask_dev.shape[1]), -1)[:, :, 0].ne(0).cpu().numpy()
+            if not np.array_equal(h, d):
+                raise ValueError("mask_host differs from the device mask")
 
     def chunk_flops(self, L, mask_dev, areas):
         """FLOPs of one auto_chunk call on this mask: every area's plan decodes only the rows its mask rows are resized from"""
@@ -190,6 +212,7 @@ class SttnEngine:
         sel_arr = None if sel is None else np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
         # decode_rows=False: no promise about the mask, the whole model-resolution image is decoded (tests compare the two)
         # (mask_host: the caller's numpy copy of the mask, when it has one -- the rows are then read off it)
+        self._check_mask_host(mask_host, mask_dev)
         rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
         if decode_rows and switches.on("VSR_DECODE_COLS"):
             cols = np.ascontiguousarray(self.mask_cols(mask_dev if mask_host is None else mask_host, ar))
@@ -229,6 +252,7 @@ class SttnEngine:
         assert mask_dev.dtype == torch.uint8 and mask_dev.is_cuda and mask_dev.is_contiguous()
         L, H, W, _ = frames_dev.shape
         ar = np.ascontiguousarray(np.asarray(areas, dtype=np.int32).reshape(-1, 4))
+        self._check_mask_host(mask_host, mask_dev)
         rows = np.ascontiguousarray(self.mask_rows(mask_dev if mask_host is None else mask_host, ar)) if decode_rows else np.zeros((ar.shape[0], 2), dtype=np.int32)
         if decode_rows and switches.on("VSR_DECODE_COLS"):
             cols = np.ascontiguousarray(self.mask_cols(mask_dev if mask_host is None else mask_host, ar))
