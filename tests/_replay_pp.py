@@ -239,7 +239,9 @@ def gen_ew_reference(info, bufs):
         bufs[ib[0]][io[1]: io[1] + out.numel()] = out.reshape(-1).numpy()
     elif k == EW_PP_FOLD:
         ld, t, fh, fw, h, w, Cc, halo, normalize = ip[:9]
-        v = torch.from_numpy(bufs[ib[0]][: t * fh * fw * ld].reshape(t, fh * fw, ld)[:, :, :Cc * 49].copy()).permute(0, 2, 1)
+        # the token vectors are tap-major (element tap*C + c: csrc/pp_gen_kernels.hip); F.fold wants c*49 + tap
+        v = bufs[ib[0]][: t * fh * fw * ld].reshape(t, fh * fw, ld)[:, :, :Cc * 49].reshape(t, fh * fw, 49, Cc).transpose(0, 1, 3, 2)
+        v = torch.from_numpy(np.ascontiguousarray(v).reshape(t, fh * fw, Cc * 49)).permute(0, 2, 1)
         y = torch.nn.functional.fold(v, (h, w), (7, 7), padding=(3, 3), stride=(3, 3))
         if normalize:
             y = y / torch.nn.functional.fold(torch.ones_like(v), (h, w), (7, 7), padding=(3, 3), stride=(3, 3))
@@ -250,7 +252,8 @@ def gen_ew_reference(info, bufs):
         m = torch.from_numpy(bufs[ib[0]][: t * h * w * Cc].reshape(t, h, w, Cc).copy()).permute(0, 3, 1, 2)
         u = torch.nn.functional.unfold(m, (7, 7), padding=(3, 3), stride=(3, 3)).permute(0, 2, 1)            # t, tokens, Cc*49
         out = np.zeros((t * fh * fw, ld), dtype=np.float32)
-        out[:, :Cc * 49] = torch.nn.functional.gelu(u).reshape(t * fh * fw, Cc * 49).numpy()
+        g = torch.nn.functional.gelu(u).reshape(t * fh * fw, Cc, 49).numpy()                             # F.unfold: c*49 + tap
+        out[:, :Cc * 49] = g.transpose(0, 2, 1).reshape(t * fh * fw, Cc * 49)                              # stored tap-major
         bufs[ib[1]][: out.size] = out.reshape(-1)
     elif k == EW_PP_TANH_OUT:
         ld, n, H, W = ip[:4]

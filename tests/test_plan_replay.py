@@ -244,9 +244,11 @@ def test_window_lanes_share_nothing_but_the_running_average(built_lib, nl):
     from vsr_amd import _lib
     from vsr_amd.engine import SttnEngine
 
-    BUF_WEIGHTS, BUF_IN_U8, BUF_FEATS, BUF_COMP, BUF_MASK_U8, BUF_ROWMAX, L1_FIRST = 0, 1, 6, 20, 22, 23, 25
+    BUF_WEIGHTS, BUF_IN_U8, BUF_FEATS, BUF_COMP, BUF_MASK_U8, BUF_ROWMAX, L1_FIRST, BUF_QKV0 = 0, 1, 6, 20, 22, 23, 25, 70
     window_scoped = set(range(7, 20)) | {21, 24}            # X0 .. D4, PVPART, LSUM
-    shared_read = {BUF_WEIGHTS, BUF_IN_U8, BUF_FEATS, BUF_MASK_U8, BUF_ROWMAX}
+    # (BUF_QKV0: the first block's q/k/v of every frame of the chunk, written once in front of the windows -- VSR_QKV0_SHARED, the
+    # default since round 5 -- and only read by them)
+    shared_read = {BUF_WEIGHTS, BUF_IN_U8, BUF_FEATS, BUF_MASK_U8, BUF_ROWMAX, BUF_QKV0}
     eng = SttnEngine(make_state_dict(0, "auto"), "auto", device=None)
     try:
         views = {}
@@ -259,9 +261,9 @@ def test_window_lanes_share_nothing_but_the_running_average(built_lib, nl):
             return buf in window_scoped if lane == 0 else L1_FIRST + (lane - 1) * 15 <= buf < L1_FIRST + lane * 15
 
         assert len(one.ops) == len(two.ops) and one.flops == two.flops and list(one.counts) == list(two.counts)
-        assert len(one.buf_elems) == len(two.buf_elems) and all(one.buf_elems[b] == 0 for b in range(L1_FIRST, len(one.buf_elems)))
+        assert len(one.buf_elems) == len(two.buf_elems) == BUF_QKV0 + 1 and all(one.buf_elems[b] == 0 for b in range(L1_FIRST, BUF_QKV0))
         lanes_seen, n_decode = set(), 0
-        first_window_op = next(i for i, (b, _) in enumerate(two.ops) if b.tag == b"attn.qkv")
+        first_window_op = next(i for i, (b, it) in enumerate(two.ops) if b.tag == b"attn.qkv" and it[0].bufC != BUF_QKV0)
         for i, ((a, ai), (b, bi)) in enumerate(zip(one.ops, two.ops)):
             lane = _lib.lib.vsr_plan_op_lane(two.p, i)
             assert _lib.lib.vsr_plan_op_lane(one.p, i) == 0 and 0 <= lane < nl
@@ -312,7 +314,9 @@ def test_lane_schedule_orders_every_conflict(built_lib, nl):
         eng.set_lanes(nl)
         view = PlanView(_lib, eng, 30)                          # six windows
         lanes = [_lib.lib.vsr_plan_op_lane(view.p, i) for i in range(len(view.ops))]
-        first_window = next(i for i, (b, _) in enumerate(view.ops) if b.tag == b"attn.qkv")
+        # (the first op of the first window: the shared first-block q/k/v GEMM in front of the windows -- it writes buffer 70, BUF_QKV0 --
+        # belongs to what the lanes fork behind, Plan::firstWindowOp)
+        first_window = next(i for i, (b, it) in enumerate(view.ops) if b.tag in (b"attn.qkv", b"attn.qk") and not (b.tag == b"attn.qkv" and it[0].bufC == 70))
 
         def accesses(info, items):
             """[(location, is_write)]: location = buffer id, or (BUF_ROWMAX, offset) -- every attention instance has its own array"""

@@ -371,10 +371,18 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
 
 // kernels write interiors only and rely on zero halos: another frame size or count moves the halos, so the workspace
 // is cleared when the geometry changes (never in steady state)
-static int clear_workspace(Workspace& ws, hipStream_t stream)
+// `plan`: clear what THAT plan addresses (its bufElems) instead of every buffer's capacity.  The generator's workspace is sized by its
+// largest plan (the encoder over all 68 frames of a batch: tens of GB) while the plans that alternate -- the sliding windows, whose
+// frame counts differ by a reference frame or two -- touch a fraction of it: clearing capacities cost 300 ms per 68-frame batch
+// (2688 fills of up to 13.9 ms, profiles/r05_propainter_f32_kernel_stats.csv).  A plan never reads beyond its own bufElems.
+static int clear_workspace(Workspace& ws, hipStream_t stream, const PlanIR* plan = nullptr)
 {
-    for (size_t b = 0; b < ws.bufs.size(); ++b)
-        if ((int)b != ws.weights && ws.bufs[b]) HIPCHK(hipMemsetAsync(ws.bufs[b], 0, (size_t)ws.nbytes((int)b, ws.cap[b]), stream));
+    for (size_t b = 0; b < ws.bufs.size(); ++b) {
+        if ((int)b == ws.weights || !ws.bufs[b]) continue;
+        int64_t n = ws.cap[b];
+        if (plan && b < plan->bufElems.size() && plan->bufElems[b] < n) n = plan->bufElems[b];
+        if (n > 0) HIPCHK(hipMemsetAsync(ws.bufs[b], 0, (size_t)ws.nbytes((int)b, n), stream));
+    }
     return 0;
 }
 
@@ -669,7 +677,7 @@ int vsr_lama_inpaint(vsr_lama_t* h, const uint8_t* img_dev, int64_t img_frame_st
     FlowPlanDev* pd = nullptr;
     RCCHK(lama_plan_dev(h, B, H, W, &pd));
     if (h->geom != std::make_tuple(B, H, W)) {
-        RCCHK(clear_workspace(h->ws, stream));
+        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
         h->geom = std::make_tuple(B, H, W);
     }
     const size_t ibytes = (size_t)H * W * 3, mbytes = (size_t)H * W;
@@ -795,7 +803,7 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
     FlowPlanDev* pd = nullptr;
     RCCHK(raft_plan_dev(h, t, H, W, iters, &pd));
     if (h->geom != std::make_tuple(t, H, W)) {
-        RCCHK(clear_workspace(h->ws, stream));
+        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
         h->geom = std::make_tuple(t, H, W);
     }
     RCCHK(range_guard_arm(h->ws, stream));
@@ -912,7 +920,7 @@ int vsr_rfc_complete(vsr_rfc_t* h, const float* flows_f_dev, const float* flows_
     FlowPlanDev* pd = nullptr;
     RCCHK(rfc_plan_dev(h, t, H, W, &pd));
     if (h->geom != std::make_tuple(t, H, W)) {
-        RCCHK(clear_workspace(h->ws, stream));
+        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
         h->geom = std::make_tuple(t, H, W);
     }
     const size_t fbytes = (size_t)(t - 1) * 2 * H * W * sizeof(float);
@@ -1086,7 +1094,7 @@ int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_
     }
     const std::string geom = "gen:" + std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W);
     if (h->geom != geom) {
-        RCCHK(clear_workspace(h->ws, stream));
+        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
         h->geom = geom;
     }
     const size_t hw = (size_t)H * W;
@@ -1149,7 +1157,7 @@ int vsr_pp_encode(vsr_pp_t* h, const float* frames_dev, const uint8_t* masks_in_
     FlowPlanDev* pd = nullptr;
     RCCHK(pp_plan_for(h, geom, n, ntok_frames, H, W, nullptr, 0, 0, 0, 0, 0, PP_PLAN_ENCODE, &pd));
     if (h->geom != geom) {
-        RCCHK(clear_workspace(h->ws, stream));
+        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
         h->geom = geom;
     }
     const size_t hw = (size_t)H * W;
@@ -1202,7 +1210,7 @@ int vsr_pp_forward_cached(vsr_pp_t* h, const float* feat_cache_dev, const float*
     FlowPlanDev* pd = nullptr;
     RCCHK(pp_plan_for(h, key, t, lt, H, W, window_flags, nflags, row_lo, row_hi, col_lo, col_hi, PP_PLAN_CACHED, &pd));
     if (h->geom != geom) {
-        RCCHK(clear_workspace(h->ws, stream));
+        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
         h->geom = geom;
     }
     const PpGenPlan& gp = static_cast<const PpGenPlan&>(*pd->plan);

@@ -253,9 +253,11 @@ k_pp_pool(const float* __restrict__ y, const float* __restrict__ wgt /*[C][16]*/
 }
 
 // ---------------------------------------------------------------------------------------
-// EW_PP_FOLD: F.fold(kernel 7, stride 3, padding 3) of token vectors [t*fh*fw][ld] (element ch*49 + ky*7 + kx) into an
-// NHWC map [t][h+2*halo][w+2*halo][C]; normalize = 1 divides by the fold of ones (FusionFeedForward.forward :82-96),
-// 0 is SoftComp's plain fold (:59-64).
+// EW_PP_FOLD: F.fold(kernel 7, stride 3, padding 3) of token vectors [t*fh*fw][ld] into an NHWC map [t][h+2*halo][w+2*halo][C];
+// normalize = 1 divides by the fold of ones (FusionFeedForward.forward :82-96), 0 is SoftComp's plain fold (:59-64).
+// The vectors are TAP-MAJOR: element (ky*7 + kx)*C + ch (F.fold's own order is ch*49 + tap; the producing GEMM's weight rows are
+// permuted at pack time, PpModel::pack / patch_perm): the C channels of a pixel are neighbours in the token row as they are in the
+// map, so a wave's loads are runs of C floats instead of single floats 196 bytes apart.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* __restrict__ out)
@@ -272,7 +274,7 @@ k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, i
             const int ky = y + 3 - 3 * ty;
             for (int tx = (x + 3 - 6 + 2) / 3 > 0 ? (x + 3 - 6 + 2) / 3 : 0; tx < fw && 3 * tx <= x + 3; ++tx) {
                 const int kx = x + 3 - 3 * tx;
-                acc += vec[(((int64_t)f * fh + ty) * fw + tx) * ld + c * 49 + ky * 7 + kx];
+                acc += vec[(((int64_t)f * fh + ty) * fw + tx) * ld + (ky * 7 + kx) * C + c];
                 ++cnt;
             }
         }
@@ -280,8 +282,9 @@ k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, i
     }
 }
 
-// EW_PP_UNFOLD_GELU: F.unfold of the normalised map followed by fc2's nn.GELU() (exact erf form) (:98-103):
-// out[(f,ty,tx)][ch*49 + ky*7 + kx] = gelu(map[f][3ty-3+ky][3tx-3+kx][ch]) (zero padding), columns n..ld-1 zero
+// EW_PP_UNFOLD_GELU: F.unfold of the normalised map followed by fc2's nn.GELU() (exact erf form) (:98-103), tap-major like
+// EW_PP_FOLD (fc2's K positions are permuted to match):
+// out[(f,ty,tx)][(ky*7 + kx)*C + ch] = gelu(map[f][3ty-3+ky][3tx-3+kx][ch]) (zero padding), columns C*49..ld-1 zero
 __global__ void __launch_bounds__(256)
 k_pp_unfold_gelu(const float* __restrict__ map, int t, int fh, int fw, int h, int w, int C, int ld, float* __restrict__ out)
 {
@@ -291,7 +294,7 @@ k_pp_unfold_gelu(const float* __restrict__ map, int t, int fh, int fw, int h, in
         const int64_t tok = i / ld;
         float v = 0.f;
         if (e < C * 49) {
-            const int c = e / 49, tap = e - 49 * c;
+            const int tap = e / C, c = e - C * tap;
             const int tx = (int)(tok % fw), ty = (int)((tok / fw) % fh), f = (int)(tok / ((int64_t)fw * fh));
             const int y = 3 * ty - 3 + tap / 7, x = 3 * tx - 3 + tap % 7;
             if (y >= 0 && y < h && x >= 0 && x < w) {

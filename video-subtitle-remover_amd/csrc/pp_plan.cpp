@@ -145,9 +145,24 @@ bool PpModel::pack_conv(const std::string& key, ConvW& cw, int cout, int cin, in
 }
 
 // all rows, channels in place; cin % 32 != 0 -> tap-major K (k = tap*cin + ci) padded up to a multiple of 32
-bool PpModel::pack_plain(const std::string& key, ConvW& cw, int cout, int cin, int taps, std::string& err)
+// F.fold / F.unfold order the 7x7 patch vectors channel-major (element c*49 + tap).  The fold / unfold kernels want the channel
+// fastest: lanes that are neighbours in the NHWC map then read / write neighbouring floats of a token's row (a 49-float stride between
+// lanes made k_pp_fold run at 0.4 TB/s, profiles/r05_propainter_f32_kernel_stats.csv).  The token rows are GEMM outputs / inputs, so
+// their column order is free: it is the row order of the producing weight (fc1, soft composition embedding) and the K order of the
+// consuming one (fc2).  patch_perm(C)[c*49 + tap] = tap*C + c.
+static std::vector<int> patch_perm(int C)
 {
-    if (cin % VSR_GG_KC == 0) return pack_conv(key, cw, cout, cin, taps, 0, cout, iota(cin), cin, iota(cout), cout, err);
+    std::vector<int> v((size_t)C * 49);
+    for (int c = 0; c < C; ++c)
+        for (int tap = 0; tap < 49; ++tap) v[(size_t)c * 49 + tap] = tap * C + c;
+    return v;
+}
+
+bool PpModel::pack_plain(const std::string& key, ConvW& cw, int cout, int cin, int taps, std::string& err, const std::vector<int>* outPos,
+                         const std::vector<int>* ciPos)
+{
+    if (cin % VSR_GG_KC == 0 && !ciPos) return pack_conv(key, cw, cout, cin, taps, 0, cout, iota(cin), cin, outPos ? *outPos : iota(cout), cout, err);
+    if (outPos || (ciPos && taps != 1)) { err = "pack_plain: unsupported permutation for " + key; return false; }
     auto wi = raw_.find(key + ".weight"), bi = raw_.find(key + ".bias");
     if (wi == raw_.end() || bi == raw_.end()) { err = "missing key in state_dict: " + key; return false; }
     const Raw& w = wi->second;
@@ -162,7 +177,8 @@ bool PpModel::pack_plain(const std::string& key, ConvW& cw, int cout, int cin, i
     packed.resize(packed.size() + (size_t)rup((int64_t)cout * K, 32), 0.f);
     for (int n = 0; n < cout; ++n)
         for (int ci = 0; ci < cin; ++ci)
-            for (int tap = 0; tap < taps; ++tap) packed[cw.w + (int64_t)n * K + tap * cin + ci] = w.v[((int64_t)n * cin + ci) * taps + tap];
+            for (int tap = 0; tap < taps; ++tap)
+                packed[cw.w + (int64_t)n * K + tap * cin + (ciPos ? (*ciPos)[ci] : ci)] = w.v[((int64_t)n * cin + ci) * taps + tap];
     cw.b = (int64_t)packed.size();
     packed.resize(packed.size() + (size_t)rup(cout, 32), 0.f);
     for (int n = 0; n < cout; ++n) packed[cw.b + n] = bi->second.v[n];
@@ -220,7 +236,8 @@ bool PpModel::pack(std::string& err)
     if (!pack_conv("feat_prop_module.fuse.0", fuse1, 128, 258, 9, 0, 128, iota(258), 288, iota(128), 128, err)) return false;
     if (!pack_plain("feat_prop_module.fuse.2", fuse2, 128, 128, 9, err)) return false;
     if (!pack_plain("ss.embedding", ss, 512, 128, 49, err)) return false;   // Linear(128*49, 512) on unfold's (c, ky, kx) order = conv [512][128][7][7]
-    if (!pack_plain("sc.embedding", sc, 6272, 512, 1, err) || !pack_plain("sc.bias_conv", scConv, 128, 128, 9, err)) return false;
+    const std::vector<int> perm128 = patch_perm(128), perm40 = patch_perm(40);
+    if (!pack_plain("sc.embedding", sc, 6272, 512, 1, err, &perm128) || !pack_plain("sc.bias_conv", scConv, 128, 128, 9, err)) return false;
     if (!pack_plain("decoder.0.conv", dec0, 128, 128, 9, err) || !pack_plain("decoder.2", dec2, 64, 128, 9, err) ||
         !pack_plain("decoder.4.conv", dec4, 64, 64, 9, err) || !pack_plain("decoder.6", dec6, 3, 64, 9, err))
         return false;
@@ -241,8 +258,8 @@ bool PpModel::pack(std::string& err)
             for (int64_t e = 0; e < 512 * 512; ++e) packed[f.w + (int64_t)j * 512 * 512 + e] = packed[src[j]->w + e];
             for (int e = 0; e < 512; ++e) packed[f.b + j * 512 + e] = packed[src[j]->b + e];
         }
-        if (!pack_plain(p + "attention.proj", blk[i].proj, 512, 512, 1, err) || !pack_plain(p + "mlp.fc1.0", blk[i].fc1, 1960, 512, 1, err) ||
-            !pack_plain(p + "mlp.fc2.1", blk[i].fc2, 512, 1960, 1, err))
+        if (!pack_plain(p + "attention.proj", blk[i].proj, 512, 512, 1, err) || !pack_plain(p + "mlp.fc1.0", blk[i].fc1, 1960, 512, 1, err, &perm40) ||
+            !pack_plain(p + "mlp.fc2.1", blk[i].fc2, 512, 1960, 1, err, nullptr, &perm40))
             return false;
         blk[i].ln1g = push_vec(p + "norm1.weight", 512, err); blk[i].ln1b = push_vec(p + "norm1.bias", 512, err);
         blk[i].ln2g = push_vec(p + "norm2.weight", 512, err); blk[i].ln2b = push_vec(p + "norm2.bias", 512, err);

@@ -75,7 +75,8 @@ private:
     // padded channel axis of length cinPad (a multiple of 32); outPos[n] = row of output n in the padded row axis of length nPad
     bool pack_conv(const std::string& key, ConvW& cw, int cout, int cin, int taps, int r0, int nrows, const std::vector<int>& ciPos, int cinPad,
                    const std::vector<int>& outPos, int nPad, std::string& err);
-    bool pack_plain(const std::string& key, ConvW& cw, int cout, int cin, int taps, std::string& err);
+    bool pack_plain(const std::string& key, ConvW& cw, int cout, int cin, int taps, std::string& err, const std::vector<int>* outPos = nullptr,
+                    const std::vector<int>* ciPos = nullptr);   // outPos / ciPos: row / K-position permutations (patch_perm)
     int64_t push_vec(const std::string& key, int n, std::string& err);
 };
 
