@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--det-program", default="ppocr_det_graph.json", help="detector program fixture under tests/golden (server: ppocr_det_graph.json, "
                                                                           "mobile: ppocr_det_fast_graph.json)")
     ap.add_argument("--resident", default="1", choices=["0", "1"], help="0: force the host-frame loop")
+    ap.add_argument("--always-on", action="store_true", help="subtitle on every frame: ONE interval, i.e. the batch sizes batch_generator makes of "
+                                                             "the whole clip (1200 frames -> 17 x 68 + 44 for propainter, 25 x 47 + 25 for sttn-det / lama)")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--clip", default=None, help="reuse / create the input clip at this path (several runs over one clip)")
     args = ap.parse_args()
@@ -126,7 +128,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="vsr_e2e_")
     src, dst = args.clip or os.path.join(tmp, "in.y4m"), os.path.join(tmp, "out.y4m")
     # subtitle on screen 100 frames out of every 120 (ten intervals in 1200 frames)
-    on_of = lambda i: (i % 120) < 100
+    on_of = (lambda i: True) if args.always_on else (lambda i: (i % 120) < 100)
     t_gen = 0.0
     if not os.path.exists(src):
         t_gen = write_clip(src, args.frames, H, W, box, on_of)
@@ -178,7 +180,8 @@ def main():
            "frames_written": out_frames, "resident": args.resident == "1",
            "batch_lanes": int(os.environ.get("VSR_BATCH_LANES", "1")), "sttn_window_lanes": int(os.environ.get("VSR_STTN_LANES", "2")),
            "precision": os.environ.get("VSR_PP_PRECISION", "f32") if args.mode == "propainter" else "f32",
-           "clip": f"synthetic {W}x{H} y4m 4:2:0, subtitle on 100 of every 120 frames in box {box}; generated in {t_gen:.0f} s (not timed)"}
+           "clip": f"synthetic {W}x{H} y4m 4:2:0, subtitle on {'every frame' if args.always_on else '100 of every 120 frames'} in box {box}; "
+                   f"generated in {t_gen:.0f} s (not timed)"}
     print(json.dumps(res), flush=True)
     if not args.keep:
         import shutil

@@ -113,6 +113,7 @@ class PropainterInpaint:
         self.mask_dilation = 4
         self.ref_stride = 10
         self.raft_iter = 20
+        self.raft_max_pairs = int(os.environ.get("VSR_RAFT_MAX_PAIRS", "35"))      # consecutive pairs per RAFT call (see inpaint())
         di = _device_index(device)
         self.fix_raft = RaftEngine(_load(model_dir, "raft", "raft-things.pth"), device=di)
         self.fix_flow_complete = RfcEngine(_load(model_dir, "rfc", "recurrent_flow_completion.pth"), device=di)
@@ -169,8 +170,24 @@ class PropainterInpaint:
             lap.t0 = time.perf_counter()
         with torch.cuda.device(dev):
             # ---- flows (:217-247): every consecutive pair in both directions, fp32; cv2.COLOR_BGR2RGB (:192) inside the stem kernel
-            gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
-            lap("raft", lambda: self.fix_raft.flops(n, h, w, self.raft_iter))
+            # Pairs are independent (instance norm and the correlation volume are per pair), so the batch goes through RAFT in equal
+            # runs of at most raft_max_pairs consecutive pairs -- the reference does the same for its memory's sake (short_clip_len 2
+            # at this width, :221-247).  The all-pairs correlation pyramid of ONE 1920x360 pair-direction is 0.62 GB: all 67 pairs of a
+            # 68-frame batch at once made the engine's workspace 125 GB; two runs of 34 + 33 pairs need 64 GB and launch the same kernels on
+            # 734 000 GEMM rows instead of 1.45 million (three runs of 23 cost 3 % of the RAFT stage: profiles/r05_sixth_call.log).
+            npairs = n - 1
+            runs = max(1, -(-npairs // self.raft_max_pairs))
+            per = -(-npairs // runs)
+            if runs == 1:
+                gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
+            else:
+                ff, fb = [], []
+                for s0 in range(0, npairs, per):
+                    a, b = self.fix_raft.flows(bgr[s0:min(n, s0 + per + 1)], iters=self.raft_iter, bgr=True)
+                    ff.append(a)
+                    fb.append(b)
+                gt_f, gt_b = torch.cat(ff), torch.cat(fb)
+            lap("raft", lambda: sum(self.fix_raft.flops(min(n, s0 + per + 1) - s0, h, w, self.raft_iter) for s0 in range(0, npairs, per)))
             # ---- flow completion (:253-281)
             flow_length, svl = n - 1, self.sub_video_length
             if flow_length > svl:
