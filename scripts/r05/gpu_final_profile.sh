@@ -20,11 +20,47 @@ F1="$B1 --precision f16"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f16_pmc_fetch -o r -- $F1 > $OUT/f16_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/f16_pmc_write -o r -- $F1 > $OUT/f16_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/f16_pmc_sq -o r -- $F1 > $OUT/f16_pmc_sq.log 2>&1
-(timeout 400 python scripts/bench_configs.py 2>&1 | grep '^{') > $OUT/configs.log; cut -c1-250 $OUT/configs.log
+# (BASELINE configs 2-5 are inside bench.log's line now: `configs`)
+python - <<'PY'
+import json
+d = [json.loads(l) for l in open("gpurun_out/r05/bench.log") if l.startswith("{")][-1]
+print("headline", d["value"], "fps", d["ms_per_step"], "ms; GFLOP/frame", d["gflop_per_frame"], "|", d["gflop_per_frame_reference"], "roofline", d["roofline"]["achieved"], d["roofline"]["frac"], "traffic", d["roofline"]["traffic"])
+for k, v in d.get("configs", {}).items():
+    r = v.get("roofline") or {}
+    print("  config", k, v.get("value"), v.get("unit"), "|", v.get("model_tflops"), "TF |", r.get("kernel"), r.get("achieved"), r.get("frac"), v.get("error"), v.get("leg_seconds"), "s")
+PY
+# HBM traffic of config 4's kernels (separate PMC passes, as for the headline)
+P4="python scripts/bench_configs.py 4"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pp_pmc_fetch -o r -- $P4 > $OUT/pp_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pp_pmc_write -o r -- $P4 > $OUT/pp_pmc_write.log 2>&1
+python - <<'PY'
+import csv, collections, json, os
+agg = collections.defaultdict(lambda: [0, 0.0])
+for d in ("pp_pmc_fetch", "pp_pmc_write"):
+    p = os.path.join("gpurun_out/r05", d, "r_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    for row in csv.DictReader(open(p, newline="")):
+        k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+        agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
+out = {}
+for (k, c), (n, tot) in agg.items():
+    out.setdefault(k, {})[c] = {"dispatches": n, "mean_KB": tot / n}
+rows = []
+for k, v in out.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        rows.append((v["FETCH_SIZE"]["dispatches"] * (2 * v["FETCH_SIZE"]["mean_KB"] + v["WRITE_SIZE"]["mean_KB"]), k, v))
+rows.sort(reverse=True)
+res = [{"kernel": k, "launches": v["FETCH_SIZE"]["dispatches"], "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"]["mean_KB"] + v["WRITE_SIZE"]["mean_KB"]) * 1024)} for _, k, v in rows[:12]]
+json.dump({"command": "python scripts/bench_configs.py 4 (three 68-frame propainter calls)", "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950, MI355X_MICROARCH.md)", "kernels": res},
+          open("gpurun_out/r05/pp_pmc_summary.json", "w"), indent=1)
+for r in res[:6]:
+    print(r)
+PY
+rm -rf $OUT/pp_pmc_fetch $OUT/pp_pmc_write
 for a in "--res 720p --frames 300" "--res 1080p --frames 600"; do (timeout 300 python scripts/bench_cli.py $a 2>/dev/null | grep '^{') >> $OUT/cli.log; done; cut -c1-200 $OUT/cli.log
-for corrupt in 0 1; do
-  VSR_BENCH_DRYRUN_1GPU=1 VSR_BENCH_SELFTEST_CORRUPT=$corrupt timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-    --master-port 2951$corrupt bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/dryrun_2ranks_corrupt$corrupt.log 2>&1
+for corrupt in 0 1; do      # (no launcher: bench.py starts its own ranks)
+  VSR_BENCH_DRYRUN_1GPU=1 VSR_BENCH_SELFTEST_CORRUPT=$corrupt timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/dryrun_2ranks_corrupt$corrupt.log 2>&1
   echo "corrupt=$corrupt rc=$?"; grep -o '"selftest": {[^}]*}' $OUT/dryrun_2ranks_corrupt$corrupt.log | cut -c1-300; grep "SELFTEST" $OUT/dryrun_2ranks_corrupt$corrupt.log
   grep -o '"value": [0-9.]*, "unit": "frames/s", "n_gpus": 2' $OUT/dryrun_2ranks_corrupt$corrupt.log
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, end of round: the whole GPU suite + smoke() with the final library
+# round 5, end of round: the whole GPU suite + smoke() with the final library
 OUT=gpurun_out/r05; mkdir -p $OUT
 (timeout 1500 python -m pytest tests -m gpu -q --tb=short --durations=8 2>&1 | tail -60) > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log

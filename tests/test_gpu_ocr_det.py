@@ -74,6 +74,17 @@ def test_gemm_convs_agree_with_direct_convs(built_lib, gpu_device, fixture, H, W
     print(f"{fixture}: {n_plans} convs on the gather-GEMM; err vs fp64 {ea:.2e} (GEMM) / {eb:.2e} (direct) / {cpu32:.2e} (fp32 CPU)")
     assert n_plans > 10 and len(r._gemm) == n_plans and torch.equal(a, a2)
     assert ea <= 1e-4 and eb <= 1e-4                                   # absolute, on calibrated weights (round 3)
+    # round 5: the server program's 64 -> 64 2x2 transposed conv runs as a GEMM too (bias on the GEMM, batch_norm + ReLU on the
+    # pass that writes its result); the mobile program's 24-channel one stays on the direct kernel
+    n_deconv = sum(1 for k in r._gemm if k[0] == "deconv")
+    assert n_deconv == (1 if fixture == "ppocr_det_graph.json" else 0)
+    if n_deconv:
+        r.use_gemm, r.deconv_gemm = True, False
+        c = r.run(x).clone()
+        torch.cuda.synchronize()
+        ec = (c.cpu().double() - ref64).abs().max().item()
+        print(f"{fixture}: transposed conv on the direct kernel instead: err vs fp64 {ec:.2e}; GEMM form vs direct {(a - c).abs().max().item():.2e}")
+        assert ec <= 1e-4
     r.close()
 
 

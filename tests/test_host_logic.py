@@ -140,10 +140,21 @@ def test_mask_rows_promise_from_the_host_mask(built_lib, monkeypatch):
             assert a.value <= (lo + 0.5) * 640 / W - 0.5 and b.value >= (hi - 0.5) * 640 / W - 0.5 + 1 or b.value == 640
             assert lib.vsr_sttn_flops_box(eng._h, 50, 76, 120, a.value, b.value) < lib.vsr_sttn_flops_rows(eng._h, 50, 76, 120)
         assert lib.vsr_sttn_decode_cols(eng._h, W, 5, 5, C.byref(a), C.byref(b)) != 0             # an empty promise is an error
-        monkeypatch.setenv("VSR_DECODE_COLS", "1")     # chunk_flops prices what the engine would run with the switch on
-        with_cols = eng.chunk_flops(50, mask[:, :, 0], areas)
+        # chunk_flops prices what the engine runs: the host side asks the LIBRARY how it read the switch (once per process), so an
+        # environment change in mid-process cannot make the two disagree; with the columns on (default since round 5) a
+        # chunk costs less than the rows promise alone
+        from vsr_amd import switches
+
+        monkeypatch.setenv("VSR_DECODE_COLS", "0" if switches.on("VSR_DECODE_COLS") else "1")
+        assert switches.on("VSR_DECODE_COLS") == (lib.vsr_switch_state(b"VSR_DECODE_COLS") == 1)
         monkeypatch.delenv("VSR_DECODE_COLS")
-        assert with_cols < eng.chunk_flops(50, mask[:, :, 0], areas)
+        rows_only = 0.0
+        for (ymin, ymax, _, _), (lo, hi) in zip(areas, eng.mask_rows(mask[:, :, 0], areas)):
+            a, b = C.c_int32(), C.c_int32()
+            assert lib.vsr_sttn_decode_rows(eng._h, int(ymax - ymin), int(lo), int(hi), C.byref(a), C.byref(b)) == 0
+            rows_only += lib.vsr_sttn_flops_rows(eng._h, 50, a.value, b.value)
+        priced = eng.chunk_flops(50, mask[:, :, 0], areas)
+        assert priced < rows_only if switches.on("VSR_DECODE_COLS") else priced == rows_only
     finally:
         eng.close()
 

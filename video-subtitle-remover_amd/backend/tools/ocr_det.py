@@ -116,6 +116,52 @@ def conv_fusions(graph):
     return fuse
 
 
+def deconv_fusions(graph):
+    """Per conv2d_transpose op, the chain that can ride on its GEMM form (PaddleGraphRunner._deconv_gemm): {op index: (bias, bn, act)}
+    with bias = None | (add op index, id of the bias parameter) -- folded into the GEMM's bias --, bn = None | batch_norm_ op index and
+    act = None | (op index, 1 relu / 2 hardswish) -- both applied by the pass that writes the NCHW result; every folded intermediate
+    has exactly one reader."""
+    uses, consumer, producer = {}, {}, {}
+    for i, (kind, ins, outs, a) in enumerate(graph.ops):
+        for v in ins:
+            uses[v] = uses.get(v, 0) + 1
+            consumer.setdefault(v, []).append(i)
+        for v in outs:
+            producer[v] = i
+    uses[graph.output_id] = uses.get(graph.output_id, 0) + 1
+
+    def sole_reader(v):
+        c = consumer.get(v, [])
+        return c[0] if uses.get(v, 0) == 1 and len(c) == 1 else None
+
+    def param_behind(v):
+        if v in graph.params:
+            return v
+        j = producer.get(v)
+        return graph.ops[j][1][0] if j is not None and graph.ops[j][0] == "reshape" and graph.ops[j][1][0] in graph.params else None
+
+    fuse = {}
+    for i, (kind, ins, outs, a) in enumerate(graph.ops):
+        if kind != "conv2d_transpose":
+            continue
+        bias = bn = act = None
+        cur = outs[0]
+        j = sole_reader(cur)
+        if j is not None and graph.ops[j][0] == "add" and len(graph.ops[j][1]) == 2:
+            i2 = graph.ops[j][1]
+            pb = param_behind(i2[1] if i2[0] == cur else i2[0])
+            if pb is not None:
+                bias, cur = (j, pb), graph.ops[j][2][0]
+                j = sole_reader(cur)
+        if j is not None and graph.ops[j][0] == "batch_norm_" and graph.ops[j][1][0] == cur:
+            bn, cur = j, graph.ops[j][2][0]
+            j = sole_reader(cur)
+        if (bias is not None or bn is not None) and j is not None and graph.ops[j][0] in ("relu", "hardswish"):
+            act = (j, 1 if graph.ops[j][0] == "relu" else 2)
+        fuse[i] = (bias, bn, act)
+    return fuse
+
+
 def pack_conv_weights(w, cp):
     """[cout][cin][kh][kw] -> [cout][(ky, kx, channel padded to cp)], the K order of conv_gemm_layout"""
     cout, cin, kh, kw = w.shape
@@ -150,10 +196,12 @@ class PaddleGraphRunner:
                 s = gamma / torch.sqrt(var + a["epsilon"])
                 self.bn[i] = (s.float().contiguous(), (beta - mean * s).float().contiguous())
         self._fuse = conv_fusions(graph)      # conv op index -> (bn op index or None, relu op index or None)
+        self._dfuse = deconv_fusions(graph)   # conv2d_transpose op index -> (bias, bn, act) riding on its GEMM form
         self._one = {}
         self._graphs = {}                     # input shape -> (captured graph, static input, static output)
         self._gemm = {}                       # (conv op index, input shape) -> resident plan, tables, buffers
         self.use_gemm = os.environ.get("VSR_DET_GEMM", "1") != "0"
+        self.deconv_gemm = os.environ.get("VSR_DET_DECONV_GEMM", "1") != "0"     # 0: the 2x2 transposed convs stay on the direct kernel
         self._sa = C.c_void_p(0)              # the stream argument every launch shares (set per run / replay)
         self._tape = None                     # launches being recorded: [(C function, argument tuple)]
         self._tapes = {}                      # input shape -> (tape, static input, output, tensors kept alive)
@@ -285,6 +333,68 @@ class PaddleGraphRunner:
                                               _p(out), self._sa)
         return out, [j for j in (affine[1] if affine is not None else None, act[0] if act is not None else None) if j is not None]
 
+    def _deconv_gemm(self, i, xin, w):
+        """conv2d_transpose 2x2 / stride 2 (dense, Cin and Cout whole 32-float chunks) as ONE gather-GEMM: every input pixel is a row,
+        the columns are (dy, dx, cout) -- out[2y+dy][2x+dx][co] = sum_ci x[y][x][ci] * W[ci][co][dy][dx] -- and the C tables scatter the
+        four taps of a row to their places in the NHWC image [n][2h][2w][cout]; the bias add that follows rides on the GEMM's bias, the
+        batch_norm / activation on the pass that writes the NCHW result.  (The direct kernel spent 5.3 ms on the 64 -> 64 deconv of a
+        16-frame forward, profiles/r05_detector_kernel_stats.csv: one thread per output element looping over Cin.)
+        Returns (output NCHW, op indices folded into it)."""
+        nb, cin, h, wd = xin.shape
+        cout = int(w.shape[1])
+        key = ("deconv", i, tuple(xin.shape))
+        bias, bn, act = self._dfuse.get(i, (None, None, None))
+        st = self._gemm.get(key)
+        if st is None:
+            dev = self.device
+            M, N, K = nb * h * wd, 4 * cout, cin
+            bm, bn_, cfg = 128, 128, TILE_128x128
+            tiles_m, tiles_n = -(-M // bm), -(-N // bn_)
+            if nb * 4 * h * wd * cout >= 2 ** 31 or M * cin >= 2 ** 31:
+                raise ValueError("transposed convolution too large for 32-bit offset tables")
+            img, pix = np.divmod(np.arange(M, dtype=np.int64), h * wd)
+            y, x = np.divmod(pix, wd)
+            row_a = np.zeros(tiles_m * bm, np.int64)
+            row_a[:M] = np.arange(M, dtype=np.int64) * cin
+            row_c = np.zeros(tiles_m * bm, np.int64)
+            row_c[:M] = ((img * 2 * h + 2 * y) * 2 * wd + 2 * x) * cout
+            tap, cc = np.divmod(np.arange(tiles_n * bn_ // 32, dtype=np.int64), cout // 32)
+            tap = np.minimum(tap, 3)                                    # (columns beyond N are never stored)
+            col_c = ((tap // 2) * 2 * wd + tap % 2) * cout + cc * 32
+            row_b = np.zeros(tiles_n * bn_, np.int64)
+            row_b[:N] = np.arange(N, dtype=np.int64) * K
+            tabs = dict(rowA=row_a, colA=np.arange(K // 32, dtype=np.int64) * 32, rowB=row_b, colB=np.arange(K // 32, dtype=np.int64) * 32,
+                        rowC=row_c, colC=col_c)
+            wn = np.asarray(w.cpu().numpy(), np.float32)                # [cin][cout][2][2] -> B[(dy, dx, co)][ci]
+            wp = np.ascontiguousarray(wn.transpose(2, 3, 1, 0).reshape(N, K))
+            bvec = np.zeros(tiles_n * bn_, np.float32)
+            if bias is not None:
+                bvec[:N] = np.tile(self.params[bias[1]].reshape(-1).cpu().numpy().astype(np.float32), 4)
+            st = dict(tabs={k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in tabs.items()}, wp=torch.from_numpy(wp).to(dev),
+                      bias=torch.from_numpy(bvec).to(dev), a=torch.empty(M * cin, dtype=torch.float32, device=dev),
+                      c=torch.empty(nb * 4 * h * wd * cout, dtype=torch.float32, device=dev), M=M, N=N)
+            pr = (_lib.GGProblem * 1)()
+            q, t = pr[0], st["tabs"]
+            q.A, q.B, q.C, q.bias, q.R = st["a"].data_ptr(), st["wp"].data_ptr(), st["c"].data_ptr(), st["bias"].data_ptr() if bias is not None else None, None
+            q.rowA, q.colA, q.rowB, q.colB = t["rowA"].data_ptr(), t["colA"].data_ptr(), t["rowB"].data_ptr(), t["colB"].data_ptr()
+            q.rowC, q.colC, q.rowR = t["rowC"].data_ptr(), t["colC"].data_ptr(), None
+            q.M, q.N, q.K, q.tilesM, q.tilesN = M, N, K, tiles_m, tiles_n
+            q.splitK, q.chunksPerSplit, q.act, q.alpha, q.splitStride = 1, K // 32, 0, 1.0, 0
+            plan = C.c_void_p()
+            check(lib.vsr_gemm_plan_create(pr, 1, cfg, BMODE_NK, 3, C.byref(plan)))
+            st["plan"] = plan
+            self._gemm[key] = st
+        self._call(lib.vsr_det_launch_nchw_to_nhwc, _p(xin), nb, cin, h, wd, 0, 0, h, wd, cin, _p(st["a"]), self._sa)
+        self._call(lib.vsr_gemm_plan_run, st["plan"], self._sa)
+        scale = shift = None
+        if bn is not None:
+            scale, shift = self.bn[bn]
+        out = self._new(nb, cout, 2 * h, 2 * wd)
+        self._call(lib.vsr_det_launch_nhwc_to_nchw, _p(st["c"]), nb, cout, 4 * h * wd, cout, _p(scale), _p(shift), act[1] if act is not None else 0,
+                   _p(out), self._sa)
+        done = [j for j in (bias[0] if bias is not None else None, bn, act[0] if act is not None else None) if j is not None]
+        return out, done
+
     def _ones(self, n):
         if n not in self._one:
             self._one[n] = torch.ones(n, dtype=torch.float32, device=self.device)
@@ -367,6 +477,12 @@ class PaddleGraphRunner:
                     dw = 1 if a["groups"] == cin and a["groups"] > 1 else 0
                     cout = cin if dw else w.shape[1]
                     fl += 2.0 * n * h * wd * 4 * cout * (1 if dw else cin)
+                    if self.use_gemm and self.deconv_gemm and not dw and a["groups"] == 1 and cin % 32 == 0 and cout % 32 == 0:
+                        out, done = self._deconv_gemm(i, xin, w)
+                        # a chain is folded only as a whole prefix: bias alone, bias + bn, bias + bn + act (deconv_fusions builds it so)
+                        folded.update({j: out for j in done})
+                        val[outs[0]] = out
+                        continue
                     out = self._new(n, cout, 2 * h, 2 * wd)
                     self._call(lib.vsr_det_launch_deconv2x2, _p(xin), _p(w), n, cin, h, wd, cout, dw, _p(out), self._sa)
                     val[outs[0]] = out
