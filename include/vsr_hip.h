@@ -89,7 +89,7 @@ int vsr_sttn_auto_chunk(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W,
 int vsr_sttn_auto_chunk_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
                              int n_areas, const int32_t* areas, const int32_t* mask_rows, const int32_t* sel, int nsel, void* stream);
 /* ... and about its columns: mask_cols host [n_areas][2] = the frame columns [lo, hi) outside which the mask is zero.  The GEMMs of
- * the decoder and of the last block then take rectangles.  Built and replayed on the CPU in round 4, not yet run on a GPU: calling
+ * the decoder and of the last block then take rectangles.  Built and replayed on the CPU in round 4, run on the GPU in round 5 (bit-equal frames; the default of the Python side since): calling
  * this entry point is the opt-in (the Python side does so with its VSR_DECODE_COLS switch); VSR_DECODE_COLS=0 in the environment makes
  * it ignore mask_cols (= vsr_sttn_auto_chunk_rows). */
 int vsr_sttn_auto_chunk_box(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, int W, const uint8_t* mask_dev,
@@ -377,8 +377,8 @@ int vsr_pp_forward(vsr_pp_t* h, const float* frames_dev, const float* flows_f_de
 /* The same with a promise of the caller: of the output it reads rows [row_lo, row_hi) and columns [col_lo, col_hi) only (the
  * plugin blends a window's prediction into its frames under the dilated mask, propainter_inpaint.py:350-357); lo = hi = 0: the
  * whole axis.  The soft composition's embedding and the decoder's convs then run on what that box depends on; inside it the
- * output is the one of vsr_pp_forward, outside it is undefined.  (Built and replayed on the CPU in round 4; the plugin passes the
- * promise only with VSR_PP_DECODE_BOX=1 until it has run on a GPU.) */
+ * output is the one of vsr_pp_forward, outside it is undefined.  (Built and replayed on the CPU in round 4, run on the GPU in round 5: the plugin's
+ * default since; VSR_PP_DECODE_BOX=0 makes it promise nothing.) */
 int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_f_dev, const float* flows_b_dev,
                        const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int t, int lt, int H, int W,
                        const uint8_t* window_flags, int nflags, int row_lo, int row_hi, int col_lo, int col_hi, float* out_dev, void* stream);
@@ -395,7 +395,8 @@ double vsr_pp_flops_box(vsr_pp_t* h, int t, int lt, int H, int W, const uint8_t*
  *   vsr_pp_forward_cached vsr_pp_forward_box without the encoder: cache_idx (host, t entries) names for each of the lt local frames
  *                         its entry of the feature cache and for each reference frame its entry of the token cache.
  * Same GEMM rows in the same K order as in vsr_pp_forward: the output is the same.  Built and replayed on the CPU in round 4
- * (tests/test_pp_replay.py::test_generator_replay_encoder_cache), not yet run on a GPU: the plugin uses it with VSR_PP_ENC_CACHE=1. */
+ * (tests/test_pp_replay.py::test_generator_replay_encoder_cache) and on the GPU in round 5 (tests/test_gpu_pp.py::test_generator_encoder_cache:
+ * bit equality with vsr_pp_forward); the plugin's default since (VSR_PP_ENC_CACHE=0 restores the per-window encoder). */
 int vsr_pp_encode(vsr_pp_t* h, const float* frames_dev, const uint8_t* masks_in_dev, const uint8_t* masks_updated_dev, int n, int ntok_frames,
                   int H, int W, float* feat_out_dev, float* tok_out_dev, void* stream);
 int vsr_pp_forward_cached(vsr_pp_t* h, const float* feat_cache_dev, const float* tok_cache_dev, const int32_t* cache_idx,

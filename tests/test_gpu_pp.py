@@ -91,7 +91,7 @@ def test_generator_strip_size_smoke(gen_engine, gpu_device):
 
 
 @pytest.mark.skipif(not switches.on("VSR_PP_DECODE_BOX"),
-                    reason="the generator's decoder box is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_PP_DECODE_BOX=1 pytest -k decoder_box")
+                    reason="the generator's decoder box is switched off (VSR_PP_DECODE_BOX=0; default on since round 5)")
 @pytest.mark.parametrize("box", [(224, 360, 0, 0), (224, 360, 280, 1640), (0, 64, 0, 512), (120, 200, 1400, 1920)])
 def test_generator_decoder_box(gen_engine, gpu_device, box):
     """vsr_pp_forward_box at the 1080p strip size: inside the promised box the output is the one of the call without a promise bit
@@ -111,7 +111,7 @@ def test_generator_decoder_box(gen_engine, gpu_device, box):
 
 
 @pytest.mark.skipif(not switches.on("VSR_PP_ENC_CACHE"),
-                    reason="the per-frame encoder cache is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_PP_ENC_CACHE=1 pytest -k encoder_cache")
+                    reason="the per-frame encoder cache is switched off (VSR_PP_ENC_CACHE=0; default on since round 5)")
 @pytest.mark.parametrize("t,lt,H,W", [(5, 3, 128, 192), (15, 11, 360, 1920)])
 def test_generator_encoder_cache(gen_engine, gpu_device, t, lt, H, W):
     """vsr_pp_encode + vsr_pp_forward_cached: the frames encoded once, in two calls and in another order than the window's, give the

@@ -400,7 +400,7 @@ def test_decoder_rows_give_the_same_frames(built_lib, gpu_device, sd, mode, H, W
 
 
 @pytest.mark.skipif(not switches.on("VSR_DECODE_COLS"),
-                    reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
+                    reason="column ranges are switched off (VSR_DECODE_COLS=0; default on since round 5)")
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("H,W,boxes", [
     (720, 1280, [(620, 700, 400, 900)]),                           # a centred line: columns [400, 900) of 1280
@@ -454,7 +454,7 @@ def test_decoder_rows_give_the_same_frames_det(built_lib, gpu_device, sd_det, H,
 
 
 @pytest.mark.skipif(not switches.on("VSR_DECODE_COLS"),
-                    reason="column ranges are opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_DECODE_COLS=1 pytest -k decoder_box")
+                    reason="column ranges are switched off (VSR_DECODE_COLS=0; default on since round 5)")
 @pytest.mark.parametrize("H,W,box", [(720, 1280, (620, 700, 400, 900)), (1080, 1920, (40, 160, 1500, 1900)), (480, 852, (150, 400, 0, 200))])
 def test_decoder_box_gives_the_same_frames_det(built_lib, gpu_device, sd_det, H, W, box):
     """vsr_sttn_det_batch_box with VSR_DECODE_COLS=1: the frames are those of the call without a promise, bit for bit"""
@@ -477,7 +477,7 @@ def test_decoder_box_gives_the_same_frames_det(built_lib, gpu_device, sd_det, H,
 
 
 @pytest.mark.skipif(not switches.on("VSR_QKV0_SHARED"),
-                    reason="the shared first-block q/k/v is opt-in (built and CPU-replayed in round 4, not yet run on a GPU): VSR_QKV0_SHARED=1 pytest -k shared_first")
+                    reason="the shared first-block q/k/v is switched off (VSR_QKV0_SHARED=0; default on since round 5)")
 @pytest.mark.parametrize("L,H,W,lanes", [(50, 1080, 1920, 2), (23, 720, 1280, 1), (7, 480, 852, 3)])
 def test_shared_first_block_qkv_gives_the_same_frames(built_lib, gpu_device, L, H, W, lanes):
     """VSR_QKV0_SHARED (read once per process, hence two children): the first block's q/k/v once per frame of the chunk instead of once

@@ -6,7 +6,8 @@ Mirrors backend/inpaint/propainter_inpaint.py:
       inpaint(frames, mask) -> comp frames                                    :190-361
   read_mask :32-77 (numpy-mask branch), get_ref_index :122-136
 All network arithmetic happens in libvsr_hip.so (RAFT, flow completion, image propagation, generator: vsr_raft_* /
-vsr_rfc_* / vsr_pp_*), in exact fp32 -- `use_fp16` is accepted for signature compatibility and ignored.  This file is the
+vsr_rfc_* / vsr_pp_*), in exact fp32 by default; `precision="f16"` is the reference's own GPU arithmetic (flow completion and generator on
+fp16 operands with fp32 accumulation, RAFT fp32) -- `use_fp16` itself is accepted for signature compatibility.  This file is the
 host loop: mask dilation (scipy, once per batch, as in the reference), sub-video / neighbour / reference schedules.  The frames
 stay in HBM as uint8 BGR from upload to download; normalise + mask, compose and the u8 blend of overlapping windows are kernels.  `model_dir` may also be a dict
 {"raft": sd, "rfc": sd, "propainter": sd} of already loaded state_dicts (the shipped checkpoints are missing blobs).
@@ -233,8 +234,8 @@ class PropainterInpaint:
             flags_cache = {}
             # The window's prediction is blended in under the dilated mask only (vsr_pp_blend_window below, :350-357): with the promise
             # about those rows / columns the generator's decoder runs on what they depend on (vsr_pp_forward_box; whole groups of
-            # eight, so that the boxes of a video that differ by a few pixels share their plans).  Built and replayed on the CPU in
-            # round 4, not yet run on a GPU: opt-in.
+            # eight, so that the boxes of a video that differ by a few pixels share their plans).  GPU-tested in round 5, default ON
+            # (VSR_PP_DECODE_BOX=0: no promise).
             box = None
             if switches.on("VSR_PP_DECODE_BOX") and md.any():
                 ys, xs = np.flatnonzero(md.any(axis=1)), np.flatnonzero(md.any(axis=0))
@@ -244,8 +245,8 @@ class PropainterInpaint:
                 nb = [i for i in range(max(0, f - stride), min(n, f + stride + 1))]
                 windows.append((nb, get_ref_index(f, nb, n, self.ref_stride, ref_num)))
             # The encoder (and a reference frame's soft split) is a per-frame function and the windows overlap: with the switch on every
-            # frame is encoded once per call instead of once per window it appears in (vsr_pp_encode / vsr_pp_forward_cached).  Built and
-            # replayed on the CPU in round 4, not yet run on a GPU: opt-in.
+            # frame is encoded once per call instead of once per window it appears in (vsr_pp_encode / vsr_pp_forward_cached).  GPU-tested in
+            # round 5, default ON (VSR_PP_ENC_CACHE=0: the encoder once per window, as InpaintGenerator.forward does).
             enc_cache = None
             if switches.on("VSR_PP_ENC_CACHE"):
                 calls, feat_slot, tok_slot = encoder_cache_plan(windows)

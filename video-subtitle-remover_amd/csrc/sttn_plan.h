@@ -37,7 +37,7 @@ struct Tuning {
     int convChannelMajor; // VSR_CONV_KORDER: 1 = K ordered (channel-chunk, tap), 0 = (tap, channel-chunk)
     int outConvBlocked;  // VSR_OUT_CONV_BLOCKED: 1 = the 64 -> 3 output conv runs over 2x4 output blocks (Model::pack_conv_blocked)
     int shareQkv0;       // VSR_QKV0_SHARED: 1 = the first block's q/k/v once per frame of the chunk (BUF_QKV0) instead of once per window;
-                         // built and replayed on the CPU in round 4, not yet run on a GPU: default 0
+                         // built and replayed on the CPU in round 4, bit-equal frames on the GPU in round 5: the Python side exports 1 (switches.py)
     int trimLastBlock;   // VSR_TRIM_LAST_BLOCK: 1 = the last transformer block of a window computes its attention output, out-conv and
                          //   FFN for the NEIGHBOUR frames only -- the decoder reads nothing else (Plan::buildWindow); same bits
     int fuseSoftmax;     // VSR_FUSE_SOFTMAX: 1 = exact-fp32 mode keeps no probability matrix for the scales whose scores are not
