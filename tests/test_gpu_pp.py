@@ -168,3 +168,31 @@ def test_propainter_plugin_matches_oracle(built_lib, gpu_device, pp_sd):
     dmax = np.abs(g - r).max()
     print(f"propainter plugin: PSNR vs oracle on repainted pixels {psnr:.1f} dB, max |d| {dmax:.0f}, repainted {changed.mean():.3f} of the frame")
     assert psnr >= 50.0
+
+
+@pytest.mark.parametrize("precision,lanes", [("f32", 2), ("f32", 3), ("f16", 2)])
+def test_generator_window_lanes_give_the_same_frames(built_lib, gpu_device, pp_sd, precision, lanes):
+    """VSR_PP_LANES / PropainterInpaint.gen_lanes: the sliding windows of a call alternate over generator instances on their own
+    streams, the blends chained in window order -- the frames are those of the single-stream loop bit for bit, repeatedly (a race
+    would show as run-to-run differences); 23 frames = five windows, reference frames included.  In the guarded arithmetics ("f16")
+    every lane has a host thread of its own (each generator call ends with a read of the range flag)."""
+    from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+    from vsr_amd.backend.tools.inpaint_tools import create_mask
+    from vsr_amd.synth import make_clip, make_raft_state_dict, make_rfc_state_dict
+
+    H, W, n = 288, 704, 23
+    box = (236, 268, 120, 600)
+    frames = list(make_clip(n, H, W, box, seed=8))
+    mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
+    sds = {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": pp_sd}
+    plug = PropainterInpaint("cuda:0", sds, precision=precision)
+    plug.raft_iter = 3
+    plug.gen_lanes = 1
+    want = np.stack(plug(frames, mask))
+    plug.gen_lanes = lanes
+    for _ in range(3):
+        got = np.stack(plug(frames, mask))
+        assert np.array_equal(got, want)
+    assert len(plug._lane_models) == lanes - 1
+    plug.close()
+    assert (want != np.stack(frames)).any()

@@ -12,8 +12,10 @@ host loop: mask dilation (scipy, once per batch, as in the reference), sub-video
 stay in HBM as uint8 BGR from upload to download; normalise + mask, compose and the u8 blend of overlapping windows are kernels.  `model_dir` may also be a dict
 {"raft": sd, "rfc": sd, "propainter": sd} of already loaded state_dicts (the shipped checkpoints are missing blobs).
 """
+import contextlib
 import ctypes as C
 import os
+import threading
 import time
 
 import numpy as np
@@ -115,6 +117,8 @@ class PropainterInpaint:
         self.ref_stride = 10
         self.raft_iter = 20
         self.raft_max_pairs = int(os.environ.get("VSR_RAFT_MAX_PAIRS", "35"))      # consecutive pairs per RAFT call (see inpaint())
+        self.gen_lanes = int(os.environ.get("VSR_PP_LANES", "2"))                  # generator instances the sliding windows alternate over
+        self._lane_models, self._streams = {}, None
         di = _device_index(device)
         self.fix_raft = RaftEngine(_load(model_dir, "raft", "raft-things.pth"), device=di)
         self.fix_flow_complete = RfcEngine(_load(model_dir, "rfc", "recurrent_flow_completion.pth"), device=di)
@@ -133,9 +137,25 @@ class PropainterInpaint:
         other.raft_iter = self.raft_iter
         return other
 
+    def _lane_model(self, k):
+        """the generator instance of window lane k >= 1: same checkpoint and arithmetic, its own workspace (built on first use)"""
+        if k not in self._lane_models:
+            e = PpEngine(device=self.model.device_index, state_dict=_load(self.model_dir, "propainter", "ProPainter.pth"))
+            mode = self.PRECISIONS[self.precision][2]
+            if mode != "f32":
+                e.set_precision(mode)
+            self._lane_models[k] = e
+        return self._lane_models[k]
+
+    def _lane_streams(self, lanes, dev):
+        if self._streams is None or len(self._streams) < lanes:
+            self._streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+        return self._streams[:lanes]
+
     def close(self):
-        for e in (self.fix_raft, self.fix_flow_complete, self.model):
+        for e in [self.fix_raft, self.fix_flow_complete, self.model] + list(self._lane_models.values()):
             e.close()
+        self._lane_models = {}
 
     def inpaint(self, frames, mask):
         """frames: list of HxWx3 uint8 BGR crops (H, W multiples of 8), mask: HxW(x1) uint8 -> list of HxWx3 uint8 BGR.
@@ -258,32 +278,92 @@ class PropainterInpaint:
                 enc_cache = (torch.cat(fc), torch.cat(tc) if tok_slot else None)
                 if prof is not None:
                     lap("generator", lambda: sum(self.model.plan_flops(len(cids), ntok, h, w, [], None, 1) for cids, ntok in calls))
-            for nb, ref in windows:
-                ids = nb + ref
-                l_t = len(nb)
-                if l_t not in flags_cache:                                                  # the same mask on every frame
-                    flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
-                if enc_cache is not None:
-                    pred = self.model.forward_cached(enc_cache[0], enc_cache[1], [feat_slot[i] for i in nb] + [tok_slot[i] for i in ref],
-                                                     pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(), md_dev[ids].contiguous(),
-                                                     updated_masks[ids].contiguous(), l_t, h, w, flags_cache[l_t], box=box)
-                else:
-                    pred = self.model.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
-                                              md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t], box=box)
-                idx = torch.tensor(nb, dtype=torch.int32).to(dev, non_blocking=True)
-                first = torch.tensor([0 if visited[i] else 1 for i in nb], dtype=torch.int32).to(dev, non_blocking=True)
-                check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), stream()))
+            # Generator lanes (VSR_PP_LANES, round 5): the windows are independent until their predictions are blended into `comp` in
+            # window order -- as the STTN engine's window lanes, window k runs on lane k % lanes: its own generator instance (own
+            # workspace, same weights) on its own stream, the blends chained by events in window order.  What overlaps is one
+            # window's small / memory-bound launches (propagation steps, softmax, fold) with the other's GEMMs.
+            lanes = 1 if (prof is not None or len(windows) < 2) else max(1, min(self.gen_lanes, len(windows)))
+            engines = [self.model] + [self._lane_model(k) for k in range(1, lanes)]
+            if lanes > 1:
+                main = torch.cuda.current_stream(dev)
+                ready = torch.cuda.Event()
+                ready.record(main)                                                              # flows, masks, encoder cache are complete
+                lane_streams = self._lane_streams(lanes, dev)
+                for st in lane_streams:
+                    st.wait_event(ready)
+            # which frames a window sees first is a function of the window order alone
+            firsts = []
+            for nb, _ in windows:
+                firsts.append([0 if visited[i] else 1 for i in nb])
                 for i in nb:
                     visited[i] = True
-                if prof is not None:
-                    key = (len(ids), l_t, enc_cache is not None)
+            for l_t in sorted({len(nb) for nb, _ in windows}):                              # the same mask on every frame
+                flags_cache[l_t] = self.model.window_flags(np.repeat(md[None], l_t, 0))
+            blend_ev = [None] * len(windows)                                                # CUDA event after window k's blend
+            blend_set = [threading.Event() for _ in windows]                                # ... and "it has been recorded" (host side)
 
-                    def window_flops(key=key, ids=ids, l_t=l_t):
-                        if key not in flags_cache:
-                            flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
-                        return flags_cache[key]
+            def run_window(k):
+                nb, ref = windows[k]
+                ids, l_t, eng = nb + ref, len(nb), engines[k % lanes]
+                ctx = torch.cuda.stream(lane_streams[k % lanes]) if lanes > 1 else contextlib.nullcontext()
+                try:
+                    with torch.cuda.device(dev), ctx:
+                        if enc_cache is not None:
+                            pred = eng.forward_cached(enc_cache[0], enc_cache[1], [feat_slot[i] for i in nb] + [tok_slot[i] for i in ref],
+                                                      pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(), md_dev[ids].contiguous(),
+                                                      updated_masks[ids].contiguous(), l_t, h, w, flags_cache[l_t], box=box)
+                        else:
+                            pred = eng.forward(updated_frames[ids].contiguous(), pred_f[nb[:-1]].contiguous(), pred_b[nb[:-1]].contiguous(),
+                                               md_dev[ids].contiguous(), updated_masks[ids].contiguous(), l_t, flags=flags_cache[l_t], box=box)
+                        idx = torch.tensor(nb, dtype=torch.int32).to(dev, non_blocking=True)
+                        first = torch.tensor(firsts[k], dtype=torch.int32).to(dev, non_blocking=True)
+                        cur = torch.cuda.current_stream(dev)
+                        if lanes > 1 and k > 0:
+                            blend_set[k - 1].wait()                                         # (threaded lanes: window k - 1 runs on another thread)
+                            if blend_ev[k - 1] is not None:
+                                cur.wait_event(blend_ev[k - 1])                             # the running average is taken in window order
+                        check(lib.vsr_pp_blend_window(P(pred), P(bgr), P(md1), P(idx), P(first), l_t, h, w, P(comp), C.c_void_p(cur.cuda_stream)))
+                        if lanes > 1:
+                            ev = torch.cuda.Event()
+                            ev.record(cur)
+                            blend_ev[k] = ev
+                finally:
+                    blend_set[k].set()                                                      # also after an error: nobody waits forever
 
-                    lap("generator", window_flops)
+            # In the guarded arithmetics (fp16 operands / split-half) every generator call ends with a read of the range flag, i.e. the
+            # host waits for the window: the lanes then need a host thread each, or the second lane would never be fed while the first
+            # one is waited for.  (ctypes releases the GIL for the duration of a library call.)
+            threaded = lanes > 1 and self.PRECISIONS[self.precision][2] != "f32"
+            if threaded:
+                from concurrent.futures import ThreadPoolExecutor
+
+                pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"vsr-pp-lane{j}") for j in range(lanes)]
+                try:
+                    futs = [pools[k % lanes].submit(run_window, k) for k in range(len(windows))]
+                    for f in futs:
+                        f.result()
+                finally:
+                    for pl in pools:
+                        pl.shutdown(wait=True)
+            else:
+                for k in range(len(windows)):
+                    run_window(k)
+                    if prof is not None:
+                        nb, ref = windows[k]
+                        ids, l_t = nb + ref, len(nb)
+                        key = (len(ids), l_t, enc_cache is not None)
+
+                        def window_flops(key=key, ids=ids, l_t=l_t):
+                            if key not in flags_cache:
+                                flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
+                            return flags_cache[key]
+
+                        lap("generator", window_flops)
+            if lanes > 1:
+                for st in lane_streams:                                                         # the caller's stream ends behind every lane
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    main.wait_event(ev)
             if resident:
                 return comp
             out = comp.cpu().numpy()                                                        # already BGR (:360)
