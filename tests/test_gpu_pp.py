@@ -196,3 +196,28 @@ def test_generator_window_lanes_give_the_same_frames(built_lib, gpu_device, pp_s
     assert len(plug._lane_models) == lanes - 1
     plug.close()
     assert (want != np.stack(frames)).any()
+
+
+def test_raft_run_lanes_give_the_same_frames(built_lib, gpu_device, pp_sd):
+    """VSR_RAFT_LANES / PropainterInpaint.raft_lanes: the runs of consecutive pairs a call's RAFT pass is cut into alternate over RAFT
+    instances on their own streams; pairs are independent, so the frames are those of one run on one stream, bit for bit"""
+    from vsr_amd.backend.inpaint.propainter_inpaint import PropainterInpaint
+    from vsr_amd.backend.tools.inpaint_tools import create_mask
+    from vsr_amd.synth import make_clip, make_raft_state_dict, make_rfc_state_dict
+
+    H, W, n = 288, 704, 23
+    box = (236, 268, 120, 600)
+    frames = list(make_clip(n, H, W, box, seed=9))
+    mask = create_mask((H, W), [(box[2], box[3], box[0], box[1])])
+    sds = {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": pp_sd}
+    plug = PropainterInpaint("cuda:0", sds)
+    plug.raft_iter = 3
+    plug.raft_lanes, plug.raft_max_pairs = 1, 64                        # one run of 22 pairs
+    want = np.stack(plug(frames, mask))
+    plug.raft_lanes, plug.raft_max_pairs = 2, 12                        # four runs of <= 6 pairs on two lanes
+    for _ in range(3):
+        assert np.array_equal(np.stack(plug(frames, mask)), want)
+    assert len(plug._lane_rafts) == 1
+    plug.raft_lanes = 1                                                 # ... and the same runs on one lane
+    assert np.array_equal(np.stack(plug(frames, mask)), want)
+    plug.close()

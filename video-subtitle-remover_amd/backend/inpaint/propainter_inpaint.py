@@ -118,7 +118,8 @@ class PropainterInpaint:
         self.raft_iter = 20
         self.raft_max_pairs = int(os.environ.get("VSR_RAFT_MAX_PAIRS", "35"))      # consecutive pairs per RAFT call (see inpaint())
         self.gen_lanes = int(os.environ.get("VSR_PP_LANES", "2"))                  # generator instances the sliding windows alternate over
-        self._lane_models, self._streams = {}, None
+        self.raft_lanes = int(os.environ.get("VSR_RAFT_LANES", "2"))               # RAFT instances the runs of a call alternate over (exact fp32 only)
+        self._lane_models, self._lane_rafts, self._streams = {}, {}, None
         di = _device_index(device)
         self.fix_raft = RaftEngine(_load(model_dir, "raft", "raft-things.pth"), device=di)
         self.fix_flow_complete = RfcEngine(_load(model_dir, "rfc", "recurrent_flow_completion.pth"), device=di)
@@ -147,15 +148,21 @@ class PropainterInpaint:
             self._lane_models[k] = e
         return self._lane_models[k]
 
+    def _lane_raft(self, k):
+        """the RAFT instance of run lane k >= 1 (exact fp32: the guarded modes would need a host thread per lane)"""
+        if k not in self._lane_rafts:
+            self._lane_rafts[k] = RaftEngine(_load(self.model_dir, "raft", "raft-things.pth"), device=self.model.device_index)
+        return self._lane_rafts[k]
+
     def _lane_streams(self, lanes, dev):
         if self._streams is None or len(self._streams) < lanes:
             self._streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
         return self._streams[:lanes]
 
     def close(self):
-        for e in [self.fix_raft, self.fix_flow_complete, self.model] + list(self._lane_models.values()):
+        for e in [self.fix_raft, self.fix_flow_complete, self.model] + list(self._lane_models.values()) + list(self._lane_rafts.values()):
             e.close()
-        self._lane_models = {}
+        self._lane_models, self._lane_rafts = {}, {}
 
     def inpaint(self, frames, mask):
         """frames: list of HxWx3 uint8 BGR crops (H, W multiples of 8), mask: HxW(x1) uint8 -> list of HxWx3 uint8 BGR.
@@ -197,18 +204,41 @@ class PropainterInpaint:
             # 68-frame batch at once made the engine's workspace 125 GB; two runs of 34 + 33 pairs need 64 GB and launch the same kernels on
             # 734 000 GEMM rows instead of 1.45 million (three runs of 23 cost 3 % of the RAFT stage: profiles/r05_sixth_call.log).
             npairs = n - 1
-            runs = max(1, -(-npairs // self.raft_max_pairs))
+            rl = self.raft_lanes if (prof is None and self.PRECISIONS[self.precision][0] == "f32") else 1
+            runs = max(1, -(-npairs // max(1, self.raft_max_pairs // rl)))
+            rl = min(rl, runs)
             per = -(-npairs // runs)
+            spans = [(s0, min(n, s0 + per + 1)) for s0 in range(0, npairs, per)]
             if runs == 1:
                 gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
+            elif rl == 1:
+                outs = [self.fix_raft.flows(bgr[a:b], iters=self.raft_iter, bgr=True) for a, b in spans]
+                gt_f, gt_b = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
             else:
-                ff, fb = [], []
-                for s0 in range(0, npairs, per):
-                    a, b = self.fix_raft.flows(bgr[s0:min(n, s0 + per + 1)], iters=self.raft_iter, bgr=True)
-                    ff.append(a)
-                    fb.append(b)
-                gt_f, gt_b = torch.cat(ff), torch.cat(fb)
-            lap("raft", lambda: sum(self.fix_raft.flops(min(n, s0 + per + 1) - s0, h, w, self.raft_iter) for s0 in range(0, npairs, per)))
+                # RAFT lanes (VSR_RAFT_LANES, round 5): the runs alternate over RAFT instances on their own streams -- one run's
+                # memory-bound kernels (correlation lookup, GRU gates, instance norm: a tenth of the stage) under the other's GEMMs.
+                # The pairs per run shrink with the lanes, so the workspaces together stay what one lane's was.
+                main = torch.cuda.current_stream(dev)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                streams = self._lane_streams(rl, dev)
+                engines = [self.fix_raft] + [self._lane_raft(k) for k in range(1, rl)]
+                outs = []
+                for j, (a, b) in enumerate(spans):
+                    st = streams[j % rl]
+                    if j < rl:
+                        st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        outs.append(engines[j % rl].flows(bgr[a:b], iters=self.raft_iter, bgr=True))
+                for st in streams:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    main.wait_event(ev)
+                for o in outs:
+                    for t_ in o:
+                        t_.record_stream(main)                                          # allocated on a lane's stream, read on the caller's
+                gt_f, gt_b = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+            lap("raft", lambda: sum(self.fix_raft.flops(b - a, h, w, self.raft_iter) for a, b in spans))
             # ---- flow completion (:253-281)
             flow_length, svl = n - 1, self.sub_video_length
             if flow_length > svl:
