@@ -204,9 +204,9 @@ class PropainterInpaint:
             # 68-frame batch at once made the engine's workspace 125 GB; two runs of 34 + 33 pairs need 64 GB and launch the same kernels on
             # 734 000 GEMM rows instead of 1.45 million (three runs of 23 cost 3 % of the RAFT stage: profiles/r05_sixth_call.log).
             npairs = n - 1
-            rl = self.raft_lanes if (prof is None and self.PRECISIONS[self.precision][0] == "f32") else 1
-            runs = max(1, -(-npairs // max(1, self.raft_max_pairs // rl)))
-            rl = min(rl, runs)
+            part = max(1, self.raft_lanes) if self.PRECISIONS[self.precision][0] == "f32" else 1
+            runs = max(1, -(-npairs // max(1, self.raft_max_pairs // part)))      # (a profiled call keeps the runs and issues them on one stream)
+            rl = 1 if prof is not None else min(part, runs)
             per = -(-npairs // runs)
             spans = [(s0, min(n, s0 + per + 1)) for s0 in range(0, npairs, per)]
             if runs == 1:
