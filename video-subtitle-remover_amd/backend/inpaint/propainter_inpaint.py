@@ -120,7 +120,9 @@ class PropainterInpaint:
         self.gen_lanes = int(os.environ.get("VSR_PP_LANES", "2"))                  # generator instances the sliding windows alternate over
         self.raft_lanes = int(os.environ.get("VSR_RAFT_LANES", "2"))               # RAFT instances the runs of a call alternate over (exact fp32 only)
         self._lane_models, self._lane_rafts, self._streams = {}, {}, None
+        self._lane_error, self._lane_thread = None, None
         di = _device_index(device)
+        self._di = di
         self.fix_raft = RaftEngine(_load(model_dir, "raft", "raft-things.pth"), device=di)
         self.fix_flow_complete = RfcEngine(_load(model_dir, "rfc", "recurrent_flow_completion.pth"), device=di)
         self.model = PpEngine(device=di, state_dict=_load(model_dir, "propainter", "ProPainter.pth"))
@@ -131,6 +133,10 @@ class PropainterInpaint:
         for e, mode in zip((self.fix_raft, self.fix_flow_complete, self.model), self.PRECISIONS[self.precision]):
             if mode != "f32":
                 e.set_precision(mode)
+        # the lane instances pack and upload their weights on a helper thread from here on (1-2 s each: built on first use they were
+        # 3 s in front of a 600-frame run's first batch, profiles/r05_e2e_pp_lanes.log); _lane_model / _lane_raft wait for the thread
+        self._lane_thread = threading.Thread(target=self._build_lanes, name="vsr-pp-lane-build", daemon=True)
+        self._lane_thread.start()
 
     def clone(self):
         """a second instance on the same device from the same checkpoints: its own three engines and workspaces (tools/batch_lanes.py)"""
@@ -138,20 +144,47 @@ class PropainterInpaint:
         other.raft_iter = self.raft_iter
         return other
 
+    def _new_lane_model(self):
+        e = PpEngine(device=self._di, state_dict=_load(self.model_dir, "propainter", "ProPainter.pth"))
+        mode = self.PRECISIONS[self.precision][2]
+        if mode != "f32":
+            e.set_precision(mode)
+        return e
+
+    def _new_lane_raft(self):
+        return RaftEngine(_load(self.model_dir, "raft", "raft-things.pth"), device=self._di)
+
+    def _build_lanes(self):
+        try:
+            if self.PRECISIONS[self.precision][0] == "f32":
+                for k in range(1, max(1, self.raft_lanes)):
+                    self._lane_rafts[k] = self._new_lane_raft()
+            for k in range(1, max(1, self.gen_lanes)):
+                self._lane_models[k] = self._new_lane_model()
+        except BaseException as e:            # noqa: BLE001 -- re-raised by the first call that needs a lane
+            self._lane_error = e
+
+    def _lanes_built(self):
+        t = self._lane_thread
+        if t is not None:
+            t.join()
+            self._lane_thread = None
+        if self._lane_error is not None:
+            e, self._lane_error = self._lane_error, None
+            raise e
+
     def _lane_model(self, k):
-        """the generator instance of window lane k >= 1: same checkpoint and arithmetic, its own workspace (built on first use)"""
-        if k not in self._lane_models:
-            e = PpEngine(device=self.model.device_index, state_dict=_load(self.model_dir, "propainter", "ProPainter.pth"))
-            mode = self.PRECISIONS[self.precision][2]
-            if mode != "f32":
-                e.set_precision(mode)
-            self._lane_models[k] = e
+        """the generator instance of window lane k >= 1: same checkpoint and arithmetic, its own workspace"""
+        self._lanes_built()
+        if k not in self._lane_models:            # more lanes than the constructor knew of (gen_lanes set later)
+            self._lane_models[k] = self._new_lane_model()
         return self._lane_models[k]
 
     def _lane_raft(self, k):
         """the RAFT instance of run lane k >= 1 (exact fp32: the guarded modes would need a host thread per lane)"""
+        self._lanes_built()
         if k not in self._lane_rafts:
-            self._lane_rafts[k] = RaftEngine(_load(self.model_dir, "raft", "raft-things.pth"), device=self.model.device_index)
+            self._lane_rafts[k] = self._new_lane_raft()
         return self._lane_rafts[k]
 
     def _lane_streams(self, lanes, dev):
@@ -160,6 +193,10 @@ class PropainterInpaint:
         return self._streams[:lanes]
 
     def close(self):
+        try:
+            self._lanes_built()
+        except BaseException:                 # noqa: BLE001 -- closing: a lane that failed to build has nothing to release
+            pass
         for e in [self.fix_raft, self.fix_flow_complete, self.model] + list(self._lane_models.values()) + list(self._lane_rafts.values()):
             e.close()
         self._lane_models, self._lane_rafts = {}, {}
