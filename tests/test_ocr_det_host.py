@@ -265,3 +265,25 @@ def test_min_area_rect_is_minimal_and_encloses():
         brute = ((pu.max(0) - pu.min(0)) * (pv.max(0) - pv.min(0))).min()
         assert w * h <= brute + 1e-6, (trial, w * h, brute)
         assert w * h >= brute * (1 - 2e-3) - 1e-6, (trial, w * h, brute)
+
+
+def test_transposed_conv_fusion_chains():
+    """deconv_fusions (round 5: the 2x2 transposed conv as a gather-GEMM): the chains found in the two shipped programs -- the server
+    head's 64 -> 64 deconv carries its bias add, batch_norm and ReLU; the 64 -> 1 one its bias add only (the sigmoid stays a kernel);
+    every folded op has exactly one reader"""
+    import os
+
+    from vsr_amd.backend.tools.ocr_det import deconv_fusions
+    from vsr_amd.backend.tools.paddle_graph import load_graph
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for fixture, first_cout in (("ppocr_det_graph.json", 64), ("ppocr_det_fast_graph.json", 24)):
+        g = load_graph(os.path.join(gold, fixture))
+        fz = deconv_fusions(g)
+        assert len(fz) == 2
+        (i0, (bias0, bn0, act0)), (i1, (bias1, bn1, act1)) = sorted(fz.items())
+        assert g.params[g.ops[i0][1][1]][1][1] == first_cout and g.params[g.ops[i1][1][1]][1][1] == 1
+        assert bias0 is not None and bn0 is not None and act0 is not None and act0[1] == 1
+        assert g.ops[bias0[0]][0] == "add" and g.ops[bn0][0] == "batch_norm_" and g.ops[act0[0]][0] == "relu"
+        assert i0 < bias0[0] < bn0 < act0[0]
+        assert bias1 is not None and bn1 is None and act1 is None
