@@ -345,3 +345,21 @@ def test_decode_rows_and_cols_cover_what_the_resize_back_reads(built_lib):
     finally:
         eng.close()
         det.close()
+
+
+def test_propainter_raft_runs():
+    """PropainterInpaint cuts a batch's RAFT pass into runs of consecutive pairs (memory; two RAFT lanes): every pair exactly once, in
+    order, neighbouring runs sharing one frame; the sizes BASELINE config 4 produces"""
+    from vsr_amd.backend.inpaint.propainter_inpaint import raft_runs
+
+    for n in (2, 3, 18, 44, 68, 70, 71):
+        for max_pairs, lanes in ((35, 1), (35, 2), (24, 1), (12, 2), (64, 1)):
+            spans = raft_runs(n, max_pairs, lanes)
+            pairs = [(a + i, a + i + 1) for a, b in spans for i in range(b - a - 1)]
+            assert pairs == [(i, i + 1) for i in range(n - 1)]
+            assert all(b - a - 1 <= max(1, max_pairs // lanes) for a, b in spans)
+            assert all(spans[j + 1][0] == spans[j][1] - 1 for j in range(len(spans) - 1))
+    assert [b - a - 1 for a, b in raft_runs(68, 35, 2)] == [17, 17, 17, 16]
+    assert [b - a - 1 for a, b in raft_runs(68, 35, 1)] == [34, 33]
+    assert [b - a - 1 for a, b in raft_runs(44, 35, 2)] == [15, 15, 13]
+    assert raft_runs(20, 35, 1) == [(0, 20)] and raft_runs(1, 35, 2) == []

@@ -89,6 +89,18 @@ def _load(model_dir, name, file):
     return torch.load(checkpoint_path(os.path.join(model_dir, file)), map_location="cpu")
 
 
+def raft_runs(n, max_pairs, lanes=1):
+    """[(first frame, end frame)] of the runs of consecutive pairs an n-frame batch goes through RAFT in: at most max_pairs // lanes
+    pairs per run, as equal as possible; a run of p pairs takes p + 1 frames (neighbouring runs share one).  Pairs are independent,
+    so the flows do not depend on the cut."""
+    npairs = n - 1
+    if npairs <= 0:
+        return []
+    runs = max(1, -(-npairs // max(1, max_pairs // max(1, lanes))))
+    per = -(-npairs // runs)
+    return [(s0, min(n, s0 + per + 1)) for s0 in range(0, npairs, per)]
+
+
 class PropainterInpaint:
     accepts_device_frames = True      # __call__ also takes a uint8 [n,H,W,3] device tensor and inpaints it in place (tools/resident.py)
     # precision name -> arithmetic of (RAFT, flow completion, generator)
@@ -240,12 +252,10 @@ class PropainterInpaint:
             # at this width, :221-247).  The all-pairs correlation pyramid of ONE 1920x360 pair-direction is 0.62 GB: all 67 pairs of a
             # 68-frame batch at once made the engine's workspace 125 GB; two runs of 34 + 33 pairs need 64 GB and launch the same kernels on
             # 734 000 GEMM rows instead of 1.45 million (three runs of 23 cost 3 % of the RAFT stage: profiles/r05_sixth_call.log).
-            npairs = n - 1
             part = max(1, self.raft_lanes) if self.PRECISIONS[self.precision][0] == "f32" else 1
-            runs = max(1, -(-npairs // max(1, self.raft_max_pairs // part)))      # (a profiled call keeps the runs and issues them on one stream)
-            rl = 1 if prof is not None else min(part, runs)
-            per = -(-npairs // runs)
-            spans = [(s0, min(n, s0 + per + 1)) for s0 in range(0, npairs, per)]
+            spans = raft_runs(n, self.raft_max_pairs, part)
+            runs = len(spans)
+            rl = 1 if prof is not None else min(part, runs)                       # (a profiled call keeps the runs and issues them on one stream)
             if runs == 1:
                 gt_f, gt_b = self.fix_raft.flows(bgr, iters=self.raft_iter, bgr=True)
             elif rl == 1:
