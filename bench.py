@@ -20,6 +20,9 @@ Extra objects in the line:
                   the GPU time), algorithmic FLOPs / HIP-event time on the launch stream against the 157.3 TFLOP/s
                   fp32 MFMA peak of MI355X_MICROARCH.md; `every_gemm_launch` beside it is the same ratio over
                   ALL gather-GEMM launches of a chunk (every symbol).
+  configs_multi -- N > 1 only: BASELINE.json's multi-GPU configurations through their own sharding (scripts/bench_multi.py): "5" = 4K
+                  fp16-operand chunks through chunk_parallel, "4h" / "4" = 68-frame propainter batches through batch_parallel
+                  (reference GPU arithmetic / exact fp32); each with value, replicas, efficiency, hbm_gbps; a watchdog per phase.
   configs      -- BASELINE.json's other configurations on this GPU, each with its own `roofline` (scripts/bench_configs.py:
                   2 = 720p sttn-auto, 3 = 1080p sttn-det 47-frame batches + the text detector's forward, 4 = 1080p
                   propainter 68-frame batches in exact fp32 and in the reference's GPU arithmetic, 5 = 4K sttn-auto on
@@ -249,6 +252,8 @@ def main():
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2-5, scripts/bench_configs.py)")
     ap.add_argument("--configs", default=None, help="comma-separated legs of scripts/bench_configs.py (default: 2,3,3d,4,4h,5)")
+    ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip the N-rank legs of BASELINE configs 5 and 4 (scripts/bench_multi.py)")
+    ap.add_argument("--multi-configs", default=None, help="N > 1: comma-separated legs of scripts/bench_multi.py (default: 5,4h,4)")
     ap.add_argument("--no-full-work", action="store_true",
                     help="skip the `full_work` leg: the same step with every row the reference's modules compute (a child process with "
                          "VSR_TRIM_LAST_BLOCK=0 VSR_DECODE_ROWS=0 -- the library reads these once per process)")
@@ -494,14 +499,21 @@ def main():
         per_kernel = kernels_timed()
         dom = max(per_kernel, key=lambda k: per_kernel[k][0])
         ms, n, fl = per_kernel[dom]
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")     # PMC passes are separate rocprofv3 runs (scripts/profile_round.sh)
-        if os.path.exists(prof):
-            try:
-                pj = json.load(open(prof))
-                traffic = pj.get("hbm_bytes_per_launch") if pj.get("kernel", "").endswith(dom) else None
-            except Exception:
-                traffic = None
+        traffic, unit_traffic = None, None
+        # PMC passes are separate rocprofv3 runs: scripts/pmc_configs.py (leg "1" = this chunk; profiles/config_traffic.json), before
+        # round 6 scripts/summarize_profile.py (profiles/dominant_kernel_pmc.json)
+        try:
+            leg1 = json.load(open(os.path.join(ROOT, "profiles", "config_traffic.json")))["legs"]["1"]
+            traffic = leg1["kernels"][dom]["hbm_bytes_per_launch"]
+            unit_traffic = leg1["hbm_bytes_per_unit"]
+        except Exception:
+            prof = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")
+            if os.path.exists(prof):
+                try:
+                    pj = json.load(open(prof))
+                    traffic = pj.get("hbm_bytes_per_launch") if pj.get("kernel", "").endswith(dom) else None
+                except Exception:
+                    traffic = None
         ach = fl / ms / 1e9 if ms > 0 else 0.0
         # --precision split / split-format / f16 (never the default line): the products run on the f16 matrix cores; FLOPs stay the
         # algorithmic 2 per product (three MFMAs each in the split modes), the peak is the dense f16 one
@@ -513,6 +525,10 @@ def main():
                            "flops_per_launch": round(fl / n) if n else None,
                            "measured_on": f"{args.steps} single-lane steps after the timed region (`single_lane`): with {args.lanes} lanes the "
                                           "launches of the two streams overlap, so a launch's own duration is taken with one"}
+        if unit_traffic and args.res == "1080p" and base_precision == "f32":
+            # the whole chunk's HBM bytes (every kernel, PMC) at the measured chunk rate
+            out["hbm_gb_per_chunk"] = round(unit_traffic / 1e9, 3)
+            out["hbm_gbps"] = round(unit_traffic * fps / L / world / 1e9, 1)
         if world == 1:
             # per-op and per-kernel breakdown: events around every launch of two extra chunks, outside the timed region
             eng.timing_reset()
@@ -657,12 +673,24 @@ def main():
                 out["configs"] = bench_configs.run_all(args.configs.split(",") if args.configs else None)
             except Exception as e:                 # noqa: BLE001 -- never fatal for the headline line
                 out["configs"] = {"error": repr(e)[:300]}
+    eng.close()
+    if world > 1 and not args.no_multi_configs:
+        # BASELINE.json's own multi-GPU configurations after the headline: config 5 (4K, fp16 operands, chunk-parallel) and config 4
+        # (propainter batches, batch-parallel; reference arithmetic and exact), every rank takes part.  A leg that hangs is cut by
+        # a watchdog which prints this line with what there is (scripts/bench_multi.py).
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_multi
+
+        res = bench_multi.run_multi(dist, rank, world, device, dry, out if rank == 0 else {},
+                                    legs=args.multi_configs.split(",") if args.multi_configs else None, steps=2, warmup=1)
+        if rank == 0:
+            out["configs_multi"] = res
+    if rank == 0:
         print(json.dumps(out), flush=True)
         if world > 1 and replicas is not None and not replicas.get("selftest", {"ok": True})["ok"]:
             print("SELFTEST FAILED: gathered chunks differ from the ranks' replica results", file=sys.stderr, flush=True)
             selftest_failed = True
 
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,6 +33,52 @@ PEAK_F16 = 2500.0          # TFLOP/s, dense f16 MFMA
 RES = {"720p": (720, 1280, (620, 700, 192, 1088)), "1080p": (1080, 1920, (950, 1070, 288, 1632)),
        "4k": (2160, 3840, (1900, 2140, 576, 3264))}
 TILE_DIMS = {0: (128, 128, 2, 2), 1: (256, 32, 4, 1), 2: (256, 64, 4, 1), 3: (128, 64, 2, 2)}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "config_traffic.json")     # written by scripts/pmc_configs.py from rocprofv3 --pmc passes
+UNIT_ONLY = False           # scripts/pmc_configs.py: one warm unit, a marker kernel, ONE measured unit, a marker kernel -- nothing else
+
+
+def pmc_marker():
+    """a kernel whose name appears nowhere else in a run (at::native nextafter): scripts/pmc_configs.py counts the dispatches between
+    two of them"""
+    torch.cuda.synchronize()
+    a = torch.zeros(64, device="cuda")
+    torch.nextafter(a, a + 1)
+    torch.cuda.synchronize()
+
+
+def unit_only(step):
+    step()
+    pmc_marker()
+    step()
+    pmc_marker()
+    return {"unit_only": True}
+
+
+def attach_traffic(leg, out, units_per_s):
+    """roofline.traffic (HBM bytes per launch of the dominant kernel symbol) and the whole unit's HBM bytes -> hbm_gbps, from the
+    committed PMC summary of this leg (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied there)"""
+    try:
+        t = json.load(open(TRAFFIC_FILE))["legs"].get(leg)
+    except (OSError, ValueError, KeyError):
+        t = None
+    if not t:
+        return out
+    roofs = [out.get("roofline")] + [st.get("roofline") for st in (out.get("stages") or {}).values() if isinstance(st, dict)]
+    for r in roofs:
+        if not r or not r.get("kernel"):
+            continue
+        k = t["kernels"].get(r["kernel"])
+        if k:
+            r["traffic"] = k["hbm_bytes_per_launch"]
+            r["traffic_launches_counted"] = k["launches"]
+            if r.get("avg_launch_ms"):
+                r["hbm_gbps_in_kernel"] = round(k["hbm_bytes_per_launch"] / r["avg_launch_ms"] / 1e6, 1)
+    out["hbm_gb_per_unit"] = round(t["hbm_bytes_per_unit"] / 1e9, 3)
+    if units_per_s:
+        out["hbm_gbps"] = round(t["hbm_bytes_per_unit"] * units_per_s / 1e9, 1)
+        out["hbm_frac_of_peak"] = round(t["hbm_bytes_per_unit"] * units_per_s / 8.0e12, 4)
+    out["hbm_note"] = t.get("note")
+    return out
 
 
 def make_chunk_on_device(L, H, W, box, seed, device):
@@ -126,6 +172,10 @@ def run_auto(name, res, precision, steps=4, warmup=1, L=50):
         work.copy_(src)
         eng.auto_chunk(work, dmask, areas)
 
+    if UNIT_ONLY:
+        r = unit_only(step)
+        eng.close()
+        return r
     dt = timed(step, steps, warmup)
     fps = steps * L / dt
     fl = eng.chunk_flops(L, dmask, areas)
@@ -135,7 +185,7 @@ def run_auto(name, res, precision, steps=4, warmup=1, L=50):
            "model_tflops": round(fl / L * fps / 1e12, 2), "model_frac_of_peak": round(fl / L * fps / 1e12 / peak, 4),
            "fp32_fallback_chunks": eng.fallbacks(), "roofline": sttn_roofline(eng, step, precision)}
     eng.close()
-    return out
+    return attach_traffic(name.split(":")[0], out, fps / L)
 
 
 def run_det(name, res, precision, total=1200):
@@ -156,6 +206,10 @@ def run_det(name, res, precision, total=1200):
             eng.det_batch(work[:L], dmask, areas)
         return step
 
+    if UNIT_ONLY:
+        r = unit_only(make(Lmax))
+        eng.close()
+        return r
     per = {}
     for L in sample:
         dt = timed(make(L), 3 if L == Lmax else 2, 1)
@@ -169,7 +223,7 @@ def run_det(name, res, precision, total=1200):
            "gflop_per_frame": round(flops / total / 1e9, 1), "roofline": sttn_roofline(eng, make(Lmax), precision),
            "note": "inpainting only, the known box injected on every frame; the detector forward is the `detector` entry"}
     eng.close()
-    return out
+    return attach_traffic("3", out, 1.0 / per[Lmax])
 
 
 def run_detector(name, nb=16, reps=3):
@@ -184,6 +238,11 @@ def run_detector(name, nb=16, reps=3):
     det.use_tape = True
     img = np.random.default_rng(3).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
     imgs = [img] * nb
+    if UNIT_ONLY:
+        det.probability_maps(imgs)
+        r = unit_only(lambda: det.probability_maps(imgs))
+        det.runner.close()
+        return r
     dt = timed(lambda: det.probability_maps(imgs), reps, 3)
     ms = dt / reps / nb * 1e3
     gflop = det.gflop_per_frame(544, 960)             # from the walk of the program itself (270.8 for the server program)
@@ -194,12 +253,14 @@ def run_detector(name, nb=16, reps=3):
                         "achieved": round(tf, 2), "peak": PEAK_FP32, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32, 4), "traffic": None,
                         "measured_on": f"{reps} forwards of {nb} frames, wall clock around the recorded launch list"}}
     det.runner.close()
-    return out
+    return attach_traffic("3d", out, 1e3 / ms / nb)
 
 
 def flow_kernel_symbol(name):
     """'gg:<cfg>:<bmode>:v<variant>' -> the kernel symbol the flow engines launch for it"""
     _, cfg, bmode, var = name.split(":")
+    if cfg == "flash":                     # the generator's fused window attention (pp_attn_kernels.hip): exact fp32 in every mode
+        return "k_pp_flash_attn_f32"
     bm, bn, wm, wn = TILE_DIMS[int(cfg)]
     v = int(var[1:])
     if v == 3:
@@ -223,6 +284,10 @@ def run_propainter(name, precision="f32", L=68, reps=1):
     mask[box[0]:box[1], box[2]:box[3]] = 255
     plug = PropainterInpaint("cuda:0", {"raft": make_raft_state_dict(0), "rfc": make_rfc_state_dict(0), "propainter": make_propainter_state_dict(0)},
                              precision=precision)
+    if UNIT_ONLY:
+        r = unit_only(lambda: plug.inpaint(frames, mask))
+        plug.close()
+        return r
     dt = timed(lambda: plug.inpaint(frames, mask), reps, 1) / reps
     # profiled call (device-synchronised around every stage + events around every launch: slower than the timed one)
     plug.profile = {}
@@ -266,10 +331,11 @@ def run_propainter(name, precision="f32", L=68, reps=1):
            "value": round(L / dt, 2), "unit": "frames/s", "s_per_batch": round(dt, 3), "tflop_per_frame": round(total_fl / L / 1e12, 3),
            "model_tflops": round(total_fl / dt / 1e12, 2), "range_guard_fallbacks": fb, "psnr_db_vs_exact_mode": psnr, "stages": stages, "roofline": stages[dom]["roofline"],
            "roofline_stage": dom}
-    return out
+    return attach_traffic({"f32": "4", "f16": "4h", "f16-raft-split": "4s", "split": "4x"}[precision], out, 1.0 / dt)
 
 
 LEGS = {
+    "1": lambda: run_auto("1: 1080p sttn-auto fp32 (the headline's unit; bench.py times it)", "1080p", "f32"),
     "2": lambda: run_auto("2: 720p sttn-auto fp32", "720p", "f32"),
     "3": lambda: run_det("3: 1080p sttn-det fp32, 47-frame batches", "1080p", "f32"),
     "3d": lambda: run_detector("3: text detector forward"),
@@ -297,5 +363,9 @@ def run_all(which=None):
 
 
 if __name__ == "__main__":
-    for k, v in run_all(sys.argv[1:] or None).items():
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--unit":        # scripts/pmc_configs.py
+        UNIT_ONLY = True
+        argv = argv[1:]
+    for k, v in run_all(argv or None).items():
         print(json.dumps(v), flush=True)

@@ -74,6 +74,28 @@ def test_generator_matches_oracle(gen_engine, pp_sd, gpu_device, t, lt, H, W):
     assert err <= 2e-3
 
 
+@pytest.mark.parametrize("t,lt,H,W,precision", [(7, 5, 64, 96, "f32"), (6, 4, 240, 432, "f32"), (6, 4, 240, 432, "f16")])
+def test_fused_window_attention_equals_three_ops(built_lib, gpu_device, tmp_path, t, lt, H, W, precision):
+    """VSR_PP_FLASH=1 (default: ONE fused launch per block, online softmax, no score matrix -- pp_attn_kernels.hip) against
+    VSR_PP_FLASH=0 (the plan's three ops QK^T / k_softmax_rows / P.V) on the same inputs: the same tanh output up to fp32 summation
+    order in the exact mode; in the f16 mode the fused attention is MORE exact than the three-op form (it stays fp32), so the two
+    differ by that mode's own error."""
+    import subprocess
+    import sys
+
+    outs = {}
+    for v in ("0", "1"):
+        path = str(tmp_path / f"flash{v}.npy")
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_pp_flash_child.py"), str(t), str(lt), str(H), str(W), precision, path],
+                           env=dict(os.environ, VSR_PP_FLASH=v), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        outs[v] = np.load(path)
+    err = float(np.abs(outs["0"] - outs["1"]).max())
+    print(f"fused vs three-op window attention {t}/{lt} x {H}x{W} [{precision}]: max |d| {err:.3e} (tanh output)")
+    assert np.isfinite(outs["1"]).all()
+    assert err <= (2e-5 if precision == "f32" else 2e-2)
+
+
 def test_generator_strip_size_smoke(gen_engine, gpu_device):
     """1080p strip (1920x360), 11 local + 4 reference frames: finite, deterministic, survives a plan change."""
     t, lt, H, W = 15, 11, 360, 1920

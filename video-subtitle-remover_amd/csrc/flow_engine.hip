@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -22,6 +24,7 @@
 #include "raft_plan.h"
 #include "rfc_plan.h"
 #include "pp_kernels.h"
+#include "pp_attn.h"
 #include "pp_plan.h"
 #include "lama_kernels.h"
 #include "lama_plan.h"
@@ -47,13 +50,27 @@ namespace {
 // off by default; vsr_flow_timing_get sums the records whose key starts with a prefix (resolving the pending events first).
 struct FlowTimingRec { hipEvent_t a, b; std::string key; double flops; };
 static int g_flowTiming = 0;
+static std::mutex g_flowTimingMu;      // run_plan() runs on several host threads at once (generator lanes in the guarded arithmetics, batch lanes)
 static std::vector<FlowTimingRec> g_flowPending;
 static std::map<std::string, std::pair<double, std::pair<int64_t, double>>> g_flowTimed;
+
+// VSR_PP_FLASH (default 1): the generator's window attention as ONE fused launch per transformer block (pp_attn_kernels.hip) instead of
+// the plan's three ops QK^T / row softmax / P.V; 0 keeps the three launches (A/B runs, and the form tests/_replay_pp.py replays)
+static bool pp_flash_enabled()
+{
+    static const bool on = [] { const char* e = getenv("VSR_PP_FLASH"); return !(e && atoi(e) == 0); }();
+    return on;
+}
 
 struct FlowOpDev {
     const Op* op = nullptr;
     const void* dDesc = nullptr;   // GGProblem* (device)
     int nitems = 0, total = 0, nQueues = 1;
+    // fused window attention: 1 = this op (the QK^T of an attention triple) launches the fused kernel instead, 2 = covered by it (skipped)
+    int fused = 0;
+    const void* dAttn = nullptr;   // PpAttnProblem* (device), fused == 1
+    int attnItems = 0, attnTiles = 0;
+    double attnFlops = 0;
 };
 
 // a plan on the device: tables, gather-GEMM descriptors with baked buffer pointers, tile queues
@@ -64,9 +81,11 @@ struct FlowPlanDev {
     void* dDescs = nullptr;
     unsigned int* dQueues = nullptr;
     float* dConsts = nullptr;      // PlanIR::consts (BUF_PLAN_CONST)
+    void* dAttn = nullptr;         // PpAttnProblem descriptors of the fused window-attention launches
     std::vector<FlowOpDev> ops;
     ~FlowPlanDev()
     {
+        if (dAttn) (void)hipFree(dAttn);
         if (dConsts) (void)hipFree(dConsts);
         if (dTables) (void)hipFree(dTables);
         if (dDescs) (void)hipFree(dDescs);
@@ -201,6 +220,55 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
     }
     HIPCHK(hipMemcpy(pd->dDescs, hostDesc.data(), descBytes, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&pd->dQueues, (pd->ops.size() + 1) * 8 * sizeof(unsigned int)));
+    // ---- fused window attention: every [attn.qk, attn.softmax, attn.pv] triple of the generator's plan (pp_plan.cpp attention(): item j
+    // of the three ops is the same (window, head) problem) becomes one launch of k_pp_flash_attn_f32.  The plan itself keeps the three
+    // ops -- they are what the CPU replay executes and what the FLOP counts are taken from.
+    if (pp_flash_enabled()) {
+        std::vector<PpAttnProblem> all;
+        struct Span { size_t op, first, count; int tiles; double flops; };
+        std::vector<Span> spans;
+        for (size_t i = 0; i + 2 < P.ops.size(); ++i) {
+            const Op &qk = P.ops[i], &sm = P.ops[i + 1], &pv = P.ops[i + 2];
+            if (qk.kind != OP_GEMM || sm.kind != OP_SOFTMAX || pv.kind != OP_GEMM || qk.tag != "attn.qk" || pv.tag != "attn.pv") continue;
+            if (qk.gemm.size() != sm.softmax.size() || qk.gemm.size() != pv.gemm.size() || qk.gemm.empty()) continue;
+            bool ok = qk.bmode == VSR_BMODE_NK && pv.bmode == VSR_BMODE_KN;
+            for (size_t j = 0; ok && j < qk.gemm.size(); ++j) {
+                const GemmItem &a = qk.gemm[j], &b = pv.gemm[j];
+                ok = a.K == 128 && b.N == 128 && a.M == b.M && a.splitK == 1 && b.splitK == 1 && a.bufB == b.bufB && a.offBias < 0 && b.offBias < 0 &&
+                     a.bufR < 0 && b.bufR < 0 && sm.softmax[j].nsplit == 1 && sm.softmax[j].N == a.N && a.act == VSR_ACT_NONE && b.act == VSR_ACT_NONE;
+            }
+            if (!ok) continue;
+            // large problems first: their workgroups walk thousands of keys, the per-frame problems of the unmasked windows 45
+            std::vector<size_t> order(qk.gemm.size());
+            for (size_t j = 0; j < order.size(); ++j) order[j] = j;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return qk.gemm[x].N > qk.gemm[y].N; });
+            Span sp{i, all.size(), order.size(), 0, qk.flops + pv.flops};
+            for (size_t j : order) {
+                const GemmItem &a = qk.gemm[j], &b = pv.gemm[j];
+                PpAttnProblem q;
+                q.Q = F(a.bufA, a.offA); q.K = F(a.bufB, a.offB); q.V = F(b.bufB, b.offB); q.O = F(b.bufC, b.offC);
+                q.qrow = T(a.tRowA); q.krow = T(a.tRowB); q.orow = T(b.tRowC);
+                q.M = a.M; q.nk = a.N; q.tileStart = sp.tiles;
+                q.scale = sm.softmax[j].scale * 1.4426950408889634f;
+                sp.tiles += (a.M + 127) / 128;
+                all.push_back(q);
+            }
+            spans.push_back(sp);
+            i += 2;
+        }
+        if (!all.empty()) {
+            HIPCHK(hipMalloc(&pd->dAttn, all.size() * sizeof(PpAttnProblem)));
+            HIPCHK(hipMemcpy(pd->dAttn, all.data(), all.size() * sizeof(PpAttnProblem), hipMemcpyHostToDevice));
+            for (const Span& sp : spans) {
+                FlowOpDev& od = pd->ops[sp.op];
+                od.fused = 1;
+                od.dAttn = (const PpAttnProblem*)pd->dAttn + sp.first;
+                od.attnItems = (int)sp.count; od.attnTiles = sp.tiles; od.attnFlops = sp.flops;
+                pd->ops[sp.op + 1].fused = 2;
+                pd->ops[sp.op + 2].fused = 2;
+            }
+        }
+    }
     *out = std::move(pd);
     return 0;
 }
@@ -217,16 +285,21 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         const Op& op = *od.op;
         unsigned int* queue = pd->dQueues + 8 * idx++;
         int rc = 0;
+        if (od.fused == 2) continue;                     // part of a fused attention launch
         FlowTimingRec tr;
         if (g_flowTiming) {
+            if (od.fused == 1) tr.key = std::string(ws.engine) + ":gg:flash:0:v3:attn.flash";      // exact fp32 in every arithmetic mode
+            else
             tr.key = std::string(ws.engine) + (op.kind == OP_GEMM ? ":gg:" + std::to_string(op.tileCfg) + ":" + std::to_string(op.bmode) + ":v" +
                                                                         std::to_string(variant) + ":" : ":op:") + op.tag;
-            tr.flops = op.flops;
+            tr.flops = od.fused == 1 ? od.attnFlops : op.flops;
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
             HIPCHK(hipEventRecord(tr.a, stream));
         }
-        if (op.kind == OP_GEMM) {
+        if (od.fused == 1) {
+            rc = vsr_pp_launch_flash_attn((const PpAttnProblem*)od.dAttn, od.attnItems, od.attnTiles, stream);
+        } else if (op.kind == OP_GEMM) {
             rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, variant, od.nQueues,
                                             rangeFlag, stream);
         } else if (op.kind == OP_SOFTMAX) {
@@ -363,6 +436,7 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         if (rc != 0) return rfail(VSR_ERR_HIP, "kernel launch failed: " + op.tag + ": " + hipGetErrorString(hipGetLastError()));
         if (g_flowTiming) {
             HIPCHK(hipEventRecord(tr.b, stream));
+            std::lock_guard<std::mutex> lk(g_flowTimingMu);
             g_flowPending.push_back(tr);
         }
     }
@@ -561,6 +635,7 @@ int vsr_flow_timing(int enable)
 
 static int flow_timing_collect()
 {
+    std::lock_guard<std::mutex> lk(g_flowTimingMu);
     if (g_flowPending.empty()) return 0;
     HIPCHK(hipDeviceSynchronize());
     for (FlowTimingRec& tr : g_flowPending) {
@@ -580,6 +655,7 @@ static int flow_timing_collect()
 int vsr_flow_timing_reset(void)
 {
     RCCHK(flow_timing_collect());
+    std::lock_guard<std::mutex> lk(g_flowTimingMu);
     g_flowTimed.clear();
     return 0;
 }
@@ -588,6 +664,7 @@ int vsr_flow_timing_get(const char* prefix, double* total_ms, int64_t* launches,
 {
     if (!prefix) return rfail(VSR_ERR_ARG, "bad argument");
     RCCHK(flow_timing_collect());
+    std::lock_guard<std::mutex> lk(g_flowTimingMu);
     double ms = 0, fl = 0;
     int64_t n = 0;
     const size_t pl = strlen(prefix);
@@ -603,6 +680,7 @@ int vsr_flow_timing_get(const char* prefix, double* total_ms, int64_t* launches,
 int64_t vsr_flow_timing_keys(char* buf, int64_t capacity)
 {
     if (flow_timing_collect() != 0) return -1;
+    std::lock_guard<std::mutex> lk(g_flowTimingMu);
     std::string all;
     for (const auto& kv : g_flowTimed) { all += kv.first; all += '\n'; }
     if (buf && capacity > 0) {
