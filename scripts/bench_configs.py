@@ -259,8 +259,8 @@ def run_detector(name, nb=16, reps=3):
 def flow_kernel_symbol(name):
     """'gg:<cfg>:<bmode>:v<variant>' -> the kernel symbol the flow engines launch for it"""
     _, cfg, bmode, var = name.split(":")
-    if cfg == "flash":                     # the generator's fused window attention (pp_attn_kernels.hip): exact fp32 in every mode
-        return "k_pp_flash_attn_f32"
+    if cfg == "flash":                     # the generator's fused window attention (pp_attn_kernels.hip)
+        return "k_pp_flash_attn_f16" if var == "v7" else "k_pp_flash_attn_f32"
     bm, bn, wm, wn = TILE_DIMS[int(cfg)]
     v = int(var[1:])
     if v == 3:

@@ -78,8 +78,8 @@ def test_generator_matches_oracle(gen_engine, pp_sd, gpu_device, t, lt, H, W):
 def test_fused_window_attention_equals_three_ops(built_lib, gpu_device, tmp_path, t, lt, H, W, precision):
     """VSR_PP_FLASH=1 (default: ONE fused launch per block, online softmax, no score matrix -- pp_attn_kernels.hip) against
     VSR_PP_FLASH=0 (the plan's three ops QK^T / k_softmax_rows / P.V) on the same inputs: the same tanh output up to fp32 summation
-    order in the exact mode; in the f16 mode the fused attention is MORE exact than the three-op form (it stays fp32), so the two
-    differ by that mode's own error."""
+    order in the exact mode; in the f16 mode both run on fp16 operands (k_pp_flash_attn_f16 keeps the softmax and the running output
+    in fp32) and differ by that mode's own rounding."""
     import subprocess
     import sys
 

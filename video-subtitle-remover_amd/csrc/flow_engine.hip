@@ -288,7 +288,7 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         if (od.fused == 2) continue;                     // part of a fused attention launch
         FlowTimingRec tr;
         if (g_flowTiming) {
-            if (od.fused == 1) tr.key = std::string(ws.engine) + ":gg:flash:0:v3:attn.flash";      // exact fp32 in every arithmetic mode
+            if (od.fused == 1) tr.key = std::string(ws.engine) + ":gg:flash:0:v" + (ws.precision == 2 ? "7" : "3") + ":attn.flash";
             else
             tr.key = std::string(ws.engine) + (op.kind == OP_GEMM ? ":gg:" + std::to_string(op.tileCfg) + ":" + std::to_string(op.bmode) + ":v" +
                                                                         std::to_string(variant) + ":" : ":op:") + op.tag;
@@ -298,7 +298,8 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
             HIPCHK(hipEventRecord(tr.a, stream));
         }
         if (od.fused == 1) {
-            rc = vsr_pp_launch_flash_attn((const PpAttnProblem*)od.dAttn, od.attnItems, od.attnTiles, stream);
+            // fp16 operands in the fp16-operand mode; the split-half mode (operands as hi / lo pairs) keeps the exact kernel
+            rc = vsr_pp_launch_flash_attn((const PpAttnProblem*)od.dAttn, od.attnItems, od.attnTiles, ws.precision == 2 ? 1 : 0, rangeFlag, stream);
         } else if (op.kind == OP_GEMM) {
             rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, variant, od.nQueues,
                                             rangeFlag, stream);

@@ -15,4 +15,5 @@ struct PpAttnProblem {
     float scale;             // log2(e) / sqrt(D)
 };
 
-extern "C" int vsr_pp_launch_flash_attn(const PpAttnProblem* d_probs, int nprobs, int totalTiles, void* stream);
+// f16 = 0: exact fp32 (v_mfma_f32_32x32x2_f32); 1: fp16 operands, fp32 accumulation and softmax (rangeFlag OR-ed with 1 on a non-finite output)
+extern "C" int vsr_pp_launch_flash_attn(const PpAttnProblem* d_probs, int nprobs, int totalTiles, int f16, unsigned int* rangeFlag, void* stream);
