@@ -19,6 +19,33 @@ import numpy as np
 _GAINS = dict(enc=1.8, qk=0.8, v=1.0, tr=0.35, dec=1.3, last=0.7)
 _BIAS_STD = 0.02
 
+# Weight-statistics profiles (round 6).  Every parity number of rounds 1-5 was taken on ONE benign draw per network:
+# Gaussian, variance-preserving.  Trained checkpoints are not like that, so each stand-in checkpoint can also be drawn
+#   "peaked"    query / key gain x4: attention rows close to one-hot (what a trained attention looks like);
+#   "heavy"     Student-t (nu = 3) weights of the same variance -- a few weights many sigmas out -- and the first layer scaled up by
+#               HEAVY_SCALE with the last layer scaled down by the same factor: the activations in between sit a few times below the
+#               fp16 limit (65504), where the fp16-operand modes either hold their accuracy or must trip the range guard;
+#   "undamped"  RAFT only: the flow head's last conv at the gain of every other conv -- flow updates of tens of pixels per iteration.
+# The same seeds as the benign draw; oracle/make_golden_sweep.py loads every profile into the reference modules (strict=True).
+PROFILES = ("benign", "peaked", "heavy", "undamped")
+HEAVY_SCALE = dict(sttn=600.0, propainter=30.0, propainter_ffn=1000.0, rfc=900.0, raft=1.0)
+# (ProPainter: the feature propagation gates its deformable offsets with tanh / sigmoid of conv outputs -- scaled by hundreds every gate
+#  saturates and the REFERENCE module in fp32 lands 0.14-0.32 of the tanh range away from its own float64 run, no fp32 implementation can
+#  be compared on that.  So the encoder is scaled by 30 only (fp32-vs-float64 gap 3e-6) and the large activations are put where the
+#  network is smooth: every block's fc1 x 1000, fc2 / 1000 -- the FFN hidden tensor, the largest fp16 operand of the generator.)
+
+
+def _draw(rng, shape, profile):
+    """unit-variance weights of a profile (float32)"""
+    if profile == "heavy":
+        return (rng.standard_t(3, shape) / np.sqrt(3.0)).astype(np.float32)
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def _check_profile(profile):
+    if profile not in PROFILES:
+        raise ValueError(f"weight profile {profile!r}: expected one of {PROFILES}")
+
 
 def state_dict_spec(variant="auto"):
     """(key, shape) in the reference's state_dict order (auto_sttn.py:64-95 / network_sttn.py:64-95)."""
@@ -53,15 +80,22 @@ def _gain_for(key):
     return _GAINS["dec"]
 
 
-def make_state_dict(seed=0, variant="auto"):
-    """dict key -> float32 ndarray; numpy PCG64 so it is identical on every machine."""
+def make_state_dict(seed=0, variant="auto", profile="benign"):
+    """dict key -> float32 ndarray; numpy PCG64 so it is identical on every machine.  profile: PROFILES above."""
+    _check_profile(profile)
     rng = np.random.default_rng(seed)
     sd = {}
     for key, shape in state_dict_spec(variant):
         if key.endswith("weight"):
             fan_in = int(np.prod(shape[1:]))
-            sd[key] = (rng.standard_normal(shape).astype(np.float32)
-                       * np.float32(_gain_for(key) / np.sqrt(fan_in)))
+            gain = _gain_for(key)
+            if profile == "peaked" and ("query" in key or "key_embedding" in key):
+                gain *= 4.0
+            if profile == "heavy" and key.startswith("encoder.0"):
+                gain *= HEAVY_SCALE["sttn"]
+            if profile == "heavy" and key.startswith("decoder.6"):
+                gain /= HEAVY_SCALE["sttn"]
+            sd[key] = _draw(rng, shape, profile) * np.float32(gain / np.sqrt(fan_in))
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(_BIAS_STD)
     return sd
@@ -156,10 +190,11 @@ def raft_state_dict_spec():
     return spec
 
 
-def make_raft_state_dict(seed=0):
+def make_raft_state_dict(seed=0, profile="benign"):
     """Stand-in for weights/raft-things.pth (missing blob): He-style conv weights, non-trivial BatchNorm statistics,
-    a damped flow head so that 20 GRU iterations stay in a few-pixel regime.  Keys as saved by the reference's
-    checkpoint minus DataParallel's "module." prefix (flow_comp_raft.py:17-19)."""
+    a damped flow head so that 20 GRU iterations stay in a few-pixel regime ("undamped": it is not; "heavy": Student-t weights).
+    Keys as saved by the reference's checkpoint minus DataParallel's "module." prefix (flow_comp_raft.py:17-19)."""
+    _check_profile(profile)
     rng = np.random.default_rng(seed + 77)
     sd = {}
     for key, shape in raft_state_dict_spec():
@@ -185,10 +220,10 @@ def make_raft_state_dict(seed=0):
             fan_in = int(np.prod(shape[1:]))
             gain = 1.3
             if "flow_head.conv2" in key:
-                gain = 0.25
+                gain = 1.3 if profile == "undamped" else 0.25
             elif "gru.conv" in key or "mask.2" in key:
                 gain = 0.9
-            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
+            sd[key] = _draw(rng, shape, profile) * np.float32(gain / np.sqrt(fan_in))
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
     # the reference's state_dict order lists norm3 before downsample.*; order does not matter for loading
@@ -259,10 +294,11 @@ def rfc_state_dict_spec():
     return spec
 
 
-def make_rfc_state_dict(seed=0):
+def make_rfc_state_dict(seed=0, profile="benign"):
     """Stand-in for weights/recurrent_flow_completion.pth (missing blob).  The offset head is NOT zero-initialised as
     in the reference's constructor (:27-28): offsets of a few pixels and non-trivial masks exercise the deformable
-    sampling."""
+    sampling.  profile "heavy": Student-t weights, first conv x HEAVY_SCALE, the two output convs / HEAVY_SCALE."""
+    _check_profile(profile)
     rng = np.random.default_rng(seed + 991)
     sd = {}
     for key, shape in rfc_state_dict_spec():
@@ -273,7 +309,11 @@ def make_rfc_state_dict(seed=0):
                 gain = 0.4
             elif "conv2.0" in key or "backbone" in key or "fusion" in key:
                 gain = 0.9
-            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
+            if profile == "heavy" and key.startswith("downsample.0"):
+                gain *= HEAVY_SCALE["rfc"]
+            if profile == "heavy" and key.startswith("upsample.2.conv"):
+                gain /= HEAVY_SCALE["rfc"]
+            sd[key] = _draw(rng, shape, profile) * np.float32(gain / np.sqrt(fan_in))
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
     return sd
@@ -336,9 +376,11 @@ def propainter_state_dict_spec():
     return spec
 
 
-def make_propainter_state_dict(seed=0):
+def make_propainter_state_dict(seed=0, profile="benign"):
     """Stand-in for weights/ProPainter.pth (missing blob): variance-preserving weights, non-trivial LayerNorm affine and
-    deformable offsets (the reference zero-initialises the offset head, propainter.py:56-57)."""
+    deformable offsets (the reference zero-initialises the offset head, propainter.py:56-57).  profile "peaked": query / key gain
+    x4; "heavy": Student-t weights, encoder.layers.0 x 30 and decoder.6 / 30, every block's fc1 x 1000 and fc2 / 1000 (HEAVY_SCALE)."""
+    _check_profile(profile)
     rng = np.random.default_rng(seed + 313)
     sd = {}
     for key, shape in propainter_state_dict_spec():
@@ -355,12 +397,20 @@ def make_propainter_state_dict(seed=0):
             if "conv_offset.6" in key:
                 gain = 0.4
             elif "attention.query" in key or "attention.key" in key:
-                gain = 1.6
+                gain = 1.6 * (4.0 if profile == "peaked" else 1.0)
             elif "mlp.fc2" in key or "attention.proj" in key or "sc.embedding" in key:
                 gain = 0.7
             elif key.startswith("decoder.6"):
                 gain = 0.7
-            sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(gain / np.sqrt(fan_in))
+            if profile == "heavy" and key.startswith("encoder.layers.0."):
+                gain *= HEAVY_SCALE["propainter"]
+            if profile == "heavy" and key.startswith("decoder.6"):
+                gain /= HEAVY_SCALE["propainter"]
+            if profile == "heavy" and "mlp.fc1" in key:
+                gain *= HEAVY_SCALE["propainter_ffn"]
+            if profile == "heavy" and "mlp.fc2" in key:
+                gain /= HEAVY_SCALE["propainter_ffn"]
+            sd[key] = _draw(rng, shape, profile) * np.float32(gain / np.sqrt(fan_in))
         else:
             sd[key] = rng.standard_normal(shape).astype(np.float32) * np.float32(0.05)
     return sd
