@@ -66,7 +66,8 @@ struct FlowOpDev {
     const Op* op = nullptr;
     const void* dDesc = nullptr;   // GGProblem* (device)
     int nitems = 0, total = 0, nQueues = 1;
-    // fused window attention: 1 = this op (the QK^T of an attention triple) launches the fused kernel instead, 2 = covered by it (skipped)
+    // fused window attention: 1 = this op (the QK^T of an attention triple) launches the fused kernel instead, 2 = covered by it (skipped);
+    // 3 / 4: the fold / unfold of an FFN pair whose GELU moved into the fold
     int fused = 0;
     const void* dAttn = nullptr;   // PpAttnProblem* (device), fused == 1
     int attnItems = 0, attnTiles = 0;
@@ -109,6 +110,9 @@ struct Workspace {
     int precision = 0;
     unsigned int* dRangeFlag = nullptr;
     int64_t fallbacks = 0;
+    // ensure_clean(): the per-frame layout the zero halos are currently valid for, and how far into every buffer (elements)
+    std::string layout;
+    std::vector<int64_t> clean;
     void init(int n, int weightsBuf, std::initializer_list<int> byteBufs)
     {
         bufs.assign(n, nullptr);
@@ -269,6 +273,21 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
             }
         }
     }
+    // ---- the FFN's fold -> unfold + GELU pair (pp_plan.cpp "tr.fold" / "tr.unfold"): the GELU once per map element inside the fold, the
+    // unfold as a float4 copy (pp_gen_kernels.hip).  VSR_PP_FOLD_GELU=0 keeps the plan's two kernels.
+    static const bool foldGelu = [] { const char* e = getenv("VSR_PP_FOLD_GELU"); return !(e && atoi(e) == 0); }();
+    if (foldGelu) {
+        for (size_t i = 0; i + 1 < P.ops.size(); ++i) {
+            const Op &a = P.ops[i], &b = P.ops[i + 1];
+            if (a.kind != OP_EW || b.kind != OP_EW || a.ew != EW_PP_FOLD || b.ew != EW_PP_UNFOLD_GELU) continue;
+            // same map: the fold's output buffer, frames, size and channels are the unfold's input; no halo; C and ld multiples of 4
+            if (a.ibuf[1] != b.ibuf[0] || a.ipar[7] != 0 || a.ipar[1] != b.ipar[0] || a.ipar[4] != b.ipar[3] || a.ipar[5] != b.ipar[4] ||
+                a.ipar[6] != b.ipar[5] || b.ipar[5] % 4 || b.ipar[6] % 4)
+                continue;
+            pd->ops[i].fused = 3;
+            pd->ops[i + 1].fused = 4;
+        }
+    }
     *out = std::move(pd);
     return 0;
 }
@@ -406,10 +425,12 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
                                         ip[5], B(op.ibuf[0], op.ioff[1]), stream);
                 break;
             case EW_PP_FOLD:
-                rc = vsr_pp_launch_fold(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], ip[8], B(op.ibuf[1], 0), stream);
+                rc = (od.fused == 3 ? vsr_pp_launch_fold_gelu : vsr_pp_launch_fold)(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6],
+                                                                                    ip[7], ip[8], B(op.ibuf[1], 0), stream);
                 break;
             case EW_PP_UNFOLD_GELU:
-                rc = vsr_pp_launch_unfold_gelu(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], B(op.ibuf[1], 0), stream);
+                rc = (od.fused == 4 ? vsr_pp_launch_unfold_plain : vsr_pp_launch_unfold_gelu)(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], ip[4], ip[5],
+                                                                                              ip[6], B(op.ibuf[1], 0), stream);
                 break;
             case EW_PP_TANH_OUT:
                 rc = vsr_pp_launch_tanh_out(B(op.ibuf[0], 0), ip[0], ip[1], ip[2], ip[3], B(op.ibuf[1], 0), stream);
@@ -457,6 +478,30 @@ static int clear_workspace(Workspace& ws, hipStream_t stream, const PlanIR* plan
         int64_t n = ws.cap[b];
         if (plan && b < plan->bufElems.size() && plan->bufElems[b] < n) n = plan->bufElems[b];
         if (n > 0) HIPCHK(hipMemsetAsync(ws.bufs[b], 0, (size_t)ws.nbytes((int)b, n), stream));
+    }
+    return 0;
+}
+
+// The generator's variant of the rule above.  Its plans for one (kind of call, lt, H, W) differ in the NUMBER of frames only (the
+// sliding windows of a batch carry 5 or 6 reference frames: t alternates), and every frame-indexed buffer is laid out frame after
+// frame with the same per-frame geometry: a plan with more frames reaches further into the buffers, it does not move a halo.  So the
+// workspace keeps, per buffer, the extent that has been cleared since the layout last changed, and a call clears only what its plan
+// addresses beyond that -- nothing at all in steady state.  (Clearing on every change of t was 1 890 fills and 66 ms per 68-frame
+// batch, profiles/r05_propainter_f32_kernel_stats_after.csv.)  Buffers that grew were zeroed by materialize().
+static int ensure_clean(Workspace& ws, const std::string& layout, const PlanIR& plan, hipStream_t stream)
+{
+    if (ws.clean.size() != ws.bufs.size()) ws.clean.assign(ws.bufs.size(), 0);
+    if (ws.layout != layout) {
+        ws.layout = layout;
+        std::fill(ws.clean.begin(), ws.clean.end(), 0);
+    }
+    for (size_t b = 0; b < ws.bufs.size(); ++b) {
+        if ((int)b == ws.weights || !ws.bufs[b] || b >= plan.bufElems.size()) continue;
+        const int64_t need = plan.bufElems[b] < ws.cap[b] ? plan.bufElems[b] : ws.cap[b];
+        if (need <= ws.clean[b]) continue;
+        const int64_t from = ws.clean[b];
+        HIPCHK(hipMemsetAsync((char*)ws.bufs[b] + ws.nbytes((int)b, from), 0, (size_t)ws.nbytes((int)b, need - from), stream));
+        ws.clean[b] = need;
     }
     return 0;
 }
@@ -1171,11 +1216,9 @@ int vsr_pp_forward_box(vsr_pp_t* h, const float* frames_dev, const float* flows_
         pd = npd.get();
         h->genPlans[key] = std::move(npd);
     }
-    const std::string geom = "gen:" + std::to_string(t) + ":" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W);
-    if (h->geom != geom) {
-        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
-        h->geom = geom;
-    }
+    const std::string geom = "gen:" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W);      // (not t: ensure_clean)
+    RCCHK(ensure_clean(h->ws, geom, *pd->plan, stream));
+    h->geom = geom;
     const size_t hw = (size_t)H * W;
     HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FRAMES], frames_dev, (size_t)t * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_in_dev, (size_t)t * hw, hipMemcpyDeviceToDevice, stream));
@@ -1235,10 +1278,8 @@ int vsr_pp_encode(vsr_pp_t* h, const float* frames_dev, const uint8_t* masks_in_
     const std::string geom = "enc:" + std::to_string(n) + ":" + std::to_string(ntok_frames) + ":" + std::to_string(H) + ":" + std::to_string(W);
     FlowPlanDev* pd = nullptr;
     RCCHK(pp_plan_for(h, geom, n, ntok_frames, H, W, nullptr, 0, 0, 0, 0, 0, PP_PLAN_ENCODE, &pd));
-    if (h->geom != geom) {
-        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
-        h->geom = geom;
-    }
+    RCCHK(ensure_clean(h->ws, "enc:" + std::to_string(H) + ":" + std::to_string(W), *pd->plan, stream));      // (frame counts only reach further)
+    h->geom = geom;
     const size_t hw = (size_t)H * W;
     HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_FRAMES], frames_dev, (size_t)n * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[PB_IN_MASK_U8], masks_in_dev, (size_t)n * hw, hipMemcpyDeviceToDevice, stream));
@@ -1288,10 +1329,8 @@ int vsr_pp_forward_cached(vsr_pp_t* h, const float* feat_cache_dev, const float*
     key.append((const char*)window_flags, (size_t)nflags);
     FlowPlanDev* pd = nullptr;
     RCCHK(pp_plan_for(h, key, t, lt, H, W, window_flags, nflags, row_lo, row_hi, col_lo, col_hi, PP_PLAN_CACHED, &pd));
-    if (h->geom != geom) {
-        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
-        h->geom = geom;
-    }
+    RCCHK(ensure_clean(h->ws, "genc:" + std::to_string(lt) + ":" + std::to_string(H) + ":" + std::to_string(W), *pd->plan, stream));
+    h->geom = geom;
     const PpGenPlan& gp = static_cast<const PpGenPlan&>(*pd->plan);
     const size_t hw = (size_t)H * W;
     {   // the local frames' features into the propagation buffer's input slots (interiors; the halos stay zero), the reference frames' tokens

@@ -259,8 +259,12 @@ k_pp_pool(const float* __restrict__ y, const float* __restrict__ wgt /*[C][16]*/
 // permuted at pack time, PpModel::pack / patch_perm): the C channels of a pixel are neighbours in the token row as they are in the
 // map, so a wave's loads are runs of C floats instead of single floats 196 bytes apart.
 // ---------------------------------------------------------------------------------------
+// gelu != 0 (engine-level fusion, flow_engine.hip): the fold that feeds EW_PP_UNFOLD_GELU applies the GELU itself, once per map element --
+// the unfold that follows copies a map element into up to nine token rows, and k_pp_unfold_gelu evaluated erff for every copy (152 M
+// per launch at the 1080p strip against 28 M map elements; 61 ms per 68-frame batch, profiles/r06_third_call.log).  Same value, same
+// function: the token rows are bit-identical.
 __global__ void __launch_bounds__(256)
-k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* __restrict__ out)
+k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, int gelu, float* __restrict__ out)
 {
     const int64_t total = (int64_t)t * h * w * C;
     const int Wp = w + 2 * halo, Hp = h + 2 * halo;
@@ -278,7 +282,9 @@ k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, i
                 ++cnt;
             }
         }
-        out[(((int64_t)f * Hp + y + halo) * Wp + x + halo) * C + c] = normalize ? acc / (float)cnt : acc;
+        float v = normalize ? acc / (float)cnt : acc;
+        if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        out[(((int64_t)f * Hp + y + halo) * Wp + x + halo) * C + c] = v;
     }
 }
 
@@ -303,6 +309,27 @@ k_pp_unfold_gelu(const float* __restrict__ map, int t, int fh, int fw, int h, in
             }
         }
         out[i] = v;
+    }
+}
+
+// the unfold alone (the map already went through the GELU in k_pp_fold): four floats per thread.  C and ld multiples of 4: a float4
+// never straddles two taps, every address is 16-byte aligned
+__global__ void __launch_bounds__(256)
+k_pp_unfold_copy4(const float* __restrict__ map, int t, int fh, int fw, int h, int w, int C, int ld, float* __restrict__ out)
+{
+    const int ld4 = ld / 4;
+    const int64_t total = (int64_t)t * fh * fw * ld4;
+    GRID_STRIDE(i, total) {
+        const int e = 4 * (int)(i % ld4);
+        const int64_t tok = i / ld4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e < C * 49) {
+            const int tap = e / C, c = e - C * tap;
+            const int tx = (int)(tok % fw), ty = (int)((tok / fw) % fh), f = (int)(tok / ((int64_t)fw * fh));
+            const int y = 3 * ty - 3 + tap / 7, x = 3 * tx - 3 + tap % 7;
+            if (y >= 0 && y < h && x >= 0 && x < w) v = *reinterpret_cast<const f32x4*>(map + (((int64_t)f * h + y) * w + x) * C + c);
+        }
+        *reinterpret_cast<f32x4*>(out + 4 * i) = v;
     }
 }
 
@@ -355,11 +382,22 @@ extern "C" int vsr_pp_launch_pool(const float* y, const float* wgt, const float*
 extern "C" int vsr_pp_launch_fold(const float* vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* out,
                                   void* stream)
 {
-    LAUNCH(k_pp_fold, (int64_t)t * h * w * C, vec, ld, t, fh, fw, h, w, C, halo, normalize, out);
+    LAUNCH(k_pp_fold, (int64_t)t * h * w * C, vec, ld, t, fh, fw, h, w, C, halo, normalize, 0, out);
 }
 extern "C" int vsr_pp_launch_unfold_gelu(const float* map, int t, int fh, int fw, int h, int w, int C, int ld, float* out, void* stream)
 {
     LAUNCH(k_pp_unfold_gelu, (int64_t)t * fh * fw * ld, map, t, fh, fw, h, w, C, ld, out);
+}
+// the pair EW_PP_FOLD -> EW_PP_UNFOLD_GELU with the GELU moved into the fold (see k_pp_fold): the two launches of the fused form
+extern "C" int vsr_pp_launch_fold_gelu(const float* vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* out,
+                                       void* stream)
+{
+    LAUNCH(k_pp_fold, (int64_t)t * h * w * C, vec, ld, t, fh, fw, h, w, C, halo, normalize, 1, out);
+}
+extern "C" int vsr_pp_launch_unfold_plain(const float* map, int t, int fh, int fw, int h, int w, int C, int ld, float* out, void* stream)
+{
+    if (C % 4 || ld % 4) return -2;         // (the caller keeps the unfused pair for such shapes)
+    LAUNCH(k_pp_unfold_copy4, (int64_t)t * fh * fw * (ld / 4), map, t, fh, fw, h, w, C, ld, out);
 }
 extern "C" int vsr_pp_launch_tanh_out(const float* y, int ld, int n, int H, int W, float* out, void* stream)
 {

@@ -24,4 +24,7 @@ int vsr_pp_launch_pool(const float* y, const float* wgt, const float* bias, int 
 int vsr_pp_launch_fold(const float* vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* out, void* stream);
 int vsr_pp_launch_unfold_gelu(const float* map, int t, int fh, int fw, int h, int w, int C, int ld, float* out, void* stream);
 int vsr_pp_launch_tanh_out(const float* y, int ld, int n, int H, int W, float* out, void* stream);
+// the pair fold -> unfold + GELU with the GELU applied once per map element inside the fold (bit-identical token rows)
+int vsr_pp_launch_fold_gelu(const float* vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* out, void* stream);
+int vsr_pp_launch_unfold_plain(const float* map, int t, int fh, int fw, int h, int w, int C, int ld, float* out, void* stream);
 }
