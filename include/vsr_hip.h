@@ -186,10 +186,9 @@ enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2, VSR_ACT_LRELU01 
 #define VSR_VARIANT_A_EXP 0x100 /* OR-ed into the kernel variant 1 of a KN launch whose problems may carry VSR_ACT_A_EXP */
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3,
        VSR_TILE_256x128 = 4, /* 8 waves; the fp16-operand kernel (variant 6, NK) only */
-       VSR_TILE_256x256 = 5, /* 8 waves, one workgroup per CU; variants 5 / 6, NK only.  tilesM may exceed ceil(M / 256): a tile then covers
-                              * roundup32(ceil(M / tilesM)) rows (gather_gemm_v7.h), which is how a launch is cut into whole rounds */
-       VSR_TILE_288x256 = 6  /* 8 waves, one workgroup per CU; exact fp32 (variant 3), NK only, no VSR_ACT_ROW_MAX; operand tensors below
-                              * 4 GB.  Dynamic tile height as above, up to 288 rows (gather_gemm_v8.h): long-K convolutions */ };
+       VSR_TILE_256x256 = 5  /* 8 waves, one workgroup per CU; variants 5 / 6, NK only.  tilesM may exceed ceil(M / 256): a tile then covers
+                              * roundup32(ceil(M / tilesM)) rows (gather_gemm_v7.h), which is how a launch is cut into whole rounds.
+                              * (6 was the exact-fp32 288 x 256 tile of round 4, opt-in, removed in round 6: DESIGN 4.1) */ };
 
 /* C[rowC[m]+colC[n/32]+n%32] = act(alpha*sum_k A[rowA[m]+colA[k/32]+k%32]*B(k,n) + bias[n]) + R[rowR[m]+colC[n/32]+n%32]
  *   NK: B(k,n) = B[rowB[n]+colB[k/32]+k%32]   KN: B(k,n) = B[rowB[k]+colB[n/32]+n%32]

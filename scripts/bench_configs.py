@@ -118,9 +118,6 @@ def sttn_kernels_timed(eng, precision="f32"):
             a, b, c = eng.timing_get(f"kernel:gg:{cfg}:1:v1x")          # P.V of the fused attention (gather_gemm_pvx.h)
             if b:
                 per_kernel[f"gather_gemm_f32_aexp<{bm}, {bn}, {wm}, {wn}>"] = (a, b, c)
-    a, b, c = eng.timing_get("kernel:gg:6:0:v8")                    # the 288 x 256 tile of the long-K convolutions (gather_gemm_v8.h)
-    if b:
-        per_kernel["gather_gemm_f32_v8<9>"] = (a, b, c)
     a, b, c = eng.timing_get("kernel:gg:5:0:v7")                    # split-format modes: the 256 x 256 tile (gather_gemm_v7.h)
     if b:
         per_kernel["gather_gemm_f16_v7<%d>" % (0 if precision == "f16" else 1)] = (a, b, c)

@@ -405,42 +405,6 @@ def test_gather_gemm_256x256_split_k(built_lib, gpu_device, variant, M, N, K, sp
     assert np.array_equal(outs["TILE_128x64"].view(np.uint32), outs["TILE_256x256"].view(np.uint32))
 
 
-@pytest.mark.parametrize("M,N,K,tilesM,bias,act,res", [
-    (513, 257, 2304, None, True, 1, True),      # N not a multiple of 32: the element-wise epilogue; a partial last tile
-    (300, 256, 576, None, True, 1, True),       # two tiles of roundup32(150) = 160 rows
-    (2000, 256, 320, 7, True, 1, True),         # tile height 288: 5 + 4 blocks over the two wave rows
-    (1000, 512, 320, 8, True, 0, False),        # tile height 128, two N tiles, no bias / residual path
-    (200, 64, 352, 7, False, 0, True),          # tile height 32: the second wave row owns no block
-    (700, 320, 64, 3, True, 2, True),           # second N tile 64 columns wide; ReLU
-    (4800, 256, 32 * 150, None, True, 1, True), # 150 chunks: crosses a 128-chunk super-block
-])
-def test_gather_gemm_f32_288x256(built_lib, gpu_device, M, N, K, tilesM, bias, act, res):
-    """TILE_288x256 (variant 3, NK) = gather_gemm_f32_v8: exact fp32, 8 waves, up to 288 x 256 per workgroup with dynamic tile height,
-    output turned through LDS; against the CPU replay of the descriptor, exact store footprint."""
-    rng = np.random.default_rng(8000 + M + N + K)
-    c = _make_gemm_case(rng, M, N, K, 1152, 256, 0, 1, bias, act, res, alpha=0.5)
-    c.tilesM, c.tilesN = (tilesM if tilesM is not None else -(-M // 288)), -(-N // 256)
-    got = _run_cases(built_lib, gpu_device, [c], built_lib.TILE_288x256, 0, 3)[0]
-    _assert_close(got, _reference(c), K, f"v8 288x256 {M}x{N}x{K} tilesM={tilesM}", case=c)
-
-
-@pytest.mark.parametrize("act", [1, 0x200 | 2, 3])
-def test_gather_gemm_f32_288x256_equals_128x64(built_lib, gpu_device, act):
-    """Same k order, same MFMAs in the same order, same epilogue arithmetic: the 288 x 256 kernel writes the bits the 128 x 64 kernel
-    (gather_gemm_f32_v3) writes -- also as two problems of one launch, with POST_RELU and with split-K partial planes."""
-    outs = {}
-    for cfg, bm, bn in (("TILE_128x64", 128, 64), ("TILE_288x256", 288, 256)):
-        rng = np.random.default_rng(8100)
-        cases = []
-        for (M, N, K, splitK) in ((1300, 256, 576, 1), (900, 384, 960, 1), (700, 320, 480, 2)):
-            c = _make_gemm_case(rng, M, N, K, 1152, 256, 0, splitK, True, act, True, alpha=0.75 if splitK == 1 else 1.0)
-            c.tilesM, c.tilesN = -(-M // bm), -(-N // bn)
-            cases.append(c)
-        outs[cfg] = _run_cases(built_lib, gpu_device, cases, getattr(built_lib, cfg), 0, 3)
-    for a, b in zip(outs["TILE_128x64"], outs["TILE_288x256"]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-
-
 def test_kn_to_nk_split(built_lib, gpu_device):
     """vsr_launch_kn_to_nk_split: a gathered KN operand in split format becomes the dense NK operand dst[n * ld + k] in split format"""
     rng = np.random.default_rng(7400)

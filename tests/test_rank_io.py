@@ -136,3 +136,23 @@ def test_a_failing_rank_fails_the_run_everywhere(tmp_path):
     src, dst, ref, nrec, msgs = _run(tmp_path, 3, 41, 4, fail_rank=1)
     errs = {rank: err for rank, _, _, err in msgs}
     assert errs[1] == "ValueError" and errs[0] == "RankIOError" and errs[2] == "RankIOError"
+    # the pre-sized sink of a failed run is a full-size file with holes: rank 0 moves it out of the way
+    assert not os.path.exists(dst) and os.path.exists(dst + ".failed")
+
+
+def test_read_into_asks_again_after_a_short_read(tmp_path, monkeypatch):
+    """a pread that returns fewer bytes than asked is not the end of the file"""
+    from vsr_amd.backend.tools import rank_io
+
+    path = str(tmp_path / "r.bin")
+    recs = np.random.default_rng(1).integers(0, 256, size=(3, 1000), dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"HDR\n")
+        for r in recs:
+            f.write(b"FRAME\n" + r.tobytes())
+    real = os.preadv
+    monkeypatch.setattr(os, "preadv", lambda fd, bufs, off: real(fd, [bufs[0][:337]], off))     # at most 337 bytes per call
+    rf = rank_io.RecordFile(path, 4, b"FRAME\n", 1000)
+    out = np.zeros((3, 1000), dtype=np.uint8)
+    assert rf.read_into(0, out) == 3 and np.array_equal(out, recs)
+    rf.close()

@@ -16,9 +16,7 @@ BMODE_NK, BMODE_KN = 0, 1
 ACT_NONE, ACT_LRELU02 = 0, 1
 TILE_128x128, TILE_256x32, TILE_256x64, TILE_128x64 = 0, 1, 2, 3
 TILE_256x128, TILE_256x256 = 4, 5      # 8-wave tiles of the fp16-operand kernels (variant 6, NK)
-TILE_288x256 = 6                       # 8-wave tile of the exact-fp32 kernel for long-K NK problems (variant 3; gather_gemm_v8.h)
-TILE_DIMS = {TILE_128x128: (128, 128), TILE_256x32: (256, 32), TILE_256x64: (256, 64), TILE_128x64: (128, 64), TILE_256x128: (256, 128), TILE_256x256: (256, 256),
-             TILE_288x256: (288, 256)}
+TILE_DIMS = {TILE_128x128: (128, 128), TILE_256x32: (256, 32), TILE_256x64: (256, 64), TILE_128x64: (128, 64), TILE_256x128: (256, 128), TILE_256x256: (256, 256)}
 
 
 class VsrError(RuntimeError):

@@ -147,8 +147,16 @@ class PropainterInpaint:
                 e.set_precision(mode)
         # the lane instances pack and upload their weights on a helper thread from here on (1-2 s each: built on first use they were
         # 3 s in front of a 600-frame run's first batch, profiles/r05_e2e_pp_lanes.log); _lane_model / _lane_raft wait for the thread
-        self._lane_thread = threading.Thread(target=self._build_lanes, name="vsr-pp-lane-build", daemon=True)
-        self._lane_thread.start()
+        # (not a daemon, and joined at interpreter exit: a daemon thread can die in the middle of a hipMalloc / hipMemcpy when the
+        # interpreter goes down before close() -- ADVICE r5.  VSR_PP_LANE_PREBUILD=0: build the lanes on first use instead.)
+        if os.environ.get("VSR_PP_LANE_PREBUILD", "1") != "0":
+            import atexit
+            import weakref
+
+            self._lane_thread = threading.Thread(target=self._build_lanes, name="vsr-pp-lane-build", daemon=False)
+            self._lane_thread.start()
+            ref = weakref.ref(self)
+            atexit.register(lambda: (lambda o: o is not None and o._join_lane_thread())(ref()))
 
     def clone(self):
         """a second instance on the same device from the same checkpoints: its own three engines and workspaces (tools/batch_lanes.py)"""
@@ -176,11 +184,14 @@ class PropainterInpaint:
         except BaseException as e:            # noqa: BLE001 -- re-raised by the first call that needs a lane
             self._lane_error = e
 
-    def _lanes_built(self):
+    def _join_lane_thread(self):
         t = self._lane_thread
         if t is not None:
             t.join()
             self._lane_thread = None
+
+    def _lanes_built(self):
+        self._join_lane_thread()
         if self._lane_error is not None:
             e, self._lane_error = self._lane_error, None
             raise e
@@ -411,36 +422,41 @@ class PropainterInpaint:
             # host waits for the window: the lanes then need a host thread each, or the second lane would never be fed while the first
             # one is waited for.  (ctypes releases the GIL for the duration of a library call.)
             threaded = lanes > 1 and self.PRECISIONS[self.precision][2] != "f32"
-            if threaded:
-                from concurrent.futures import ThreadPoolExecutor
+            try:
+                if threaded:
+                    from concurrent.futures import ThreadPoolExecutor
 
-                pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"vsr-pp-lane{j}") for j in range(lanes)]
-                try:
-                    futs = [pools[k % lanes].submit(run_window, k) for k in range(len(windows))]
-                    for f in futs:
-                        f.result()
-                finally:
-                    for pl in pools:
-                        pl.shutdown(wait=True)
-            else:
-                for k in range(len(windows)):
-                    run_window(k)
-                    if prof is not None:
-                        nb, ref = windows[k]
-                        ids, l_t = nb + ref, len(nb)
-                        key = (len(ids), l_t, enc_cache is not None)
+                    pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"vsr-pp-lane{j}") for j in range(lanes)]
+                    try:
+                        futs = [pools[k % lanes].submit(run_window, k) for k in range(len(windows))]
+                        for f in futs:
+                            f.result()
+                    finally:
+                        for pl in pools:
+                            pl.shutdown(wait=True)
+                else:
+                    for k in range(len(windows)):
+                        run_window(k)
+                        if prof is not None:
+                            nb, ref = windows[k]
+                            ids, l_t = nb + ref, len(nb)
+                            key = (len(ids), l_t, enc_cache is not None)
 
-                        def window_flops(key=key, ids=ids, l_t=l_t):
-                            if key not in flags_cache:
-                                flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
-                            return flags_cache[key]
+                            def window_flops(key=key, ids=ids, l_t=l_t):
+                                if key not in flags_cache:
+                                    flags_cache[key] = self.model.plan_flops(len(ids), l_t, h, w, flags_cache[l_t], box, 2 if enc_cache is not None else 0)
+                                return flags_cache[key]
 
-                        lap("generator", window_flops)
-            if lanes > 1:
-                for st in lane_streams:                                                         # the caller's stream ends behind every lane
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    main.wait_event(ev)
+                            lap("generator", window_flops)
+            finally:
+                # also when a window raised: tensors allocated on the caller's stream (flows, encoder cache, comp) are read
+                # and written by kernels still queued on the lane streams -- the caller's stream must end behind every lane before they
+                # can go out of scope, or the allocator hands their memory to the next batch under those kernels
+                if lanes > 1:
+                    for st in lane_streams:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        main.wait_event(ev)
             if resident:
                 return comp
             out = comp.cpu().numpy()                                                        # already BGR (:360)

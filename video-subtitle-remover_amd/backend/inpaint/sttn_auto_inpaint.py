@@ -230,24 +230,32 @@ class STTNAutoInpaint:
         with fixed-size records and a *.y4m sink on rank 0, colour conversion on the GPU, no preview consumer.  Rank 0 decides and
         tells the others (the sink is its object); the sink is grown to its final size before anybody writes."""
         want = os.environ.get("VSR_IO_PER_RANK", "1" if dist is not None else "0")
-        if want != "1" or gui or not inpaint_area:
-            return None
         rl = getattr(reader, "record_layout", None)
         pf = getattr(reader, "planes_format", None)
-        src = rl() if rl is not None else None
-        rf = pf() if pf is not None else None
+        src = rl() if (rl is not None and want == "1" and not gui and inpaint_area) else None
+        rf = pf() if (pf is not None and src is not None) else None
+        # The decision is COLLECTIVE (ADVICE r5): a rank that cannot take the path (the file is not visible on its node, colour conversion
+        # off there, VSR_IO_PER_RANK differing per rank) must not fall through to chunk_parallel's exchanges while rank 0 waits in
+        # run_rank_local.  Every rank says whether IT can; only when all can does rank 0 size the sink and publish its layout.
+        able = src is not None and rf is not None
+        if dist is not None:
+            flag = torch.tensor([1 if able else 0], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            able = bool(int(flag.item()))
         decision = [None]
-        if rank == 0:
+        if rank == 0 and able:
             wl = getattr(writer, "record_layout", None)
             wpf = getattr(writer, "planes_format", None)
             wf = wpf() if wpf is not None else None
-            if src is not None and rf is not None and wl is not None and wf is not None and src["count"] == total:
+            if wl is not None and wf is not None and src["count"] == total:
                 dst = wl(total)
                 if dst is not None:
                     decision = [(dst, wf)]
         if dist is not None:
             dist.broadcast_object_list(decision, src=0)         # also orders "the sink has its final size" before every rank's first write
-        if decision[0] is None or src is None or rf is None:
+        if decision[0] is None or not able:
             return None
         return src, decision[0][0], rf, decision[0][1]
 

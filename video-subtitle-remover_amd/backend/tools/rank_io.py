@@ -40,7 +40,12 @@ class RecordFile:
             off = self.offset(k0 + j)
             if j == 0 and self.prefix and os.pread(self.fd, len(self.prefix), off) != self.prefix:
                 break                                    # not a record boundary: the file is not what its header said
-            got = os.preadv(self.fd, [memoryview(out[j])], off + len(self.prefix))
+            mv, got = memoryview(out[j]), 0
+            while got < self.frame_bytes:                # a short pread is not the end of the file (signals, network filesystems): ask again
+                k = os.preadv(self.fd, [mv[got:]], off + len(self.prefix) + got)
+                if k <= 0:
+                    break
+                got += k
             if got < self.frame_bytes:
                 break
             n += 1
@@ -152,6 +157,7 @@ def run_rank_local(ranges, src, dst, work, dist=None, alloc=None, tick=None):
         for f in (fin, fout):
             if f is not None:
                 f.close()
+    bad = 1 << 30
     if dist is not None:
         import torch
 
@@ -161,9 +167,19 @@ def run_rank_local(ranges, src, dst, work, dist=None, alloc=None, tick=None):
             status = status.cuda()
         dist.all_reduce(status, op=dist.ReduceOp.MIN)
         bad = int(status.item())
-        if failure:
-            raise failure[0]
-        if bad != 1 << 30:
-            raise RankIOError(f"rank {bad - 1} failed in its chunks; this rank ({rank}) finished its own")
-    elif failure:
+    if (failure or bad != 1 << 30) and rank == 0:
+        mark_failed(dst["path"])
+    if failure:
         raise failure[0]
+    if bad != 1 << 30:
+        raise RankIOError(f"rank {bad - 1} failed in its chunks; this rank ({rank}) finished its own")
+
+
+def mark_failed(path):
+    """The sink was grown to its final size before anybody wrote (presize): after a failed run it is a full-size file with holes where
+    records are missing -- nothing about it says so (the rank-0 funnel left a visibly truncated file).  Rank 0 renames it to
+    `<path>.failed`; the exception still reaches the caller."""
+    try:
+        os.replace(path, path + ".failed")
+    except OSError:
+        pass

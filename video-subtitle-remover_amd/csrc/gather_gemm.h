@@ -22,6 +22,3 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
 // whole rounds of 256-row tiles and a remainder of short tiles (out: room for 2 problems; returns how many); CUs of the device
 extern "C" int vsr_v7_split(const GGProblem* p, int cus, GGProblem* out);
 extern "C" int vsr_gg_cus(void);
-// the 288 x 256 exact-fp32 kernel (tile config VSR_TILE_288x256, variant 3, NK; gather_gemm_v8.h): out[0] = the problem with tilesN
-// and a tilesM that makes the launch whole rounds of equal tiles (out may alias p); returns 1
-extern "C" int vsr_v8_split(const GGProblem* p, int cus, GGProblem* out);

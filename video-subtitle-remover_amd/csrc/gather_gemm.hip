@@ -42,7 +42,7 @@ __device__ __forceinline__ float f32_from_ordered(unsigned int e)
     return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
-// Ablation hooks (scripts/gg_ablate.hip defines GG_ABLATE and adds an ABL template argument that
+// Ablation hooks (scripts/attic/gg_ablate.hip defines GG_ABLATE and adds an ABL template argument that
 // switches single mechanisms off to price them); compiled out of the product.
 #ifdef GG_ABLATE
 #define GG_ABL_PARAM , int ABL
@@ -318,39 +318,6 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #include "gather_gemm_v5.h"
 #include "gather_gemm_v6.h"
 #include "gather_gemm_v7.h"
-#include "gather_gemm_v8.h"
-
-// How a problem is laid out for the 288 x 256 exact-fp32 kernel (gather_gemm_v8.h; one workgroup per CU: a launch runs in whole
-// rounds of equal tiles).  Picks the tile height h (in 32-row blocks, <= 9) that minimises rounds x (h + the fixed cost of a tile,
-// priced in blocks of this K) and writes the problem with tilesN = ceil(N / 256) and tilesM = ceil(blocks / h) to out[0] (out may
-// be p itself); the kernel derives the height again from M and tilesM.  Returns 1.  tileStart is left to the caller.
-extern "C" int vsr_v8_split(const GGProblem* p, int cus, GGProblem* out)
-{
-    if (cus <= 0) cus = 256;
-    GGProblem q = *p;
-    const int tilesN = (q.N + 255) / 256;
-    const int splitK = q.splitK > 0 ? q.splitK : 1;
-    const int perM = tilesN * splitK;                          // workgroups one M tile needs (N tiles x K slices)
-    const int nblk = (q.M + 31) / 32;
-    const int chunks = q.chunksPerSplit > 0 ? q.chunksPerSplit : (q.K / VSR_GG_KC > 0 ? q.K / VSR_GG_KC : 1);
-    // prologue + epilogue of a tile ~ 25 us; one block of a 72-chunk problem ~ 62 us (profiles/r04_v8_probe_*.log)
-    const double ovh = 0.4 * 72.0 / chunks;
-    int bestTiles = (nblk + 8) / 9;
-    double bestCost = 1e30;
-    for (int h = 1; h <= 9; ++h) {
-        const int tilesM = (nblk + h - 1) / h;
-        const int rows = ((q.M + tilesM - 1) / tilesM + 31) & ~31;         // the height the kernel will derive
-        if (rows > 288) continue;
-        const long long wgs = (long long)tilesM * perM;
-        const long long rounds = (wgs + cus - 1) / cus;
-        const double cost = (double)rounds * (rows / 32 + ovh);
-        if (cost < bestCost - 1e-9) { bestCost = cost; bestTiles = tilesM; }
-    }
-    q.tilesN = tilesN;
-    q.tilesM = bestTiles;
-    *out = q;
-    return 1;
-}
 
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
@@ -545,13 +512,6 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
     if (tileCfg == VSR_TILE_256x256) {         // the 8-wave 256 x 256 tile of the split-format modes (variant 5: split-half, 6: fp16 operands; dynamic tile height, see gather_gemm_v7.h)
         if (bmode != VSR_BMODE_NK || (variant != 6 && variant != 5) || !queue) return -1;
         launch_v7(d_probs, nprobs, totalBlocks, queue, rangeFlag, variant == 6, stream);
-        return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
-    }
-    if (tileCfg == VSR_TILE_288x256) {         // exact fp32, 8 waves, up to 288 x 256 per workgroup, one workgroup per CU (gather_gemm_v8.h)
-        if (bmode != VSR_BMODE_NK || (variant != 3 && variant != 2) || !queue) return -1;
-        static const int resident = resident_blocks(gather_gemm_f32_v8<9>, 512);
-        const int g = totalBlocks < resident ? totalBlocks : resident;
-        hipLaunchKernelGGL((gather_gemm_f32_v8<9>), dim3(g), dim3(512), 0, stream, d_probs, nprobs, totalBlocks, queue);
         return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
     }
     if (tileCfg == VSR_TILE_128x128 && bmode == VSR_BMODE_NK) GG_LAUNCH(128, 128, 2, 2, VSR_BMODE_NK);

@@ -3,7 +3,7 @@
 // v4 showed that the split-half arithmetic (a = hi + lo in fp16, a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi,
 // fp32 accumulation) is as accurate as the fp32 kernels on this network, but that splitting inside the
 // GEMM costs more than the MFMAs it feeds: 235 TF with the global->VGPR->cvt->ds_write staging vs 400 TF
-// without it (scripts/gg_ablate.hip).  v5 therefore moves the split to the PRODUCER: every tensor that is
+// without it (scripts/attic/gg_ablate.hip).  v5 therefore moves the split to the PRODUCER: every tensor that is
 // a GEMM operand lives in HBM in "split format" -- each 32-float chunk (128 B) holds [32 hi halves | 32 lo
 // halves] of the same 32 values -- so all offset tables (which address 32-element chunks) are unchanged,
 // an operand tile reaches LDS by LDS-DMA exactly like v3 (no VGPR staging, no conversion, no ds_write), and

@@ -224,23 +224,12 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
     // split-format modes (precision 2, 3): the large NK problems of an op (convs, QKV, the fine attention scales) go to the 256 x 256 kernel, each cut
     // into whole rounds + a remainder (vsr_v7_split: up to two descriptors); the rest of the op stays on the 128 x 64 kernel
     static const bool v7on = [] { const char* e = getenv("VSR_F16_V7"); return !(e && atoi(e) == 0); }();
-    // exact fp32 (precision 0), OPT-IN (VSR_F32_V8=1): the long-K, wide NK problems -- the 3x3 256 -> 256 convolutions -- on the
-    // 288 x 256 kernel (gather_gemm_v8.h; bit-identical to the 128 x 64 kernel).  Measured (profiles/r04_f32_knobs_ab.log): the
-    // convolutions go 125 -> 128-129 TF and a single-lane step 177.9 -> 179.1 fps, but with the default two window lanes the step
-    // goes 197.0 -> 192.9 fps -- one 136 KB workgroup per CU leaves no room for the other lane's kernel, and what the lanes buy
-    // (the tails of the 128 x 64 launches filled by the other lane) is worth more than the tile.  Off by default.
-    static const bool v8on = [] { const char* e = getenv("VSR_F32_V8"); return e && atoi(e) == 1; }();
+    // (exact fp32 stays on the 128 x 64 kernel: the 288 x 256 one-workgroup-per-CU tile of round 4 -- gather_gemm_v8.h, opt-in, deleted in
+    // round 6 -- won 0.7 % on a single-lane step and lost 2 % with the default two window lanes)
     const int cus = vsr_gg_cus();
     // NK problems as they are; KN problems (P.V: B = V, n-contiguous) after their B operand has been turned to NK form into a
     // scratch tensor (one pass over V per product, ~2 % of the product's own time).  Split-K problems keep their partial planes.
     auto forV7 = [&](const Op& op, const GemmItem& g) {
-        if (precision == 0) {
-            // one workgroup per CU and no co-resident workgroup to hide a tile's prologue / epilogue: only where a tile is long
-            // (K >= 1024) and the problem fills the chip; operand row offsets must fit the kernel's 32-bit byte offsets
-            if (!v8on || op.bmode != VSR_BMODE_NK || (g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP)) || g.splitK != 1) return false;
-            if (g.N < 192 || g.N % 32 || g.K < 1024 || (int64_t)g.M * ((g.N + 255) / 256) < (int64_t)32 * cus) return false;
-            return P.bufElems[g.bufA] < ((int64_t)1 << 30) && (g.bufB == BUF_WEIGHTS ? (int64_t)h->model.packed.size() : P.bufElems[g.bufB]) < ((int64_t)1 << 30);
-        }
         if (!v7on || precision < 2 || (g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP))) return false;
         if (op.bmode == VSR_BMODE_KN && (g.K % 32 || g.N % 32)) return false;
         const int64_t units = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitK;
@@ -306,7 +295,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
                         od.vts.push_back(vt);
                     }
                     GGProblem two[2];
-                    const int n = precision == 0 ? vsr_v8_split(&q, cus, two) : vsr_v7_split(&q, cus, two);
+                    const int n = vsr_v7_split(&q, cus, two);
                     for (int k = 0; k < n; ++k) big.push_back(two[k]);
                 } else {
                     small.push_back(q);
@@ -448,16 +437,14 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
         if (laned && od.kind == OP_DECODE_OUT && lastDecodeLane >= 0 && lastDecodeLane != od.lane)
             HIPCHK(hipStreamWaitEvent(stream, h->evDecode[nDecode - 1], 0));
         TimingRec tr;
-        // (mode 2 brackets the launches of the two NK kernels the convolutions can be on -- the 128 x 64 tile and the 288 x 256 tile --
-        // so that whichever symbol carries the most time is the one `roofline` is taken on)
+        // (mode 2 brackets the launches of the NK kernel the convolutions are on, the 128 x 64 tile: the symbol `roofline` is taken on)
         const bool timed = h->timing == 1 || (h->timing == 2 && od.kind == OP_GEMM && od.tileCfg == VSR_TILE_128x64 && od.bmode == VSR_BMODE_NK);
         if (timed) {
             tr.tag = od.tag; tr.flops = od.flops;
             // an op whose problems all went to the 8-wave kernel is that kernel's launch; one that was cut in two keeps the tile's name + "m"
             const bool big = od.kind == OP_GEMM && od.total7 > 0;
             tr.kernel = od.kind != OP_GEMM ? ("kernel:op:" + std::to_string(od.kind))
-                      : (big && od.total == 0) ? ("kernel:gg:" + std::to_string(prec == 0 ? VSR_TILE_288x256 : VSR_TILE_256x256) + ":0:v" +
-                                                  std::to_string(prec == 0 ? 8 : 7))
+                      : (big && od.total == 0) ? ("kernel:gg:" + std::to_string(VSR_TILE_256x256) + ":0:v7")
                       : ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode) + ":v" +
                          std::to_string(gg_variant(od.bmode, prec)) + (od.aexp ? "x" : "") + (big ? "m" : ""));
             HIPCHK(hipEventCreate(&tr.a));
@@ -478,10 +465,8 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             for (const OpDev::Vt& vt : od.vts)
                 if (rc == 0) rc = vsr_launch_kn_to_nk_split(vt.B, vt.rowB, vt.colB, vt.K, vt.N, vt.ld, vt.dst, stream);
             if (rc == 0 && od.total7 > 0)
-                rc = prec == 0 ? vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_288x256, VSR_BMODE_NK,
-                                                            queue + 8, 3, 1, nullptr, stream)
-                               : vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_256x256, VSR_BMODE_NK,
-                                                            queue + 8, (prec == 3 && !scoresSplit) ? 6 : 5, 1, h->dRangeFlag, stream);
+                rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc7, od.nitems7, od.total7, VSR_TILE_256x256, VSR_BMODE_NK, queue + 8,
+                                                (prec == 3 && !scoresSplit) ? 6 : 5, 1, h->dRangeFlag, stream);
             if (rc == 0 && od.total > 0)
                 rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue,
                                                 (scoresSplit ? 5 : gg_variant(od.bmode, prec)) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
@@ -1132,8 +1117,8 @@ int vsr_sttn_timing_get(vsr_sttn_t* h, const char* prefix, double* total_ms, int
 // ---- kernel-level entry points -----------------------------------------------------------
 static void tile_dims(int cfg, int& BM, int& BN)
 {
-    BM = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_128x64) ? 128 : (cfg == VSR_TILE_288x256 ? 288 : 256);
-    BN = (cfg == VSR_TILE_256x256 || cfg == VSR_TILE_288x256) ? 256 : (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_256x128) ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
+    BM = (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_128x64) ? 128 : 256;
+    BN = cfg == VSR_TILE_256x256 ? 256 : (cfg == VSR_TILE_128x128 || cfg == VSR_TILE_256x128) ? 128 : ((cfg == VSR_TILE_256x64 || cfg == VSR_TILE_128x64) ? 64 : 32);
 }
 
 static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_);
@@ -1219,13 +1204,11 @@ static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_
     int total = 0;
     for (auto& p : hp) {
         if (p.K % VSR_GG_KC) return fail(VSR_ERR_ARG, "K must be a multiple of 32");
-        if (tile_cfg == VSR_TILE_256x256 || tile_cfg == VSR_TILE_288x256) {
-            // dynamic tile height: any tilesM whose tiles of roundup32(ceil(M / tilesM)) <= BM rows cover M (gather_gemm_v7.h, _v8.h)
+        if (tile_cfg == VSR_TILE_256x256) {
+            // dynamic tile height: any tilesM whose tiles of roundup32(ceil(M / tilesM)) <= BM rows cover M (gather_gemm_v7.h)
             const int rows = p.tilesM > 0 ? (((p.M + p.tilesM - 1) / p.tilesM) + 31) / 32 * 32 : 0;
             if (p.tilesM <= 0 || rows > BM || (int64_t)rows * p.tilesM < p.M || p.tilesN != (p.N + BN - 1) / BN)
-                return fail(VSR_ERR_ARG, "256x256 / 288x256 tile: tilesM must give tiles of at most 256 / 288 rows that cover M");
-            if (tile_cfg == VSR_TILE_288x256 && (p.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP)))
-                return fail(VSR_ERR_ARG, "288x256 tile: no VSR_ACT_ROW_MAX / VSR_ACT_A_EXP");
+                return fail(VSR_ERR_ARG, "256x256 tile: tilesM must give tiles of at most 256 rows that cover M");
         } else
         if (p.tilesM != (p.M + BM - 1) / BM || p.tilesN != (p.N + BN - 1) / BN) return fail(VSR_ERR_ARG, "tile counts do not match the tile config");
         if (p.splitK < 1 || (int64_t)p.splitK * p.chunksPerSplit < p.K / VSR_GG_KC) return fail(VSR_ERR_ARG, "bad split-K");
