@@ -35,6 +35,7 @@ RES = {"720p": (720, 1280, (620, 700, 192, 1088)), "1080p": (1080, 1920, (950, 1
 TILE_DIMS = {0: (128, 128, 2, 2), 1: (256, 32, 4, 1), 2: (256, 64, 4, 1), 3: (128, 64, 2, 2)}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "config_traffic.json")     # written by scripts/pmc_configs.py from rocprofv3 --pmc passes
 UNIT_ONLY = False           # scripts/pmc_configs.py: one warm unit, a marker kernel, ONE measured unit, a marker kernel -- nothing else
+STAGE_MARKERS = False       # scripts/stage_stats.py (propainter legs): a marker kernel after every stage of one profiled batch
 
 
 def pmc_marker():
@@ -285,6 +286,26 @@ def run_propainter(name, precision="f32", L=68, reps=1):
         r = unit_only(lambda: plug.inpaint(frames, mask))
         plug.close()
         return r
+    if STAGE_MARKERS:
+        # scripts/stage_stats.py: one warm call, then ONE profiled call (every stage on one stream, device-synchronised between stages)
+        # in which a marker kernel closes every stage -- the kernel trace is cut at the markers into one summary per engine
+        plug.profile = {}
+        plug.inpaint(frames, mask)
+        plug.profile = {}
+        ops = {"raft": torch.nextafter, "flow_completion": torch.hypot, "other": torch.copysign, "generator": torch.logaddexp}
+        z = torch.ones(64, device="cuda")
+
+        def marker(stage):
+            ops[stage](z, z + 1)
+
+        torch.cuda.synchronize()
+        torch.fmod(z, z + 1)                     # "begin": everything before it is warm-up
+        plug.stage_marker = marker
+        plug.inpaint(frames, mask)
+        torch.cuda.synchronize()
+        plug.stage_marker = None
+        plug.close()
+        return {"stage_markers": True}
     dt = timed(lambda: plug.inpaint(frames, mask), reps, 1) / reps
     # profiled call (device-synchronised around every stage + events around every launch: slower than the timed one)
     plug.profile = {}
@@ -363,6 +384,9 @@ if __name__ == "__main__":
     argv = sys.argv[1:]
     if argv and argv[0] == "--unit":        # scripts/pmc_configs.py
         UNIT_ONLY = True
+        argv = argv[1:]
+    if argv and argv[0] == "--stages":      # scripts/stage_stats.py
+        STAGE_MARKERS = True
         argv = argv[1:]
     for k, v in run_all(argv or None).items():
         print(json.dumps(v), flush=True)

@@ -191,7 +191,8 @@ def leg_propainter_batches(dist, rank, world, device, dry, wd, leg, precision, s
                "efficiency_note": "value / replicas.value; the exchange of batch_parallel goes through host frames on rank 0 (the reader's and the "
                                   "sink's side of backend/main.py:229-245), the replicas start from HBM",
                "backend": dist.get_backend(), "range_guard_fallbacks": [e.fallbacks() for e in (plug.fix_raft, plug.fix_flow_complete, plug.model)]}
-        attach_traffic(leg, out, fps / L)
+        if L == 68:                              # the PMC summary's unit is a 68-frame batch (a dry run with a shorter batch has no traffic figure)
+            attach_traffic(leg, out, fps / L)
     plug.close()
     return out
 

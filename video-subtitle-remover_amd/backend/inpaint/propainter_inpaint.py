@@ -251,6 +251,10 @@ class PropainterInpaint:
                 acc[0] += time.perf_counter() - lap.t0
                 if flop is not None:
                     acc[1] += flop()
+                mk = getattr(self, "stage_marker", None)
+                if mk is not None:
+                    mk(stage)                 # scripts/stage_stats.py: a marker kernel closes the stage in a rocprofv3 kernel trace
+                    torch.cuda.synchronize(dev)
                 lap.t0 = time.perf_counter()
 
         if prof is not None:

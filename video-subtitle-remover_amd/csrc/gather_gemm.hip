@@ -318,6 +318,9 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #include "gather_gemm_v5.h"
 #include "gather_gemm_v6.h"
 #include "gather_gemm_v7.h"
+#ifdef GG_WITH_V9_PROBE          // scripts/r06/v9_probe.hip only: an experiment that did not make it into the library
+#include "../../scripts/r06/gather_gemm_v9.h"
+#endif
 
 #ifndef GG_ABLATE
 // resident workgroups for the persistent kernel: CUs x occupancy of that instantiation (cached)
