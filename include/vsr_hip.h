@@ -139,7 +139,12 @@ int vsr_sttn_det_batch_rows(vsr_sttn_t* h, uint8_t* frames_dev, int L, int H, in
  * 3: fp16 operands, fp32 accumulation (BASELINE.json's "fp16 MFMA path"): mode 2's tensors and kernels with the
  * lo halves left out of the contractions -- one v_mfma_f32_32x32x16_f16 per product, 11-bit operands; bias,
  * activation, residual adds, softmax and the decoder output stay fp32-accurate.  Same guard and fallback.
- * Environment default: VSR_PRECISION=split (mode 1) / VSR_PRECISION=2 / VSR_PRECISION=3. */
+ * Environment default: VSR_PRECISION=split (mode 1) / VSR_PRECISION=2 / VSR_PRECISION=3.
+ * WHAT THE RANGE GUARD DOES NOT SEE (round 6): modes 1-3 can stay inside the fp16 range and still miss the 50 dB bar --
+ * on weights with sharp attention rows or heavy tails mode 3 measured 47 / 28 dB (STTN) where the benign draw gives 60.  Accuracy is
+ * a property of the checkpoint, so the HOST side checks it: vsr_amd.engine.AccuracyGuard runs the first unit of work of a
+ * reduced-precision mode (and every 256th) in mode 0 as well and demotes the handle when they differ by more than 50 dB.  A caller
+ * that binds this ABI directly and uses modes 1-3 should do the same with its first chunk. */
 /* how THIS library instance reads one of its process-wide switches (read once, at first use): "VSR_DECODE_ROWS", "VSR_DECODE_COLS",
  * "VSR_QKV0_SHARED", "VSR_TRIM_LAST_BLOCK" -> 0 / 1, anything else -> -1.  The Python side (vsr_amd/switches.py) asserts that both agree. */
 int vsr_switch_state(const char* name);
