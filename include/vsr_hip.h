@@ -189,6 +189,11 @@ enum { VSR_ACT_NONE = 0, VSR_ACT_LRELU02 = 1, VSR_ACT_RELU = 2, VSR_ACT_LRELU01 
         * ((float*)R)[split * tilesM * BM + m], for vsr_launch_reduce_scatter's caller to divide by their total. */
        VSR_ACT_ROW_MAX = 0x400, VSR_ACT_A_EXP = 0x800 };
 #define VSR_VARIANT_A_EXP 0x100 /* OR-ed into the kernel variant 1 of a KN launch whose problems may carry VSR_ACT_A_EXP */
+#define VSR_VARIANT_NARROW 8    /* problems of at most FOUR output columns (the last conv of a head: RAFT update.py:6-12 flow head conv2,
+                                 * recurrent_flow_completion.py:271-276 upsample.2, propainter.py:268-276 decoder's last conv): a dot-product
+                                 * kernel, exact fp32, no matrix cores (csrc/gather_gemm_narrow.h).  NK problems laid out for VSR_TILE_256x32,
+                                 * splitK = 1, no residual, act in VSR_ACT_NONE..VSR_ACT_LRELU01, N * K floats of weights within 40 KB of LDS.
+                                 * The flow engines pick it by themselves (VSR_GG_NARROW=0: never) */
 enum { VSR_TILE_128x128 = 0, VSR_TILE_256x32 = 1, VSR_TILE_256x64 = 2, VSR_TILE_128x64 = 3,
        VSR_TILE_256x128 = 4, /* 8 waves; the fp16-operand kernel (variant 6, NK) only */
        VSR_TILE_256x256 = 5  /* 8 waves, one workgroup per CU; variants 5 / 6, NK only.  tilesM may exceed ceil(M / 256): a tile then covers
@@ -246,7 +251,7 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
  * LDS-DMA (fp32 MFMA), 4 persistent split-half operands on the f16 matrix cores (see vsr_sttn_set_precision),
  * 5 the same on split-format tensors: A, B and R are read in split format; C is written in split format when
  * act carries VSR_ACT_OUT_SPLIT, as plain fp32 otherwise; 6 = variant 5 with the fp16 hi halves alone as
- * operands (fp16 x fp16 -> fp32 accumulate, one MFMA per product) */
+ * operands (fp16 x fp16 -> fp32 accumulate, one MFMA per product); VSR_VARIANT_NARROW: see above */
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream);
 int vsr_run_softmax(const SMProblem* probs, int nprobs, void* stream);
 /* fp32 -> split format (variant 5 operands): dst[32c .. 32c+31] as bytes = fp16 hi[0..31] | fp16 lo[0..31] of

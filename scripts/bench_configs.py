@@ -259,6 +259,8 @@ def flow_kernel_symbol(name):
     _, cfg, bmode, var = name.split(":")
     if cfg == "flash":                     # the generator's fused window attention (pp_attn_kernels.hip)
         return "k_pp_flash_attn_f16" if var == "v7" else "k_pp_flash_attn_f32"
+    if cfg == "narrow":                    # GEMMs of <= 4 output columns on the dot-product kernel (gather_gemm_narrow.h)
+        return "gather_gemm_f32_narrow"
     bm, bn, wm, wn = TILE_DIMS[int(cfg)]
     v = int(var[1:])
     if v == 3:

@@ -187,6 +187,34 @@ def test_gather_gemm_narrow_tiles(built_lib, gpu_device, cfg, bn, M, N, K):
     _assert_close(got, _reference(c), K, f"{cfg} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,act,bias", [(700, 3, 64, 1, True), (1000, 2, 2304, 0, True), (513, 1, 288, 2, False), (300, 4, 576, 3, True),
+                                             (256, 2, 32, 0, True)])
+def test_gather_gemm_dot_product_kernel(built_lib, gpu_device, M, N, K, act, bias):
+    """VSR_VARIANT_NARROW (csrc/gather_gemm_narrow.h): problems of at most four output columns on the 256 x 32 tile's tables -- the
+    descriptor semantics of the MFMA kernels (scattered rows / chunks, alpha, bias, activation, exact store footprint), and the MFMA
+    kernel's result within fp32 summation-order noise."""
+    VARIANT_NARROW = 8
+    rng = np.random.default_rng(M + 17 * N + K)
+    c = _make_gemm_case(rng, M, N, K, 256, 32, 0, 1, bias, act, False, alpha=0.75)
+    got = _run_cases(built_lib, gpu_device, [c], built_lib.TILE_256x32, 0, VARIANT_NARROW)[0]
+    _assert_close(got, _reference(c), K, f"narrow {M}x{N}x{K}", case=c)
+    mfma = _run_cases(built_lib, gpu_device, [c], built_lib.TILE_256x32, 0, 3)[0]
+    assert np.abs(got - mfma).max() <= 2e-5 * np.sqrt(K)
+
+
+def test_gather_gemm_dot_product_kernel_grouped_and_refused(built_lib, gpu_device):
+    """several problems of one launch (N = 2 and N = 3 together run on the 4-column instance); a residual, split-K or N = 5 is refused"""
+    rng = np.random.default_rng(99)
+    cases = [_make_gemm_case(rng, 333, 2, 288, 256, 32, 0, 1, True, 0, False), _make_gemm_case(rng, 700, 3, 576, 256, 32, 0, 1, True, 1, False),
+             _make_gemm_case(rng, 5, 2, 64, 256, 32, 0, 1, False, 0, False)]
+    for c, got in zip(cases, _run_cases(built_lib, gpu_device, cases, built_lib.TILE_256x32, 0, 8)):
+        _assert_close(got, _reference(c), c.K, f"narrow grouped {c.M}x{c.N}x{c.K}", case=c)
+    for bad in (_make_gemm_case(rng, 300, 5, 64, 256, 32, 0), _make_gemm_case(rng, 300, 2, 64, 256, 32, 0, 1, True, 0, True),
+                _make_gemm_case(rng, 300, 2, 128, 256, 32, 0, 2)):
+        with pytest.raises(built_lib.VsrError):
+            _run_cases(built_lib, gpu_device, [bad], built_lib.TILE_256x32, 0, 8)
+
+
 @pytest.mark.parametrize("variant", [1, 3, 4])
 @pytest.mark.parametrize("cfg,bm,bn,bmode,M,N,K,splitK", [
     ("TILE_128x128", 128, 128, 0, 513, 257, 2304, 1), ("TILE_128x64", 128, 64, 0, 300, 256, 576, 1),

@@ -67,8 +67,9 @@ struct FlowOpDev {
     const void* dDesc = nullptr;   // GGProblem* (device)
     int nitems = 0, total = 0, nQueues = 1;
     // fused window attention: 1 = this op (the QK^T of an attention triple) launches the fused kernel instead, 2 = covered by it (skipped);
-    // 3 / 4: the fold / unfold of an FFN pair whose GELU moved into the fold
+    // 3 / 4: the fold / unfold of an FFN pair whose GELU moved into the fold; 5: a GEMM of <= 4 output columns on the dot-product kernel
     int fused = 0;
+    int narrowN = 0, narrowK = 0;  // fused == 5: the largest N / K of the op's problems
     const void* dAttn = nullptr;   // PpAttnProblem* (device), fused == 1
     int attnItems = 0, attnTiles = 0;
     double attnFlops = 0;
@@ -288,6 +289,29 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
             pd->ops[i + 1].fused = 4;
         }
     }
+    // ---- GEMMs of at most four output columns (the last conv of a head: RAFT "upd.fh2", flow completion "dec.u1", generator "dec.6"):
+    // the dot-product kernel of gather_gemm_narrow.h instead of the 256 x 32 MFMA tile, in every arithmetic mode (it is exact fp32).
+    // VSR_GG_NARROW=0 keeps the plan's tile.
+    static const bool narrow = [] { const char* e = getenv("VSR_GG_NARROW"); return !(e && atoi(e) == 0); }();
+    if (narrow) {
+        for (size_t i = 0; i < P.ops.size(); ++i) {
+            const Op& op = P.ops[i];
+            if (op.kind != OP_GEMM || op.bmode != VSR_BMODE_NK || op.tileCfg != VSR_TILE_256x32 || op.gemm.empty() || pd->ops[i].fused) continue;
+            bool ok = true;
+            int maxN = 0, maxK = 0;
+            for (const GemmItem& g : op.gemm) {
+                ok = ok && g.N <= 4 && g.tilesN == 1 && g.splitK == 1 && g.bufR < 0 && g.K % VSR_GG_KC == 0 &&
+                     (int64_t)(g.N <= 2 ? 2 : 4) * g.K <= vsr_gg_narrow_cap() &&
+                     (g.act == VSR_ACT_NONE || g.act == VSR_ACT_LRELU02 || g.act == VSR_ACT_RELU || g.act == VSR_ACT_LRELU01);
+                maxN = std::max(maxN, g.N);
+                maxK = std::max(maxK, g.K);
+            }
+            if (!ok || (int64_t)(maxN <= 2 ? 2 : 4) * maxK > vsr_gg_narrow_cap()) continue;
+            pd->ops[i].fused = 5;
+            pd->ops[i].narrowN = maxN;
+            pd->ops[i].narrowK = maxK;
+        }
+    }
     *out = std::move(pd);
     return 0;
 }
@@ -308,6 +332,7 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         FlowTimingRec tr;
         if (g_flowTiming) {
             if (od.fused == 1) tr.key = std::string(ws.engine) + ":gg:flash:0:v" + (ws.precision == 2 ? "7" : "3") + ":attn.flash";
+            else if (od.fused == 5) tr.key = std::string(ws.engine) + ":gg:narrow:0:v3:" + op.tag;
             else
             tr.key = std::string(ws.engine) + (op.kind == OP_GEMM ? ":gg:" + std::to_string(op.tileCfg) + ":" + std::to_string(op.bmode) + ":v" +
                                                                         std::to_string(variant) + ":" : ":op:") + op.tag;
@@ -319,6 +344,8 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         if (od.fused == 1) {
             // fp16 operands in the fp16-operand mode; the split-half mode (operands as hi / lo pairs) keeps the exact kernel
             rc = vsr_pp_launch_flash_attn((const PpAttnProblem*)od.dAttn, od.attnItems, od.attnTiles, ws.precision == 2 ? 1 : 0, rangeFlag, stream);
+        } else if (od.fused == 5) {
+            rc = vsr_launch_gather_gemm_narrow_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.narrowN, od.narrowK, stream);
         } else if (op.kind == OP_GEMM) {
             rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, variant, od.nQueues,
                                             rangeFlag, stream);

@@ -22,3 +22,8 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
 // whole rounds of 256-row tiles and a remainder of short tiles (out: room for 2 problems; returns how many); CUs of the device
 extern "C" int vsr_v7_split(const GGProblem* p, int cus, GGProblem* out);
 extern "C" int vsr_gg_cus(void);
+
+// at most four output columns: the dot-product kernel (gather_gemm_narrow.h).  Problems laid out for the 256 x 32 tile (tilesN = 1),
+// splitK = 1, NK, no residual, N * K <= vsr_gg_narrow_cap(); maxN / maxK = the largest N / K among them
+extern "C" int vsr_gg_narrow_cap(void);
+extern "C" int vsr_launch_gather_gemm_narrow_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int maxN, int maxK, void* stream);

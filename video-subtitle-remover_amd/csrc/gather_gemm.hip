@@ -318,6 +318,7 @@ gather_gemm_f32(const GGProblem* __restrict__ probs, int nprobs)
 #include "gather_gemm_v5.h"
 #include "gather_gemm_v6.h"
 #include "gather_gemm_v7.h"
+#include "gather_gemm_narrow.h"
 #ifdef GG_WITH_V9_PROBE          // scripts/r06/v9_probe.hip only: an experiment that did not make it into the library
 #include "../../scripts/r06/gather_gemm_v9.h"
 #endif
@@ -525,6 +526,21 @@ extern "C" int vsr_launch_gather_gemm_dev(const GGProblem* d_probs, int nprobs, 
     else if (tileCfg == VSR_TILE_128x64 && bmode == VSR_BMODE_KN) GG_LAUNCH(128, 64, 2, 2, VSR_BMODE_KN);
     else
         return -1;
+    return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
+}
+
+// problems of at most four output columns (gather_gemm_narrow.h): NK, tiles of 256 rows (tilesN = 1, splitK = 1), no residual,
+// N x K <= vsr_gg_narrow_cap() floats -- the caller checks (flow_engine.hip); maxN / maxK = the largest N / K of the launch
+extern "C" int vsr_gg_narrow_cap(void) { return GG_NARROW_WCAP; }
+extern "C" int vsr_launch_gather_gemm_narrow_dev(const GGProblem* d_probs, int nprobs, int totalBlocks, int maxN, int maxK, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nprobs <= 0 || totalBlocks <= 0) return 0;
+    const int nn = maxN <= 2 ? 2 : 4;
+    if (maxN < 1 || maxN > 4 || maxK < VSR_GG_KC || (int64_t)nn * maxK > GG_NARROW_WCAP) return -1;
+    const size_t lds = (size_t)nn * maxK * sizeof(float);
+    if (nn == 2) hipLaunchKernelGGL((gather_gemm_f32_narrow<2>), dim3(totalBlocks), dim3(256), lds, stream, d_probs, nprobs);
+    else hipLaunchKernelGGL((gather_gemm_f32_narrow<4>), dim3(totalBlocks), dim3(256), lds, stream, d_probs, nprobs);
     return hipGetLastError() == hipSuccess ? 0 : VSR_ERR_HIP;
 }
 #endif // GG_ABLATE

@@ -1130,7 +1130,8 @@ int vsr_run_gather_gemm(const GGProblem* probs, int nprobs, int tile_cfg, int bm
 
 int vsr_run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_cfg, int bmode, int variant, void* stream_)
 {
-    if (variant != (1 | VSR_VARIANT_A_EXP) && (variant < 1 || variant > 6)) return fail(VSR_ERR_ARG, "kernel variant must be 1..6 (or 1 | VSR_VARIANT_A_EXP)");
+    if (variant != (1 | VSR_VARIANT_A_EXP) && variant != VSR_VARIANT_NARROW && (variant < 1 || variant > 6))
+        return fail(VSR_ERR_ARG, "kernel variant must be 1..6, VSR_VARIANT_NARROW or 1 | VSR_VARIANT_A_EXP");
     return run_gather_gemm_variant(probs, nprobs, tile_cfg, bmode, variant, stream_);
 }
 
@@ -1175,11 +1176,20 @@ int vsr_gemm_plan_create(const GGProblem* probs, int nprobs, int tile_cfg, int b
     return 0;
 }
 
+__global__ void k_zero_queue(unsigned int* q) { if (threadIdx.x < 8) q[threadIdx.x] = 0u; }
+
 int vsr_gemm_plan_run(vsr_gemm_plan_t* p, void* stream_)
 {
     if (!p || !p->d) return fail(VSR_ERR_ARG, "null plan");
     hipStream_t stream = (hipStream_t)stream_;
-    if (p->variant >= 2) HIPCHK(hipMemsetAsync(p->queue, 0, 8 * sizeof(unsigned int), stream));
+    // The tile counters are zeroed by a KERNEL, not by hipMemsetAsync: a resident plan is what a caller may capture into a HIP graph
+    // (ocr_det.py run_graphed), and a graph holding captured memset nodes faulted on its second replay after eager work on the same
+    // stream -- every time with this kernel family, never with kernel nodes only, and a queue that is not zeroed at all is harmless at
+    // those sizes, so the faulting write is the memset node's own (profiles/r06_det_graph_triage.log).
+    // VSR_PLAN_ZERO_KERNEL=0: hipMemsetAsync as before (reproduces the fault); 2: not zeroed at all (triage only).
+    static const int zeroMode = [] { const char* e = getenv("VSR_PLAN_ZERO_KERNEL"); return e ? atoi(e) : 1; }();
+    if (p->variant >= 2 && zeroMode == 0) HIPCHK(hipMemsetAsync(p->queue, 0, 8 * sizeof(unsigned int), stream));
+    else if (p->variant >= 2 && zeroMode != 2) hipLaunchKernelGGL(k_zero_queue, dim3(1), dim3(64), 0, stream, p->queue);
     const int rc = vsr_launch_gather_gemm_dev(p->d, p->nprobs, p->total, p->tileCfg, p->bmode, p->variant >= 2 ? p->queue : nullptr, p->variant,
                                               p->nQueues, nullptr, stream);
     if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");
@@ -1226,7 +1236,23 @@ static int run_gather_gemm_variant(const GGProblem* probs, int nprobs, int tile_
     int nQueues = 8;
     for (const auto& p : hp)
         if (p.tilesN > 4) nQueues = gg_wide_queues();
-    const int rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, variant, nQueues, nullptr, stream);
+    int rc;
+    if (variant == VSR_VARIANT_NARROW) {       // the dot-product kernel: what the flow engines check before they pick it (flow_engine.hip)
+        int maxN = 0, maxK = 0;
+        bool ok = tile_cfg == VSR_TILE_256x32 && bmode == VSR_BMODE_NK;
+        for (const auto& p : hp) {
+            ok = ok && p.N >= 1 && p.N <= 4 && p.splitK == 1 && p.R == nullptr && (p.act & ~3) == 0;
+            maxN = std::max(maxN, (int)p.N);
+            maxK = std::max(maxK, (int)p.K);
+        }
+        ok = ok && (int64_t)(maxN <= 2 ? 2 : 4) * maxK <= vsr_gg_narrow_cap();
+        if (!ok) {
+            (void)hipFree(d);
+            return fail(VSR_ERR_ARG, "VSR_VARIANT_NARROW: NK problems on the 256x32 tile with N <= 4, no split-K, no residual, a plain activation and N * K within vsr_gg_narrow_cap()");
+        }
+        rc = vsr_launch_gather_gemm_narrow_dev(d, nprobs, total, maxN, maxK, stream);
+    } else
+    rc = vsr_launch_gather_gemm_dev(d, nprobs, total, tile_cfg, bmode, queue, variant, nQueues, nullptr, stream);
     hipError_t e = hipStreamSynchronize(stream);
     (void)hipFree(d);
     if (rc != 0) return fail(VSR_ERR_HIP, "gather-gemm launch failed (unsupported tile/bmode?)");
