@@ -263,7 +263,9 @@ class PaddleGraphRunner:
         self._gemm.clear()
 
     def run_graphed(self, x):
-        """EXPERIMENTAL, not used by default (faulted on its first MI355X run, undiagnosed).
+        """Opt-in (VSR_DET_GRAPH=1).  Round 1's fault at replay: captured hipMemsetAsync nodes (vsr_gemm_plan_run zeroed its tile counters
+        with one per conv) -- a graph holding them faulted on a later replay in 4 of 9 processes, a graph of kernel nodes only in 0 of 9
+        (profiles/r06_det_graph_triage.log); the plans zero with a kernel since.
         run() replayed from a HIP graph: the forward is ~300-450 small launches and host-bound when issued one by one.  The first
         call for an input shape runs eagerly once (creates the resident GEMM plans: allocations and uploads cannot be captured), then
         captures a second pass; later calls copy the input into the captured buffer and replay.  The returned tensor is the graph's
@@ -898,8 +900,10 @@ class TextDetection:
         self.runner = PaddleGraphRunner(self.graph, weights, device)
         self.resize_long = resize_long
         self.limit_type = limit_type
-        # VSR_DET_GRAPH=1 replays the forward from a captured HIP graph.  OFF by default: the first capture attempt on the MI355X
-        # ended in a GPU memory access fault at replay and has not been debugged yet.
+        # VSR_DET_GRAPH=1 replays the forward from a captured HIP graph.  OFF by default: the recorded launch list (run_taped) is as fast
+        # (the forward is not launch-bound at the batch sizes used) and needs nothing from the driver.  The memory access fault of round 1
+        # was traced in round 6 to the captured hipMemsetAsync nodes of the resident GEMM plans (profiles/r06_det_graph_triage.log):
+        # the plans now zero their tile counters with a kernel and the replay is clean.
         self.use_graph = os.environ.get("VSR_DET_GRAPH", "0") == "1"
         # VSR_DET_TAPE=0 walks the program op by op on every frame (the recorded launch list is the default, see run_taped)
         self.use_tape = os.environ.get("VSR_DET_TAPE", "1") != "0"
