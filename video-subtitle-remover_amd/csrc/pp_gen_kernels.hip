@@ -233,6 +233,41 @@ k_pp_layernorm(const float* __restrict__ x, const float* __restrict__ gamma, con
     float* d = y + (((int64_t)f * gh + yy) * gw + xx) * C;
     for (int c = lane; c < C; c += 64) d[c] = (s[c] - mean) * rstd * gamma[c] + beta[c];
 }
+// the same with the token held in registers (C = 64 * J): one read of the row -- J independent loads in flight per lane -- instead of
+// three dependent passes; a lane owns the same channels and adds them in the same order, so the result is the plain kernel's bit for bit
+template <int J>
+__global__ void __launch_bounds__(256)
+k_pp_layernorm_reg(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, int t, int fh, int fw,
+                   int gh, int gw, float* __restrict__ y)
+{
+    constexpr int C = 64 * J;
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t ntok = (int64_t)t * fh * fw;
+    if (tok >= ntok) return;
+    const int xx = (int)(tok % fw), yy = (int)((tok / fw) % fh), f = (int)(tok / ((int64_t)fw * fh));
+    const float* s = x + tok * C;
+    float v[J], g[J], b[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) v[j] = s[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { g[j] = gamma[lane + 64 * j]; b[j] = beta[lane + 64 * j]; }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) sum += v[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { const float d = v[j] - mean; var += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = 1.0f / sqrtf(var / (float)C + 1e-5f);
+    float* d = y + (((int64_t)f * gh + yy) * gw + xx) * C;
+#pragma unroll
+    for (int j = 0; j < J; ++j) d[lane + 64 * j] = (v[j] - mean) * rstd * g[j] + b[j];
+}
 
 // EW_PP_POOL: pool_layer, a depthwise Conv2d(C, C, 4, stride 4) (:134-138,219-222) over the (padded) token grid
 // [t][gh][gw][C] -> [t][ph][pw][C]
@@ -285,6 +320,40 @@ k_pp_fold(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, i
         float v = normalize ? acc / (float)cnt : acc;
         if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         out[(((int64_t)f * Hp + y + halo) * Wp + x + halo) * C + c] = v;
+    }
+}
+
+// four channels per thread (C and ld multiples of 4, 16-byte aligned tensors): every load and the store are float4, a quarter of the threads
+// and of the index arithmetic; per element the same patches in the same order -- the plain kernel's result bit for bit
+__global__ void __launch_bounds__(256)
+k_pp_fold4(const float* __restrict__ vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, int gelu, float* __restrict__ out)
+{
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)t * h * w * C4;
+    const int Wp = w + 2 * halo, Hp = h + 2 * halo;
+    GRID_STRIDE(i, total) {
+        const int c = 4 * (int)(i % C4);
+        const int x = (int)((i / C4) % w), y = (int)((i / ((int64_t)C4 * w)) % h), f = (int)(i / ((int64_t)C4 * w * h));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int cnt = 0;
+        for (int ty = (y + 3 - 6 + 2) / 3 > 0 ? (y + 3 - 6 + 2) / 3 : 0; ty < fh && 3 * ty <= y + 3; ++ty) {
+            const int ky = y + 3 - 3 * ty;
+            for (int tx = (x + 3 - 6 + 2) / 3 > 0 ? (x + 3 - 6 + 2) / 3 : 0; tx < fw && 3 * tx <= x + 3; ++tx) {
+                const int kx = x + 3 - 3 * tx;
+                const f32x4 u = *reinterpret_cast<const f32x4*>(vec + (((int64_t)f * fh + ty) * fw + tx) * ld + (ky * 7 + kx) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += u[e];
+                ++cnt;
+            }
+        }
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = normalize ? acc[e] / (float)cnt : acc[e];
+            if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            r[e] = v;
+        }
+        *reinterpret_cast<f32x4*>(out + (((int64_t)f * Hp + y + halo) * Wp + x + halo) * C + c) = r;
     }
 }
 
@@ -371,6 +440,8 @@ extern "C" int vsr_pp_launch_layernorm(const float* x, const float* gamma, const
 {
     const int64_t ntok = (int64_t)t * fh * fw;
     if (ntok <= 0) return 0;
+    if (C == 512) hipLaunchKernelGGL((k_pp_layernorm_reg<8>), dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, t, fh, fw, gh, gw, y);
+    else
     hipLaunchKernelGGL(k_pp_layernorm, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, t, fh, fw, C, gh, gw, y);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -382,6 +453,8 @@ extern "C" int vsr_pp_launch_pool(const float* y, const float* wgt, const float*
 extern "C" int vsr_pp_launch_fold(const float* vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* out,
                                   void* stream)
 {
+    if (C % 4 == 0 && ld % 4 == 0 && ((reinterpret_cast<uintptr_t>(vec) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        LAUNCH(k_pp_fold4, (int64_t)t * h * w * (C / 4), vec, ld, t, fh, fw, h, w, C, halo, normalize, 0, out);
     LAUNCH(k_pp_fold, (int64_t)t * h * w * C, vec, ld, t, fh, fw, h, w, C, halo, normalize, 0, out);
 }
 extern "C" int vsr_pp_launch_unfold_gelu(const float* map, int t, int fh, int fw, int h, int w, int C, int ld, float* out, void* stream)
@@ -392,6 +465,8 @@ extern "C" int vsr_pp_launch_unfold_gelu(const float* map, int t, int fh, int fw
 extern "C" int vsr_pp_launch_fold_gelu(const float* vec, int ld, int t, int fh, int fw, int h, int w, int C, int halo, int normalize, float* out,
                                        void* stream)
 {
+    if (C % 4 == 0 && ld % 4 == 0 && ((reinterpret_cast<uintptr_t>(vec) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        LAUNCH(k_pp_fold4, (int64_t)t * h * w * (C / 4), vec, ld, t, fh, fw, h, w, C, halo, normalize, 1, out);
     LAUNCH(k_pp_fold, (int64_t)t * h * w * C, vec, ld, t, fh, fw, h, w, C, halo, normalize, 1, out);
 }
 extern "C" int vsr_pp_launch_unfold_plain(const float* map, int t, int fh, int fw, int h, int w, int C, int ld, float* out, void* stream)
