@@ -70,3 +70,18 @@ def test_time_reversal_property_at_strip_size(engine, gpu_device):
     assert torch.isfinite(fwd).all() and torch.isfinite(bwd).all()
     assert torch.equal(torch.flip(rb, dims=[0]), fwd) and torch.equal(torch.flip(rf, dims=[0]), bwd)
     assert torch.equal(s1[0], s2[0]) and torch.equal(s1[1], s2[1])
+
+
+def test_frame_count_alternation_shares_one_clean_workspace(engine, raft_sd, built_lib, gpu_device):
+    """The runs of a ProPainter batch alternate between frame counts at one frame size (raft_runs: 18, 18, 18, 17 frames of 68): the
+    workspace is cleared by extent, not on every change of t (flow_engine.hip ensure_clean).  4 -> 3 -> 4 -> 2 frames on one engine give
+    what a fresh engine gives for each clip, bit for bit -- a shorter run leaves the longer run's frames behind it and must not see them."""
+    clips = [make_flow_frames(t, 136, 200, seed=20 + i) for i, t in enumerate((4, 3, 4, 2))]
+    got = [engine.flows(torch.from_numpy(c).to(gpu_device), iters=4) for c in clips]
+    torch.cuda.synchronize()
+    for c, (f, b) in zip(clips, got):
+        fresh = RaftEngine(raft_sd, device=0)
+        ff, fb = fresh.flows(torch.from_numpy(c).to(gpu_device), iters=4)
+        torch.cuda.synchronize()
+        assert torch.equal(f, ff) and torch.equal(b, fb)
+        fresh.close()

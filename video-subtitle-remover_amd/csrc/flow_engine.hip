@@ -953,10 +953,12 @@ int vsr_raft_flows(vsr_raft_t* h, const uint8_t* frames_dev, int t, int H, int W
     hipStream_t stream = (hipStream_t)stream_;
     FlowPlanDev* pd = nullptr;
     RCCHK(raft_plan_dev(h, t, H, W, iters, &pd));
-    if (h->geom != std::make_tuple(t, H, W)) {
-        RCCHK(clear_workspace(h->ws, stream, pd->plan.get()));
-        h->geom = std::make_tuple(t, H, W);
-    }
+    // every halo'd buffer of a RAFT plan (encoder stages, the recurrent state, c1 / corflo / f1 / fh: raft_plan.cpp) is frame after frame
+    // (or pair after pair) with a per-frame geometry fixed by (H, W): another frame count reaches further, it does not move a halo.  The
+    // runs of a batch (propainter_inpaint.py raft_runs: 18, 18, 18, 17 frames of a 68-frame batch) therefore share one clean workspace;
+    // clearing on every change of t was 124 fills and 10 ms per batch (profiles/r06_propainter_f32_raft_kernel_stats.csv)
+    RCCHK(ensure_clean(h->ws, "raft:" + std::to_string(H) + ":" + std::to_string(W), *pd->plan, stream));
+    h->geom = std::make_tuple(t, H, W);
     RCCHK(range_guard_arm(h->ws, stream));
     HIPCHK(hipMemcpyAsync(h->ws.bufs[RB_IN_U8], frames_dev, (size_t)t * H * W * 3, hipMemcpyDeviceToDevice, stream));
     RCCHK(run_plan(h->ws, pd, bgr ? 1 : 0, stream));
