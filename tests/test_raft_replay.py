@@ -54,6 +54,51 @@ def test_schedule_shape(host_engine):
     view.close()
 
 
+def test_context_share_of_the_gru_is_computed_once(host_engine, raft_sd):
+    """conv(cat[h, inp, motion]) = conv_inp(inp) + bias + conv_rest(cat[h, motion]) and inp never changes over the iterations
+    (raft.py:114-116,127-133): the plan holds four context products (z|r and q of both GRU passes, K = 5 x 128) in front of the loop,
+    the per-iteration GRU convs contract K = 5 x 256 and take the context product as their residual -- and the plan without the hoist
+    (VSR_RAFT_CTX_HOIST=0, a fresh process: the library reads the switch once) replays to the same flows within fp32 rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    t, H, W, iters = 2, 128, 160, 4
+    view = rr.raft_plan_view(_lib, host_engine, t, H, W, iters)
+    ops = [(info.tag.decode(), items) for info, items in view.ops]
+    tags = [tg for tg, _ in ops]
+    assert tags.count("gru.zr.ctx") == 2 and tags.count("gru.q.ctx") == 2
+    assert max(tags.index("gru.zr.ctx"), tags.index("gru.q.ctx")) < tags.index("corr.lookup")          # in front of the first iteration
+    for tg, items in ops:
+        if tg in ("gru.zr", "gru.q"):
+            assert items[0].K == 5 * 256 and items[0].bufR >= 0 and items[0].offBias < 0
+        if tg in ("gru.zr.ctx", "gru.q.ctx"):
+            assert items[0].K == 5 * 128 and items[0].bufR < 0 and items[0].offBias >= 0
+    frames = make_flow_frames(t, H, W, seed=9)
+    fwd, bwd, _ = rr.replay_raft(view, host_engine.packed_weights(), frames)
+    flops = view.flops
+    view.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\nimport _replay_raft as rr\nfrom vsr_amd import _lib\nfrom vsr_amd.engine import RaftEngine\n"
+            "from vsr_amd.synth import make_flow_frames, make_raft_state_dict\n"
+            "e = RaftEngine(make_raft_state_dict(0), device=-1)\nview = rr.raft_plan_view(_lib, e, %d, %d, %d, %d)\n"
+            "tags = [info.tag.decode() for info, _ in view.ops]\n"
+            "f, b, _ = rr.replay_raft(view, e.packed_weights(), make_flow_frames(%d, %d, %d, seed=9))\n"
+            "np.save(sys.argv[1], np.stack([f, b]))\nprint(json.dumps({'ctx': tags.count('gru.zr.ctx'), 'flops': view.flops}))\n"
+            ) % (os.path.dirname(here), here, t, H, W, iters, t, H, W)
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"raft_nohoist_{os.getpid()}.npy")
+    r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, VSR_RAFT_CTX_HOIST="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    plain = json.loads(r.stdout.strip().splitlines()[-1])
+    ref = np.load(out)
+    os.remove(out)
+    assert plain["ctx"] == 0 and flops < plain["flops"]
+    err = max(np.abs(fwd - ref[0]).max(), np.abs(bwd - ref[1]).max())
+    assert err <= 2e-4, f"hoisted vs plain plan: {err:.3e} px"
+
+
 def test_strict_state_dict(raft_sd, built_lib):
     bad = dict(raft_sd)
     bad.pop("update_block.gru.convq2.bias")

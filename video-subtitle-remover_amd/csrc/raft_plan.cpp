@@ -166,6 +166,33 @@ bool RaftModel::fuse_rows(const ConvW& a, const ConvW& b, ConvW& out)
     return true;
 }
 
+bool RaftModel::slice_cin(const ConvW& src, int cin, int taps, int c0, int n, int c1, int n1, bool keepBias, ConvW& out)
+{
+    // channel-major K order (pack_conv): k = ((ci / 32) * taps + tap) * 32 + ci % 32 -- a 32-channel block is `taps` whole chunks
+    if (!Tuning::get().convChannelMajor || cin % VSR_GG_KC || c0 % VSR_GG_KC || n % VSR_GG_KC || c1 % VSR_GG_KC || n1 % VSR_GG_KC) return false;
+    if (src.K != taps * cin) return false;
+    const int K = taps * (n + n1);
+    out.cout = src.cout;
+    out.K = K;
+    out.w = (int64_t)packed.size();
+    packed.resize(packed.size() + (size_t)rup((int64_t)out.cout * K, 32), 0.f);
+    for (int row = 0; row < src.cout; ++row) {
+        int64_t d = out.w + (int64_t)row * K;
+        for (int part = 0; part < 2; ++part) {
+            const int cb = part ? c1 : c0, cn = part ? n1 : n;
+            const int64_t from = src.w + (int64_t)row * src.K + (int64_t)(cb / VSR_GG_KC) * taps * VSR_GG_KC;
+            for (int64_t i = 0; i < (int64_t)(cn / VSR_GG_KC) * taps * VSR_GG_KC; ++i) packed[d++] = packed[from + i];
+        }
+    }
+    out.b = -1;
+    if (keepBias) {
+        out.b = (int64_t)packed.size();
+        packed.resize(packed.size() + (size_t)rup(out.cout, 32), 0.f);
+        for (int i = 0; i < out.cout; ++i) packed[out.b + i] = packed[src.b + i];
+    }
+    return true;
+}
+
 bool RaftModel::pack(std::string& err)
 {
     packed.clear();
@@ -187,6 +214,13 @@ bool RaftModel::pack(std::string& err)
         if (!pack_conv(u + "gru.convr" + s, r, 128, 384, kh, kw, "", 1.f, err)) return false;
         if (!fuse_rows(z, r, zr[pass])) { err = "gru z/r fuse"; return false; }
         if (!pack_conv(u + "gru.convq" + s, q[pass], 128, 384, kh, kw, "", 1.f, err)) return false;
+        // input channels: 0..127 h (or r*h), 128..255 inp (the context), 256..383 motion features
+        if (Tuning::get().convChannelMajor &&
+            (!slice_cin(zr[pass], 384, 5, 128, 128, 0, 0, true, zrCtx[pass]) || !slice_cin(zr[pass], 384, 5, 0, 128, 256, 128, false, zrVar[pass]) ||
+             !slice_cin(q[pass], 384, 5, 128, 128, 0, 0, true, qCtx[pass]) || !slice_cin(q[pass], 384, 5, 0, 128, 256, 128, false, qVar[pass]))) {
+            err = "gru context slices";
+            return false;
+        }
     }
     if (!pack_conv(u + "flow_head.conv1", fh1, 256, 128, 3, 3, "", 1.f, err)) return false;
     if (!pack_conv(u + "flow_head.conv2", fh2, 2, 256, 3, 3, "", 1.f, err)) return false;
@@ -418,6 +452,25 @@ RaftPlan::RaftPlan(const RaftModel& model, int t_, int H_, int W_, int iters_)
     std::vector<int> chunksQ;                       // cat[r*h, x]: r*h at channels 384.., x at 128..383
     for (int c = 0; c < 4; ++c) chunksQ.push_back(384 + 32 * c);
     for (int c = 4; c < 12; ++c) chunksQ.push_back(32 * c);
+    // The context's share of the GRU convs, once per call.  x = cat[inp, motion] (update.py:128) and inp = relu(cnet[128:]) never changes
+    // over the iterations (raft.py:114-116,127-133), and a conv is linear in its input channels: conv(cat[h, inp, motion]) =
+    // conv_inp(inp) + bias + conv_rest(cat[h, motion]).  The four context products (z|r and q of both passes, K = 5 x 128) are computed
+    // here and ride into the per-iteration convs as their residual operand; those contract K = 5 x 256 instead of 5 x 384: a third of
+    // the GRU's FLOPs (33 of RAFT's 178 TFLOP per 68-frame batch) is not recomputed twenty times.  Same sums, another association:
+    // fp32 results move by rounding (the parity bars are unchanged, tests/test_gpu_raft.py).  VSR_RAFT_CTX_HOIST=0: the plain convs.
+    static const bool hoistEnv = [] { const char* e = getenv("VSR_RAFT_CTX_HOIST"); return !(e && atoi(e) == 0); }();
+    const bool ctxHoist = hoistEnv && Tuning::get().convChannelMajor;
+    const Act zrCtx[2] = {{RB_ZRCTX0, pairs, h8, w8, 256, 0}, {RB_ZRCTX1, pairs, h8, w8, 256, 0}};
+    const Act qCtx[2] = {{RB_QCTX0, pairs, h8, w8, 128, 0}, {RB_QCTX1, pairs, h8, w8, 128, 0}};
+    std::vector<int> chunksZRv, chunksQv;           // the per-iteration inputs without the context: [h | motion], [r*h | motion]
+    for (int c = 0; c < 4; ++c) { chunksZRv.push_back(32 * c); chunksQv.push_back(384 + 32 * c); }
+    for (int c = 8; c < 12; ++c) { chunksZRv.push_back(32 * c); chunksQv.push_back(32 * c); }
+    if (ctxHoist)
+        for (int pass = 0; pass < 2; ++pass) {
+            const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
+            conv("gru.zr.ctx", hxr, idsP, 128, 128, zrCtx[pass], 0, pairs, kh, kw, 1, m_.zrCtx[pass], VSR_ACT_NONE, nullptr);
+            conv("gru.q.ctx", hxr, idsP, 128, 128, qCtx[pass], 0, pairs, kh, kw, 1, m_.qCtx[pass], VSR_ACT_NONE, nullptr);
+        }
     for (int it = 0; it < iters; ++it) {
         {
             Op& op = ew(EW_CORR_LOOKUP, "corr.lookup");
@@ -441,12 +494,16 @@ RaftPlan::RaftPlan(const RaftModel& model, int t_, int H_, int W_, int iters_)
         // SepConvGRU (update.py:33-60)
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass == 0 ? 1 : 5, kw = pass == 0 ? 5 : 1;
+            if (ctxHoist) conv("gru.zr", hxr, idsP, 0, 256, zr, 0, pairs, kh, kw, 1, m_.zrVar[pass], VSR_ACT_NONE, &zrCtx[pass], &chunksZRv);
+            else
             conv("gru.zr", hxr, idsP, 0, 384, zr, 0, pairs, kh, kw, 1, m_.zr[pass], VSR_ACT_NONE, nullptr);
             {
                 Op& op = ew(EW_GRU_RH, "gru.rh");
                 op.ibuf[0] = RB_ZR; op.ibuf[1] = RB_HXR;
                 op.ipar[0] = pairs; op.ipar[1] = h8; op.ipar[2] = w8; op.ipar[3] = hxr.halo; op.ipar[4] = hxr.C; op.ipar[5] = 0; op.ipar[6] = 384;
             }
+            if (ctxHoist) conv("gru.q", hxr, idsP, 0, 256, qb, 0, pairs, kh, kw, 1, m_.qVar[pass], VSR_ACT_NONE, &qCtx[pass], &chunksQv);
+            else
             conv("gru.q", hxr, idsP, 0, 384, qb, 0, pairs, kh, kw, 1, m_.q[pass], VSR_ACT_NONE, nullptr, &chunksQ);
             {
                 Op& op = ew(EW_GRU_UPDATE, "gru.update");

@@ -27,7 +27,9 @@ enum EwKind {
 enum RaftBuf {
     RB_WEIGHTS = 0, RB_IN_U8, RB_IM2COL, RB_S1A, RB_S1B, RB_S1C, RB_S2A, RB_S2B, RB_S2C, RB_S3A, RB_S3B, RB_S3C,
     RB_STATS, RB_FMAP, RB_CMAP, RB_PYR, RB_COORDS, RB_FLOW, RB_CORRF, RB_C1, RB_CORFLO, RB_FLOWCOL, RB_F1, RB_HXR,
-    RB_ZR, RB_Q, RB_FH1, RB_DELTA, RB_MASKH, RB_MASK, RB_OUT, RB_COUNT
+    RB_ZR, RB_Q, RB_FH1, RB_DELTA, RB_MASKH, RB_MASK, RB_OUT,
+    RB_ZRCTX0, RB_ZRCTX1, RB_QCTX0, RB_QCTX1,   // the context's share of the GRU convs, computed once per call (RaftPlan: ctxHoist)
+    RB_COUNT
 };
 
 struct RaftEncW {                 // BasicEncoder (extractor.py:118-160)
@@ -46,6 +48,10 @@ public:
     static std::vector<std::string> expected_keys();
     RaftEncW fnet, cnet;
     ConvW convc1, convc2, convf1, convf2, conv, zr[2], q[2], fh1, fh2, mask1, mask2;
+    // the GRU convs cut along their input channels (cat[h | inp | motion], update.py:47-58): the `inp` third -- the context features, the
+    // same in every iteration (raft.py:114-116,127) -- with the bias, and the rest (h or r*h, motion) without one.  conv(cat[a, b]) =
+    // conv_a(a) + conv_b(b): the plan computes the context's share once per call and adds it in the epilogue of the per-iteration conv
+    ConvW zrCtx[2], qCtx[2], zrVar[2], qVar[2];
     std::vector<float> packed;
 private:
     struct Raw { std::vector<float> v; std::vector<int64_t> shape; };
@@ -57,6 +63,8 @@ private:
                    std::string& err);
     bool pack_encoder(const std::string& prefix, RaftEncW& e, bool batchNorm, std::string& err);
     bool fuse_rows(const ConvW& a, const ConvW& b, ConvW& out);
+    // input channels [c0, c0 + n) (and [c1, c1 + n1) behind them) of a packed conv with `cin` input channels as a conv of their own
+    bool slice_cin(const ConvW& src, int cin, int taps, int c0, int n, int c1, int n1, bool keepBias, ConvW& out);
 };
 
 class RaftPlan : public PlanBuilder {
