@@ -8,7 +8,7 @@ import torch
 import _replay
 
 (EW_IM2COL7_U8, EW_INORM_STATS, EW_INORM_APPLY, EW_CTX_SPLIT, EW_FLOW_UPDATE, EW_IM2COL7_FLOW, EW_AVGPOOL2, EW_CORR_LOOKUP, EW_GRU_RH,
- EW_GRU_UPDATE, EW_CONVEX_UP) = range(1, 12)
+ EW_GRU_UPDATE, EW_CONVEX_UP, EW_CORR_TRANSPOSE) = range(1, 13)
 RB_WEIGHTS, RB_IN_U8, RB_OUT = 0, 1, 30
 OP_EW = 6
 
@@ -95,6 +95,10 @@ def ew_reference(info, bufs, tables):
         out = np.zeros((pairs * h * w, 128), dtype=np.float32)
         out[:, :98] = cols.numpy()
         bufs[ib[1]][: out.size] = out.reshape(-1)
+    elif k == EW_CORR_TRANSPOSE:
+        n, hw = ip[:2]
+        src = bufs[ib[0]][io[0]: io[0] + n * hw * hw].reshape(n, hw, hw)
+        bufs[ib[0]][io[1]: io[1] + n * hw * hw] = np.ascontiguousarray(src.transpose(0, 2, 1)).reshape(-1)
     elif k == EW_AVGPOOL2:
         rows, hs, ws = ip[:3]
         src = bufs[ib[0]][io[0]: io[0] + rows * hs * ws].reshape(rows, hs, ws)

@@ -45,7 +45,8 @@ def test_schedule_shape(host_engine):
     view = rr.raft_plan_view(_lib, host_engine, t, 128, 128, iters)
     tags = [info.tag.decode() for info, _ in view.ops]
     corr = [items for info, items in view.ops if info.tag == b"corr.volume"]
-    assert len(corr) == 1 and len(corr[0]) == 2 * (t - 1)
+    # forward pair-directions by GEMM; the backward ones are their transposes (one pass right behind the GEMMs)
+    assert len(corr) == 1 and len(corr[0]) == t - 1 and tags[tags.index("corr.volume") + 1] == "corr.transpose"
     assert tags.count("upd.mask1") == 1 and tags.count("upd.mask2") == 1 and tags.count("flow.upsample") == 1
     assert tags.count("corr.lookup") == iters and tags.count("gru.zr") == 2 * iters and tags.count("flow.update") == iters
     assert tags.count("fnet.stem") == 1 and tags.count("cnet.stem") == 1

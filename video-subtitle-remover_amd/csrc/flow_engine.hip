@@ -380,6 +380,9 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
             case EW_AVGPOOL2:
                 rc = vsr_raft_launch_avgpool2(B(op.ibuf[0], op.ioff[0]), ip[0], ip[1], ip[2], B(op.ibuf[0], op.ioff[1]), stream);
                 break;
+            case EW_CORR_TRANSPOSE:
+                rc = vsr_raft_launch_corr_transpose(B(op.ibuf[0], op.ioff[0]), B(op.ibuf[0], op.ioff[1]), ip[0], ip[1], stream);
+                break;
             case EW_CORR_LOOKUP: {
                 const float* lv[4];
                 for (int l = 0; l < 4; ++l) lv[l] = B(op.ibuf[0], op.ioff[l]);

@@ -15,6 +15,8 @@ int vsr_raft_launch_flow_update(const float* delta, int ldDelta, float* coords, 
                                 int init, int halo, int Chx, int chFlow, void* stream);
 int vsr_raft_launch_im2col7_flow(const float* flow, int pairs, int h, int w, float* out, void* stream);
 int vsr_raft_launch_avgpool2(const float* src, int64_t rows, int hs, int ws, float* dst, void* stream);
+// dst[p] = src[p]^T, n square planes of hw x hw floats
+int vsr_raft_launch_corr_transpose(const float* src, float* dst, int n, int hw, void* stream);
 int vsr_raft_launch_corr_lookup(const float* const* levels, const int* lvlH, const int* lvlW, const float* coords, int64_t M, int ld,
                                 float* out, void* stream);
 int vsr_raft_launch_gru_rh(const float* zr, float* hxr, int pairs, int h, int w, int halo, int Chx, int chH, int chRH, void* stream);

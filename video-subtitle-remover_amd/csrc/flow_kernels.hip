@@ -263,6 +263,35 @@ k_raft_avgpool2(const float* __restrict__ src, int64_t rows, int hs, int ws, flo
 }
 
 // ---------------------------------------------------------------------------------------
+// EW_CORR_TRANSPOSE: dst[p] = src[p]^T for n square planes of hw x hw floats (raft_plan.cpp: the backward pair-directions' correlation
+// volumes).  64 x 64 tiles through LDS (row pitch 65: conflict-free both ways); both the reads and the writes are 256-byte runs per wave.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_raft_corr_transpose(const float* __restrict__ src, float* __restrict__ dst, int hw, int tiles)
+{
+    __shared__ float tile[64][65];
+    const int64_t plane = (int64_t)hw * hw;
+    const int p = blockIdx.x / (tiles * tiles), tt = blockIdx.x - p * tiles * tiles;
+    const int ty = tt / tiles, tx = tt - ty * tiles;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const float* s = src + p * plane;
+    float* d = dst + p * plane;
+    const int x = tx * 64 + lx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int y = ty * 64 + ly + 4 * r;
+        if (x < hw && y < hw) tile[ly + 4 * r][lx] = s[(int64_t)y * hw + x];
+    }
+    __syncthreads();
+    const int ox = ty * 64 + lx;                 // output column = input row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oy = tx * 64 + ly + 4 * r;     // output row = input column
+        if (ox < hw && oy < hw) d[(int64_t)oy * hw + ox] = tile[lx][ly + 4 * r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // EW_CORR_LOOKUP: CorrBlock.__call__ (corr.py:29-50) + bilinear_sampler (utils/utils.py:57-70; grid_sample,
 // align_corners=True, zero padding).  Row m, column lvl*81 + 9*i + j samples level lvl at
 // (x, y) = (coords.x / 2^lvl + (i-4), coords.y / 2^lvl + (j-4)) -- the reference's meshgrid(dy, dx) is added to (x, y),
@@ -443,6 +472,14 @@ extern "C" int vsr_raft_launch_im2col7_flow(const float* flow, int pairs, int h,
 extern "C" int vsr_raft_launch_avgpool2(const float* src, int64_t rows, int hs, int ws, float* dst, void* stream)
 {
     LAUNCH(k_raft_avgpool2, rows * (hs / 2) * (ws / 2), src, rows, hs, ws, dst);
+}
+extern "C" int vsr_raft_launch_corr_transpose(const float* src, float* dst, int n, int hw, void* stream)
+{
+    if (n <= 0 || hw <= 0) return 0;
+    const int tiles = (hw + 63) / 64;
+    if ((int64_t)n * tiles * tiles > 2147483647LL) return -1;
+    hipLaunchKernelGGL(k_raft_corr_transpose, dim3((unsigned)(n * tiles * tiles)), dim3(256), 0, (hipStream_t)stream, src, dst, hw, tiles);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int vsr_raft_launch_corr_lookup(const float* const* levels, const int* lvlH, const int* lvlW, const float* coords, int64_t M, int ld,
                                            float* out, void* stream)

@@ -394,7 +394,12 @@ RaftPlan::RaftPlan(const RaftModel& model, int t_, int H_, int W_, int iters_)
         op.kind = OP_GEMM; op.tag = "corr.volume"; op.bmode = VSR_BMODE_NK; op.tileCfg = VSR_TILE_128x64;
         int BM, BN;
         tileDims(op.tileCfg, BM, BN);
-        for (int p = 0; p < pairs; ++p) {
+        // The backward pair-direction of frames (q, q+1) correlates f(q+1) with f(q): its volume is the TRANSPOSE of the forward one's,
+        // C_b[i][j] = f(q+1)_i . f(q)_j = C_f[j][i] -- the same products added in the same k order, so the same bits (a*b = b*a).  Half of the
+        // correlation GEMMs (4 of RAFT's 151 TFLOP per 68-frame batch) become a tiled transpose pass.  VSR_RAFT_CORR_TRANSPOSE=0: 2 (t-1) GEMMs.
+        static const bool transposeEnv = [] { const char* e = getenv("VSR_RAFT_CORR_TRANSPOSE"); return !(e && atoi(e) == 0); }();
+        const int nGemm = transposeEnv ? t - 1 : pairs;
+        for (int p = 0; p < nGemm; ++p) {
             GemmItem it{};
             it.M = hw; it.N = hw; it.K = 256;
             it.tilesM = cdiv(hw, BM); it.tilesN = cdiv(hw, BN);
@@ -414,6 +419,11 @@ RaftPlan::RaftPlan(const RaftModel& model, int t_, int H_, int W_, int iters_)
         }
         flops += op.flops;
         ops.push_back(std::move(op));
+        if (nGemm < pairs) {
+            Op& tr = ew(EW_CORR_TRANSPOSE, "corr.transpose");
+            tr.ibuf[0] = RB_PYR; tr.ioff[0] = 0; tr.ioff[1] = (int64_t)(t - 1) * hw * hw;
+            tr.ipar[0] = t - 1; tr.ipar[1] = hw;
+        }
     }
     lvlH[0] = h8; lvlW[0] = w8; lvlOff[0] = 0;
     for (int l = 1; l < 4; ++l) {

@@ -21,7 +21,8 @@ enum EwKind {
     EW_CORR_LOOKUP = 8,  // 4 levels x 9x9 bilinear samples around coords1
     EW_GRU_RH = 9,       // r * h
     EW_GRU_UPDATE = 10,  // h = (1-z) h + z q
-    EW_CONVEX_UP = 11    // convex 8x upsampling of the final flow
+    EW_CONVEX_UP = 11,   // convex 8x upsampling of the final flow
+    EW_CORR_TRANSPOSE = 12 // correlation volumes of the backward pair-directions = transposes of the forward ones
 };
 
 enum RaftBuf {
