@@ -281,7 +281,12 @@ void PpGenPlan::token_grid(int H, int W, int& fh, int& fw, int& gh, int& gw)
     gh = cdiv(fh, 5) * 5; gw = cdiv(fw, 9) * 9;                   // window (5, 9)
 }
 
-int PpGenPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : VSR_TILE_128x64); }
+static int wideTile(int N)
+{
+    static const bool narrowEnv = [] { const char* e = getenv("VSR_PP_TR_TILE"); return e && std::string(e) == "128x64"; }();
+    return (N >= 512 && !narrowEnv) ? VSR_TILE_128x128 : VSR_TILE_128x64;
+}
+int PpGenPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : wideTile(N)); }
 
 Op& PpGenPlan::ew(int kind, const char* tag)
 {
@@ -311,6 +316,12 @@ void PpGenPlan::gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tCo
                      const ConvW& w, int act, int bufR, int64_t offR, int tRowR, int tile, Op* appendTo)
 {
     if (w.K != K) throw std::runtime_error(std::string("propainter gemm K mismatch: ") + tag);
+    // Wide problems (N >= 512: the transformer's token GEMMs, soft split / composition) run on 128 x 128 tiles: with operands rounded to
+    // fp16 in the staging registers (gather_gemm_f32_v4<HI_ONLY>, the reference's GPU arithmetic) a square tile halves the B fragments
+    // staged per MFMA -- tr.fc2 (K = 1984) 66.5 -> 43.2 ms per 68-frame batch, fc1 58.8 -> 52.1, qkv 51.4 -> 45.9 -- and in exact fp32 the two
+    // shapes are within 1 % of each other (profiles/r06_pp_square_tiles_ab.log).  BM is 128 either way: the row tables are the same.
+    // VSR_PP_TR_TILE=128x64 keeps the old shape.
+    if (!appendTo && tile == VSR_TILE_128x64) tile = wideTile(w.cout);
     int BM, BN;
     tileDims(tile, BM, BN);
     GemmItem it{};
