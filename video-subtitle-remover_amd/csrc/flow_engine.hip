@@ -1409,7 +1409,22 @@ int vsr_pp_token_count(int H, int W)
     return fh * fw;
 }
 
-int vsr_pp_set_precision(vsr_pp_t* h, int mode) { return h ? set_precision(h->ws, mode) : rfail(VSR_ERR_ARG, "null handle"); }
+int vsr_pp_set_precision(vsr_pp_t* h, int mode)
+{
+    if (!h) return rfail(VSR_ERR_ARG, "null handle");
+    const int rc = set_precision(h->ws, mode);
+    if (rc != 0) return rc;
+    // the tile shape of the wide GEMMs follows the arithmetic (PpGenPlan::wideTile): plans baked for the other shape go
+    const int wideN = mode == 2 ? 128 : 512;
+    if (wideN != h->model.wideN) {
+        h->model.wideN = wideN;
+        if (!h->genPlans.empty()) {
+            if (h->device >= 0) { HIPCHK(hipSetDevice(h->device)); HIPCHK(hipDeviceSynchronize()); }      // nothing in flight may still read their tables
+            h->genPlans.clear();
+        }
+    }
+    return 0;
+}
 int64_t vsr_pp_fallbacks(const vsr_pp_t* h) { return h ? h->ws.fallbacks : -1; }
 
 int vsr_pp_read_buffer(vsr_pp_t* h, int buf, int64_t offset, int64_t count, float* out_host)

@@ -281,10 +281,18 @@ void PpGenPlan::token_grid(int H, int W, int& fh, int& fw, int& gh, int& gw)
     gh = cdiv(fh, 5) * 5; gw = cdiv(fw, 9) * 9;                   // window (5, 9)
 }
 
-static int wideTile(int N)
+// Problems of N >= wideN output columns run on 128 x 128 tiles (BM is 128 either way: same row tables, same K order, same bits).
+// wideN is the model's hint (PpModel::wideN, set with the engine's arithmetic: vsr_pp_set_precision): 512 for exact fp32 -- the token GEMMs,
+// soft split / composition; the two shapes are within 1 % there -- and 128 for the fp16-operand arithmetic, where the operands are rounded in
+// the staging registers (gather_gemm_f32_v4<HI_ONLY>) and a square tile halves the B fragments staged per MFMA: tr.fc2 66.5 -> 43.2 ms per
+// 68-frame batch, the whole generator 0.83 -> 0.75 s, while exact fp32 LOSES 48 ms with N >= 128 (profiles/r06_pp_square_tiles_ab.log).
+// VSR_PP_WIDE_N overrides the hint, VSR_PP_TR_TILE=128x64 switches the square tiles off (A/B runs).
+int PpGenPlan::wideTile(int N) const
 {
     static const bool narrowEnv = [] { const char* e = getenv("VSR_PP_TR_TILE"); return e && std::string(e) == "128x64"; }();
-    return (N >= 512 && !narrowEnv) ? VSR_TILE_128x128 : VSR_TILE_128x64;
+    static const int wideEnv = [] { const char* e = getenv("VSR_PP_WIDE_N"); const int x = e ? atoi(e) : 0; return x >= 128 ? x : 0; }();
+    const int wideN = wideEnv ? wideEnv : m_.wideN;
+    return (N >= wideN && !narrowEnv) ? VSR_TILE_128x128 : VSR_TILE_128x64;
 }
 int PpGenPlan::pickTile(int N) const { return N <= 32 ? VSR_TILE_256x32 : (N <= 64 ? n64Tile() : wideTile(N)); }
 
@@ -316,11 +324,7 @@ void PpGenPlan::gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tCo
                      const ConvW& w, int act, int bufR, int64_t offR, int tRowR, int tile, Op* appendTo)
 {
     if (w.K != K) throw std::runtime_error(std::string("propainter gemm K mismatch: ") + tag);
-    // Wide problems (N >= 512: the transformer's token GEMMs, soft split / composition) run on 128 x 128 tiles: with operands rounded to
-    // fp16 in the staging registers (gather_gemm_f32_v4<HI_ONLY>, the reference's GPU arithmetic) a square tile halves the B fragments
-    // staged per MFMA -- tr.fc2 (K = 1984) 66.5 -> 43.2 ms per 68-frame batch, fc1 58.8 -> 52.1, qkv 51.4 -> 45.9 -- and in exact fp32 the two
-    // shapes are within 1 % of each other (profiles/r06_pp_square_tiles_ab.log).  BM is 128 either way: the row tables are the same.
-    // VSR_PP_TR_TILE=128x64 keeps the old shape.
+    // (wide problems on square tiles: wideTile())
     if (!appendTo && tile == VSR_TILE_128x64) tile = wideTile(w.cout);
     int BM, BN;
     tileDims(tile, BM, BN);

@@ -67,6 +67,7 @@ public:
     ConvW ss, sc, scConv, dec0, dec2, dec4, dec6;
     PpBlockW blk[8];
     std::vector<float> packed;
+    int wideN = 512;   // plans put problems of N >= wideN on 128 x 128 tiles (PpGenPlan::wideTile; the engine sets 128 for the fp16-operand arithmetic)
 private:
     struct Raw { std::vector<float> v; std::vector<int64_t> shape; };
     std::map<std::string, Raw> raw_;
@@ -108,6 +109,7 @@ private:
     const PpModel& m_;
     double trimmedFlops_ = 0;
     int pickTile(int N) const;
+    int wideTile(int N) const;
     int tColsChunks(const Act& a, int kh, int kw, int dil, const std::vector<int>& chunkCh);
     void gemm(const char* tag, int bufA, int64_t offA, int tRowA, int tColA, int K, int M, int bufC, int64_t offC, int tRowC, int tColC,
               const ConvW& w, int act, int bufR, int64_t offR, int tRowR, int tile, Op* appendTo = nullptr);
