@@ -68,24 +68,49 @@ def _cols(table, n):
     return full[:n]
 
 
+def _gather(buf, base, rows, coltab, n):
+    """buf[base + rows[:, None] + cols(coltab, n)[None, :]] -- by whole 32-element chunks (a chunk is 32 contiguous elements: one index per
+    chunk through a sliding-window view instead of one per element; the same values, ~20x faster than the element-wise fancy index)"""
+    nfull = n // 32
+    rows = np.asarray(rows, dtype=np.int64)
+    parts = []
+    if nfull:
+        win = np.lib.stride_tricks.sliding_window_view(buf, 32)
+        parts.append(win[base + rows[:, None] + np.asarray(coltab[:nfull], dtype=np.int64)[None, :]].reshape(len(rows), nfull * 32))
+    if n % 32:
+        tail = np.asarray(coltab[nfull], dtype=np.int64) + np.arange(n % 32, dtype=np.int64)
+        parts.append(buf[base + rows[:, None] + tail[None, :]])
+    return parts[0] if len(parts) == 1 else np.concatenate(parts, axis=1)
+
+
+def _scatter(buf, base, rows, coltab, n, values):
+    """buf[base + rows[:, None] + cols(coltab, n)[None, :]] = values, by whole chunks (see _gather)"""
+    nfull = n // 32
+    rows = np.asarray(rows, dtype=np.int64)
+    values = np.ascontiguousarray(values, dtype=buf.dtype)
+    if nfull:
+        win = np.lib.stride_tricks.sliding_window_view(buf, 32, writeable=True)
+        win[base + rows[:, None] + np.asarray(coltab[:nfull], dtype=np.int64)[None, :]] = values[:, :nfull * 32].reshape(len(rows), nfull, 32)
+    if n % 32:
+        tail = np.asarray(coltab[nfull], dtype=np.int64) + np.arange(n % 32, dtype=np.int64)
+        buf[base + rows[:, None] + tail[None, :]] = values[:, nfull * 32:]
+
+
 def gemm_reference(it, bmode, bufs, tables, tile_m=128):
     """Execute one gather-GEMM descriptor exactly as include/vsr_hip.h defines it."""
     M, N, K = it.M, it.N, it.K
     A = bufs[it.bufA]
     B = bufs[it.bufB]
     rowA = tables[it.tRowA][:M]
-    colA = _cols(tables[it.tColA], K)
-    Am = torch.from_numpy(A[it.offA + rowA[:, None] + colA[None, :]])
+    Am = torch.from_numpy(_gather(A, it.offA, rowA, tables[it.tColA], K))
     if bmode == 0:      # NK
         rowB = tables[it.tRowB][:N]
-        colB = _cols(tables[it.tColB], K)
-        Bm = torch.from_numpy(B[it.offB + rowB[:, None] + colB[None, :]]).t()      # K x N
+        Bm = torch.from_numpy(_gather(B, it.offB, rowB, tables[it.tColB], K)).t()      # K x N
     else:               # KN
         rowB = tables[it.tRowB][:K]
-        colB = _cols(tables[it.tColB], N)
-        Bm = torch.from_numpy(B[it.offB + rowB[:, None] + colB[None, :]])          # K x N
+        Bm = torch.from_numpy(_gather(B, it.offB, rowB, tables[it.tColB], N))          # K x N
     rowC = tables[it.tRowC][:M]
-    colC = _cols(tables[it.tColC], N)
+    tColC = tables[it.tColC]
     Cbuf = bufs[it.bufC]
     if it.act & 0x800:                     # VSR_ACT_A_EXP: A holds scores; the product is softmax(A) . B, normalised here or by the reduce op
         Am = torch.exp2(Am - Am.max(dim=1, keepdim=True).values)    # the scores carry log2(e) / sqrt(D)
@@ -94,17 +119,17 @@ def gemm_reference(it, bmode, bufs, tables, tile_m=128):
             for s in range(it.splitK):
                 k0 = s * it.chunksPerSplit * 32
                 k1 = min(K, k0 + it.chunksPerSplit * 32)
-                Cbuf[it.offC + s * it.splitStride + rowC[:, None] + colC[None, :]] = (Am[:, k0:k1] @ Bm[k0:k1, :]).numpy()
+                _scatter(Cbuf, it.offC + s * it.splitStride, rowC, tColC, N, (Am[:, k0:k1] @ Bm[k0:k1, :]).numpy())
                 bufs[it.bufR][it.offR + s * ldl: it.offR + s * ldl + M] = Am[:, k0:k1].sum(dim=1).numpy()
         else:
-            Cbuf[it.offC + rowC[:, None] + colC[None, :]] = ((Am @ Bm) / Am.sum(dim=1, keepdim=True)).numpy()
+            _scatter(Cbuf, it.offC, rowC, tColC, N, ((Am @ Bm) / Am.sum(dim=1, keepdim=True)).numpy())
         return
     if it.splitK > 1:
         for s in range(it.splitK):
             k0 = s * it.chunksPerSplit * 32
             k1 = min(K, k0 + it.chunksPerSplit * 32)
             part = (Am[:, k0:k1] @ Bm[k0:k1, :]) * it.alpha
-            Cbuf[it.offC + s * it.splitStride + rowC[:, None] + colC[None, :]] = part.numpy()
+            _scatter(Cbuf, it.offC + s * it.splitStride, rowC, tColC, N, part.numpy())
         return
     acc = (Am @ Bm) * it.alpha
     if it.offBias >= 0:
@@ -119,10 +144,10 @@ def gemm_reference(it, bmode, bufs, tables, tile_m=128):
         pass
     elif it.bufR >= 0:
         rowR = tables[it.tRowR][:M]
-        acc = acc + torch.from_numpy(bufs[it.bufR][it.offR + rowR[:, None] + colC[None, :]])
+        acc = acc + torch.from_numpy(_gather(bufs[it.bufR], it.offR, rowR, tColC, N))
         if it.act & 0x200:                 # VSR_ACT_POST_RELU
             acc = torch.relu(acc)
-    Cbuf[it.offC + rowC[:, None] + colC[None, :]] = acc.numpy()
+    _scatter(Cbuf, it.offC, rowC, tColC, N, acc.numpy())
 
 
 def softmax_reference(it, bufs):
