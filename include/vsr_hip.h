@@ -513,6 +513,29 @@ int vsr_det_launch_copy(const void* src_dev, int64_t src_pitch, void* dst_dev, i
  * per-channel affine (the batch_norm or bias add that follows the conv) and activation (act 1 relu, 2 hardswish) */
 int vsr_det_launch_nchw_to_nhwc(const float* x, int n, int C, int H, int W, int pt, int pl, int Hp, int Wp, int Cp, float* out, void* stream);
 int vsr_det_launch_nhwc_to_nchw(const float* in, int n, int C, int64_t P, int Np, const float* scale, const float* shift, int act, float* out, void* stream);
+/* NHWC-resident detector plan (backend/tools/ocr_det_nhwc.py, round 6): activations stay in zero-haloed NHWC buffers between the convs of
+ * the program.  A VIEW is (pointer to channel c0 of interior pixel (0, 0) of image 0, floats per image, floats per row, floats per pixel):
+ * halo pixels and the channels a slice is padded with are zero and never written, so a tap outside the image reads a zero and a
+ * channel concat (paddle concat, axis 1) is its producers writing their slices of one buffer.  Pointers and strides keep 16-byte alignment.
+ *   to_view / from_view: NCHW planes <-> the interior of a view (to_view writes Cw >= C channels, a multiple of 32, zeros beyond C)
+ *   dwconv_view: depthwise_conv2d (weights tap-major [kh * kw][C]) + the inference batch_norm_ as scale / shift (nullable) + act (0, 1 relu, 2 hardswish)
+ *   nearest_view: nearest_interp by an integer scale
+ *   dots_view: n_out = 1: conv2d 1x1 to ONE channel (w [C]); n_out = 4: conv2d_transpose 2x2 / stride 2 to one channel (w [(dy, dx)][C]);
+ *              + bias (bias[0]) + act (0, 1, 2, 3 sigmoid); out is the plain [n][H][W] / [n][2H][2W] map */
+int vsr_det_launch_to_view(const float* x, int n, int C, int H, int W, int Cw, float* out, int64_t img_stride, int64_t row_stride, int Cs, void* stream);
+int vsr_det_launch_from_view(const float* in, int64_t img_stride, int64_t row_stride, int Cs, int n, int C, int H, int W, float* out,
+                             int64_t out_img_stride, void* stream);
+int vsr_det_launch_dwconv_view(const float* in, int64_t in_img, int64_t in_row, int in_cs, const float* w, const float* scale, const float* shift, int N,
+                               int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, int act, float* out, int64_t out_img,
+                               int64_t out_row, int out_cs, void* stream);
+int vsr_det_launch_nearest_view(const float* in, int64_t in_img, int64_t in_row, int in_cs, int N, int C, int Ho, int Wo, int s, float* out,
+                                int64_t out_img, int64_t out_row, int out_cs, void* stream);
+/* im2col_view: the kh x kw neighbourhoods (zero padded by pt, pl) of an NCHW map of C channels, C * kh * kw <= 32, as one 32-float chunk per
+ * pixel of a view: channel (c * kh + ky) * kw + kx, zeros beyond */
+int vsr_det_launch_im2col_view(const float* x, int N, int C, int H, int W, int kh, int kw, int pt, int pl, float* out, int64_t out_img, int64_t out_row,
+                               int out_cs, void* stream);
+int vsr_det_launch_dots_view(const float* in, int64_t in_img, int64_t in_row, int in_cs, int N, int C, int H, int W, const float* w, const float* bias,
+                             int n_out, int act, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Scene cuts: the per-frame arithmetic of the ContentDetector pass that

@@ -114,6 +114,7 @@ def test_recorded_launch_list_replay(built_lib, gpu_device, fixture, H, W):
     the HIP-graph replay of round 1 faulted)."""
     g = load_graph(os.path.join(GOLD, fixture))
     r = ocr_det.PaddleGraphRunner(g, synthetic_weights(g), device=0)
+    r.nhwc = "0"                                          # the recorded WALK is under test (the server program's default is the NHWC plan)
     rng = np.random.default_rng(17)
     xs = [torch.from_numpy(rng.standard_normal((1, 3, H, W)).astype(np.float32)).to(gpu_device) for _ in range(3)]
     small = torch.from_numpy(rng.standard_normal((1, 3, 96, 160)).astype(np.float32)).to(gpu_device)
@@ -137,6 +138,7 @@ def test_batched_forward_equals_single_frames(built_lib, gpu_device, fixture):
     as it does alone (batched layout kernels, GEMM row tables over [n][Hp][Wp][Cp], strided channel concat, recorded replay)."""
     g = load_graph(os.path.join(GOLD, fixture))
     r = ocr_det.PaddleGraphRunner(g, synthetic_weights(g), device=0)
+    r.nhwc = "0"                                          # walk + recorded walk here; the NHWC plan's batches: test_nhwc_plan_batches_and_replays
     rng = np.random.default_rng(23)
     x = torch.from_numpy(rng.standard_normal((3, 3, 96, 160)).astype(np.float32)).to(gpu_device)
     single = torch.cat([r.run(x[b:b + 1].contiguous()).clone() for b in range(3)])
@@ -151,6 +153,60 @@ def test_batched_forward_equals_single_frames(built_lib, gpu_device, fixture):
     maps = det.probability_maps(imgs)
     for b, img in enumerate(imgs):
         assert torch.equal(maps[b], det.probability_map(img)[0])
+
+
+@pytest.mark.parametrize("fixture,nb,H,W", [("ppocr_det_graph.json", 1, 96, 160), ("ppocr_det_graph.json", 2, 224, 352), ("ppocr_det_graph.json", 1, 544, 960),
+                                            ("ppocr_det_graph.json", 8, 544, 960), ("ppocr_det_fast_graph.json", 2, 160, 224)])
+def test_nhwc_plan_matches_interpreter(built_lib, gpu_device, fixture, nb, H, W):
+    """the compiled NHWC-resident plan (ocr_det_nhwc.py; the server program's default path) against the fp64 interpreter -- the bar of
+    test_program_matches_interpreter -- and against the op-by-op walk on the NCHW kernels (same fp32 products, batch_norm folded into the
+    weights instead of applied after: two fp32 evaluations, each within the bar of the fp64 result, so within twice the bar of each other);
+    the mobile program is forced onto a plan (its blocks keep most values NCHW)"""
+    g = load_graph(os.path.join(GOLD, fixture))
+    w = synthetic_weights(g)
+    x = torch.from_numpy(np.random.default_rng(H + W + nb).standard_normal((nb, 3, H, W)).astype(np.float32))
+    r = ocr_det.PaddleGraphRunner(g, w, device=0)
+    r.nhwc = "1"
+    xd = x.to(gpu_device).contiguous()
+    got = r.run_planned(xd).clone()
+    walk = r.run(xd).clone()
+    torch.cuda.synchronize()
+    kinds = r.plan_for(xd.shape)["kinds"]
+    vs_walk = (got - walk).abs().max().item()
+    nref = min(nb, 2)                                       # (the interpreter takes minutes per 1080p frame in fp64)
+    ref64 = run_graph(g, w, x[:nref], dtype=torch.float64)
+    err = (got[:nref].cpu().double() - ref64).abs().max().item()
+    print(f"{fixture} {nb}x{H}x{W}: NHWC plan vs fp64 interpreter {err:.2e}, vs the NCHW walk {vs_walk:.2e}; steps {kinds}")
+    assert got.shape == walk.shape and err <= 1e-4 and vs_walk <= 2e-4
+    if nb > 2:                                              # the images the interpreter did not see: against the walk
+        assert (got[nref:] - walk[nref:]).abs().max().item() <= 2e-4
+    if fixture == "ppocr_det_graph.json":
+        assert kinds.get("from_view", 0) == 0 and kinds["to_view"] + kinds.get("im2col_view", 0) == 3
+        auto = ocr_det.PaddleGraphRunner(g, w, device=0)
+        assert auto.nhwc == "auto" and auto.plan_for(xd.shape) is not None          # the server program's default
+        auto.close()
+    r.close()
+
+
+def test_nhwc_plan_batches_and_replays(built_lib, gpu_device):
+    """every image of a batch comes out of the plan exactly as it does alone (a GEMM row's sum does not depend on the other rows), replays
+    on fresh inputs and after another shape are bit-equal to first runs, two instances agree bit for bit"""
+    g = load_graph(os.path.join(GOLD, "ppocr_det_graph.json"))
+    w = synthetic_weights(g)
+    r, r2 = ocr_det.PaddleGraphRunner(g, w, device=0), ocr_det.PaddleGraphRunner(g, w, device=0)
+    rng = np.random.default_rng(31)
+    x = torch.from_numpy(rng.standard_normal((3, 3, 96, 160)).astype(np.float32)).to(gpu_device)
+    y = torch.from_numpy(rng.standard_normal((3, 3, 96, 160)).astype(np.float32)).to(gpu_device)
+    single = torch.cat([r.run_taped(x[b:b + 1].contiguous()).clone() for b in range(3)])
+    batched = r.run_taped(x).clone()
+    other = r.run_taped(y).clone()
+    again = r.run_taped(x).clone()
+    second = r2.run_taped(x).clone()
+    torch.cuda.synchronize()
+    assert r.plan_for(x.shape) is not None and not r._tapes
+    assert torch.equal(batched, single) and torch.equal(again, batched) and torch.equal(second, batched) and not torch.equal(other, batched)
+    r.close()
+    r2.close()
 
 
 def test_detector_lanes_on_the_device(built_lib, gpu_device, monkeypatch):

@@ -154,6 +154,12 @@ SIGNATURES = {
     "vsr_det_launch_db_boxes": (_I, [_P, _I, _I, C.c_float, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "vsr_det_launch_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vsr_det_launch_nhwc_to_nchw": (_I, [_P, _I, _I, _L, _I, _P, _P, _I, _P, _P]),
+    "vsr_det_launch_to_view": (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _L, _I, _P]),
+    "vsr_det_launch_from_view": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "vsr_det_launch_dwconv_view": (_I, [_P, _L, _L, _I, _P, _P, _P] + [_I] * 11 + [_P, _L, _L, _I, _P]),
+    "vsr_det_launch_nearest_view": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _L, _L, _I, _P]),
+    "vsr_det_launch_im2col_view": (_I, [_P] + [_I] * 8 + [_P, _L, _L, _I, _P]),
+    "vsr_det_launch_dots_view": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "vsr_gemm_plan_create": (_I, [C.POINTER(GGProblem), _I, _I, _I, _I, C.POINTER(_P)]),
     "vsr_gemm_plan_run": (_I, [_P, _P]),
     "vsr_gemm_plan_destroy": (None, [_P]),

@@ -21,6 +21,7 @@ import torch
 
 from ... import _lib
 from ..._lib import check, lib
+from . import ocr_det_nhwc
 from .paddle_graph import load_graph, read_pdiparams
 
 
@@ -206,6 +207,11 @@ class PaddleGraphRunner:
         self._tape = None                     # launches being recorded: [(C function, argument tuple)]
         self._tapes = {}                      # input shape -> (tape, static input, output, tensors kept alive)
         self.flops = {}                       # input shape -> algorithmic FLOPs of one forward (2 * MACs of every conv / transposed conv)
+        # NHWC-resident compiled plan (ocr_det_nhwc.py): "1" always, "0" never (the recorded op-by-op walk), "auto" (default) when the
+        # program compiles to few layout passes (the server program: 3 for 114 GEMMs; the mobile program's squeeze-excite / hardswish
+        # blocks keep it on the NCHW kernels)
+        self.nhwc = os.environ.get("VSR_DET_NHWC", "auto")
+        self._plans = {}                      # input shape -> instantiated plan (buffers, constants, resident GEMM plans, launch list) or None
 
     def _c(self, t):
         """t as a contiguous tensor.  While a tape is open an implicit torch copy would be a launch the tape does not hold (and
@@ -224,6 +230,136 @@ class PaddleGraphRunner:
         if self._tape is not None:
             self._tape.append((fn, args))
 
+    def plan_for(self, shape):
+        """the instantiated NHWC plan of this input shape, or None when the program does not lend itself to one (VSR_DET_NHWC)"""
+        key = tuple(int(v) for v in shape)
+        if key in self._plans:
+            return self._plans[key]
+        st = None
+        if self.nhwc != "0" and self.use_gemm:
+            params = {vid: t.cpu().numpy() for vid, t in self.params.items()}
+            try:
+                plan = ocr_det_nhwc.compile_plan(self.graph, params, key)
+            except ValueError:                      # a buffer beyond the 32-bit offset tables: the walk (which checks conv by conv) decides
+                plan = None
+            kinds = {}
+            for k, _ in (plan.steps if plan is not None else []):
+                kinds[k] = kinds.get(k, 0) + 1
+            passes = kinds.get("to_view", 0) + kinds.get("from_view", 0)
+            if plan is not None and (self.nhwc == "1" or passes * 4 <= kinds.get("gemm", 0)):
+                with torch.cuda.device(self.device):
+                    st = self._instantiate(plan)
+                st["kinds"] = kinds
+                self.flops[key] = plan.flops
+        self._plans[key] = st
+        return st
+
+    def _instantiate(self, plan):
+        """buffers, constants and resident GEMM plans of a compiled plan on the device + its launch list [(C function, arguments)]"""
+        dev = self.device
+        bufs = {k: (torch.zeros if zero else torch.empty)(max(sz, 4), dtype=torch.float32, device=dev) for k, (sz, zero) in plan.buffers.items()}
+        consts = {k: torch.from_numpy(a).to(dev) for k, a in plan.consts.items()}
+        bp = lambda name, off=0: C.c_void_p(bufs[name].data_ptr() + 4 * int(off))
+        cp = lambda name: C.c_void_p(consts[name].data_ptr()) if name is not None else None
+        sa = self._sa
+        tape, handles, pending = [], [], []
+
+        def flush():
+            """the GEMM steps gathered so far (one, or a group that shares nothing) as one resident launch list"""
+            if not pending:
+                return
+            pr = (_lib.GGProblem * len(pending))()
+            for q, p in zip(pr, pending):
+                t = p["tables"]
+                q.A, q.B, q.C = bufs[p["A"]].data_ptr(), consts[p["B"]].data_ptr(), bufs[p["C"]].data_ptr()
+                q.bias = consts[p["bias"]].data_ptr() if p["bias"] is not None else None
+                q.R = bufs[p["R"]].data_ptr() if p["R"] is not None else None
+                q.rowA, q.colA, q.rowB, q.colB = (consts[t[k]].data_ptr() for k in ("rowA", "colA", "rowB", "colB"))
+                q.rowC, q.colC = consts[t["rowC"]].data_ptr(), consts[t["colC"]].data_ptr()
+                q.rowR = consts[t["rowR"]].data_ptr() if "rowR" in t else None
+                q.M, q.N, q.K, q.tilesM, q.tilesN = p["M"], p["N"], p["K"], p["tiles_m"], p["tiles_n"]
+                q.splitK, q.chunksPerSplit, q.act, q.alpha, q.splitStride = 1, p["K"] // 32, p["act"], 1.0, 0
+            h = C.c_void_p()
+            check(lib.vsr_gemm_plan_create(pr, len(pending), pending[0]["tile_cfg"], BMODE_NK, pending[0]["variant"], C.byref(h)))
+            handles.append(h)
+            tape.append((lib.vsr_gemm_plan_run, (h, sa)))
+            launches.append(("gemm", list(pending)))
+            pending.clear()
+
+        launches = []                             # what each tape entry is: (kind, step parameters) -- for per-launch timing
+        for kind, p in plan.steps:
+            if kind == "gemm":
+                if p["group"] is not None and pending and pending[0]["group"] == p["group"]:
+                    pending.append(p)
+                    continue
+                flush()
+                pending.append(p)
+                continue
+            flush()
+            if kind == "to_view":
+                tape.append((lib.vsr_det_launch_to_view, (bp(p["x"]), p["n"], p["C"], p["H"], p["W"], p["Cw"], bp(p["out"], p["out_off"]), p["img_stride"],
+                                                           p["row_stride"], p["Cs"], sa)))
+            elif kind == "from_view":
+                tape.append((lib.vsr_det_launch_from_view, (bp(p["inp"], p["in_off"]), p["img_stride"], p["row_stride"], p["Cs"], p["n"], p["C"], p["H"], p["W"],
+                                                             bp(p["out"], p["out_off"]), p["out_img_stride"], sa)))
+            elif kind == "dwconv_view":
+                tape.append((lib.vsr_det_launch_dwconv_view, (bp(p["inp"], p["in_off"]), p["in_img"], p["in_row"], p["in_cs"], cp(p["w"]), cp(p["scale"]), cp(p["shift"]),
+                                                               p["n"], p["C"], p["kh"], p["kw"], p["sh"], p["sw"], p["pt"], p["pl"], p["Ho"], p["Wo"], p["act"],
+                                                               bp(p["out"], p["out_off"]), p["out_img"], p["out_row"], p["out_cs"], sa)))
+            elif kind == "nearest_view":
+                tape.append((lib.vsr_det_launch_nearest_view, (bp(p["inp"], p["in_off"]), p["in_img"], p["in_row"], p["in_cs"], p["n"], p["C"], p["Ho"], p["Wo"], p["s"],
+                                                                bp(p["out"], p["out_off"]), p["out_img"], p["out_row"], p["out_cs"], sa)))
+            elif kind == "im2col_view":
+                tape.append((lib.vsr_det_launch_im2col_view, (bp(p["x"]), p["n"], p["C"], p["H"], p["W"], p["kh"], p["kw"], p["pt"], p["pl"], bp(p["out"], p["out_off"]),
+                                                               p["out_img"], p["out_row"], p["out_cs"], sa)))
+            elif kind == "dots_view":
+                tape.append((lib.vsr_det_launch_dots_view, (bp(p["inp"], p["in_off"]), p["in_img"], p["in_row"], p["in_cs"], p["n"], p["C"], p["H"], p["W"], cp(p["w"]),
+                                                             cp(p["bias"]), p["n_out"], p["act"], bp(p["out"]), sa)))
+            elif kind == "conv_nchw":
+                tape.append((lib.vsr_det_launch_conv2d, (bp(p["x"]), cp(p["w"]), None, p["n"], p["cin"], p["h"], p["wd"], p["cout"], p["kh"], p["kw"], p["sh"], p["sw"],
+                                                          p["pt"], p["pl"], p["ho"], p["wo"], p["dw"], 0, bp(p["out"]), sa)))
+            elif kind == "deconv_nchw":
+                tape.append((lib.vsr_det_launch_deconv2x2, (bp(p["x"]), cp(p["w"]), p["n"], p["cin"], p["h"], p["wd"], p["cout"], p["dw"], bp(p["out"]), sa)))
+            elif kind == "affine":
+                tape.append((lib.vsr_det_launch_affine, (bp(p["x"]), cp(p["scale"]), cp(p["shift"]), p["total"], p["C"], p["HW"], bp(p["out"]), sa)))
+            elif kind == "binary":
+                b = cp(p["b"][1]) if p["b"][0] == "const" else bp(p["b"][1])
+                tape.append((lib.vsr_det_launch_binary, (bp(p["a"]), b, p["op"], p["total"], p["C"], p["HW"], p["mode"], bp(p["out"]), sa)))
+            elif kind == "unary":
+                tape.append((lib.vsr_det_launch_unary, (bp(p["x"]), p["total"], p["kind"], C.c_float(p["p0"]), C.c_float(p["p1"]), bp(p["out"]), sa)))
+            elif kind == "gap":
+                tape.append((lib.vsr_det_launch_gap, (bp(p["x"]), p["planes"], p["HW"], bp(p["out"]), sa)))
+            elif kind == "maxpool":
+                tape.append((lib.vsr_det_launch_maxpool, (bp(p["x"]), p["planes"], p["H"], p["W"], p["kh"], p["kw"], p["sh"], p["sw"], p["pt"], p["pl"], p["Ho"],
+                                                           p["Wo"], bp(p["out"]), sa)))
+            elif kind == "nearest_nchw":
+                tape.append((lib.vsr_det_launch_nearest, (bp(p["x"]), p["planes"], p["H"], p["W"], p["s"], bp(p["out"]), sa)))
+            elif kind == "copy":
+                tape.append((lib.vsr_det_launch_copy, (bp(p["src"]), 4 * p["src_pitch"], bp(p["dst"], p["dst_off"]), 4 * p["dst_pitch"], 4 * p["width"], p["rows"], sa)))
+            else:
+                raise NotImplementedError(kind)
+            launches.append((kind, p))
+        flush()
+        name, shape = plan.output
+        out = bufs[name][:int(np.prod(shape))].view(*shape)
+        xin = bufs[plan.input][:plan.buffers[plan.input][0]]
+        return dict(tape=tape, bufs=bufs, consts=consts, gemm_plans=handles, out=out, xin=xin, plan=plan, launches=launches)
+
+    def run_planned(self, x, st=None):
+        """the forward from the compiled NHWC plan of x's shape (plan_for): the input is copied into the plan's buffer, the launch list is
+        issued on the caller's current stream; the returned tensor is the plan's output buffer, valid until the next call for that shape"""
+        st = st if st is not None else self.plan_for(x.shape)
+        if st is None:
+            raise _lib.VsrError(_lib.VSR_ERR_ARG, "no NHWC plan for this program (VSR_DET_NHWC)")
+        with torch.cuda.device(self.device):
+            st["xin"].copy_(x.reshape(-1))
+            self._sa.value = torch.cuda.current_stream().cuda_stream
+            for fn, args in st["tape"]:
+                rc = fn(*args)
+                if rc != 0:
+                    check(rc)
+        return st["out"]
+
     def run_taped(self, x):
         """run() replayed from a recorded launch list.  The forward is 300-450 launches and, walked op by op in Python (shape
         logic, allocations, ctypes marshalling), host-bound; every launch of a fixed input shape has fixed arguments, so the
@@ -232,6 +368,9 @@ class PaddleGraphRunner:
         captured by the driver: the same launches, on the caller's current stream.  The returned tensor is the recorded output
         buffer: valid until the next call for that shape."""
         key = tuple(x.shape)
+        pst = self.plan_for(key)
+        if pst is not None:
+            return self.run_planned(x, pst)
         st = self._tapes.get(key)
         if st is None:
             with torch.cuda.device(self.device):
@@ -258,6 +397,11 @@ class PaddleGraphRunner:
     def close(self):
         self._tapes.clear()
         self._graphs.clear()                  # captured graphs reference the plans' buffers: drop them first
+        for st in self._plans.values():
+            if st is not None:
+                for h in st["gemm_plans"]:
+                    lib.vsr_gemm_plan_destroy(h)
+        self._plans.clear()
         for st in self._gemm.values():
             lib.vsr_gemm_plan_destroy(st["plan"])
         self._gemm.clear()

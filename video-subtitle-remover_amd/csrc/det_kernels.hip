@@ -261,6 +261,190 @@ k_det_nhwc_to_nchw(const float* __restrict__ in, int C, int64_t P, int Np, const
     }
 }
 
+// ---- NHWC-resident plan (round 6; backend/tools/ocr_det_nhwc.py).  Activations stay in zero-haloed NHWC buffers between the GEMM convs:
+// a "view" is (pointer to channel c0 of interior pixel (0, 0) of image 0, floats per image, floats per row, floats per pixel); the halo
+// around the interior and the channels a slice is padded with are zero and nothing writes them, so the kernels below need no border
+// predicates and the concat of the HGNet blocks is the producers writing their channel slices of one buffer. ----
+
+// NCHW [n][C][H][W] -> interior of a view, channels [0, Cw) (Cw a multiple of 32; zeros at and beyond C)
+__global__ void __launch_bounds__(256)
+k_det_to_view(const float* __restrict__ x, int C, int H, int W, int Cw, float* __restrict__ out, int64_t imgStride, int64_t rowStride, int Cs)
+{
+    x += (int64_t)blockIdx.z * C * H * W;
+    out += (int64_t)blockIdx.z * imgStride;
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t q0 = (int64_t)blockIdx.x * 32, total = (int64_t)H * W;
+    const int c0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        t[j][tx] = (q0 + tx < total && c < C) ? x[(int64_t)c * total + q0 + tx] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t q = q0 + j;
+        if (q < total) {
+            const int y = (int)(q / W), xx = (int)(q - (int64_t)y * W);
+            out[y * rowStride + (int64_t)xx * Cs + c0 + tx] = t[tx][j];
+        }
+    }
+}
+
+// interior of a view, channels [0, C) -> NCHW planes out[img * outImgStride + c * H * W + pixel]
+__global__ void __launch_bounds__(256)
+k_det_from_view(const float* __restrict__ in, int64_t imgStride, int64_t rowStride, int Cs, int C, int H, int W, float* __restrict__ out,
+                int64_t outImgStride)
+{
+    in += (int64_t)blockIdx.z * imgStride;
+    out += (int64_t)blockIdx.z * outImgStride;
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 32, total = (int64_t)H * W;
+    const int c0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t p = p0 + j;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (p < total && c < C) {
+            const int y = (int)(p / W), xx = (int)(p - (int64_t)y * W);
+            v = in[y * rowStride + (int64_t)xx * Cs + c];
+        }
+        t[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const int64_t p = p0 + tx;
+        if (c < C && p < total) out[(int64_t)c * total + p] = t[tx][j];
+    }
+}
+
+// depthwise conv on views, 4 channels per thread: out = act((sum_taps x * w[tap][c]) * scale[c] + shift[c]); the taps outside the image
+// are the halo's zeros (pt, pl <= halo), weights tap-major [kh * kw][C]; the sum runs over (ky, kx) as k_det_dwconv's
+__global__ void __launch_bounds__(256)
+k_det_dwconv_view(const float* __restrict__ in, int64_t inImg, int64_t inRow, int inCs, const float* __restrict__ w, const float* __restrict__ scale,
+                  const float* __restrict__ shift, int N, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, int act,
+                  float* __restrict__ out, int64_t outImg, int64_t outRow, int outCs)
+{
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4) * 4;
+        const int64_t pix = i / C4;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), n = (int)(pix / ((int64_t)Wo * Ho));
+        const float* xp = in + n * inImg + (int64_t)(oy * sh - pt) * inRow + (int64_t)(ox * sw - pl) * inCs + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int ky = 0; ky < kh; ++ky)
+            for (int kx = 0; kx < kw; ++kx) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + ky * inRow + (int64_t)kx * inCs);
+                const float4 ww = *reinterpret_cast<const float4*>(w + (int64_t)(ky * kw + kx) * C + c);
+                a0 += v.x * ww.x; a1 += v.y * ww.y; a2 += v.z * ww.z; a3 += v.w * ww.w;
+            }
+        if (scale != nullptr) {
+            const float4 s = *reinterpret_cast<const float4*>(scale + c), t = *reinterpret_cast<const float4*>(shift + c);
+            a0 = a0 * s.x + t.x; a1 = a1 * s.y + t.y; a2 = a2 * s.z + t.z; a3 = a3 * s.w + t.w;
+        }
+        float4 o;
+        o.x = det_act(a0, act); o.y = det_act(a1, act); o.z = det_act(a2, act); o.w = det_act(a3, act);
+        *reinterpret_cast<float4*>(out + n * outImg + oy * outRow + (int64_t)ox * outCs + c) = o;
+    }
+}
+
+// nearest_interp (integer scale s) view -> view, 4 channels per thread
+__global__ void __launch_bounds__(256)
+k_det_nearest_view(const float* __restrict__ in, int64_t inImg, int64_t inRow, int inCs, int N, int C, int Ho, int Wo, int s, float* __restrict__ out,
+                   int64_t outImg, int64_t outRow, int outCs)
+{
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4) * 4;
+        const int64_t pix = i / C4;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), n = (int)(pix / ((int64_t)Wo * Ho));
+        *reinterpret_cast<float4*>(out + n * outImg + oy * outRow + (int64_t)ox * outCs + c) =
+            *reinterpret_cast<const float4*>(in + n * inImg + (int64_t)(oy / s) * inRow + (int64_t)(ox / s) * inCs + c);
+    }
+}
+
+// the kh x kw neighbourhoods of a few-channel NCHW map as ONE 32-float chunk per pixel of a view: channel (c * kh + ky) * kw + kx of pixel
+// (y, x) = x[c][y + ky - pt][x + kx - pl] (zero outside the image), zeros beyond C * kh * kw -- the conv over concat(probability map, features)
+// of the DB head then spends one K chunk on the map instead of one per tap
+__global__ void __launch_bounds__(256)
+k_det_im2col_view(const float* __restrict__ x, int N, int C, int H, int W, int kh, int kw, int pt, int pl, float* __restrict__ out, int64_t outImg,
+                  int64_t outRow, int outCs)
+{
+    const int64_t total = (int64_t)N * H * W * 8;
+    const int taps = C * kh * kw;
+    GRID_STRIDE(i, total) {
+        const int q = (int)(i & 7);
+        const int64_t pix = i >> 3;
+        const int xx = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((int64_t)W * H));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = q * 4 + e;
+            float r = 0.f;
+            if (j < taps) {
+                const int c = j / (kh * kw), t = j - c * kh * kw;
+                const int sy = y + t / kw - pt, sx = xx + t % kw - pl;
+                if (sy >= 0 && sy < H && sx >= 0 && sx < W) r = x[(((int64_t)n * C + c) * H + sy) * W + sx];
+            }
+            v[e] = r;
+        }
+        *reinterpret_cast<float4*>(out + n * outImg + y * outRow + (int64_t)xx * outCs + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__device__ __forceinline__ float det_act4(float v, int act)
+{
+    if (act == 3) return 1.0f / (1.0f + expf(-v));                             // sigmoid
+    return det_act(v, act);
+}
+
+// NO (1 or 4) dot products per pixel of a view over its C channels (C % 4 == 0): the 1x1 conv to one channel (NO = 1: out[n][H][W]) and
+// the 2x2 / stride 2 transposed conv to one channel (NO = 4, taps (dy, dx): out[n][2H][2W]) of the DB head; 16 lanes per pixel, w [NO][C]
+template <int NO>
+__global__ void __launch_bounds__(256)
+k_det_dots_view(const float* __restrict__ in, int64_t inImg, int64_t inRow, int inCs, int N, int C, int H, int W, const float* __restrict__ w,
+                const float* __restrict__ bias, int act, float* __restrict__ out)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t step = (int64_t)gridDim.x * (blockDim.x >> 4);
+    const int64_t rounds = (total + step - 1) / step;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t pix = r * step + (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+        const bool ok = pix < total;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((int64_t)W * H));
+        float acc[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] = 0.f;
+        if (ok) {
+            const float* xp = in + n * inImg + y * inRow + (int64_t)x * inCs;
+            for (int c = sub * 4; c < C; c += 64) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    const float4 ww = *reinterpret_cast<const float4*>(w + (int64_t)j * C + c);
+                    acc[j] += v.x * ww.x; acc[j] += v.y * ww.y; acc[j] += v.z * ww.z; acc[j] += v.w * ww.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NO; ++j)
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (ok && sub == 0) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const float v = det_act4(acc[j] + (bias != nullptr ? bias[0] : 0.f), act);
+                if (NO == 1) out[pix] = v;
+                else out[((int64_t)n * 2 * H + 2 * y + (j >> 1)) * 2 * W + 2 * x + (j & 1)] = v;
+            }
+        }
+    }
+}
+
 // ---- DBPostProcess, device part (inference.yml PostProcess; paddleocr DBPostProcess.boxes_from_bitmap): bitmap = prob > thresh,
 // 8-connected components (what cv2.findContours' outer contours enclose), per-component area and bounding box.  Union-find
 // labelling (one merge pass over the four forward neighbours with atomicMin on the parent links, then path flattening): the
@@ -769,6 +953,73 @@ int vsr_det_launch_nhwc_to_nchw(const float* in, int n, int C, int64_t P, int Np
     if (!in || !out || n <= 0 || n > 65535 || C <= 0 || Np < C || P <= 0 || (scale && !shift)) return VSR_ERR_ARG;
     hipLaunchKernelGGL(k_det_nhwc_to_nchw, dim3((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, in,
                        C, P, Np, scale, shift, act, out);
+    DONE();
+}
+
+int vsr_det_launch_to_view(const float* x, int n, int C, int H, int W, int Cw, float* out, int64_t img_stride, int64_t row_stride, int Cs, void* stream)
+{
+    if (!x || !out || n <= 0 || n > 65535 || C <= 0 || Cw % 32 || Cw < C || Cs < Cw) return VSR_ERR_ARG;
+    const int64_t total = (int64_t)H * W;
+    hipLaunchKernelGGL(k_det_to_view, dim3((unsigned)((total + 31) / 32), (unsigned)(Cw / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, C, H, W,
+                       Cw, out, img_stride, row_stride, Cs);
+    DONE();
+}
+
+int vsr_det_launch_from_view(const float* in, int64_t img_stride, int64_t row_stride, int Cs, int n, int C, int H, int W, float* out,
+                             int64_t out_img_stride, void* stream)
+{
+    if (!in || !out || n <= 0 || n > 65535 || C <= 0 || Cs < C) return VSR_ERR_ARG;
+    const int64_t total = (int64_t)H * W;
+    hipLaunchKernelGGL(k_det_from_view, dim3((unsigned)((total + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, in,
+                       img_stride, row_stride, Cs, C, H, W, out, out_img_stride);
+    DONE();
+}
+
+int vsr_det_launch_dwconv_view(const float* in, int64_t in_img, int64_t in_row, int in_cs, const float* w, const float* scale, const float* shift, int N,
+                               int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, int act, float* out, int64_t out_img,
+                               int64_t out_row, int out_cs, void* stream)
+{
+    if (!in || !out || !w || C <= 0 || C % 4 || in_cs % 4 || out_cs % 4 || (scale && !shift) || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)w) & 15))
+        return VSR_ERR_ARG;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_det_dwconv_view, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_img, in_row, in_cs, w, scale, shift, N, C, kh, kw,
+                       sh, sw, pt, pl, Ho, Wo, act, out, out_img, out_row, out_cs);
+    DONE();
+}
+
+int vsr_det_launch_nearest_view(const float* in, int64_t in_img, int64_t in_row, int in_cs, int N, int C, int Ho, int Wo, int s, float* out,
+                                int64_t out_img, int64_t out_row, int out_cs, void* stream)
+{
+    if (!in || !out || C <= 0 || C % 4 || s < 1 || in_cs % 4 || out_cs % 4 || (((uintptr_t)in | (uintptr_t)out) & 15)) return VSR_ERR_ARG;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_det_nearest_view, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_img, in_row, in_cs, N, C, Ho, Wo, s, out,
+                       out_img, out_row, out_cs);
+    DONE();
+}
+
+int vsr_det_launch_im2col_view(const float* x, int N, int C, int H, int W, int kh, int kw, int pt, int pl, float* out, int64_t out_img, int64_t out_row,
+                               int out_cs, void* stream)
+{
+    if (!x || !out || C <= 0 || kh <= 0 || kw <= 0 || C * kh * kw > 32 || out_cs % 4 || ((uintptr_t)out & 15)) return VSR_ERR_ARG;
+    const int64_t total = (int64_t)N * H * W * 8;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_det_im2col_view, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, kh, kw, pt, pl, out, out_img, out_row, out_cs);
+    DONE();
+}
+
+int vsr_det_launch_dots_view(const float* in, int64_t in_img, int64_t in_row, int in_cs, int N, int C, int H, int W, const float* w, const float* bias,
+                             int n_out, int act, float* out, void* stream)
+{
+    if (!in || !out || !w || C <= 0 || C % 4 || in_cs % 4 || (n_out != 1 && n_out != 4) || (((uintptr_t)in | (uintptr_t)w) & 15)) return VSR_ERR_ARG;
+    const int64_t total = (int64_t)N * H * W;
+    if (total <= 0) return 0;
+    const int grid = grid_for(total * 16);
+    if (n_out == 1)
+        hipLaunchKernelGGL(k_det_dots_view<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_img, in_row, in_cs, N, C, H, W, w, bias, act, out);
+    else
+        hipLaunchKernelGGL(k_det_dots_view<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_img, in_row, in_cs, N, C, H, W, w, bias, act, out);
     DONE();
 }
 
