@@ -93,12 +93,10 @@ class InjectedDetection(ocr_det.TextDetection):
         self.forwards += 1
         self.frames_seen += int(frames_dev.shape[0])
         H, W = int(frames_dev.shape[1]), int(frames_dev.shape[2])
-        out = []
-        for has in self._verdicts(frames_dev):
-            self.positives += int(has)
-            boxes, scores = self._post(self._on if has else self._off, H, W)
-            out.append({"dt_polys": boxes, "dt_scores": scores})
-        return out
+        verdicts = self._verdicts(frames_dev)
+        self.positives += sum(int(has) for has in verdicts)
+        maps = torch.stack([self._on if has else self._off for has in verdicts])
+        return [{"dt_polys": boxes, "dt_scores": scores} for boxes, scores in self._post_batch(maps, H, W)]      # as TextDetection.predict_batch_device
 
     def predict_batch(self, imgs):                          # host frames (the non-resident loop)
         d = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device)

@@ -289,7 +289,7 @@ def test_device_db_postprocess_equals_the_oracle(built_lib, gpu_device, seed, H,
     if to_host:
         assert np.array_equal(got_b, want_b)
     # the labelling itself: same partition as scipy's, labels = raster index of the first pixel
-    labels = post._work[(H, W)][0].view(H, W).cpu().numpy()
+    labels = post._work[(H, W, 0)][0].view(H, W).cpu().numpy()
     assert ((labels >= 0) == (ref > 0)).all()
     flat_ref, flat_lab = ref.reshape(-1), labels.reshape(-1)
     idx = np.nonzero(flat_ref)[0]
@@ -297,6 +297,24 @@ def test_device_db_postprocess_equals_the_oracle(built_lib, gpu_device, seed, H,
     for i in idx[::-1]:
         firsts[flat_ref[i]] = i
     assert np.array_equal(flat_lab[idx], firsts[flat_ref[idx]])
+
+
+def test_device_db_postprocess_batch_equals_per_map(built_lib, gpu_device):
+    """DeviceDBPostProcess.batch (every map of a forward in work buffers of its own, ONE read-back -- what predict_batch /
+    predict_batch_device use) gives, map by map, exactly what the per-map call gives: boxes, scores, and the host fallback of the map with
+    holes; an empty map among them stays empty; a second batch reuses the slots"""
+    cases = [(1, 6, 0, 0, 0.3), (8, 12, 6, 5, 0.3), (4, 0, 0, 0, 0.3), (5, 10, 0, 30, 1.2), (9, 9, 0, 6, 0.2), (2, 60, 0, 12, 0.3), (6, 8, 0, 0, 0.0), (11, 5, 0, 0, 0.05)]
+    maps = np.stack([blob_map(seed, 544, 960, nb, holes, specks, max_tilt=tilt) for seed, nb, holes, specks, tilt in cases])
+    dev = torch.from_numpy(maps).to(gpu_device)
+    single, batched = ocr_det.DeviceDBPostProcess(gpu_device), ocr_det.DeviceDBPostProcess(gpu_device)
+    want = [single(dev[b], 1080, 1920) for b in range(len(cases))]
+    for _ in range(2):
+        got = batched.batch(dev, 1080, 1920)
+        assert len(got) == len(want)
+        for (gb, gs), (wb, ws) in zip(got, want):
+            assert np.array_equal(gb, wb) and gs == ws
+    assert 1 <= single.host_fallbacks < len(cases) and batched.host_fallbacks == 2 * single.host_fallbacks and len(want[2][1]) == 0 and len(want[0][1]) >= 3
+    assert batched.batch(dev[:0], 1080, 1920) == []
 
 
 def test_device_hole_count(built_lib, gpu_device):
@@ -312,7 +330,7 @@ def test_device_hole_count(built_lib, gpu_device):
     prob[6, 6] = 0.9                                             # diagonal pair: one component
     post = ocr_det.DeviceDBPostProcess(gpu_device)
     post(torch.from_numpy(prob).to(gpu_device), 64, 96)
-    host = post._work[(64, 96)][5].cpu().numpy()
+    host = post._work[(64, 96, 0)][5].cpu().numpy()
     assert host[0] == 3 and host[1] == 2
     assert post.host_fallbacks == 1
 

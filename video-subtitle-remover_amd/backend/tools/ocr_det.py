@@ -968,8 +968,8 @@ class DeviceDBPostProcess:
         self._work = {}
         self.host_fallbacks = 0
 
-    def _buffers(self, H, W):
-        key = (H, W)
+    def _buffers(self, H, W, slot=0):
+        key = (H, W, slot)
         if key not in self._work:
             dev, i32 = self.device, torch.int32
             self._work[key] = (torch.empty(H * W, dtype=i32, device=dev), torch.empty(H * W * 5, dtype=i32, device=dev),
@@ -977,15 +977,16 @@ class DeviceDBPostProcess:
                                torch.empty(self.cap * H * 2, dtype=i32, device=dev), torch.zeros(self.HDR + self.cap * self.REC, dtype=i32, device=dev))
         return self._work[key]
 
-    def __call__(self, prob_dev, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
-        assert prob_dev.is_cuda and prob_dev.dtype == torch.float32 and prob_dev.dim() == 2
-        prob_dev = prob_dev.contiguous()
+    def _launch(self, prob_dev, src_h, src_w, thresh, box_thresh, unclip_ratio, min_size, slot=0):
+        """the post-process kernels of one map on the current stream, in the work buffers of `slot`; -> (header + records, components)"""
         H, W = prob_dev.shape
-        labels, stats, comps, count, ext, out = self._buffers(H, W)
-        with torch.cuda.device(self.device):
-            check(lib.vsr_det_launch_db_boxes(_p(prob_dev), H, W, C.c_float(thresh), src_h, src_w, C.c_float(box_thresh), C.c_float(unclip_ratio),
-                                              min_size, _p(labels), _p(stats), _p(comps), _p(count), _p(ext), _p(out), self.cap, _stream()))
-            host = torch.cat([out, comps]).cpu().numpy()                             # the one synchronisation of the post-process
+        labels, stats, comps, count, ext, out = self._buffers(H, W, slot)
+        check(lib.vsr_det_launch_db_boxes(_p(prob_dev), H, W, C.c_float(thresh), src_h, src_w, C.c_float(box_thresh), C.c_float(unclip_ratio),
+                                          min_size, _p(labels), _p(stats), _p(comps), _p(count), _p(ext), _p(out), self.cap, _stream()))
+        return out, comps
+
+    def _decode(self, host, prob_dev, src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size):
+        """boxes and scores from the downloaded header + records + components of one map"""
         n, holes = int(host[0]), int(host[1])
         if n == 0:
             return np.zeros((0, 4, 2), np.int16), []
@@ -1000,6 +1001,30 @@ class DeviceDBPostProcess:
         boxes = rec[:, 1:9].reshape(-1, 4, 2).astype(np.int16)
         scores = [float(v) for v in np.ascontiguousarray(rec[:, 9]).view(np.float32)]
         return boxes, scores
+
+    def __call__(self, prob_dev, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
+        assert prob_dev.is_cuda and prob_dev.dtype == torch.float32 and prob_dev.dim() == 2
+        prob_dev = prob_dev.contiguous()
+        with torch.cuda.device(self.device):
+            out, comps = self._launch(prob_dev, src_h, src_w, thresh, box_thresh, unclip_ratio, min_size)
+            host = torch.cat([out, comps]).cpu().numpy()                             # the one synchronisation of the post-process
+        return self._decode(host, prob_dev, src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size)
+
+    def batch(self, probs_dev, src_h, src_w, thresh=0.3, box_thresh=0.6, max_candidates=1000, unclip_ratio=1.5, min_size=3):
+        """[self(p, ...) for p in probs_dev] for the maps [n, H, W] of one forward with ONE synchronisation: every map is post-processed in
+        work buffers of its own (slot = index in the batch), the n record buffers come down in one copy (a per-frame read-back leaves the
+        GPU idle for a host round trip between the maps: 8 of them per forward)"""
+        assert probs_dev.is_cuda and probs_dev.dtype == torch.float32 and probs_dev.dim() == 3
+        n = probs_dev.shape[0]
+        if n == 0:
+            return []
+        with torch.cuda.device(self.device):
+            maps = [probs_dev[b].contiguous() for b in range(n)]
+            parts = []
+            for b in range(n):
+                parts.extend(self._launch(maps[b], src_h, src_w, thresh, box_thresh, unclip_ratio, min_size, slot=b))
+            host = torch.cat(parts).cpu().numpy().reshape(n, -1)
+        return [self._decode(host[b], maps[b], src_h, src_w, thresh, box_thresh, max_candidates, unclip_ratio, min_size) for b in range(n)]
 
 
 def det_resize_shape(H, W, limit_side_len=960, limit_type="max", max_side_limit=4000):
@@ -1101,6 +1126,14 @@ class TextDetection:
             return db_postprocess(prob_dev.cpu().numpy(), src_h, src_w)
         return self._db(prob_dev, src_h, src_w)
 
+    def _post_batch(self, probs_dev, src_h, src_w):
+        """[_post(p) for p in probs_dev] with one read-back for the whole forward (DeviceDBPostProcess.batch; VSR_DET_POST_BATCH=0: per map)"""
+        if getattr(self, "_db", None) is None:
+            self._db = DeviceDBPostProcess(self.device)
+        if os.environ.get("VSR_DET_POST", "device") == "host" or os.environ.get("VSR_DET_POST_BATCH", "1") == "0":
+            return [self._post(probs_dev[b], src_h, src_w) for b in range(probs_dev.shape[0])]
+        return self._db.batch(probs_dev, src_h, src_w)
+
     def predict(self, img):
         prob, _, _ = self.probability_map(img)
         boxes, scores = self._post(prob, img.shape[0], img.shape[1])
@@ -1149,22 +1182,14 @@ class TextDetection:
             return []
         prob = self.probability_maps_device(frames_dev)
         H, W = int(frames_dev.shape[1]), int(frames_dev.shape[2])
-        out = []
-        for b in range(frames_dev.shape[0]):
-            boxes, scores = self._post(prob[b], H, W)
-            out.append({"dt_polys": boxes, "dt_scores": scores})
-        return out
+        return [{"dt_polys": boxes, "dt_scores": scores} for boxes, scores in self._post_batch(prob, H, W)]
 
     def predict_batch(self, imgs):
         """[predict(img)[0] for img in imgs] with one forward for all frames (independent per frame: same results)"""
         if len(imgs) == 0:
             return []
         prob = self.probability_maps(imgs)
-        out = []
-        for b, img in enumerate(imgs):
-            boxes, scores = self._post(prob[b], img.shape[0], img.shape[1])
-            out.append({"dt_polys": boxes, "dt_scores": scores})
-        return out
+        return [{"dt_polys": boxes, "dt_scores": scores} for boxes, scores in self._post_batch(prob, imgs[0].shape[0], imgs[0].shape[1])]
 
 
 def from_env(device=0):
