@@ -226,7 +226,7 @@ def run_det(name, res, precision, total=1200):
 
 def run_detector(name, nb=16, reps=3):
     """config 3's other half: the PP-OCRv5 server detector's forward at the 1080p net input (960x544), `nb` frames per forward, from the
-    recorded launch list (subtitle_detect.py:41-82's TextDetection.predict without the DB post-process)."""
+    compiled NHWC plan's launch list (subtitle_detect.py:41-82's TextDetection.predict without the DB post-process)."""
     from vsr_amd.backend.tools import ocr_det
     from vsr_amd.backend.tools.paddle_graph import load_graph
     from vsr_amd.synth import make_det_weights
@@ -247,7 +247,7 @@ def run_detector(name, nb=16, reps=3):
     tf = gflop / ms
     out = {"config": name, "mode": "text detector forward (server program)", "res": "1080p -> 960x544 net input", "dtype": "f32",
            "value": round(1e3 / ms, 1), "unit": "frames/s", "ms_per_frame": round(ms, 3), "frames_per_forward": nb, "gflop_per_frame": round(gflop, 1),
-           "roofline": {"bound": "mfma", "kernel": "whole forward (144 convs as gather-GEMMs + layout / depthwise / transposed-conv kernels)",
+           "roofline": {"bound": "mfma", "kernel": "whole forward (NHWC-resident plan: 114 gather-GEMM steps, 27 depthwise, 2 per-pixel dots, stem; 150 launches)",
                         "achieved": round(tf, 2), "peak": PEAK_FP32, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32, 4), "traffic": None,
                         "measured_on": f"{reps} forwards of {nb} frames, wall clock around the recorded launch list"}}
     det.runner.close()

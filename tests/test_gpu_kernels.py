@@ -233,6 +233,24 @@ def test_gather_gemm_every_variant(built_lib, gpu_device, variant, cfg, bm, bn, 
     _assert_close(got, _reference(c), K, f"v{variant} {cfg} mode{bmode} {M}x{N}x{K}", case=c)
 
 
+@pytest.mark.parametrize("cfg,bm,bn,M,N,K,splitK,act,res", [
+    ("TILE_128x64", 128, 64, 1300, 128, 1152, 1, 1, True), ("TILE_128x128", 128, 128, 700, 512, 2304, 1, 2, True),
+    ("TILE_256x32", 256, 32, 900, 32, 576, 1, 1, False), ("TILE_128x64", 128, 64, 375, 375, 384, 3, 0, False),
+    ("TILE_128x64", 128, 64, 4321, 64, 64, 1, 3, True),
+])
+def test_one_workgroup_per_tile_kernel_equals_the_persistent_one(built_lib, gpu_device, cfg, bm, bn, M, N, K, splitK, act, res):
+    """variant 1 (one workgroup per tile) and variant 3 (persistent, LDS-DMA, pipelined tiles) run the same fp32 MFMA sequence per output
+    element -- chunks in order, 16 k-steps per chunk, the same epilogue: THE SAME BITS.  What lets an engine choose the kernel per problem
+    (short / few-tile problems on variant 1: flow_engine.hip `thin_variant`, ocr_det_nhwc.thin_variant) without touching a parity claim."""
+    rng = np.random.default_rng(M + N + K)
+    full = splitK == 1
+    c = _make_gemm_case(rng, M, N, K, bm, bn, 0, splitK, full, act if full else 0, res and full)
+    one = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), 0, 1)[0]
+    per = _run_cases(built_lib, gpu_device, [c], getattr(built_lib, cfg), 0, 3)[0]
+    assert np.array_equal(one, per)
+    _assert_close(one, _reference(c), K, f"v1 {cfg} {M}x{N}x{K}", case=c)
+
+
 def _to_split_inplace(buf, starts):
     """fp32 -> split format on the 32-float chunks starting at ``starts`` (see include/vsr_hip.h, precision 2)."""
     starts = np.unique(np.asarray(starts, dtype=np.int64))

@@ -70,6 +70,7 @@ struct FlowOpDev {
     // 3 / 4: the fold / unfold of an FFN pair whose GELU moved into the fold; 5: a GEMM of <= 4 output columns on the dot-product kernel
     int fused = 0;
     int narrowN = 0, narrowK = 0;  // fused == 5: the largest N / K of the op's problems
+    bool thin = false;             // exact fp32: a short / few-tile GEMM on the one-workgroup-per-tile kernel (thin_variant below), same bits
     const void* dAttn = nullptr;   // PpAttnProblem* (device), fused == 1
     int attnItems = 0, attnTiles = 0;
     double attnFlops = 0;
@@ -141,6 +142,8 @@ struct Workspace {
 
 } // namespace
 
+static bool thin_variant(const Op& op, int totalTiles);
+
 // grows the workspace to the plan's needs and bakes the plan (callers drop their cached plans first when it grows)
 static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_ptr<FlowPlanDev>* out)
 {
@@ -201,6 +204,7 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
             od.dDesc = (char*)pd->dDescs + cursor;
             od.nitems = (int)op.gemm.size();
             od.total = tileStart;
+            od.thin = thin_variant(op, tileStart);
             od.nQueues = 8;
             for (const GemmItem& g : op.gemm)
                 if (g.tilesN > 4) od.nQueues = 1;
@@ -316,6 +320,28 @@ static int materialize(Workspace& ws, std::unique_ptr<PlanIR> plan, std::unique_
     return 0;
 }
 
+// Exact fp32: the persistent LDS-DMA kernel (variant 3) pays a fixed cost per tile (queue fetch, pipeline fill, the prologue of the next
+// tile) that long-K problems amortise and short ones do not; the one-workgroup-per-tile kernel (variant 1) runs the same MFMA sequence per
+// output element -- the same bits, tests/test_gpu_kernels.py::test_one_workgroup_per_tile_kernel_equals_the_persistent_one -- without it.
+// The rule follows the detector plan's (ocr_det_nhwc.thin_variant): K <= 256, or at most VSR_FLOW_THIN_TILES (768 = one round of three
+// workgroups per CU) tiles with K <= VSR_FLOW_THIN_K (2600).  Measured per op tag on a 68-frame propainter batch
+// (profiles/r06c_flow_thin_ab.log): the feature-propagation convs of the generator and of flow completion -- eight DEPENDENT single-round
+// launches per frame and direction, M = 43 200, N = 128, K = 1152 / 2592 -- run at 92-106 TF instead of 65-88 (-120 ms of kernel time per
+// batch), everything with more tiles or longer K (RAFT's GRU, the token GEMMs, the encoder) loses 5-12 % on variant 1 and stays.
+// VSR_FLOW_THIN=0: every GEMM on variant 3 (round 5's behaviour); =2: every GEMM on variant 1 (A/B).
+static int flow_thin_mode() { static const int m = [] { const char* e = getenv("VSR_FLOW_THIN"); return e ? atoi(e) : 1; }(); return m; }
+static bool thin_variant(const Op& op, int totalTiles)
+{
+    static const int maxTiles = [] { const char* e = getenv("VSR_FLOW_THIN_TILES"); return e ? atoi(e) : 768; }();
+    static const int maxK = [] { const char* e = getenv("VSR_FLOW_THIN_K"); return e ? atoi(e) : 2600; }();
+    static const int shortK = [] { const char* e = getenv("VSR_FLOW_THIN_SHORT_K"); return e ? atoi(e) : 256; }();
+    if (flow_thin_mode() == 0 || op.kind != OP_GEMM || op.gemm.empty()) return false;
+    if (flow_thin_mode() == 2) return true;
+    int K = 0;
+    for (const GemmItem& g : op.gemm) K = std::max(K, g.splitK > 1 ? g.chunksPerSplit * VSR_GG_KC : g.K);
+    return K <= shortK || (totalTiles <= maxTiles && K <= maxK);
+}
+
 // replays a materialised plan; `bgr`: channel order of RAFT's u8 input frames
 static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t stream)
 {
@@ -329,13 +355,14 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         unsigned int* queue = pd->dQueues + 8 * idx++;
         int rc = 0;
         if (od.fused == 2) continue;                     // part of a fused attention launch
+        const int opVariant = (variant == 3 && od.thin) ? 1 : variant;
         FlowTimingRec tr;
         if (g_flowTiming) {
             if (od.fused == 1) tr.key = std::string(ws.engine) + ":gg:flash:0:v" + (ws.precision == 2 ? "7" : "3") + ":attn.flash";
             else if (od.fused == 5) tr.key = std::string(ws.engine) + ":gg:narrow:0:v3:" + op.tag;
             else
             tr.key = std::string(ws.engine) + (op.kind == OP_GEMM ? ":gg:" + std::to_string(op.tileCfg) + ":" + std::to_string(op.bmode) + ":v" +
-                                                                        std::to_string(variant) + ":" : ":op:") + op.tag;
+                                                                        std::to_string(opVariant) + ":" : ":op:") + op.tag;
             tr.flops = od.fused == 1 ? od.attnFlops : op.flops;
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
@@ -347,7 +374,7 @@ static int run_plan(const Workspace& ws, FlowPlanDev* pd, int bgr, hipStream_t s
         } else if (od.fused == 5) {
             rc = vsr_launch_gather_gemm_narrow_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.narrowN, od.narrowK, stream);
         } else if (op.kind == OP_GEMM) {
-            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, variant, od.nQueues,
+            rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, op.tileCfg, op.bmode, queue, opVariant, od.nQueues,
                                             rangeFlag, stream);
         } else if (op.kind == OP_SOFTMAX) {
             rc = vsr_launch_softmax_dev((const SMProblem*)od.dDesc, od.nitems, od.total, stream);

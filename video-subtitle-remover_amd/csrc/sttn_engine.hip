@@ -70,6 +70,7 @@ struct OpDev {
     int rowLo = 0, rowHi = 0;    // UPSAMPLE2X: output rows written; DECODE_OUT: image rows decoded (Plan::decLo)
     int split = 0;               // precision mode 2: this elementwise op reads / writes split-format tensors
     bool aexp = false;           // GEMM: the launch carries VSR_ACT_A_EXP problems (P.V of a fused attention)
+    bool thin = false;           // exact fp32, NK: a short-K / single-round launch on the one-workgroup-per-tile kernel (sttn_thin below): same bits
     const float* lsum = nullptr; // reduce_scatter of a fused attention: partial row sums [nsplit][ldL]
     int ldL = 0;
     double flops = 0;
@@ -112,6 +113,8 @@ struct TimingRec {
 };
 
 } // namespace
+
+static bool sttn_thin(int precision, int bmode, const std::vector<GGProblem>& probs, int totalTiles);
 
 struct vsr_sttn {
     Model model;
@@ -318,6 +321,7 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
             od.total = tileStart;
             od.nQueues = 8;
             od.aexp = op.ipar[0] != 0;
+            od.thin = sttn_thin(precision, op.bmode, small, tileStart);
             for (const GGProblem& q : small)
                 if (q.tilesN > 4) od.nQueues = gg_wide_queues();
             cursor += smallBytes + (big.size() * sizeof(GGProblem) + 63) / 64 * 64;
@@ -401,6 +405,29 @@ static int gg_variant(int bmode, int precision = 0)
 }
 static bool use_persistent() { return gg_variant(VSR_BMODE_NK) >= 2 || gg_variant(VSR_BMODE_KN) >= 2; }
 
+// Exact fp32, NK problems on the default persistent kernel (variant 3): a launch whose problems are short (K <= VSR_STTN_THIN_SHORT_K) or
+// that is a single round of tiles (<= VSR_STTN_THIN_TILES with K <= VSR_STTN_THIN_K) goes to the one-workgroup-per-tile kernel (variant 1) --
+// the same MFMA sequence per output element, the same bits (tests/test_gpu_kernels.py::test_one_workgroup_per_tile_kernel_equals_the_
+// persistent_one), without the persistent kernel's per-tile fixed cost.  The flow engines' rule (flow_engine.hip thin_variant); the score GEMM
+// of a fused attention leaves its row maxima in variant 3's epilogue and stays.  OPT-IN (VSR_STTN_THIN=1), measured on the headline
+// (profiles/r06c_sttn_thin_ab.log): the decoder's launches 72.7 -> 76.9 TF, the single-lane step +1.3 %, but with the default two window
+// lanes -- whose launches already fill each other's tails -- 220.2 -> 219.7 fps; the fused QKV 1x1 conv (K = 256, 6 750 tiles) is 100 TF on
+// either kernel.  Off; the flow engines, whose feature-propagation launches are dependent single rounds, gain (flow_engine.hip).
+static bool sttn_thin(int precision, int bmode, const std::vector<GGProblem>& probs, int totalTiles)
+{
+    static const int mode = [] { const char* e = getenv("VSR_STTN_THIN"); return e ? atoi(e) : 0; }();
+    static const int maxTiles = [] { const char* e = getenv("VSR_STTN_THIN_TILES"); return e ? atoi(e) : 768; }();
+    static const int maxK = [] { const char* e = getenv("VSR_STTN_THIN_K"); return e ? atoi(e) : 2600; }();
+    static const int shortK = [] { const char* e = getenv("VSR_STTN_THIN_SHORT_K"); return e ? atoi(e) : 256; }();
+    if (mode == 0 || precision != 0 || bmode != VSR_BMODE_NK || probs.empty() || gg_variant(VSR_BMODE_NK) != 3) return false;
+    int K = 0;
+    for (const GGProblem& q : probs) {
+        if (q.act & VSR_ACT_ROW_MAX) return false;
+        K = std::max(K, q.splitK > 1 ? q.chunksPerSplit * VSR_GG_KC : q.K);
+    }
+    return K <= shortK || (totalTiles <= maxTiles && K <= maxK);
+}
+
 static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
 {
     const int prec = pd->plan->precision;
@@ -438,7 +465,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             HIPCHK(hipStreamWaitEvent(stream, h->evDecode[nDecode - 1], 0));
         TimingRec tr;
         // (mode 2 brackets the launches of the NK kernel the convolutions are on, the 128 x 64 tile: the symbol `roofline` is taken on)
-        const bool timed = h->timing == 1 || (h->timing == 2 && od.kind == OP_GEMM && od.tileCfg == VSR_TILE_128x64 && od.bmode == VSR_BMODE_NK);
+        const bool timed = h->timing == 1 || (h->timing == 2 && od.kind == OP_GEMM && od.tileCfg == VSR_TILE_128x64 && od.bmode == VSR_BMODE_NK && !od.thin);
         if (timed) {
             tr.tag = od.tag; tr.flops = od.flops;
             // an op whose problems all went to the 8-wave kernel is that kernel's launch; one that was cut in two keeps the tile's name + "m"
@@ -446,7 +473,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
             tr.kernel = od.kind != OP_GEMM ? ("kernel:op:" + std::to_string(od.kind))
                       : (big && od.total == 0) ? ("kernel:gg:" + std::to_string(VSR_TILE_256x256) + ":0:v7")
                       : ("kernel:gg:" + std::to_string(od.tileCfg) + ":" + std::to_string(od.bmode) + ":v" +
-                         std::to_string(gg_variant(od.bmode, prec)) + (od.aexp ? "x" : "") + (big ? "m" : ""));
+                         std::to_string(od.thin ? 1 : gg_variant(od.bmode, prec)) + (od.aexp ? "x" : "") + (big ? "m" : ""));
             HIPCHK(hipEventCreate(&tr.a));
             HIPCHK(hipEventCreate(&tr.b));
             HIPCHK(hipEventRecord(tr.a, stream));
@@ -469,7 +496,7 @@ static int run_plan(vsr_sttn* h, PlanDev* pd, hipStream_t stream)
                                                 (prec == 3 && !scoresSplit) ? 6 : 5, 1, h->dRangeFlag, stream);
             if (rc == 0 && od.total > 0)
                 rc = vsr_launch_gather_gemm_dev((const GGProblem*)od.dDesc, od.nitems, od.total, od.tileCfg, od.bmode, queue,
-                                                (scoresSplit ? 5 : gg_variant(od.bmode, prec)) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
+                                                (scoresSplit ? 5 : od.thin ? 1 : gg_variant(od.bmode, prec)) | (od.aexp ? VSR_VARIANT_A_EXP : 0), od.nQueues,
                                                 prec ? h->dRangeFlag : nullptr, stream);
             break;
         case OP_SOFTMAX:
