@@ -299,6 +299,47 @@ def test_device_db_postprocess_equals_the_oracle(built_lib, gpu_device, seed, H,
     assert np.array_equal(flat_lab[idx], firsts[flat_ref[idx]])
 
 
+@pytest.mark.parametrize("H,W,density", [(17, 37, 0.5), (64, 65, 0.6), (33, 100, 0.45), (8, 64, 0.9), (5, 1, 1.0), (1, 130, 0.7), (40, 63, 0.55), (96, 160, 0.35),
+                                         (30, 128, 1.0), (50, 200, 0.62)])
+def test_ccl_labels_random_maps(built_lib, gpu_device, H, W, density):
+    """vsr_det_launch_ccl (run-start labels by wave ballot, only the unions no neighbour pair implies, one set of statistics atomics per wave)
+    on random maps whose rows straddle the 64-pixel waves in every way: the partition is scipy's 8-connected one, every label is the raster
+    index of its component's first pixel, area and bounding box per component are exact"""
+    import ctypes as C
+
+    import scipy.ndimage
+
+    from vsr_amd._lib import check, lib
+
+    rng = np.random.default_rng(H * 1000 + W)
+    prob = (rng.random((H, W)) < density).astype(np.float32) * 0.8 + 0.1
+    if H >= 30 and W >= 100:
+        prob[5:25, 10:90] = 0.9                                # a solid block: long runs, wave-uniform roots
+    ref, n = scipy.ndimage.label(prob > 0.3, structure=np.ones((3, 3), dtype=int))
+    cap = max(n, 1) + 4
+    i32 = torch.int32
+    d = torch.from_numpy(prob).to(gpu_device)
+    labels, stats = torch.empty(H * W, dtype=i32, device=gpu_device), torch.empty(H * W * 5, dtype=i32, device=gpu_device)
+    comps, count = torch.empty(cap * 6, dtype=i32, device=gpu_device), torch.zeros(4, dtype=i32, device=gpu_device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for _ in range(3):                                         # (the unions race: every run must give the same partition)
+        check(lib.vsr_det_launch_ccl(p(d), H, W, C.c_float(0.3), p(labels), p(stats), p(comps), cap, p(count), None))
+        torch.cuda.synchronize()
+        lab = labels.cpu().numpy().reshape(H, W)
+        assert int(count[0].item()) == n
+        assert ((lab >= 0) == (ref > 0)).all()
+        got = comps.cpu().numpy().reshape(cap, 6)[:n]
+        got = got[np.argsort(got[:, 0])]
+        want = []
+        for k, sl in enumerate(scipy.ndimage.find_objects(ref), start=1):
+            ys, xs = np.nonzero(ref == k)
+            first = int((ys * W + xs).min())
+            assert (lab[ref == k] == first).all()
+            want.append((first, len(ys), xs.min(), xs.max(), ys.min(), ys.max()))
+        want = np.array(sorted(want), dtype=np.int64).reshape(-1, 6)
+        assert np.array_equal(got, want)
+
+
 def test_device_db_postprocess_batch_equals_per_map(built_lib, gpu_device):
     """DeviceDBPostProcess.batch (every map of a forward in work buffers of its own, ONE read-back -- what predict_batch /
     predict_batch_device use) gives, map by map, exactly what the per-map call gives: boxes, scores, and the host fallback of the map with

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -232,11 +233,28 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
     const int cus = vsr_gg_cus();
     // NK problems as they are; KN problems (P.V: B = V, n-contiguous) after their B operand has been turned to NK form into a
     // scratch tensor (one pass over V per product, ~2 % of the product's own time).  Split-K problems keep their partial planes.
-    auto forV7 = [&](const Op& op, const GemmItem& g) {
+    // COMPANIONS (round 6, OPT-IN: VSR_F16_V7_COMPANIONS=1): an op whose launch already has such a problem (the fine attention scales) takes its
+    // smaller problems along -- the coarse scales of the same product (375 / 60 tokens, K = 12 288 / 76 800 split 12 / 75 ways; P.V with
+    // N = 3 200 / 12 288) are a second launch on the 128 x 64 kernel, which cannot share a CU with this one (one workgroup per CU: 128 KB
+    // of LDS).  Measured and NOT a win (profiles/r06c_f16_companions_ab.log): the score launches 40.4 -> 37.9 ms per two chunks, P.V
+    // unchanged, config 5 681 / 669 -> 668 / 651 fps -- the short tiles cost the 256 x 256 launch what the second launch cost, and the two
+    // window lanes were hiding that one.  Same bits either way (test_gather_gemm_fp16_256x256_equals_128x64).
+    static const bool companions = [] { const char* e = getenv("VSR_F16_V7_COMPANIONS"); return e && atoi(e) == 1; }();
+    auto anchorV7 = [&](const Op& op, const GemmItem& g) {
         if (!v7on || precision < 2 || (g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP))) return false;
         if (op.bmode == VSR_BMODE_KN && (g.K % 32 || g.N % 32)) return false;
         const int64_t units = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splitK;
         return g.N >= 192 && g.K >= 256 && g.M >= 1024 && units * 2 >= cus;
+    };
+    auto forV7 = [&](const Op& op, const GemmItem& g) {
+        if (anchorV7(op, g)) return true;
+        if (!companions || !v7on || precision < 2 || (g.act & (VSR_ACT_ROW_MAX | VSR_ACT_A_EXP))) return false;
+        if (op.bmode == VSR_BMODE_KN && (g.K % 32 || g.N % 32)) return false;
+        const int kSlice = g.splitK > 1 ? g.chunksPerSplit * VSR_GG_KC : g.K;
+        if (kSlice < 256 || g.N < 32) return false;
+        for (const GemmItem& o : op.gemm)
+            if (anchorV7(op, o)) return true;
+        return false;
     };
     // scratch for the transposed operands: per lane the largest sum over one op's KN problems; row tables n -> n * ld
     std::vector<int64_t> vtLane(kMaxLanes, 0);
@@ -303,6 +321,12 @@ static int build_plan_dev(vsr_sttn* h, int L, int precision, PlanDev** out, int 
                 } else {
                     small.push_back(q);
                 }
+            }
+            static const bool dumpRouting = [] { const char* e = getenv("VSR_STTN_DUMP_ROUTING"); return e && atoi(e) == 1; }();
+            if (dumpRouting) {                  // which kernel every problem of the plan goes to (stderr, once per plan build)
+                for (const GemmItem& g : op.gemm)
+                    fprintf(stderr, "routing %-16s lane %d bmode %d M %6d N %6d K %6d splitK %2d tiles %3dx%-3d act %#x -> %s\n", op.tag.c_str(), op.lane, op.bmode, g.M,
+                            g.N, g.K, g.splitK, g.tilesM, g.tilesN, g.act, forV7(op, g) ? "256x256" : "tile of the op");
             }
             int tileStart = 0;
             for (GGProblem& q : small) { q.tileStart = tileStart; tileStart += q.tilesM * q.tilesN * q.splitK; }
