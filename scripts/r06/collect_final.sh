@@ -22,5 +22,6 @@ cp $S/cfg_4s.json $D/r06_config_4s.json
 cp $S/e2e_pp_f32.json $S/e2e_pp_f16.json $S/e2e_det.json $D/ 2>/dev/null
 for f in e2e_pp_f32 e2e_pp_f16 e2e_det; do mv $D/$f.json $D/r06_$f.json; done
 cp $S/cli.log $D/r06_cli.log
+cp $S/det_bench.log $D/r06_detector_bench.log
 cp $S/dryrun_2ranks.log $D/r06_final_dryrun_2ranks.log
 ls -la $D | grep r06_ | wc -l

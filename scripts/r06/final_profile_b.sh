@@ -21,10 +21,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f16_trace -o r -- $
 grep '"metric"' $OUT/f16_trace.log > $OUT/f16_bench_under_rocprof.json
 rm -f $OUT/trace/r_kernel_trace.csv $OUT/trace_lanes2/r_kernel_trace.csv $OUT/f16_trace/r_kernel_trace.csv
 for leg in 4 4h; do timeout 1200 python scripts/stage_stats.py --leg $leg --out $OUT/stages > $OUT/stage_stats_$leg.log 2>&1; cat $OUT/stage_stats_$leg.log | tail -5; done
-for s in det raft rfc lama; do
+for s in raft rfc lama; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${s}_trace -o r -- python scripts/bench_$s.py > $OUT/${s}_trace.log 2>&1
   grep '^{' $OUT/${s}_trace.log | tail -1 | cut -c1-300 > $OUT/${s}_bench_under_rocprof.json; rm -f $OUT/${s}_trace/r_kernel_trace.csv
 done
+# the detector's forward = the compiled NHWC plan only (server program, 8 frames of 960 x 544 per forward, 5 timed rounds)
+DET_AB_ONLY=plan DET_AB_CASES=ppocr_det_graph.json:8 DET_AB_REPS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/det_trace -o r -- python scripts/r06/det_nhwc_ab.py > $OUT/det_trace.log 2>&1
+grep "ms/frame" $OUT/det_trace.log | cut -c1-260 > $OUT/det_bench_under_rocprof.json; rm -f $OUT/det_trace/r_kernel_trace.csv
+timeout 300 python scripts/bench_det.py ppocr_det_graph.json 2>&1 | grep -v amdgpu.ids > $OUT/det_bench.log; cat $OUT/det_bench.log
 timeout 300 python scripts/bench_configs.py 4s 2>/dev/null | grep '^{' > $OUT/cfg_4s.json
 python - <<'PY'
 import json
