@@ -378,13 +378,51 @@ def main():
                                   store_rows,
                                   dist=dist, device=device, io="device")
 
-        run_rounds(max(1, args.warmup))
-        elapsed = timed(lambda: run_rounds(args.steps))
+        # (1) every rank on its own resident chunk, nothing exchanged: the upper bound of the path below -- and what the line falls back
+        # to when the exchange does not come through (it runs over RCCL between DEVICES for the first time on the driver's node)
         for _ in range(max(1, args.warmup)):
             step()
         dt_rep = timed(lambda: [step() for _ in range(args.steps)])
         replicas = {"value": round(args.steps * L * world / dt_rep, 3), "unit": "frames/s", "ms_per_step": round(dt_rep / args.steps * 1e3, 3),
                     "note": "every rank on its own HBM-resident chunk, nothing exchanged (upper bound of the scatter / gather path)"}
+
+        # (2) the scatter / gather path, under a watchdog: a stuck or failing exchange costs this leg, not the line -- rank 0 then prints
+        # the line with `value` = the replicas' rate (units sharded across ranks, no data-path exchange) and says so in `scatter_gather`
+        def fallback_line(reason):
+            fb = {"metric": "inpainted frames/sec @1080p (STTN, 5-frame window)" if args.res == "1080p"
+                  else f"inpainted frames/sec @{args.res} (STTN, 5-frame window)",
+                  "value": replicas["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": replicas["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                  "dtype": base_precision if base_precision != "f16" else "f16 (fp32 accumulate)", "data": "synthetic",
+                  "config": {"workload": f"{args.res} synthetic clip, --inpaint-mode sttn-auto, {L}-frame chunks resident in HBM, neighbor stride 5 / "
+                                         "refs every 10 (BASELINE.json metric)", "frame_size": [W, H], "strip": [W, int(W * 3 / 16)], "chunk_frames": L,
+                             "parallelism": f"chunk-parallel x{world}: every rank on its own resident chunks, NO exchange (the scatter / gather leg failed)"},
+                  "replicas": replicas, "scatter_gather": {"error": reason[:400]}}
+            print(json.dumps(fb), flush=True)
+
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from bench_multi import Watchdog
+
+        def on_timeout(leg, phase):
+            if rank == 0:
+                fallback_line(f"watchdog: phase '{phase}' of the scatter / gather leg did not finish within {budget:.0f} s")
+
+        budget = float(os.environ.get("VSR_BENCH_HEADLINE_TIMEOUT", "240"))
+        dog = Watchdog(budget, on_timeout)
+        try:
+            dog.phase("headline", "warm-up rounds")
+            if os.environ.get("VSR_BENCH_SCATTER_FAIL") == "1":              # test hook (tests/test_bench_multi.py)
+                raise RuntimeError("VSR_BENCH_SCATTER_FAIL=1")
+            run_rounds(max(1, args.warmup))
+            dog.phase("headline", "timed rounds")
+            elapsed = timed(lambda: run_rounds(args.steps))
+            dog.cancel()
+        except Exception as e:                   # noqa: BLE001 -- the ranks may have left the exchange at different points: no further collective
+            dog.cancel()
+            if rank == 0:
+                fallback_line(f"{type(e).__name__}: {e}")
+            sys.stdout.flush()
+            os._exit(0)
         if rank == 0:
             checksum = int(sum(int(d[::7, ::5, ::11].sum().item()) for d in dsts))
             replicas["scatter_gather_result_checksum"] = checksum

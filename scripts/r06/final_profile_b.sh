@@ -48,4 +48,7 @@ for l in sys.stdin:
     for k, v in (d.get('configs_multi') or {}).items():
         print('  multi', k, {a: v.get(a) for a in ('n_ranks', 'value', 'efficiency', 'selftest_ok', 'frames_written', 'error', 'hbm_gbps')})
 "
+# the fail-safe of the N-rank headline: the scatter / gather leg raises -> the line falls back to the replicas' rate
+VSR_BENCH_SCATTER_FAIL=1 VSR_BENCH_DRYRUN_1GPU=1 timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --no-multi-configs > $OUT/dryrun_2ranks_scatter_fail.log 2>&1
+echo "scatter-fail dry run rc=$?"; grep '^{' $OUT/dryrun_2ranks_scatter_fail.log | cut -c1-900
 ls $OUT; du -sh $OUT
