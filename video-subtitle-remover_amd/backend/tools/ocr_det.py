@@ -242,6 +242,10 @@ class PaddleGraphRunner:
                 plan = ocr_det_nhwc.compile_plan(self.graph, params, key)
             except ValueError:                      # a buffer beyond the 32-bit offset tables: the walk (which checks conv by conv) decides
                 plan = None
+            except NotImplementedError:             # an operator form the compiler has no NHWC / NCHW step for: "auto" leaves the program to
+                if self.nhwc == "1":                # the op-by-op walk (the same HIP kernels, operator by operator), "1" insists
+                    raise
+                plan = None
             kinds = {}
             for k, _ in (plan.steps if plan is not None else []):
                 kinds[k] = kinds.get(k, 0) + 1
