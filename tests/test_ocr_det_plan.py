@@ -84,3 +84,13 @@ def test_tables_are_refused_beyond_32_bits():
     params = {vid: np.zeros(shape, np.float32) + 0.01 for vid, (_, shape) in g.params.items()}
     with pytest.raises(ValueError):
         nhwc.compile_plan(g, params, (48, 3, 544, 960))
+
+
+def test_thin_variant_rule():
+    """which GEMM steps leave the persistent kernel (profiles/r06c_det_plan_variants.log): short K, narrow N with moderate K, few tiles"""
+    assert nhwc.thin_variant(1044480, 32, 128, 4080) == 1            # K <= 256
+    assert nhwc.thin_variant(261120, 64, 576, 2040) == 1             # N <= 96 and K <= 1152
+    assert nhwc.thin_variant(16320, 512, 2176, 512) == 1             # <= 512 tiles and K <= 2400
+    assert nhwc.thin_variant(261120, 64, 20736, 8160) == 3           # the neck's 9x9 convs
+    assert nhwc.thin_variant(65280, 256, 704, 2040) == 3
+    assert nhwc.thin_variant(4080, 1024, 3328, 256) == 3             # few tiles but a long K
