@@ -224,7 +224,7 @@ def run_det(name, res, precision, total=1200):
     return attach_traffic("3", out, 1.0 / per[Lmax])
 
 
-def run_detector(name, nb=16, reps=3):
+def run_detector(name, nb=8, reps=5):
     """config 3's other half: the PP-OCRv5 server detector's forward at the 1080p net input (960x544), `nb` frames per forward, from the
     compiled NHWC plan's launch list (subtitle_detect.py:41-82's TextDetection.predict without the DB post-process)."""
     from vsr_amd.backend.tools import ocr_det

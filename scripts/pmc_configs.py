@@ -5,7 +5,7 @@
 
 For each leg two SEPARATE rocprofv3 runs (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC
 slots") of `python scripts/bench_configs.py --unit <leg>`, which runs one warm unit, a marker kernel, ONE measured unit (a 50-frame
-chunk / a 47-frame sttn-det batch / a 16-frame detector forward / a 68-frame propainter batch) and a marker kernel again.  Only the
+chunk / a 47-frame sttn-det batch / an 8-frame detector forward (VSR_DET_BATCH, what the detector pass hands over) / a 68-frame propainter batch) and a marker kernel again.  Only the
 dispatches between the two markers are counted.  Leg "1" is the headline (1080p sttn-auto chunk).
 
 Correction (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE reports half the bytes of a wide streaming read, WRITE_SIZE is exact
@@ -28,7 +28,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 UNITS = {"1": "one 50-frame 1080p sttn-auto chunk", "2": "one 50-frame 720p sttn-auto chunk", "3": "one 47-frame 1080p sttn-det batch",
-         "3d": "one 16-frame detector forward (960x544)", "4": "one 68-frame 1080p propainter batch (exact fp32)",
+         "3d": "one 8-frame detector forward (960x544)", "4": "one 68-frame 1080p propainter batch (exact fp32)",
          "4h": "one 68-frame 1080p propainter batch (reference GPU arithmetic)", "4s": "one 68-frame propainter batch (f16 + split RAFT)",
          "5": "one 50-frame 4K sttn-auto chunk (fp16 operands)", "5x": "one 50-frame 4K sttn-auto chunk (fp32)"}
 MARK = "nextafter"
