@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--e2e-chunks", type=int, default=4, help="chunks of the PCIe-inclusive plugin leg (0 = skip)")
     ap.add_argument("--no-split-half", action="store_true", help="skip the informational split-half (f16 MFMA) leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2-5, scripts/bench_configs.py)")
-    ap.add_argument("--configs", default=None, help="comma-separated legs of scripts/bench_configs.py (default: 2,3,3d,4,4h,5)")
+    ap.add_argument("--configs", default=None, help="comma-separated legs of scripts/bench_configs.py (default: 2,3,3d,3e,4,4h,5)")
     ap.add_argument("--no-multi-configs", action="store_true", help="N > 1: skip the N-rank legs of BASELINE configs 5 and 4 (scripts/bench_multi.py)")
     ap.add_argument("--multi-configs", default=None, help="N > 1: comma-separated legs of scripts/bench_multi.py (default: 5,4h,4)")
     ap.add_argument("--no-full-work", action="store_true",

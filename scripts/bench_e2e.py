@@ -40,10 +40,19 @@ from vsr_amd.backend.tools.constant import InpaintMode  # noqa: E402
 from vsr_amd.backend.tools.paddle_graph import load_graph  # noqa: E402
 
 
-def write_clip(path, n, H, W, box, on_of):
-    """the synthetic clip, 50 frames at a time: moving background everywhere, glyph blocks inside `box` on the frames on_of(i) says"""
+def write_clip(path, n, H, W, box, on_of, cycle=0):
+    """the synthetic clip, 50 frames at a time: moving background everywhere, glyph blocks inside `box` on the frames on_of(i) says.
+    cycle > 0: the first `cycle` frames repeat (a clip for a timing leg inside bench.py: the cost of every stage is content-independent,
+    synthesising 1200 distinct 1080p frames on the host takes 77 s, 50 take 3)"""
     w = video_io.Y4mWriter(path, 25.0, (W, H), chroma="420")
     t0 = time.time()
+    if cycle > 0:
+        k = min(cycle, n)
+        frames = synth.make_clip(k, H, W, box, seed=100, glyph_frames=[on_of(j) for j in range(k)])
+        for i in range(n):
+            w.write(frames[i % k])
+        w.release()
+        return time.time() - t0
     for s in range(0, n, 50):
         k = min(50, n - s)
         frames = synth.make_clip(k, H, W, box, seed=100 + s, glyph_frames=[on_of(s + j) for j in range(k)])     # (one pass: the same frames as
@@ -118,6 +127,7 @@ def main():
     ap.add_argument("--always-on", action="store_true", help="subtitle on every frame: ONE interval, i.e. the batch sizes batch_generator makes of "
                                                              "the whole clip (1200 frames -> 17 x 68 + 44 for propainter, 25 x 47 + 25 for sttn-det / lama)")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--cycle", type=int, default=0, help="the clip repeats its first N frames (fast to synthesise: the timing leg of bench.py)")
     ap.add_argument("--clip", default=None, help="reuse / create the input clip at this path (several runs over one clip)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench_e2e.py needs a GPU"
@@ -129,7 +139,7 @@ def main():
     on_of = (lambda i: True) if args.always_on else (lambda i: (i % 120) < 100)
     t_gen = 0.0
     if not os.path.exists(src):
-        t_gen = write_clip(src, args.frames, H, W, box, on_of)
+        t_gen = write_clip(src, args.frames, H, W, box, on_of, args.cycle)
 
     # checkpoints as files of the real layouts
     if args.mode == "sttn-det":
@@ -179,7 +189,7 @@ def main():
            "batch_lanes": int(os.environ.get("VSR_BATCH_LANES", "1")), "sttn_window_lanes": int(os.environ.get("VSR_STTN_LANES", "2")),
            "precision": os.environ.get("VSR_PP_PRECISION", "f32") if args.mode == "propainter" else "f32",
            "clip": f"synthetic {W}x{H} y4m 4:2:0, subtitle on {'every frame' if args.always_on else '100 of every 120 frames'} in box {box}; "
-                   f"generated in {t_gen:.0f} s (not timed)"}
+                   f"generated in {t_gen:.0f} s (not timed)" + (f"; the first {args.cycle} frames repeated" if args.cycle else "")}
     print(json.dumps(res), flush=True)
     if not args.keep:
         import shutil
