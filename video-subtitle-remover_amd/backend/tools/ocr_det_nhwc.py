@@ -32,7 +32,7 @@ TILE_256x32 = 1
 
 
 def _opts():
-    """tuning switches of the plan (environment, read at compile time; defaults = what profiles/r06b_det_variants*.log measured best):
+    """tuning switches of the plan (environment, read at compile time; defaults = what profiles/r06c_det_plan_variants.log measured best):
     VSR_DET_N32_TILE=0: problems of 32 output columns on the 128 x 64 tile instead of the 256 x 32 one (a full N tile: float4 epilogue, no
         idle half of the MFMA columns)
     VSR_DET_THIN=0: every GEMM on the persistent LDS-DMA kernel (variant 3); default: short or few-tile problems (thin_variant below) on
@@ -48,7 +48,7 @@ def _opts():
 def thin_variant(M, N, K, tiles):
     """kernel variant of a GEMM problem: 1 (one workgroup per tile) for K <= 256, for N <= 96 with K <= 1152 and for launches of at most
     512 tiles with K <= 2400; 3 (persistent, LDS-DMA, pipelined tiles) otherwise -- the long-K convs of the neck and the head run at
-    115-132 TF there (measured per conv at 8 frames of 960 x 544, profiles/r06b_det_variants2.log)"""
+    115-132 TF there (measured per conv at 8 frames of 960 x 544, profiles/r06c_det_plan_variants.log)"""
     if K <= 256 or (N <= 96 and K <= 1152) or (tiles <= 512 and K <= 2400):
         return 1
     return 3
